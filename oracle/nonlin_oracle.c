@@ -1,0 +1,946 @@
+/*
+ * nonlin_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See nonlin_oracle.h for scope, pinning status and arithmetic conventions.
+ * Every routine cites the reference lines it restates (paths relative to
+ * /root/reference).  Indices are 0-based here; the reference is 1-based.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+ */
+#include "nonlin_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define A_(a, lda, i, j) ((a)[(size_t)(j) * (size_t)(lda) + (size_t)(i)])
+
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+static inline double dmin(double a, double b) { return a < b ? a : b; }
+
+void nlo_default_options(nlo_options *o)
+{
+    o->max_evals = 100;        /* src/nonlin_multi_eqn_mult_var.f90:69 */
+    o->ftol = 1.0e-8;          /* :71 */
+    o->xtol = 1.0e-12;         /* :73 */
+    o->gtol = 1.0e-12;         /* :75 */
+    o->print_status = 0;       /* :77 */
+    o->factor = 100.0;         /* src/nonlin_least_squares.f90:25 */
+    o->use_line_search = 1;    /* src/nonlin_solve.f90:30 */
+    o->ls_max_evals = 100;     /* src/nonlin_linesearch.f90:35 */
+    o->ls_alpha = 1.0e-4;      /* :38 */
+    o->ls_factor = 0.1;        /* :46 */
+}
+
+/* Fortran intrinsics as frozen for this project (header, "Arithmetic conventions").
+ * NORM2 is processor-dependent in Fortran.  This is the algorithm of the flang
+ * runtime shipped with ROCm 7.2 (amdflang 22, _FortranANorm2_8): a running
+ * maximum with a rescaled sum of squared ratios, result max*sqrt(1+sum).  It
+ * was checked bit-for-bit against amdflang's NORM2 on 300 random vectors
+ * (tests/golden/make_norm2_vectors.f90 -> tests/golden/norm2_flang.json). */
+double nlo_norm2(int32_t n, const double *x)
+{
+    double mx = 0.0, s = 0.0;
+    for (int32_t i = 0; i < n; ++i) {
+        double a = fabs(x[i]);
+        if (mx == 0.0) {
+            mx = a;
+        } else if (a > mx) {
+            double t = mx / a, tsq = t * t;
+            s = s * tsq;
+            s = s + tsq;
+            mx = a;
+        } else if (a != 0.0) {
+            double t = a / mx;
+            s = s + t * t;
+        }
+    }
+    return mx * sqrt(1.0 + s);
+}
+
+double nlo_dot(int32_t n, const double *x, const double *y)
+{
+    double s = 0.0;
+    for (int32_t i = 0; i < n; ++i) s = s + x[i] * y[i];
+    return s;
+}
+
+/* print_status: src/nonlin_helper.f90:17-33 (formats A,I0 and A,E10.3). */
+static void fmt_e10_3(char *buf, size_t nbuf, double v)
+{
+    /* Fortran E10.3: 0.ddddE+ee */
+    if (v == 0.0) { snprintf(buf, nbuf, " 0.000E+00"); return; }
+    int e = (int)floor(log10(fabs(v))) + 1;
+    double mant = v / pow(10.0, e);
+    if (fabs(mant) >= 0.9995) { mant /= 10.0; e += 1; }
+    snprintf(buf, nbuf, "%s0.%03dE%c%02d", mant < 0 ? "-" : " ",
+             (int)floor(fabs(mant) * 1000.0 + 0.5), e < 0 ? '-' : '+', abs(e));
+}
+
+static void print_status(int iter, int nfeval, int njaceval, double xnorm, double fnorm)
+{
+    char b1[32], b2[32];
+    fmt_e10_3(b1, sizeof b1, xnorm);
+    fmt_e10_3(b2, sizeof b2, fnorm);
+    printf(" \n");
+    printf("Iteration: %d\n", iter);
+    printf("Function Evaluations: %d\n", nfeval);
+    if (njaceval > 0) printf("Jacobian Evaluations: %d\n", njaceval);
+    printf("Change in Variable: %s\n", b1);
+    printf("Residual: %s\n", b2);
+}
+
+/* ---------------------------------------------------------------------------
+ * vfh_jac_fcn: src/nonlin_multi_eqn_mult_var.f90:198-277
+ * ------------------------------------------------------------------------- */
+int nlo_fd_jacobian(nlo_vecfcn fcn, nlo_jacfcn jac_or_null, void *ctx,
+                    int32_t m, int32_t n, double *x, const double *fv, double *jac)
+{
+    if (!fcn) return NLO_UNDEFINED_FUNCTION_ERROR;           /* :240 */
+    if (jac_or_null) {                                       /* :241-243 */
+        jac_or_null(ctx, n, x, m, jac);
+        return 0;
+    }
+    int lwork = fv ? m : 2 * m;                              /* :246-250 */
+    double *wrk = (double *)malloc(sizeof(double) * (size_t)(lwork > 0 ? lwork : 1)); /* :253 */
+    double *f1 = wrk;                                        /* :254 */
+    const double *f0;
+    if (fv) {
+        f0 = fv;                                             /* :256 */
+    } else {
+        fcn(ctx, n, x, m, wrk + m);                          /* :258-259 */
+        f0 = wrk + m;
+    }
+    const double eps = sqrt(DBL_EPSILON);                    /* :263-264 */
+    for (int32_t j = 0; j < n; ++j) {                        /* :267-275 */
+        double temp = x[j];
+        double h = eps * fabs(temp);
+        if (h == 0.0) h = eps;
+        x[j] = temp + h;
+        fcn(ctx, n, x, m, f1);
+        x[j] = temp;
+        for (int32_t i = 0; i < m; ++i)
+            A_(jac, m, i, j) = (f1[i] - f0[i]) / h;          /* :274, true division */
+    }
+    free(wrk);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------
+ * lmfactor (MINPACK qrfac): src/nonlin_least_squares.f90:569-667
+ * ipvt is 0-based here.
+ * ------------------------------------------------------------------------- */
+void nlo_lmfactor(int32_t m, int32_t n, double *a, int32_t lda, int32_t pivot,
+                  int32_t *ipvt, double *rdiag, double *acnorm, double *wa)
+{
+    const double p05 = 5.0e-2, epsmch = DBL_EPSILON;
+    const int32_t minmn = m < n ? m : n;
+
+    for (int32_t j = 0; j < n; ++j) {                        /* :611-616 */
+        acnorm[j] = nlo_norm2(m, &A_(a, lda, 0, j));
+        rdiag[j] = acnorm[j];
+        wa[j] = rdiag[j];
+        if (pivot) ipvt[j] = j;
+    }
+
+    for (int32_t j = 0; j < minmn; ++j) {                    /* :619-666 */
+        if (pivot) {
+            int32_t kmax = j;                                /* :622-625 */
+            for (int32_t k = j; k < n; ++k)
+                if (rdiag[k] > rdiag[kmax]) kmax = k;
+            if (kmax != j) {                                 /* :626-637 */
+                for (int32_t i = 0; i < m; ++i) {
+                    double t = A_(a, lda, i, j);
+                    A_(a, lda, i, j) = A_(a, lda, i, kmax);
+                    A_(a, lda, i, kmax) = t;
+                }
+                rdiag[kmax] = rdiag[j];
+                wa[kmax] = wa[j];
+                int32_t k = ipvt[j];
+                ipvt[j] = ipvt[kmax];
+                ipvt[kmax] = k;
+            }
+        }
+
+        double ajnorm = nlo_norm2(m - j, &A_(a, lda, j, j));  /* :642 */
+        if (ajnorm != 0.0) {
+            if (A_(a, lda, j, j) < 0.0) ajnorm = -ajnorm;    /* :644 */
+            for (int32_t i = j; i < m; ++i)                  /* :645 */
+                A_(a, lda, i, j) = A_(a, lda, i, j) / ajnorm;
+            A_(a, lda, j, j) = A_(a, lda, j, j) + 1.0;       /* :646 */
+
+            for (int32_t k = j + 1; k < n; ++k) {            /* :652-662 */
+                double sm = 0.0;
+                for (int32_t i = j; i < m; ++i)
+                    sm = sm + A_(a, lda, i, j) * A_(a, lda, i, k);
+                double temp = sm / A_(a, lda, j, j);
+                for (int32_t i = j; i < m; ++i)
+                    A_(a, lda, i, k) = A_(a, lda, i, k) - temp * A_(a, lda, i, j);
+                if (!pivot || rdiag[k] == 0.0) continue;
+                temp = A_(a, lda, j, k) / rdiag[k];
+                rdiag[k] = rdiag[k] * sqrt(dmax(0.0, 1.0 - temp * temp));
+                double q = rdiag[k] / wa[k];
+                if (p05 * (q * q) > epsmch) continue;
+                rdiag[k] = nlo_norm2(m - (j + 1), &A_(a, lda, j + 1, k));
+                wa[k] = rdiag[k];
+            }
+        }
+        rdiag[j] = -ajnorm;                                  /* :665 */
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * lmsolve (MINPACK qrsolv): src/nonlin_least_squares.f90:670-791
+ * r is the leading n-by-n block of the Jacobian workspace (leading dim ldr).
+ * ------------------------------------------------------------------------- */
+void nlo_lmsolve(int32_t n, double *r, int32_t ldr, const int32_t *ipvt,
+                 const double *diag, const double *qtb, double *x, double *sdiag,
+                 double *wa)
+{
+    const double qtr = 0.25, half = 0.5;
+
+    for (int32_t j = 0; j < n; ++j) {                        /* :710-714 */
+        for (int32_t i = j; i < n; ++i) A_(r, ldr, i, j) = A_(r, ldr, j, i);
+        x[j] = A_(r, ldr, j, j);
+        wa[j] = qtb[j];
+    }
+
+    for (int32_t j = 0; j < n; ++j) {                        /* :717-765 */
+        int32_t l = ipvt[j];
+        if (diag[l] != 0.0) {
+            for (int32_t k = j; k < n; ++k) sdiag[k] = 0.0;
+            sdiag[j] = diag[l];
+            double qtbpj = 0.0;
+            for (int32_t k = j; k < n; ++k) {
+                double cs, sn;
+                if (sdiag[k] == 0.0) continue;
+                if (fabs(A_(r, ldr, k, k)) < fabs(sdiag[k])) {   /* :733-741 */
+                    double ctan = A_(r, ldr, k, k) / sdiag[k];
+                    sn = half / sqrt(qtr + qtr * (ctan * ctan));
+                    cs = sn * ctan;
+                } else {
+                    double tn = sdiag[k] / A_(r, ldr, k, k);
+                    cs = half / sqrt(qtr + qtr * (tn * tn));
+                    sn = cs * tn;
+                }
+                A_(r, ldr, k, k) = cs * A_(r, ldr, k, k) + sn * sdiag[k];   /* :745 */
+                double temp = cs * wa[k] + sn * qtbpj;
+                qtbpj = -sn * wa[k] + cs * qtbpj;
+                wa[k] = temp;
+                for (int32_t i = k + 1; i < n; ++i) {        /* :753-757 */
+                    temp = cs * A_(r, ldr, i, k) + sn * sdiag[i];
+                    sdiag[i] = -sn * A_(r, ldr, i, k) + cs * sdiag[i];
+                    A_(r, ldr, i, k) = temp;
+                }
+            }
+        }
+        sdiag[j] = A_(r, ldr, j, j);                         /* :763-764 */
+        A_(r, ldr, j, j) = x[j];
+    }
+
+    int32_t nsing = n;                                       /* :769-773 */
+    for (int32_t j = 0; j < n; ++j) {
+        if (sdiag[j] == 0.0 && nsing == n) nsing = j;
+        if (nsing < n) wa[j] = 0.0;
+    }
+    for (int32_t k = 1; k <= nsing; ++k) {                   /* :774-784 */
+        int32_t j = nsing - k;
+        double sm = 0.0;
+        for (int32_t i = j + 1; i < nsing; ++i) sm = sm + A_(r, ldr, i, j) * wa[i];
+        wa[j] = (wa[j] - sm) / sdiag[j];
+    }
+    for (int32_t j = 0; j < n; ++j) x[ipvt[j]] = wa[j];      /* :787-790 */
+}
+
+/* ---------------------------------------------------------------------------
+ * lmpar (MINPACK lmpar + two live deviations): src/nonlin_least_squares.f90:394-566
+ *   deviation A (:531): norm2 over all m entries of wa2 (caller's wa4)
+ *   deviation B (:552): the whole wa1 vector is updated, not only rows j+1..n
+ * ------------------------------------------------------------------------- */
+void nlo_lmpar(int32_t m, int32_t n, double *r, int32_t ldr, const int32_t *ipvt,
+               const double *diag, const double *qtb, double delta, double *par,
+               double *x, double *sdiag, double *wa1, double *wa2)
+{
+    const double p001 = 1.0e-3, p1 = 0.1;
+    const double dwarf = DBL_MIN;                            /* tiny(dwarf), :442 */
+    int32_t nsing = n;
+    double dxnorm, fp, gnorm, parc, parl, paru, sm, temp;
+
+    for (int32_t j = 0; j < n; ++j) {                        /* :447-451 */
+        wa1[j] = qtb[j];
+        if (A_(r, ldr, j, j) == 0.0 && nsing == n) nsing = j;
+        if (nsing < n) wa1[j] = 0.0;
+    }
+    for (int32_t k = 1; k <= nsing; ++k) {                   /* :453-463 */
+        int32_t j = nsing - k;
+        wa1[j] = wa1[j] / A_(r, ldr, j, j);
+        temp = wa1[j];
+        for (int32_t i = 0; i < j; ++i) wa1[i] = wa1[i] - A_(r, ldr, i, j) * temp;
+    }
+    for (int32_t j = 0; j < n; ++j) x[ipvt[j]] = wa1[j];     /* :466-469 */
+
+    int32_t iter = 0;                                        /* :473-481 */
+    for (int32_t i = 0; i < n; ++i) wa2[i] = diag[i] * x[i];
+    dxnorm = nlo_norm2(n, wa2);
+    fp = dxnorm - delta;
+    if (fp <= p1 * delta) {
+        if (iter == 0) *par = 0.0;
+        return;
+    }
+
+    parl = 0.0;                                              /* :486-503 */
+    if (nsing == n) {
+        for (int32_t j = 0; j < n; ++j) {
+            int32_t l = ipvt[j];
+            wa1[j] = diag[l] * (wa2[l] / dxnorm);
+        }
+        for (int32_t j = 0; j < n; ++j) {
+            sm = 0.0;
+            if (j >= 1) sm = nlo_dot(j, &A_(r, ldr, 0, j), wa1);
+            wa1[j] = (wa1[j] - sm) / A_(r, ldr, j, j);
+        }
+        temp = nlo_norm2(n, wa1);
+        parl = ((fp / delta) / temp) / temp;
+    }
+
+    for (int32_t j = 0; j < n; ++j) {                        /* :506-513 */
+        sm = nlo_dot(j + 1, &A_(r, ldr, 0, j), qtb);
+        wa1[j] = sm / diag[ipvt[j]];
+    }
+    gnorm = nlo_norm2(n, wa1);
+    paru = gnorm / delta;
+    if (paru == 0.0) paru = dwarf / dmin(delta, p1);
+
+    *par = dmax(*par, parl);                                 /* :517-519 */
+    *par = dmin(*par, paru);
+    if (*par == 0.0) *par = gnorm / dxnorm;
+
+    for (;;) {                                               /* :522-563 */
+        iter = iter + 1;
+        if (*par == 0.0) *par = dmax(dwarf, p001 * paru);
+        temp = sqrt(*par);
+        for (int32_t i = 0; i < n; ++i) wa1[i] = temp * diag[i];
+        nlo_lmsolve(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2);
+        for (int32_t i = 0; i < n; ++i) wa2[i] = diag[i] * x[i];
+        dxnorm = nlo_norm2(m, wa2);                          /* :531 deviation A */
+        temp = fp;
+        fp = dxnorm - delta;
+
+        if (fabs(fp) <= p1 * delta ||
+            (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;  /* :538-540 */
+
+        for (int32_t j = 0; j < n; ++j) {                    /* :543-546 */
+            int32_t l = ipvt[j];
+            wa1[j] = diag[l] * (wa2[l] / dxnorm);
+        }
+        for (int32_t j = 0; j < n; ++j) {                    /* :547-553 */
+            wa1[j] = wa1[j] / sdiag[j];
+            temp = wa1[j];
+            if (n < j + 2) continue;
+            for (int32_t i = 0; i < n; ++i)                  /* :552 deviation B */
+                wa1[i] = wa1[i] - A_(r, ldr, i, j) * temp;
+        }
+        temp = nlo_norm2(n, wa1);
+        parc = ((fp / delta) / temp) / temp;
+
+        if (fp > 0.0) parl = dmax(parl, *par);               /* :558-559 */
+        if (fp < 0.0) paru = dmin(paru, *par);
+        *par = dmax(parl, *par + parc);                      /* :562 */
+    }
+    /* :564 `if (iter == zero) par = zero` is dead: iter >= 1 here. */
+}
+
+/* ---------------------------------------------------------------------------
+ * lss_solve (MINPACK lmdif, mode-1 scaling): src/nonlin_least_squares.f90:118-391
+ * ------------------------------------------------------------------------- */
+int nlo_lm_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_null,
+                 void *ctx, int32_t m, int32_t n, double *x, double *fvec,
+                 nlo_iteration_behavior *ib)
+{
+    const double p0001 = 1.0e-4, p1 = 0.1, qtr = 0.25, half = 0.5, p75 = 0.75, one = 1.0;
+    int xcnvrg = 0, fcnvrg = 0, gcnvrg = 0;
+    int32_t neval = 0, iter = 0, njac = 0, flag = 0;
+    double fac = opt->factor, ftol = opt->ftol, xtol = opt->xtol, gtol = opt->gtol;
+    int32_t maxeval = opt->max_evals;
+    const double eps = DBL_EPSILON;
+    double fnorm, par, xnorm = 0.0, delta = 0.0, sm, temp = 0.0, gnorm = 0.0, pnorm, fnorm1,
+           actred, temp1, temp2, prered, dirder, ratio;
+
+    if (ib) {                                                /* :177-185 */
+        memset(ib, 0, sizeof *ib);
+    }
+    if (!fcn) return NLO_UNDEFINED_FUNCTION_ERROR;           /* :188 */
+    if (n > m) return NLO_UNDERDEFINED_PROBLEM_ERROR;        /* :189 */
+
+    int32_t *jpvt = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));   /* :199-208 */
+    double *jac = (double *)malloc(sizeof(double) * (size_t)m * (size_t)(n > 0 ? n : 1));
+    double *diag = (double *)calloc((size_t)(6 * n + m + 1), sizeof(double));
+    double *qtf = diag + n, *wa1 = qtf + n, *wa2 = wa1 + n, *wa3 = wa2 + n, *wa4 = wa3 + n;
+
+    fcn(ctx, n, x, m, fvec);                                 /* :211-213 */
+    neval = 1;
+    fnorm = nlo_norm2(m, fvec);
+
+    par = 0.0;                                               /* :216-218 */
+    iter = 1;
+    flag = 0;
+    for (;;) {                                               /* outer loop :219-375 */
+        nlo_fd_jacobian(fcn, jac_or_null, ctx, m, n, x, fvec, jac);   /* :221 */
+        njac = njac + 1;
+
+        nlo_lmfactor(m, n, jac, m, 1, jpvt, wa1, wa2, wa3);  /* :225 */
+
+        if (iter == 1) {                                     /* :229-238 */
+            for (int32_t j = 0; j < n; ++j) {
+                diag[j] = wa2[j];
+                if (wa2[j] == 0.0) diag[j] = one;
+            }
+            for (int32_t j = 0; j < n; ++j) wa3[j] = diag[j] * x[j];
+            xnorm = nlo_norm2(n, wa3);
+            delta = fac * xnorm;
+            if (delta == 0.0) delta = fac;
+        }
+
+        memcpy(wa4, fvec, sizeof(double) * (size_t)m);       /* :241-253 */
+        for (int32_t j = 0; j < n; ++j) {
+            if (A_(jac, m, j, j) != 0.0) {
+                sm = 0.0;
+                for (int32_t i = j; i < m; ++i) sm = sm + A_(jac, m, i, j) * wa4[i];
+                temp = -sm / A_(jac, m, j, j);
+                for (int32_t i = j; i < m; ++i) wa4[i] = wa4[i] + A_(jac, m, i, j) * temp;
+            }
+            A_(jac, m, j, j) = wa1[j];
+            qtf[j] = wa4[j];
+        }
+
+        gnorm = 0.0;                                         /* :256-267 */
+        if (fnorm != 0.0) {
+            for (int32_t j = 0; j < n; ++j) {
+                int32_t l = jpvt[j];
+                if (wa2[l] == 0.0) continue;
+                sm = 0.0;
+                for (int32_t i = 0; i <= j; ++i) sm = sm + A_(jac, m, i, j) * (qtf[i] / fnorm);
+                gnorm = dmax(gnorm, fabs(sm / wa2[l]));
+            }
+        }
+
+        if (gnorm <= gtol) {                                 /* :270-273 */
+            gcnvrg = 1;
+            break;
+        }
+
+        for (int32_t j = 0; j < n; ++j) diag[j] = dmax(diag[j], wa2[j]);   /* :276-278 */
+
+        for (;;) {                                           /* inner loop :281-366 */
+            nlo_lmpar(m, n, jac, m, jpvt, diag, qtf, delta, &par, wa1, wa2, wa3, wa4);  /* :283 */
+
+            for (int32_t j = 0; j < n; ++j) {                /* :286-291 */
+                wa1[j] = -wa1[j];
+                wa2[j] = x[j] + wa1[j];
+                wa3[j] = diag[j] * wa1[j];
+            }
+            pnorm = nlo_norm2(n, wa3);
+
+            if (iter == 1) delta = dmin(delta, pnorm);       /* :294 */
+
+            fcn(ctx, n, wa2, m, wa4);                        /* :297-299 */
+            neval = neval + 1;
+            fnorm1 = nlo_norm2(m, wa4);
+
+            actred = -one;                                   /* :302-303 */
+            if (p1 * fnorm1 < fnorm) {
+                double q = fnorm1 / fnorm;
+                actred = one - q * q;
+            }
+
+            for (int32_t j = 0; j < n; ++j) {                /* :307-312 */
+                wa3[j] = 0.0;
+                int32_t l = jpvt[j];
+                temp = wa1[l];
+                for (int32_t i = 0; i <= j; ++i) wa3[i] = wa3[i] + A_(jac, m, i, j) * temp;
+            }
+            temp1 = nlo_norm2(n, wa3) / fnorm;               /* :313-316 */
+            temp2 = (sqrt(par) * pnorm) / fnorm;
+            prered = temp1 * temp1 + (temp2 * temp2) / half;
+            dirder = -(temp1 * temp1 + temp2 * temp2);
+
+            ratio = 0.0;                                     /* :319-320 */
+            if (prered != 0.0) ratio = actred / prered;
+            if (getenv("NLO_DEBUG"))
+                fprintf(stderr, "[nlo] iter=%d neval=%d fnorm=%.17g fnorm1=%.17g par=%.6g delta=%.6g pnorm=%.6g actred=%.6g prered=%.6g ratio=%.6g gnorm=%.3g\n",
+                        iter, neval, fnorm, fnorm1, par, delta, pnorm, actred, prered, ratio, gnorm);
+
+            if (ratio <= qtr) {                              /* :323-337 */
+                if (actred >= 0.0) temp = half;
+                if (actred < 0.0) temp = half * dirder / (dirder + half * actred);
+                if (p1 * fnorm1 >= fnorm || temp < p1) temp = p1;
+                delta = temp * dmin(delta, pnorm / p1);
+                par = par / temp;
+            } else {
+                if (par != 0.0 && ratio < p75) {
+                    /* no action */
+                } else {
+                    delta = pnorm / half;
+                    par = half * par;
+                }
+            }
+
+            if (ratio >= p0001) {                            /* :340-349 */
+                for (int32_t j = 0; j < n; ++j) {
+                    x[j] = wa2[j];
+                    wa2[j] = diag[j] * x[j];
+                }
+                memcpy(fvec, wa4, sizeof(double) * (size_t)m);
+                xnorm = nlo_norm2(n, wa2);
+                fnorm = fnorm1;
+                iter = iter + 1;
+            }
+
+            if (fabs(actred) <= ftol && prered <= ftol && half * ratio <= one) fcnvrg = 1;  /* :352-355 */
+            if (delta <= xtol * xnorm) xcnvrg = 1;
+            if (fcnvrg || xcnvrg) break;
+
+            if (neval >= maxeval) flag = NLO_CONVERGENCE_ERROR;    /* :358-363 */
+            if (fabs(actred) <= eps && prered <= eps && half * ratio <= one)
+                flag = NLO_TOLERANCE_TOO_SMALL_ERROR;
+            if (delta <= eps * xnorm) flag = NLO_TOLERANCE_TOO_SMALL_ERROR;
+            if (gnorm <= eps) flag = NLO_TOLERANCE_TOO_SMALL_ERROR;
+            if (flag != 0) break;
+
+            if (ratio >= p0001) break;                       /* :365 */
+        }
+
+        if (fcnvrg || xcnvrg || gcnvrg || flag != 0) break;  /* :369 */
+
+        if (opt->print_status) print_status(iter, neval, njac, xnorm, fnorm);   /* :372-374 */
+    }
+
+    if (ib) {                                                /* :378-385 */
+        ib->iter_count = iter;
+        ib->fcn_count = neval;
+        ib->jacobian_count = njac;
+        ib->converge_on_fcn = fcnvrg;
+        ib->converge_on_chng = xcnvrg;
+        ib->converge_on_zero_diff = gcnvrg;
+    }
+    free(jpvt);
+    free(jac);
+    free(diag);
+    return flag != 0 ? NLO_CONVERGENCE_ERROR : 0;            /* :388-390 */
+}
+
+/* ---------------------------------------------------------------------------
+ * lu_factor / solve_lu stand-ins (call sites src/nonlin_solve.f90:570, 577).
+ * The implementation is in the un-vendored jchristopherson/linalg (unpinned;
+ * fpm.toml:15) which forwards to LAPACK dgetrf/dgetrs.  Restated here as the
+ * published unblocked right-looking algorithm (LAPACK dgetf2 + dgetrs):
+ * first-maximum partial pivoting, reciprocal scaling of the column, rank-1
+ * update; then row interchanges, unit-lower forward and upper back solves.
+ * PARITY-UNPINNED at the bit level.  ipvt is 0-based.
+ * ------------------------------------------------------------------------- */
+int nlo_lu_factor(int32_t n, double *a, int32_t lda, int32_t *ipvt)
+{
+    int info = 0;
+    for (int32_t j = 0; j < n; ++j) {
+        int32_t p = j;
+        double best = fabs(A_(a, lda, j, j));
+        for (int32_t i = j + 1; i < n; ++i) {
+            double v = fabs(A_(a, lda, i, j));
+            if (v > best) { best = v; p = i; }
+        }
+        ipvt[j] = p;
+        if (A_(a, lda, p, j) != 0.0) {
+            if (p != j)
+                for (int32_t k = 0; k < n; ++k) {
+                    double t = A_(a, lda, j, k);
+                    A_(a, lda, j, k) = A_(a, lda, p, k);
+                    A_(a, lda, p, k) = t;
+                }
+            double rcp = 1.0 / A_(a, lda, j, j);
+            for (int32_t i = j + 1; i < n; ++i) A_(a, lda, i, j) = A_(a, lda, i, j) * rcp;
+        } else if (info == 0) {
+            info = j + 1;
+        }
+        for (int32_t k = j + 1; k < n; ++k) {
+            double ujk = A_(a, lda, j, k);
+            for (int32_t i = j + 1; i < n; ++i)
+                A_(a, lda, i, k) = A_(a, lda, i, k) - A_(a, lda, i, j) * ujk;
+        }
+    }
+    return info;
+}
+
+void nlo_lu_solve(int32_t n, const double *lu, int32_t lda, const int32_t *ipvt, double *b)
+{
+    for (int32_t j = 0; j < n; ++j) {
+        int32_t p = ipvt[j];
+        if (p != j) { double t = b[j]; b[j] = b[p]; b[p] = t; }
+    }
+    for (int32_t j = 0; j < n; ++j) {                 /* L y = Pb, unit diagonal */
+        double bj = b[j];
+        if (bj != 0.0)
+            for (int32_t i = j + 1; i < n; ++i) b[i] = b[i] - bj * A_(lu, lda, i, j);
+    }
+    for (int32_t j = n - 1; j >= 0; --j) {            /* U x = y */
+        if (b[j] != 0.0) {
+            b[j] = b[j] / A_(lu, lda, j, j);
+            double bj = b[j];
+            for (int32_t i = 0; i < j; ++i) b[i] = b[i] - bj * A_(lu, lda, i, j);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * min_backtrack_search: src/nonlin_linesearch.f90:495-551
+ * ------------------------------------------------------------------------- */
+double nlo_min_backtrack_search(int32_t mode, double f0, double f, double f1,
+                                double alam, double alam1, double slope)
+{
+    const double p5 = 0.5, two = 2.0, three = 3.0;
+    double lam;
+    if (mode == 1) {
+        lam = -slope / (two * (f - f0 - slope));             /* :529 */
+    } else {
+        double rhs1 = f - f0 - alam * slope;                 /* :532-536 */
+        double rhs2 = f1 - f0 - alam1 * slope;
+        double a = (rhs1 / (alam * alam) - rhs2 / (alam1 * alam1)) / (alam - alam1);
+        double b = (-alam1 * rhs1 / (alam * alam) + alam * rhs2 / (alam1 * alam1)) /
+                   (alam - alam1);
+        if (a == 0.0) {
+            lam = -slope / (two * b);
+        } else {
+            double disc = b * b - three * a * slope;
+            if (disc < 0.0)
+                lam = p5 * alam;
+            else if (b <= 0.0)
+                lam = (-b + sqrt(disc)) / (three * a);
+            else
+                lam = -slope / (b + sqrt(disc));
+        }
+        if (lam > p5 * alam) lam = p5 * alam;                /* :549 */
+    }
+    return lam;
+}
+
+/* limit_search_vector: src/nonlin_linesearch.f90:554-572 */
+void nlo_limit_search_vector(int32_t n, double *x, double lim)
+{
+    double mag = nlo_norm2(n, x);
+    if (mag == 0.0) return;
+    if (mag > lim) {
+        double s = lim / mag;
+        for (int32_t i = 0; i < n; ++i) x[i] = s * x[i];
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * ls_search_mimo: src/nonlin_linesearch.f90:152-326 (fold always supplied by
+ * ns_solve, so the "evaluate at xold" branch :241-246 is not needed here).
+ * ------------------------------------------------------------------------- */
+int nlo_line_search(const nlo_options *opt, nlo_vecfcn fcn, void *ctx, int32_t m,
+                    int32_t n, const double *xold, const double *grad,
+                    const double *dir, double *x, double *fvec, double fold,
+                    double *fx, nlo_iteration_behavior *ib)
+{
+    const double p5 = 0.5, one = 1.0, two = 2.0;
+    int xcnvrg = 0, fcnvrg = 0;
+    int32_t neval = 0, niter = 0, flag = 0;
+    const double tolx = two * DBL_EPSILON;                   /* :209 */
+    const double alpha = opt->ls_alpha, lambdamin = opt->ls_factor;
+    const int32_t maxeval = opt->ls_max_evals;
+    double alam, alam1 = 0.0, alamin, f1 = 0.0, slope, temp, test, tmplam, f = 0.0, fo;
+    int rc = 0;
+
+    if (fx) *fx = 0.0;
+    if (ib) memset(ib, 0, sizeof *ib);
+    if (!fcn) return NLO_UNDEFINED_FUNCTION_ERROR;
+
+    fo = fold;                                               /* :239-240 */
+
+    slope = nlo_dot(n, grad, dir);                           /* :249-253 */
+    if (slope >= 0.0) return NLO_DIVERGENT_BEHAVIOR_ERROR;
+
+    test = 0.0;                                              /* :256-262 */
+    for (int32_t i = 0; i < n; ++i) {
+        temp = fabs(dir[i]) / dmax(fabs(xold[i]), one);
+        if (temp > test) test = temp;
+    }
+    alamin = tolx / test;
+    alam = one;
+
+    for (;;) {                                               /* :266-310 */
+        for (int32_t i = 0; i < n; ++i) x[i] = xold[i] + alam * dir[i];
+        fcn(ctx, n, x, m, fvec);
+        f = p5 * nlo_dot(m, fvec, fvec);
+        neval = neval + 1;
+        niter = niter + 1;
+
+        if (alam < alamin) {                                 /* :275-287 */
+            double s = 0.0;
+            for (int32_t i = 0; i < n; ++i) { double d = x[i] - xold[i]; s = s + d * d; }
+            if (sqrt(s) == 0.0) { rc = NLO_CONVERGENCE_ERROR; break; }
+            for (int32_t i = 0; i < n; ++i) x[i] = xold[i];
+            xcnvrg = 1;
+            break;
+        } else if (f <= fo + alpha * alam * slope) {         /* :288-291 */
+            fcnvrg = 1;
+            break;
+        } else {                                             /* :292-296 */
+            tmplam = nlo_min_backtrack_search(niter, fo, f, f1, alam, alam1, slope);
+        }
+
+        alam1 = alam;                                        /* :300-302 */
+        f1 = f;
+        alam = dmax(tmplam, lambdamin * alam);
+
+        if (neval >= maxeval) { flag = 1; break; }           /* :305-309 */
+    }
+    if (fx) *fx = f;                                         /* :311 */
+
+    if (ib) {                                                /* :314-320 */
+        ib->iter_count = niter;
+        ib->fcn_count = neval;
+        ib->converge_on_fcn = fcnvrg;
+        ib->converge_on_chng = xcnvrg;
+        ib->converge_on_zero_diff = 0;
+    }
+    if (rc) return rc;
+    return flag != 0 ? NLO_CONVERGENCE_ERROR : 0;            /* :323-325 */
+}
+
+/* ---------------------------------------------------------------------------
+ * test_convergence: src/nonlin_helper.f90:36-124
+ * ------------------------------------------------------------------------- */
+void nlo_test_convergence(int32_t n, int32_t m, const double *x, const double *xo,
+                          const double *f, const double *g, int32_t lg, double xtol,
+                          double ftol, double gtol, int32_t *c, int32_t *cx,
+                          int32_t *cf, int32_t *cg, double *xnorm, double *fnorm)
+{
+    const double one = 1.0, half = 0.5;
+    *cx = 0; *cf = 0; *cg = 0; *c = 0;
+    double fc = half * nlo_dot(m, f, f);
+    *fnorm = 0.0;
+    *xnorm = 0.0;
+
+    for (int32_t i = 0; i < m; ++i) *fnorm = dmax(fabs(f[i]), *fnorm);   /* :87-94 */
+    if (*fnorm < ftol) { *cf = 1; *c = 1; return; }
+
+    for (int32_t i = 0; i < n; ++i) {                        /* :97-105 */
+        double test = fabs(x[i] - xo[i]) / dmax(fabs(x[i]), one);
+        *xnorm = dmax(test, *xnorm);
+    }
+    if (*xnorm < xtol) { *cx = 1; *c = 1; return; }
+
+    if (lg) {                                                /* :108-118 */
+        double test = 0.0;
+        double den = dmax(fc, half * (double)n);
+        for (int32_t i = 0; i < n; ++i) {
+            double dxmax = fabs(g[i]) * dmax(fabs(x[i]), one) / den;
+            test = dmax(test, dxmax);
+        }
+        if (test < gtol) *cg = 1;
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * ns_solve: src/nonlin_solve.f90:452-638
+ * ------------------------------------------------------------------------- */
+int nlo_newton_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_null,
+                     void *ctx, int32_t n, double *x, double *fvec,
+                     nlo_iteration_behavior *ib)
+{
+    const double half = 0.5, factor = 1.0e2;
+    int32_t xcnvrg = 0, fcnvrg = 0, gcnvrg = 0, check = 0;
+    int32_t neval = 0, iter = 0, njac = 0, flag = 0;
+    const double ftol = opt->ftol, xtol = opt->xtol, gtol = opt->gtol;
+    const int32_t maxeval = opt->max_evals;
+    double f, fold, stpmax, xnorm, fnorm, temp, test;
+    int rc = 0;
+    nlo_iteration_behavior lib;
+
+    if (ib) memset(ib, 0, sizeof *ib);                       /* :502-510 */
+    if (!fcn) return NLO_UNDEFINED_FUNCTION_ERROR;           /* :518 */
+
+    double *dir = (double *)calloc((size_t)(4 * n + 1), sizeof(double));   /* :529-534 */
+    double *grad = dir + n, *xold = grad + n, *rhs = xold + n;
+    double *jac = (double *)malloc(sizeof(double) * (size_t)n * (size_t)(n > 0 ? n : 1));
+    int32_t *ipvt = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+
+    /* :535 -- Jacobian requested before fvec exists; result discarded, not
+     * counted (Appendix A item 11).  Kept so callbacks fire in the same order. */
+    nlo_fd_jacobian(fcn, jac_or_null, ctx, n, n, x, fvec, jac);
+
+    fcn(ctx, n, x, n, fvec);                                 /* :538-547 */
+    f = half * nlo_dot(n, fvec, fvec);
+    neval = neval + 1;
+    test = 0.0;
+    for (int32_t i = 0; i < n; ++i) test = dmax(fabs(fvec[i]), test);
+    if (test < ftol) fcnvrg = 1;
+
+    flag = 0;
+    if (!fcnvrg) {
+        stpmax = factor * dmax(nlo_norm2(n, x), (double)n);  /* :553 */
+
+        for (;;) {                                           /* :556-620 */
+            iter = iter + 1;
+
+            nlo_fd_jacobian(fcn, jac_or_null, ctx, n, n, x, fvec, jac);   /* :561-562 */
+            njac = njac + 1;
+
+            for (int32_t i = 0; i < n; ++i)                  /* :565-567 */
+                grad[i] = nlo_dot(n, &A_(jac, n, 0, i), fvec);
+
+            nlo_lu_factor(n, jac, n, ipvt);                  /* :570 */
+
+            memcpy(xold, x, sizeof(double) * (size_t)n);     /* :573-574 */
+            fold = f;
+
+            for (int32_t i = 0; i < n; ++i) rhs[i] = -fvec[i];   /* :577 */
+            nlo_lu_solve(n, jac, n, ipvt, rhs);
+            memcpy(dir, rhs, sizeof(double) * (size_t)n);
+
+            if (opt->use_line_search) {                      /* :580-589 */
+                temp = nlo_dot(n, dir, dir);
+                if (temp > stpmax) {                         /* squared length vs stpmax: kept */
+                    double s = stpmax / temp;
+                    for (int32_t i = 0; i < n; ++i) dir[i] = dir[i] * s;
+                }
+                nlo_limit_search_vector(n, dir, stpmax);
+                rc = nlo_line_search(opt, fcn, ctx, n, n, xold, grad, dir, x, fvec, fold, &f, &lib);
+                neval = neval + lib.fcn_count;
+                if (rc) break;                               /* error stop inside the search */
+            } else {                                         /* :591-595 */
+                for (int32_t i = 0; i < n; ++i) x[i] = x[i] + dir[i];
+                fcn(ctx, n, x, n, fvec);
+                f = half * nlo_dot(n, fvec, fvec);
+                neval = neval + 1;
+            }
+
+            nlo_test_convergence(n, n, x, xold, fvec, grad, 1, xtol, ftol, gtol, &check,
+                                 &xcnvrg, &fcnvrg, &gcnvrg, &xnorm, &fnorm);   /* :599 */
+            if (check) {
+                break;
+            } else if (gcnvrg) {                             /* :604-608 */
+                rc = NLO_SPURIOUS_CONVERGENCE_ERROR;
+                break;
+            }
+
+            if (opt->print_status) print_status(iter, neval, njac, xnorm, fnorm);   /* :611-613 */
+
+            if (neval >= maxeval) { flag = 1; break; }       /* :616-619 */
+        }
+    }
+
+    if (ib) {                                                /* :624-632 */
+        ib->iter_count = iter;
+        ib->fcn_count = neval;
+        ib->jacobian_count = njac;
+        ib->gradient_count = 0;
+        ib->converge_on_fcn = fcnvrg;
+        ib->converge_on_chng = xcnvrg;
+        ib->converge_on_zero_diff = gcnvrg;
+    }
+    free(dir);
+    free(jac);
+    free(ipvt);
+    if (rc) return rc;
+    return flag != 0 ? NLO_CONVERGENCE_ERROR : 0;            /* :635-637 */
+}
+
+/* ---------------------------------------------------------------------------
+ * Synthetic dense-quadratic family; not reference code.
+ * ------------------------------------------------------------------------- */
+static void trace_push(nlo_trace *t, int32_t n, const double *x)
+{
+    if (!t) return;
+    if (t->count < t->capacity && t->xs)
+        memcpy(t->xs + (size_t)t->count * (size_t)n, x, sizeof(double) * (size_t)n);
+    t->count += 1;
+}
+
+void nlo_dq_fcn(void *ctx, int32_t n, const double *x, int32_t m, double *f)
+{
+    nlo_dq_problem *p = (nlo_dq_problem *)ctx;
+    const double *A = p->A, *b = p->b;
+    const double g = p->gamma;
+    p->ncalls += 1;
+    trace_push(p->trace, n, x);
+    for (int32_t i = 0; i < m; ++i) f[i] = 0.0;
+    /* column sweep: row i still accumulates j ascending, one mul + one add per term */
+    for (int32_t j = 0; j < n; ++j) {
+        const double xj = x[j];
+        const double *col = A + (size_t)j * (size_t)m;
+        for (int32_t i = 0; i < m; ++i) f[i] = f[i] + col[i] * xj;
+    }
+    for (int32_t i = 0; i < m; ++i) {
+        double u = f[i];
+        f[i] = (u + g * u * u) - b[i];
+    }
+}
+
+void nlo_dq_jac(void *ctx, int32_t n, const double *x, int32_t m, double *jac)
+{
+    nlo_dq_problem *p = (nlo_dq_problem *)ctx;
+    const double *A = p->A;
+    const double g = p->gamma;
+    double *u = (double *)calloc((size_t)(m > 0 ? m : 1), sizeof(double));
+    for (int32_t j = 0; j < n; ++j) {
+        const double xj = x[j];
+        const double *col = A + (size_t)j * (size_t)m;
+        for (int32_t i = 0; i < m; ++i) u[i] = u[i] + col[i] * xj;
+    }
+    for (int32_t i = 0; i < m; ++i) u[i] = 1.0 + 2.0 * g * u[i];
+    for (int32_t j = 0; j < n; ++j)
+        for (int32_t i = 0; i < m; ++i)
+            A_(jac, m, i, j) = u[i] * A_(A, m, i, j);
+    free(u);
+}
+
+static inline double sm64_uniform(uint64_t *state)
+{
+    *state += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = *state;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (double)(z >> 11) * 0x1.0p-53;
+}
+
+void nlo_dq_generate(uint64_t seed, int32_t m, int32_t n, double gamma, double sigma,
+                     double spread, int32_t square_shift, double *A, double *b,
+                     double *x_true, double *x0)
+{
+    uint64_t st = seed;
+    const double rs = sqrt((double)n);
+    for (int32_t j = 0; j < n; ++j)
+        for (int32_t i = 0; i < m; ++i)
+            A_(A, m, i, j) = (2.0 * sm64_uniform(&st) - 1.0) / rs;
+    if (square_shift)
+        for (int32_t j = 0; j < n && j < m; ++j) A_(A, m, j, j) = 2.0 + A_(A, m, j, j);
+    for (int32_t j = 0; j < n; ++j) x_true[j] = 2.0 * sm64_uniform(&st) - 1.0;
+    double *zero = (double *)calloc((size_t)(m > 0 ? m : 1), sizeof(double));
+    nlo_dq_problem p = { m, n, A, zero, gamma, 0, NULL };
+    nlo_dq_fcn(&p, n, x_true, m, b);          /* b = model(x_true), i.e. the residual with b == 0 */
+    free(zero);
+    for (int32_t i = 0; i < m; ++i) b[i] = b[i] + sigma * (2.0 * sm64_uniform(&st) - 1.0);
+    for (int32_t j = 0; j < n; ++j) x0[j] = x_true[j] + spread * (2.0 * sm64_uniform(&st) - 1.0);
+}
+
+int nlo_dq_lm_solve(const nlo_options *opt, const nlo_dq_problem *p, double *x,
+                    double *fvec, nlo_iteration_behavior *ib)
+{
+    nlo_dq_problem q = *p;
+    int rc = nlo_lm_solve(opt, nlo_dq_fcn, NULL, &q, q.m, q.n, x, fvec, ib);
+    ((nlo_dq_problem *)p)->ncalls = q.ncalls;
+    return rc;
+}
+
+int nlo_dq_newton_solve(const nlo_options *opt, const nlo_dq_problem *p, int32_t analytic,
+                        double *x, double *fvec, nlo_iteration_behavior *ib)
+{
+    nlo_dq_problem q = *p;
+    int rc = nlo_newton_solve(opt, nlo_dq_fcn, analytic ? nlo_dq_jac : NULL, &q, q.n, x, fvec, ib);
+    ((nlo_dq_problem *)p)->ncalls = q.ncalls;
+    return rc;
+}
