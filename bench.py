@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/s on batched 4096 x 256 fp64 LM problems with the finite-difference
+Jacobian (BASELINE.json metric; workload = configs[1] instantiated per SURVEY.md 8(d), batched
+as north_star's "batched 4096x256 LM problems at 1 GPU").
+
+A "step" is one pass of the hot path over one batch: every problem of the batch is solved from
+its start point by least_squares_solver (nlh_dq_lm_solve_batch): FD Jacobian (n perturbed
+evaluations + column write) -> J^T J / J^T f (fp64 MFMA) -> pivoted Cholesky -> lmpar -> trial
+evaluation -> trust-region update, until every problem has converged.  Inputs are generated on
+the device before the timed region and stay resident in HBM.
+
+value = sum of jacobian_count (= LM outer iterations) over all problems, steps and ranks,
+divided by the max-over-ranks wall time of the K timed steps.  N > 1: one process per GPU
+(torchrun), independent problems sharded block-cyclically, weak scaling (fixed batch per GPU),
+no data-path collective; RCCL is used for the config broadcast and the result gather.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M, N_VAR = 4096, 256
+GAMMA, SIGMA, SPREAD = 0.5, 1e-3, 0.3
+SEED0 = 12345
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def fd_bytes(m, n):
+    # read one m x n panel + f0 (m) + x,h (2n), write J (m x n)
+    return 8.0 * (2.0 * m * n + m + 2.0 * n)
+
+
+def cpu_baseline(sample, m, n):
+    """Oracle (C restatement of the reference path) on one host core, bounded sample."""
+    import numpy as np
+    from oracle import pyoracle as O
+    njac = 0
+    t = 0.0
+    for k in range(sample):
+        A, b, xt, x0 = O.dq_generate(SEED0 + k, m, n, gamma=GAMMA, sigma=SIGMA, spread=SPREAD)
+        t0 = time.perf_counter()
+        rc, x, f, ib, nc, _ = O.dq_lm_solve(A, b, GAMMA, x0, opts=O.default_options(max_evals=500))
+        t += time.perf_counter() - t0
+        njac += ib["jacobian_count"]
+    return {"value": njac / t, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{sample} problems {m}x{n} (seeds {SEED0}..{SEED0 + sample - 1}), single thread, "
+                      f"oracle/nonlin_oracle.c -O2 -ffp-contract=off, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("NLH_BENCH_BATCH", "128")),
+                    help="problems per GPU per step")
+    ap.add_argument("--m", type=int, default=M)
+    ap.add_argument("--n", type=int, default=N_VAR)
+    ap.add_argument("--cpu-sample", type=int, default=8, help="problems timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nonlin_amd.device import DeviceSolver
+    from nonlin_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    m, n, B = args.m, args.n, args.batch
+
+    ds = DeviceSolver(local_rank)
+    # options / seed come from rank 0 (broadcast over RCCL when N > 1)
+    cfg = sharding.broadcast_config([500, SEED0, GAMMA, SIGMA, SPREAD], dev)
+    max_evals, seed0 = int(cfg[0]), int(cfg[1])
+    gamma, sigma, spread = cfg[2], cfg[3], cfg[4]
+    nprob_total = B * world
+    # block-cyclic: local problem i is global problem rank + i*world, seed = seed0 + global index
+    A, b, xt, x0 = ds.generate(B, m, n, seed0=seed0 + rank, gamma=gamma, sigma=sigma, spread=spread,
+                               seed_stride=world)
+    opts = ds.options(max_evals=max_evals)
+    x = x0.clone()
+
+    def step():
+        x.copy_(x0)
+        fvec, ibs, status = ds.lm_solve_batch(A, b, gamma, x, opts)
+        return ibs, status
+
+    for _ in range(args.warmup):
+        step()
+    ds.h.timing_enable(True)
+    ds.h.timing_reset()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    njac = 0
+    naccept = 0
+    bad = 0
+    last_ibs = None
+    for _ in range(args.steps):
+        ibs, status = step()
+        njac += sum(ib["jacobian_count"] for ib in ibs)
+        naccept += sum(ib["iter_count"] - 1 for ib in ibs)
+        bad += sum(1 for s in status if s != 0)
+        last_ibs = ibs
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([float(njac), float(naccept), float(bad)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed = float(tt[0])
+    njac_all, naccept_all, bad_all = (float(v) for v in cnt.tolist())
+
+    # gather per-problem results (iteration counts + an x checksum) on every rank: the "gather" end
+    rows = torch.tensor([[ib["iter_count"], ib["fcn_count"], ib["jacobian_count"]] for ib in last_ibs],
+                        dtype=torch.float64, device=dev)
+    rows = torch.cat([rows, x.sum(dim=1, keepdim=True)], dim=1)
+    allrows = sharding.gather_results(rows, nprob_total, rank, world)
+
+    fd_ms, fd_launches = ds.h.timing("fd_jacobian")
+    kernel_ms = {k: ds.h.timing(k)[0] for k in
+                 ("dq_residual", "dq_panel", "fd_jacobian", "gram", "gram_reduce", "jtf", "chol", "lmpar", "qr", "update")}
+    ds.h.timing_enable(False)
+
+    if rank == 0:
+        achieved = fd_bytes(m, n) * (njac / max(fd_ms * 1e-3, 1e-30)) / 1e9      # this rank's launches
+        out = {
+            "metric": "LM iterations/sec on m=4096,n=256 fp64; FD-Jacobian GB/s vs HBM peak",
+            "value": njac_all / elapsed,
+            "unit": "LM iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"batched LM {m}x{n} fp64, FD Jacobian, dense-quadratic residual family "
+                            f"(SURVEY 8(d): gamma={gamma}, sigma={sigma}, spread={spread}, seeds {seed0}+k), "
+                            f"{B} problems per GPU per step",
+                "problems_per_gpu": B, "m": m, "n": n, "max_fcn_evals": max_evals,
+                "parallelism": f"independent problems, block-cyclic over {world} rank(s)",
+                "accepted_steps_per_s": naccept_all / elapsed,
+                "non_converged": int(bad_all),
+                "iters_first_problem": [int(v) for v in allrows[0, :3].tolist()],
+            },
+            "roofline": {
+                "kernel": "k_fd_jacobian", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_unit": fd_bytes(m, n), "units": "problem-Jacobians", "launches": int(fd_launches),
+                "avg_launch_ms": fd_ms / max(fd_launches, 1),
+            },
+            "kernel_ms_per_step": {k: v / args.steps for k, v in kernel_ms.items()},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, m, n)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

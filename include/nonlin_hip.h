@@ -1,0 +1,218 @@
+/*
+ * nonlin_hip.h -- C ABI of libnonlin_hip.so: the MI355X (gfx950) implementation of
+ * nonlin's Jacobian-evaluate + linear-solve inner loop.
+ *
+ * This is the drop-in boundary.  The reference (jchristopherson/nonlin v2.2.0) is
+ * pure Fortran with no C interface; each entry point below replaces one
+ * type-bound procedure of the reference and is what a Fortran `bind(C)`
+ * interface (nonlin_amd/fortran/) or any other FFI binds to.
+ * Signatures use plain pointers, int32_t sizes and doubles only.
+ *
+ * Conventions
+ *   - all matrices are column-major (Fortran order), fp64; integers are int32;
+ *     Fortran LOGICALs cross the boundary as int32 0/1;
+ *   - "host" entry points take HOST pointers and host callbacks, block until
+ *     the result is back in the caller's arrays, and return 0 or the NL_* code
+ *     the reference would `error stop` with (the Fortran shim performs the stop);
+ *   - "dq" (device-model) entry points take DEVICE pointers (inputs already
+ *     resident in HBM), run on the handle's HIP stream and are batched over
+ *     independent problems;
+ *   - nothing here falls back to a CPU implementation: without a GPU every
+ *     compute entry point returns NLH_ERR_NO_DEVICE.
+ */
+#ifndef NONLIN_HIP_H
+#define NONLIN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: src/nonlin_error_handling.f90:10-38 --------------------- */
+#define NLH_NO_ERROR                     0
+#define NLH_INVALID_INPUT_ERROR        201   /* NL_INVALID_INPUT_ERROR  (:12) */
+#define NLH_ARRAY_SIZE_ERROR           202   /* NL_ARRAY_SIZE_ERROR     (:14) */
+#define NLH_OUT_OF_MEMORY_ERROR        105   /* = LA_OUT_OF_MEMORY_ERROR (:16), linalg_errors un-vendored */
+#define NLH_INVALID_OPERATION_ERROR    104   /* = LA_INVALID_OPERATION_ERROR (:18) */
+#define NLH_CONVERGENCE_ERROR          106   /* = LA_CONVERGENCE_ERROR  (:21) */
+#define NLH_DIVERGENT_BEHAVIOR_ERROR   206   /* (:23) */
+#define NLH_SPURIOUS_CONVERGENCE_ERROR 207   /* (:25) */
+#define NLH_TOLERANCE_TOO_SMALL_ERROR  208   /* (:27) */
+#define NLH_UNDEFINED_FUNCTION_ERROR   211   /* (:34) */
+#define NLH_UNDERDEFINED_PROBLEM_ERROR 212   /* (:37) */
+/* library-level failures (not reference codes) */
+#define NLH_ERR_NO_DEVICE             -1
+#define NLH_ERR_HIP                   -2
+#define NLH_ERR_BAD_HANDLE            -3
+
+/* ---- iteration_behavior: src/nonlin_types.f90:8-29 ------------------------ */
+typedef struct nlh_iteration_behavior {
+    int32_t iter_count;
+    int32_t fcn_count;
+    int32_t jacobian_count;
+    int32_t gradient_count;
+    int32_t converge_on_fcn;        /* logical */
+    int32_t converge_on_chng;       /* logical */
+    int32_t converge_on_zero_diff;  /* logical */
+} nlh_iteration_behavior;
+
+/* ---- solver configuration -------------------------------------------------
+ * equation_solver   src/nonlin_multi_eqn_mult_var.f90:67-91 (defaults :69-77)
+ * least_squares_solver%m_factor   src/nonlin_least_squares.f90:25, clamp :108-114
+ * line_search_solver%m_useLineSearch   src/nonlin_solve.f90:30
+ * line_search   src/nonlin_linesearch.f90:35-53                              */
+#define NLH_FACTOR_AUTO 0  /* J^T J + pivoted Cholesky; Householder QR when the Gauss-Newton
+                              step is rejected or the Gram matrix is ill-conditioned */
+#define NLH_FACTOR_QR   1  /* always the reference's pivoted Householder QR (lmfactor) */
+typedef struct nlh_options {
+    int32_t max_evals;        /* 100   */
+    double  ftol;             /* 1e-8  */
+    double  xtol;             /* 1e-12 */
+    double  gtol;             /* 1e-12 */
+    int32_t print_status;     /* 0     */
+    double  factor;           /* 100; setters clamp to [0.1, 100] */
+    int32_t use_line_search;  /* 1     */
+    int32_t ls_max_evals;     /* 100   */
+    double  ls_alpha;         /* 1e-4  */
+    double  ls_factor;        /* 0.1   */
+    int32_t factor_policy;    /* NLH_FACTOR_AUTO */
+    double  ne_pivot_tol;     /* 1e-4: Cholesky pivot / column-norm^2 below this => QR */
+} nlh_options;
+
+void nlh_default_options(nlh_options *opts);
+
+/* ---- user callbacks: vecfcn / jacobianfcn (src/nonlin_multi_eqn_mult_var.f90:14-38)
+ * flattened to C.  The Fortran shim passes bind(C) trampolines; ctx carries the
+ * vecfcn_helper and the optional class(*) args.  jac is column-major, ld = m. */
+typedef void (*nlh_vecfcn)(void *ctx, int32_t n, const double *x, int32_t m, double *f);
+typedef void (*nlh_jacfcn)(void *ctx, int32_t n, const double *x, int32_t m, double *jac);
+
+/* ---- handle: owns a HIP stream reference, device workspaces (cached per shape)
+ * and per-kernel HIP-event timers.  Not thread-safe; use one per thread. ---- */
+typedef struct nlh_handle nlh_handle;
+int  nlh_create(nlh_handle **h, int32_t device, void *hip_stream /* NULL => own stream */);
+void nlh_destroy(nlh_handle *h);
+int  nlh_device_count(void);             /* 0 when no GPU is visible */
+const char *nlh_last_error(const nlh_handle *h);
+const char *nlh_version(void);
+
+/* ===========================================================================
+ * Host-callback ("mode H") drop-in entry points: HOST pointers.
+ * ======================================================================== */
+
+/* vecfcn_helper%jacobian -- vfh_jac_fcn, src/nonlin_multi_eqn_mult_var.f90:198-277.
+ * jacfcn != NULL: forwards to it.  Otherwise evaluates fcn at x + h_j e_j on the
+ * host (in the reference's order, x perturbed in place and restored), uploads the
+ * m-by-n residual panel and forms jac(:,j) = (f_j - f0)/h_j on the GPU.
+ * fv may be NULL (then f0 = fcn(x) is evaluated first, :257-259). */
+int nlh_fd_jacobian(nlh_handle *h, int32_t m, int32_t n, nlh_vecfcn fcn, nlh_jacfcn jacfcn,
+                    void *ctx, double *x, const double *fv, double *jac);
+
+/* least_squares_solver%solve -- lss_solve, src/nonlin_least_squares.f90:118-391. */
+int nlh_lm_solve(nlh_handle *h, const nlh_options *opts, int32_t m, int32_t n,
+                 nlh_vecfcn fcn, nlh_jacfcn jacfcn, void *ctx,
+                 double *x, double *fvec, nlh_iteration_behavior *ib);
+
+/* newton_solver%solve -- ns_solve, src/nonlin_solve.f90:452-638 (LU step: :570,577). */
+int nlh_newton_solve(nlh_handle *h, const nlh_options *opts, int32_t n,
+                     nlh_vecfcn fcn, nlh_jacfcn jacfcn, void *ctx,
+                     double *x, double *fvec, nlh_iteration_behavior *ib);
+
+/* ===========================================================================
+ * Device-model ("mode D") batched entry points: DEVICE pointers.
+ * Residual family "dense-quadratic" (SURVEY.md 8(d)), evaluated on the GPU with
+ * the exact per-row operation order of the CPU path:
+ *   u_i = sum_j A(i,j) x_j  (j ascending, separate multiply and add)
+ *   r_i = (u_i + (gamma*u_i)*u_i) - b_i ;   dr_i/dx_j = (1 + 2 gamma u_i) A(i,j)
+ * Layout: A [nprob][n][m] (each problem column-major m-by-n), b/fvec [nprob][m],
+ * x [nprob][n].  Problems are independent; status[k] receives 0 or an NL_* code.
+ * ======================================================================== */
+int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *opts, int32_t nprob,
+                          int32_t m, int32_t n, const double *dA, const double *db,
+                          double gamma, double *dx, double *dfvec,
+                          nlh_iteration_behavior *ib /* host, [nprob] */,
+                          int32_t *status /* host, [nprob] */);
+
+int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *opts, int32_t nprob,
+                              int32_t n, const double *dA, const double *db, double gamma,
+                              int32_t analytic_jacobian, double *dx, double *dfvec,
+                              nlh_iteration_behavior *ib, int32_t *status);
+
+/* Synthetic problem generator of SURVEY.md 8(d) (bench/test inputs, not part of the
+ * reference): counter-based splitmix64, U_k = mix(seed + (k+1)*0x9E3779B97F4A7C15),
+ * draw order A (column-major), x_true, noise, x0; problem p uses seed0 + p*seed_stride.
+ * A = (2U-1)/sqrt(n) (+2I when square_shift), b = model(x_true) + sigma(2U-1),
+ * x0 = x_true + spread(2U-1).  All pointers are DEVICE pointers. */
+int nlh_dq_generate(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, uint64_t seed0,
+                    uint64_t seed_stride, double gamma, double sigma, double spread, int32_t square_shift,
+                    double *dA, double *db, double *dxtrue, double *dx0);
+
+/* ---- stage-level entry points (each is one kernel family of the path; used by
+ * the parity tests and the roofline measurement).  DEVICE pointers. ---------- */
+
+/* vecfcn for the dense-quadratic model: f = F(x) for every problem. */
+int nlh_dq_residual(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dA,
+                    const double *db, double gamma, const double *dx, double *df);
+/* The n perturbed evaluations of vfh_jac_fcn (:267-273): P(:,j) = F(x + h_j e_j). */
+int nlh_dq_fd_panel(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dA,
+                    const double *db, double gamma, const double *dx, double *dP);
+/* The forward-difference column write (:274): J(:,j) = (P(:,j) - f0)/h_j,
+ * h_j = sqrt(eps)*|x_j| (sqrt(eps) if zero).  HBM-bound streaming kernel. */
+int nlh_fd_jacobian_panel(nlh_handle *h, int32_t nprob, int32_t m, int32_t n,
+                          const double *dP, const double *df0, const double *dx, double *dJ);
+/* Analytic jacobianfcn of the dense-quadratic model. */
+int nlh_dq_jacobian(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dA,
+                    double gamma, const double *dx, double *dJ);
+/* J^T J (fp64 MFMA, deterministic split-K) and J^T f.  dG [nprob][n][n], dg [nprob][n]. */
+int nlh_gram(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dJ,
+             const double *df, double *dG, double *dg);
+/* lmfactor replacement on the Gram matrix: pivoted Cholesky P^T G P = R^T R with
+ * MINPACK's pivot rule, acnorm = sqrt(diag G), qtf = R^-T P^T g.  dG is overwritten
+ * by R (upper triangle).  ipvt is 0-based.  info[k] != 0 => ill-conditioned/rank-deficient. */
+int nlh_chol_factor(nlh_handle *h, int32_t nprob, int32_t n, double *dG, const double *dg,
+                    int32_t *dipvt, double *dacnorm, double *dqtf, int32_t *dinfo);
+/* lmfactor itself (pivoted Householder QR, src/nonlin_least_squares.f90:569-667) plus
+ * Q^T f (:241-253).  dJ is overwritten as in the reference (R strict upper, reflectors
+ * below, diagonal restored to rdiag after Q^T f); dqtf [nprob][n]; dwa4 [nprob][m]. */
+int nlh_qr_factor(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, double *dJ,
+                  const double *df, int32_t *dipvt, double *drdiag, double *dacnorm,
+                  double *dqtf, double *dwa4);
+/* lmpar (:394-566, including its two deviations from MINPACK) on an n-by-n R
+ * (leading dimension ldr) for every problem.  dtailsq[k] = sum of squares of the
+ * caller's wa4(n+1:m).  Outputs: dpar (in/out), dxstep [nprob][n], dsdiag [nprob][n]. */
+int nlh_lmpar(nlh_handle *h, int32_t nprob, int32_t n, double *dR, int32_t ldr,
+              const int32_t *dipvt, const double *ddiag, const double *dqtf,
+              const double *ddelta, const double *dtailsq, double *dpar,
+              double *dxstep, double *dsdiag);
+/* lu_factor / solve_lu stand-ins (call sites src/nonlin_solve.f90:570,577):
+ * partial-pivoting LU of [nprob][n][n] in place, 0-based ipvt, then one RHS each. */
+int nlh_lu_factor(nlh_handle *h, int32_t nprob, int32_t n, double *dA, int32_t *dipvt,
+                  int32_t *dinfo);
+int nlh_lu_solve(nlh_handle *h, int32_t nprob, int32_t n, const double *dLU,
+                 const int32_t *dipvt, double *db);
+
+/* ---- per-kernel timing (HIP events on the handle's stream) ------------------ */
+#define NLH_K_DQ_RESIDUAL   0
+#define NLH_K_DQ_PANEL      1
+#define NLH_K_FD_JACOBIAN   2
+#define NLH_K_GRAM          3
+#define NLH_K_GRAM_REDUCE   4
+#define NLH_K_JTF           5
+#define NLH_K_CHOL          6
+#define NLH_K_LMPAR         7
+#define NLH_K_QR            8
+#define NLH_K_UPDATE        9
+#define NLH_K_LU           10
+#define NLH_K_DQ_JACOBIAN  11
+#define NLH_K_COUNT        12
+void nlh_timing_enable(nlh_handle *h, int32_t on);
+void nlh_timing_reset(nlh_handle *h);
+/* Synchronises the stream, then returns total milliseconds and launch count. */
+int  nlh_timing_get(nlh_handle *h, int32_t kernel_id, double *total_ms, int64_t *launches);
+const char *nlh_kernel_name(int32_t kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NONLIN_HIP_H */

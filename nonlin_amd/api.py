@@ -1,0 +1,322 @@
+"""Host-side mirror of nonlin's plugin / solver interface for the hot path.
+
+Same names, argument meaning and error behaviour as the reference types
+(src/nonlin_multi_eqn_mult_var.f90, src/nonlin_least_squares.f90, src/nonlin_solve.f90,
+src/nonlin_linesearch.f90, src/nonlin_types.f90), bound to the C ABI of
+include/nonlin_hip.h.  Where the reference `error stop`s with an NL_* code this module
+raises NonlinError(code).  All numerical work happens in libnonlin_hip.so on the GPU.
+
+User callbacks follow the Fortran subroutines:
+    fcn(x, f, args)      -- fill f (length m) in place             (vecfcn,      :14-25)
+    jac(x, jac, args)    -- fill jac (m x n, Fortran order)        (jacobianfcn, :27-38)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+# src/nonlin_error_handling.f90:10-38
+NL_NO_ERROR = 0
+NL_INVALID_INPUT_ERROR = 201
+NL_ARRAY_SIZE_ERROR = 202
+NL_OUT_OF_MEMORY_ERROR = 105
+NL_INVALID_OPERATION_ERROR = 104
+NL_CONVERGENCE_ERROR = 106
+NL_DIVERGENT_BEHAVIOR_ERROR = 206
+NL_SPURIOUS_CONVERGENCE_ERROR = 207
+NL_TOLERANCE_TOO_SMALL_ERROR = 208
+NL_INDEX_OUT_OF_RANGE_ERROR = 209
+NL_DIVIDE_BY_ZERO_ERROR = 210
+NL_UNDEFINED_FUNCTION_ERROR = 211
+NL_UNDERDEFINED_PROBLEM_ERROR = 212
+
+
+class NonlinError(RuntimeError):
+    """Raised where the reference executes `error stop <code>`."""
+
+    def __init__(self, code):
+        super().__init__(f"nonlin error stop {code}")
+        self.code = code
+
+
+class iteration_behavior:
+    """src/nonlin_types.f90:8-29."""
+
+    def __init__(self):
+        self.iter_count = 0
+        self.fcn_count = 0
+        self.jacobian_count = 0
+        self.gradient_count = 0
+        self.converge_on_fcn = False
+        self.converge_on_chng = False
+        self.converge_on_zero_diff = False
+
+    def _fill(self, c):
+        self.iter_count = int(c.iter_count)
+        self.fcn_count = int(c.fcn_count)
+        self.jacobian_count = int(c.jacobian_count)
+        self.gradient_count = int(c.gradient_count)
+        self.converge_on_fcn = bool(c.converge_on_fcn)
+        self.converge_on_chng = bool(c.converge_on_chng)
+        self.converge_on_zero_diff = bool(c.converge_on_zero_diff)
+
+    def as_dict(self):
+        return dict(self.__dict__)
+
+
+_default_handle = None
+
+
+def default_handle():
+    global _default_handle
+    if _default_handle is None:
+        _default_handle = _lib.Handle(0)
+    return _default_handle
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+class vecfcn_helper:
+    """src/nonlin_multi_eqn_mult_var.f90:41-65."""
+
+    def __init__(self):
+        self._fcn = None
+        self._jac = None
+        self._nfcn = 0
+        self._nvar = 0
+
+    def set_fcn(self, fcn, nfcn, nvar):          # :126-140
+        self._fcn = fcn
+        self._nfcn = int(nfcn)
+        self._nvar = int(nvar)
+
+    def set_jacobian(self, jac):                 # :143-153
+        self._jac = jac
+
+    def is_fcn_defined(self):                    # :156-164
+        return self._fcn is not None
+
+    def is_jacobian_defined(self):               # :167-175
+        return self._jac is not None
+
+    def get_equation_count(self):                # :280-287
+        return self._nfcn
+
+    def get_variable_count(self):                # :290-297
+        return self._nvar
+
+    def fcn(self, x, f, args=None):              # :178-195 (silently does nothing if unset)
+        if self._fcn is not None:
+            self._fcn(x, f, args)
+
+    # -- C trampolines -----------------------------------------------------
+    def _c_fcn(self, args):
+        user = self._fcn
+        if user is None:
+            return C.cast(None, _lib.VECFCN)
+
+        def tramp(ctx, n, xp, m, fp):
+            x = np.ctypeslib.as_array(xp, shape=(n,))
+            f = np.ctypeslib.as_array(fp, shape=(m,))
+            user(x, f, args)
+        return _lib.VECFCN(tramp)
+
+    def _c_jac(self, args):
+        user = self._jac
+        if user is None:
+            return C.cast(None, _lib.JACFCN)
+
+        def tramp(ctx, n, xp, m, jp):
+            x = np.ctypeslib.as_array(xp, shape=(n,))
+            J = np.ctypeslib.as_array(jp, shape=(n, m)).T   # Fortran-order m x n view
+            user(x, J, args)
+        return _lib.JACFCN(tramp)
+
+    def jacobian(self, x, jac, fv=None, args=None, handle=None):
+        """vfh_jac_fcn (:198-277): analytic dispatch or forward differences (GPU column write).
+        x is perturbed in place and restored; jac must be an m x n Fortran-order float64 array."""
+        m, n = self._nfcn, self._nvar
+        if x.shape != (n,):
+            raise NonlinError(2)                 # :232-233
+        if jac.shape != (m, n):
+            raise NonlinError(3)                 # :234-235
+        if not self.is_fcn_defined():
+            raise NonlinError(NL_UNDEFINED_FUNCTION_ERROR)   # :240
+        if not (jac.flags.f_contiguous and jac.dtype == np.float64):
+            raise ValueError("jac must be a Fortran-order float64 array")
+        h = handle or default_handle()
+        cf, cj = self._c_fcn(args), self._c_jac(args)
+        fvp = _dp(np.ascontiguousarray(fv, dtype=np.float64)) if fv is not None else None
+        rc = h.lib.nlh_fd_jacobian(h.ptr, m, n, cf, cj, None, _dp(x), fvp, _dp(jac))
+        h.check(rc, "nlh_fd_jacobian")
+        if rc:
+            raise NonlinError(rc)
+
+
+class equation_solver:
+    """src/nonlin_multi_eqn_mult_var.f90:67-91; defaults :69-77."""
+
+    def __init__(self):
+        self._max_eval = 100
+        self._fcn_tol = 1.0e-8
+        self._xtol = 1.0e-12
+        self._gtol = 1.0e-12
+        self._print_status = False
+        self.handle = None
+        self.factor_policy = 0        # extension: NLH_FACTOR_AUTO / NLH_FACTOR_QR
+
+    def get_max_fcn_evals(self): return self._max_eval
+    def set_max_fcn_evals(self, n): self._max_eval = int(n)
+    def get_fcn_tolerance(self): return self._fcn_tol
+    def set_fcn_tolerance(self, x): self._fcn_tol = float(x)
+    def get_var_tolerance(self): return self._xtol
+    def set_var_tolerance(self, x): self._xtol = float(x)
+    def get_gradient_tolerance(self): return self._gtol
+    def set_gradient_tolerance(self, x): self._gtol = float(x)
+    def get_print_status(self): return self._print_status
+    def set_print_status(self, x): self._print_status = bool(x)
+
+    def _options(self):
+        o = _lib.default_options()
+        o.max_evals = self._max_eval
+        o.ftol = self._fcn_tol
+        o.xtol = self._xtol
+        o.gtol = self._gtol
+        o.print_status = 1 if self._print_status else 0
+        o.factor_policy = int(self.factor_policy)
+        return o
+
+    def _handle(self):
+        return self.handle or default_handle()
+
+
+def _check_xf(fcn, x, fvec):
+    if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous):
+        raise ValueError("x must be a contiguous float64 numpy array (it is updated in place)")
+    if not (isinstance(fvec, np.ndarray) and fvec.dtype == np.float64 and fvec.flags.c_contiguous):
+        raise ValueError("fvec must be a contiguous float64 numpy array (it is filled in place)")
+
+
+class least_squares_solver(equation_solver):
+    """src/nonlin_least_squares.f90:20-31."""
+
+    def __init__(self):
+        super().__init__()
+        self._factor = 100.0                      # :25
+
+    def get_step_scaling_factor(self):           # :80-93
+        return self._factor
+
+    def set_step_scaling_factor(self, x):        # :96-115
+        x = float(x)
+        self._factor = 0.1 if x < 0.1 else (100.0 if x > 100.0 else x)
+
+    def solve(self, fcn, x, fvec, ib=None, args=None):
+        """lss_solve (:118-391).  x: initial estimate -> solution; fvec: F at the solution."""
+        _check_xf(fcn, x, fvec)
+        if not fcn.is_fcn_defined():
+            raise NonlinError(NL_UNDEFINED_FUNCTION_ERROR)   # :188
+        m, n = fcn.get_equation_count(), fcn.get_variable_count()
+        if n > m:
+            raise NonlinError(NL_UNDERDEFINED_PROBLEM_ERROR)  # :189
+        if x.shape != (n,):
+            raise NonlinError(3)                  # :191-192
+        if fvec.shape != (m,):
+            raise NonlinError(4)                  # :193-194
+        o = self._options()
+        o.factor = self._factor
+        h = self._handle()
+        cib = _lib.IterationBehavior()
+        cf, cj = fcn._c_fcn(args), fcn._c_jac(args)
+        rc = h.lib.nlh_lm_solve(h.ptr, C.byref(o), m, n, cf, cj, None, _dp(x), _dp(fvec), C.byref(cib))
+        h.check(rc, "nlh_lm_solve")
+        if ib is not None:
+            ib._fill(cib)
+        if rc:
+            raise NonlinError(rc)                 # :388-390
+
+
+class line_search:
+    """src/nonlin_linesearch.f90:18-65 (configuration; the search runs inside newton_solver)."""
+
+    def __init__(self):
+        self._max_eval = 100                      # :35
+        self._alpha = 1.0e-4                      # :38
+        self._factor = 0.1                        # :46
+
+    def get_max_fcn_evals(self): return self._max_eval
+    def set_max_fcn_evals(self, x): self._max_eval = int(x)
+    def get_scaling_factor(self): return self._alpha
+    def set_scaling_factor(self, x): self._alpha = float(x)
+    def get_distance_factor(self): return self._factor
+
+    def set_distance_factor(self, x):            # :133-149
+        x = float(x)
+        self._factor = 0.1 if x <= 0.0 else (0.99 if x >= 1.0 else x)
+
+
+class line_search_solver(equation_solver):
+    """src/nonlin_solve.f90:20-41, 92-151."""
+
+    def __init__(self):
+        super().__init__()
+        self._line_search = None
+        self._use_line_search = True              # :30
+
+    def get_line_search(self):                   # :92-100 (returns a copy)
+        if self._line_search is None:
+            return None
+        ls = line_search()
+        ls.__dict__.update(self._line_search.__dict__)
+        return ls
+
+    def set_line_search(self, ls):               # :103-111
+        c = line_search()
+        c.__dict__.update(ls.__dict__)
+        self._line_search = c
+
+    def set_default_line_search(self):           # :114-121
+        self.set_line_search(line_search())
+
+    def is_line_search_defined(self):            # :124-131
+        return self._line_search is not None
+
+    def get_use_line_search(self): return self._use_line_search
+    def set_use_line_search(self, x): self._use_line_search = bool(x)
+
+
+class newton_solver(line_search_solver):
+    """src/nonlin_solve.f90:60-67."""
+
+    def solve(self, fcn, x, fvec, ib=None, args=None):
+        """ns_solve (:452-638)."""
+        _check_xf(fcn, x, fvec)
+        if self.get_use_line_search() and not self.is_line_search_defined():
+            self.set_default_line_search()        # :511-515
+        if not fcn.is_fcn_defined():
+            raise NonlinError(NL_UNDEFINED_FUNCTION_ERROR)   # :518
+        m, n = fcn.get_equation_count(), fcn.get_variable_count()
+        if n != m:
+            raise NonlinError(NL_INVALID_INPUT_ERROR)        # :519
+        if x.shape != (n,):
+            raise NonlinError(3)
+        if fvec.shape != (m,):
+            raise NonlinError(4)
+        o = self._options()
+        o.use_line_search = 1 if self._use_line_search else 0
+        if self._line_search is not None:
+            o.ls_max_evals = self._line_search._max_eval
+            o.ls_alpha = self._line_search._alpha
+            o.ls_factor = self._line_search._factor
+        h = self._handle()
+        cib = _lib.IterationBehavior()
+        cf, cj = fcn._c_fcn(args), fcn._c_jac(args)
+        rc = h.lib.nlh_newton_solve(h.ptr, C.byref(o), n, cf, cj, None, _dp(x), _dp(fvec), C.byref(cib))
+        h.check(rc, "nlh_newton_solve")
+        if ib is not None:
+            ib._fill(cib)
+        if rc:
+            raise NonlinError(rc)

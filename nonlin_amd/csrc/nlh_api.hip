@@ -1,0 +1,1189 @@
+// nlh_api.hip -- C ABI (include/nonlin_hip.h) and host drivers of libnonlin_hip.so.
+//
+// Host side of the path: lss_solve (src/nonlin_least_squares.f90:118-391) as a batched,
+// device-resident state machine; ns_solve (src/nonlin_solve.f90:452-638) and ls_search_mimo
+// (src/nonlin_linesearch.f90:152-326) as host loops around device kernels; vfh_jac_fcn
+// (src/nonlin_multi_eqn_mult_var.f90:198-277) for host callbacks.
+// There is no CPU fallback: without a device every compute entry point fails.
+#include "../../include/nonlin_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "nlh_common.h"
+#include "nlh_kernels_model.h"
+#include "nlh_kernels_gram.h"
+#include "nlh_kernels_factor.h"
+#include "nlh_kernels_lm.h"
+#include "nlh_kernels_lu.h"
+
+// ---------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct nlh_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bool timing = false;
+    struct Pair { hipEvent_t a, b; int kid; };
+    std::vector<Pair> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[NLH_K_COUNT] = {0};
+    int64_t launches[NLH_K_COUNT] = {0};
+    std::vector<DevBuf *> bufs;       // every workspace buffer, for destroy
+    // named workspace buffers (grown on demand, reused across calls)
+    DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev;
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+#define HIPCHK(h, call)                                                                 \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);               \
+            return NLH_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+static int ensure(nlh_handle *h, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes && b.p) return 0;
+    if (b.p) { hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { h->err = std::string("hipMalloc: ") + hipGetErrorString(e); return NLH_OUT_OF_MEMORY_ERROR; }
+    b.bytes = want;
+    bool known = false;
+    for (auto *q : h->bufs) if (q == &b) known = true;
+    if (!known) h->bufs.push_back(&b);
+    return 0;
+}
+
+static int ensure_pinned(nlh_handle *h, size_t bytes)
+{
+    if (bytes <= h->pinned_bytes) return 0;
+    if (h->pinned) hipHostFree(h->pinned);
+    h->pinned = nullptr; h->pinned_bytes = 0;
+    hipError_t e = hipHostMalloc(&h->pinned, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { h->err = std::string("hipHostMalloc: ") + hipGetErrorString(e); return NLH_OUT_OF_MEMORY_ERROR; }
+    h->pinned_bytes = bytes;
+    return 0;
+}
+
+static const char *k_names[NLH_K_COUNT] = {
+    "k_dq_residual", "k_dq_panel", "k_fd_jacobian", "k_gram_mfma", "k_gram_reduce", "k_jtf",
+    "k_chol_factor", "k_lmpar", "k_qr_factor", "k_lm_update", "k_lu_factor", "k_dq_jacobian"};
+
+static void timing_flush(nlh_handle *h)
+{
+    if (h->pending.empty()) return;
+    hipStreamSynchronize(h->stream);
+    for (auto &pr : h->pending) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, pr.a, pr.b) == hipSuccess) h->ms[pr.kid] += (double)t;
+        h->launches[pr.kid] += 1;
+        h->pool.push_back(pr.a);
+        h->pool.push_back(pr.b);
+    }
+    h->pending.clear();
+}
+
+static hipEvent_t ev_get(nlh_handle *h)
+{
+    if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct Timed {
+    nlh_handle *h; int kid; hipEvent_t a{}, b{}; bool on;
+    Timed(nlh_handle *h_, int kid_) : h(h_), kid(kid_), on(h_->timing)
+    {
+        if (on) { a = ev_get(h); b = ev_get(h); hipEventRecord(a, h->stream); }
+    }
+    ~Timed()
+    {
+        if (on) {
+            hipEventRecord(b, h->stream);
+            h->pending.push_back({a, b, kid});
+            if (h->pending.size() > 8192) timing_flush(h);
+        }
+    }
+};
+
+__global__ void k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const double *diag_all,
+                                   const double *qtf_all, const double *delta_all, const double *tailsq_all,
+                                   double *par_all, double *x_all, double *sdiag_all);
+
+extern "C" {
+
+void nlh_default_options(nlh_options *o)
+{
+    o->max_evals = 100;          // src/nonlin_multi_eqn_mult_var.f90:69
+    o->ftol = 1.0e-8;            // :71
+    o->xtol = 1.0e-12;           // :73
+    o->gtol = 1.0e-12;           // :75
+    o->print_status = 0;         // :77
+    o->factor = 100.0;           // src/nonlin_least_squares.f90:25
+    o->use_line_search = 1;      // src/nonlin_solve.f90:30
+    o->ls_max_evals = 100;       // src/nonlin_linesearch.f90:35
+    o->ls_alpha = 1.0e-4;        // :38
+    o->ls_factor = 0.1;          // :46
+    o->factor_policy = NLH_FACTOR_AUTO;
+    o->ne_pivot_tol = 1.0e-4;
+}
+
+int nlh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *nlh_version(void) { return "nonlin_hip 0.1 (gfx950)"; }
+
+int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
+{
+    if (!out) return NLH_ERR_BAD_HANDLE;
+    *out = nullptr;
+    if (nlh_device_count() <= 0) return NLH_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return NLH_ERR_NO_DEVICE;
+    nlh_handle *h = new nlh_handle();
+    h->device = device;
+    if (hip_stream) {
+        h->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return NLH_ERR_HIP; }
+        h->own_stream = true;
+    }
+    // allow the single-workgroup kernels their full dynamic LDS (n-vectors live there)
+    const int lds_max = 160 * 1024 - 2048;
+    hipFuncSetAttribute((const void *)k_chol_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lmpar, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipGetLastError();
+    *out = h;
+    return 0;
+}
+
+void nlh_destroy(nlh_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    timing_flush(h);
+    for (auto e : h->pool) hipEventDestroy(e);
+    for (auto *b : h->bufs) if (b->p) hipFree(b->p);
+    if (h->pinned) hipHostFree(h->pinned);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *nlh_last_error(const nlh_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+void nlh_timing_enable(nlh_handle *h, int32_t on) { if (h) h->timing = on != 0; }
+void nlh_timing_reset(nlh_handle *h)
+{
+    if (!h) return;
+    timing_flush(h);
+    for (int k = 0; k < NLH_K_COUNT; ++k) { h->ms[k] = 0; h->launches[k] = 0; }
+}
+int nlh_timing_get(nlh_handle *h, int32_t kid, double *total_ms, int64_t *launches)
+{
+    if (!h || kid < 0 || kid >= NLH_K_COUNT) return NLH_ERR_BAD_HANDLE;
+    timing_flush(h);
+    if (total_ms) *total_ms = h->ms[kid];
+    if (launches) *launches = h->launches[kid];
+    return 0;
+}
+const char *nlh_kernel_name(int32_t kid) { return (kid >= 0 && kid < NLH_K_COUNT) ? k_names[kid] : "?"; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// small helper kernels of the drivers
+// ---------------------------------------------------------------------------
+__global__ void k_stage_advance(int nprob, LmState *st, int from, int to, int njac_inc)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprob) return;
+    if (st[p].stage == from) { st[p].stage = to; st[p].njac += njac_inc; }
+}
+
+// :211-218: fnorm of the starting residual, counters.
+__global__ void k_lm_init(int nprob, int nblk, const double *part, LmState *st, int first_stage)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprob) return;
+    double sq = 0.0;
+    for (int k = 0; k < nblk; ++k) sq = sq + part[((size_t)p * nblk + k) * 2];
+    LmState s;
+    memset(&s, 0, sizeof s);
+    s.fnorm = sqrt(sq);
+    s.neval = 1;
+    s.iter = 1;
+    s.par = 0.0;
+    s.stage = first_stage;
+    st[p] = s;
+}
+
+__global__ void k_count_active(int nprob, const LmState *st, int *out)
+{
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int c = 0;
+    for (int p = threadIdx.x; p < nprob; p += blockDim.x) c += (st[p].stage != ST_DONE);
+    atomicAdd(&cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = cnt;
+}
+
+// partial sums of squares of a device vector, same block structure as k_dq_residual
+template <int BS>
+__global__ void k_sumsq_part(int m, int n, const double *__restrict__ f, double *__restrict__ part)
+{
+    __shared__ double red[16];
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * BS + threadIdx.x;
+    const double v = (i < m) ? f[(size_t)p * m + i] : 0.0;
+    const double sq = v * v;
+    const double tq = (i >= n) ? sq : 0.0;
+    const double s = block_reduce_sum(sq, red);
+    const double t = block_reduce_sum(tq, red);
+    if (threadIdx.x == 0) {
+        part[((size_t)p * gridDim.x + blockIdx.x) * 2 + 0] = s;
+        part[((size_t)p * gridDim.x + blockIdx.x) * 2 + 1] = t;
+    }
+}
+
+// splitmix64 as a counter-based generator; k = 0-based draw index
+__device__ __forceinline__ double sm64_u(uint64_t seed, uint64_t k)
+{
+    uint64_t z = seed + (k + 1ULL) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (double)(z >> 11) * 0x1.0p-53;
+}
+
+__global__ void k_gen_A(int m, int n, uint64_t seed0, uint64_t stride, int square_shift, double *A, double *xtrue)
+{
+    const int p = blockIdx.y;
+    const uint64_t seed = seed0 + (uint64_t)p * stride;
+    const size_t mn = (size_t)m * n;
+    const double rs = sqrt((double)n);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < mn + (size_t)n; e += (size_t)gridDim.x * blockDim.x) {
+        const double u = 2.0 * sm64_u(seed, e) - 1.0;
+        if (e < mn) {
+            double v = u / rs;
+            const size_t i = e % m, j = e / m;
+            if (square_shift && i == j) v = 2.0 + v;
+            A[(size_t)p * mn + e] = v;
+        } else {
+            xtrue[(size_t)p * n + (e - mn)] = u;
+        }
+    }
+}
+
+__global__ void k_gen_bx(int m, int n, uint64_t seed0, uint64_t stride, double sigma, double spread, double *b,
+                         const double *xtrue, double *x0)
+{
+    const int p = blockIdx.y;
+    const uint64_t seed = seed0 + (uint64_t)p * stride;
+    const size_t base = (size_t)m * n + (size_t)n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)m + n; e += (size_t)gridDim.x * blockDim.x) {
+        const double u = 2.0 * sm64_u(seed, base + e) - 1.0;
+        if (e < (size_t)m) b[(size_t)p * m + e] = b[(size_t)p * m + e] + sigma * u;
+        else x0[(size_t)p * n + (e - m)] = xtrue[(size_t)p * n + (e - m)] + spread * u;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers (each is one timed kernel family)
+// ---------------------------------------------------------------------------
+static const int RB = 256;   // rows per block of the residual kernels
+
+static void launch_dq_residual(nlh_handle *h, int nprob, int m, int n, const double *A, const double *b,
+                               double gamma, const double *x, double *f, double *part,
+                               const LmState *st, int want)
+{
+    Timed t(h, NLH_K_DQ_RESIDUAL);
+    dim3 grid((m + RB - 1) / RB, nprob);
+    size_t sh = sizeof(double) * (size_t)(n + 32);
+    hipLaunchKernelGGL(k_dq_residual<RB>, grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, f, part, st, want);
+}
+
+static void launch_dq_panel(nlh_handle *h, int nprob, int m, int n, const double *A, const double *b,
+                            double gamma, const double *x, double *P, const LmState *st, int want)
+{
+    Timed t(h, NLH_K_DQ_PANEL);
+    constexpr int JT = 16;
+    dim3 grid((m + RB - 1) / RB, (n + JT - 1) / JT, nprob);
+    size_t sh = sizeof(double) * (size_t)n;
+    hipLaunchKernelGGL((k_dq_panel<RB, JT>), grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, P, st, want);
+}
+
+static void launch_fd(nlh_handle *h, int nprob, int m, int n, const double *P, const double *f0,
+                      const double *x, double *J, const LmState *st, int want)
+{
+    Timed t(h, NLH_K_FD_JACOBIAN);
+    constexpr int CJ = 8;
+    const bool vec2 = (m % 2 == 0) && ((((uintptr_t)P | (uintptr_t)J | (uintptr_t)f0) & 15) == 0);
+    if (vec2) {
+        dim3 grid((m / 2 + RB - 1) / RB, (n + CJ - 1) / CJ, nprob);
+        hipLaunchKernelGGL((k_fd_jacobian<RB, CJ, true>), grid, dim3(RB), 0, h->stream, m, n, P, f0, x, J, st, want);
+    } else {
+        dim3 grid((m + RB - 1) / RB, (n + CJ - 1) / CJ, nprob);
+        hipLaunchKernelGGL((k_fd_jacobian<RB, CJ, false>), grid, dim3(RB), 0, h->stream, m, n, P, f0, x, J, st, want);
+    }
+}
+
+static int gram_splits(int nprob, int m, int n)
+{
+    const int nb = (n + GRAM_BT - 1) / GRAM_BT;
+    const int nblk = nb * (nb + 1) / 2;
+    long base = (long)nprob * nblk;
+    int s = (int)((2048 + base - 1) / base);          // aim for >= 2048 workgroups
+    int smax = (m + 511) / 512;                       // keep >= 512 rows per split
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    return s;
+}
+
+static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, const double *f,
+                       double *G, double *g, const LmState *st, int want)
+{
+    const int nb = (n + GRAM_BT - 1) / GRAM_BT;
+    const int nblk = nb * (nb + 1) / 2;
+    const int ns = gram_splits(nprob, m, n);
+    int rps = (m + ns - 1) / ns;
+    rps = ((rps + GRAM_KT - 1) / GRAM_KT) * GRAM_KT;
+    int rc = ensure(h, h->Gpart, sizeof(double) * (size_t)nprob * ns * n * n);
+    if (rc) return rc;
+    {
+        Timed t(h, NLH_K_GRAM);
+        hipLaunchKernelGGL(k_gram_mfma, dim3(nblk, ns, nprob), dim3(256), 0, h->stream, m, n, rps, J,
+                           (double *)h->Gpart.p, st, want);
+    }
+    {
+        Timed t(h, NLH_K_GRAM_REDUCE);
+        dim3 grid((unsigned)(((size_t)n * n + 255) / 256), nprob);
+        hipLaunchKernelGGL(k_gram_reduce, grid, dim3(256), 0, h->stream, n, ns, (const double *)h->Gpart.p, G, st, want);
+    }
+    if (g) {
+        Timed t(h, NLH_K_JTF);
+        hipLaunchKernelGGL(k_jtf, dim3((n + 3) / 4, nprob), dim3(256), 0, h->stream, m, n, J, f, g, st, want);
+    }
+    return 0;
+}
+
+static int factor_threads(int n) { return n >= 96 ? 1024 : 256; }
+
+struct LmWs {
+    double *J, *P, *wa4, *scratch, *G, *g, *part;
+    LmVecs v;
+    LmState *st;
+    int32_t *info;
+    int nblk;
+};
+
+static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool need_panel)
+{
+    int rc;
+    const size_t mn = (size_t)nprob * m * n, pm = (size_t)nprob * m, pn = (size_t)nprob * n;
+    if ((rc = ensure(h, h->J, sizeof(double) * mn))) return rc;
+    if (need_panel && (rc = ensure(h, h->P, sizeof(double) * mn))) return rc;
+    if ((rc = ensure(h, h->wa4, sizeof(double) * pm))) return rc;
+    if ((rc = ensure(h, h->scratch, sizeof(double) * pm))) return rc;
+    if ((rc = ensure(h, h->G, sizeof(double) * (size_t)nprob * n * n))) return rc;
+    if ((rc = ensure(h, h->vecs, sizeof(double) * pn * 10))) return rc;
+    if ((rc = ensure(h, h->ipvt, sizeof(int32_t) * pn))) return rc;
+    if ((rc = ensure(h, h->gvec, sizeof(double) * pn))) return rc;
+    w.nblk = (m + RB - 1) / RB;
+    if ((rc = ensure(h, h->part, sizeof(double) * (size_t)nprob * w.nblk * 2))) return rc;
+    if ((rc = ensure(h, h->state, sizeof(LmState) * (size_t)nprob))) return rc;
+    if ((rc = ensure(h, h->info, sizeof(int32_t) * (size_t)(nprob + 16)))) return rc;
+    w.J = (double *)h->J.p; w.P = (double *)h->P.p; w.wa4 = (double *)h->wa4.p;
+    w.scratch = (double *)h->scratch.p; w.G = (double *)h->G.p; w.g = (double *)h->gvec.p;
+    w.part = (double *)h->part.p; w.st = (LmState *)h->state.p; w.info = (int32_t *)h->info.p;
+    double *vb = (double *)h->vecs.p;
+    w.v.diag = vb; w.v.diag_prev = vb + pn; w.v.qtf = vb + 2 * pn; w.v.acnorm = vb + 3 * pn;
+    w.v.rdiag = vb + 4 * pn; w.v.g = vb + 5 * pn; w.v.wa1 = vb + 6 * pn; w.v.wa2 = vb + 7 * pn;
+    w.v.wa3 = vb + 8 * pn; w.v.sdiag = vb + 9 * pn;
+    w.v.ipvt = (int32_t *)h->ipvt.p;
+    return 0;
+}
+
+// One pass over the factorisation + lmpar stages for every problem whose Jacobian is in
+// w.J (stage ST_HAVE_JAC or ST_NEED_QR) or whose factors are ready (inner-loop repeat).
+static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, int m, int n, LmWs &w,
+                              double *dx, const double *dfvec)
+{
+    const int ft = factor_threads(n);
+    int rc = launch_gram(h, nprob, m, n, w.J, dfvec, w.G, w.g, w.st, ST_HAVE_JAC);
+    if (rc) return rc;
+    {
+        Timed t(h, NLH_K_CHOL);
+        size_t sh = sizeof(double) * (size_t)(2 * n + 64);
+        hipLaunchKernelGGL(k_chol_factor, dim3(nprob), dim3(ft), sh, h->stream, n, w.G, w.g, w.v, dx, w.st,
+                           (int32_t *)nullptr, o->factor, o->gtol, o->ne_pivot_tol, 0);
+    }
+    const size_t shl = sizeof(double) * (size_t)(5 * n + 64);
+    {
+        Timed t(h, NLH_K_LMPAR);
+        hipLaunchKernelGGL(k_lmpar, dim3(nprob), dim3(ft), shl, h->stream, n, w.G, w.v, dx, w.st, (int)ST_NE_READY);
+    }
+    {
+        Timed t(h, NLH_K_QR);
+        size_t sh = sizeof(double) * (size_t)(3 * n + 64);
+        hipLaunchKernelGGL(k_qr_factor, dim3(nprob), dim3(1024), sh, h->stream, m, n, w.J, dfvec, w.G, w.v,
+                           w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, 0);
+    }
+    {
+        Timed t(h, NLH_K_LMPAR);
+        hipLaunchKernelGGL(k_lmpar, dim3(nprob), dim3(ft), shl, h->stream, n, w.G, w.v, dx, w.st, (int)ST_QR_READY);
+    }
+    return 0;
+}
+
+static void lm_update(nlh_handle *h, const nlh_options *o, int nprob, int m, int n, LmWs &w, double *dx, double *dfvec)
+{
+    Timed t(h, NLH_K_UPDATE);
+    hipLaunchKernelGGL(k_lm_update, dim3(nprob), dim3(256), 0, h->stream, m, n, w.nblk, w.part, w.v, dx, dfvec,
+                       w.wa4, w.st, o->ftol, o->xtol, (int)o->max_evals);
+}
+
+static void fill_ib(const LmState &s, nlh_iteration_behavior *ib)
+{
+    ib->iter_count = s.iter;
+    ib->fcn_count = s.neval;
+    ib->jacobian_count = s.njac;
+    ib->gradient_count = 0;
+    ib->converge_on_fcn = s.fcnvrg;
+    ib->converge_on_chng = s.xcnvrg;
+    ib->converge_on_zero_diff = s.gcnvrg;
+}
+
+static void print_status(int iter, int nfeval, int njaceval, double xnorm, double fnorm)
+{
+    // src/nonlin_helper.f90:17-33
+    printf(" \nIteration: %d\nFunction Evaluations: %d\n", iter, nfeval);
+    if (njaceval > 0) printf("Jacobian Evaluations: %d\n", njaceval);
+    printf("Change in Variable: %10.3E\nResidual: %10.3E\n", xnorm, fnorm);
+}
+
+static int check_opts_lm(const nlh_options *o, int m, int n)
+{
+    if (!o) return NLH_INVALID_INPUT_ERROR;
+    if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;          // :189
+    if (n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
+    if (n > 3000) return NLH_ARRAY_SIZE_ERROR;                 // LDS-resident n-vectors
+    return 0;
+}
+
+extern "C" {
+
+// ===========================================================================
+// Device-model LM, batched: lss_solve as a lock-step state machine.
+// ===========================================================================
+int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n,
+                          const double *dA, const double *db, double gamma, double *dx, double *dfvec,
+                          nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (nprob <= 0) return 0;
+    int rc = check_opts_lm(o, m, n);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    LmWs w;
+    if ((rc = lm_workspace(h, nprob, m, n, w, true))) return rc;
+    if ((rc = ensure_pinned(h, sizeof(LmState) * (size_t)nprob + 64))) return rc;
+    int *d_active = (int *)(w.info + nprob);
+    int *h_active = (int *)h->pinned;
+    LmState *h_state = (LmState *)((char *)h->pinned + 64);
+    const int pb = (nprob + 255) / 256;
+    const int first_stage = ST_NEED_JAC;
+
+    // :211-213  f(x0), fnorm
+    launch_dq_residual(h, nprob, m, n, dA, db, gamma, dx, dfvec, w.part, nullptr, -1);
+    hipLaunchKernelGGL(k_lm_init, dim3(pb), dim3(256), 0, h->stream, nprob, w.nblk, w.part, w.st, first_stage);
+
+    const int max_rounds = o->max_evals + 8;
+    for (int round = 0; round < max_rounds; ++round) {
+        // outer-loop head for problems that need a Jacobian (:221): n perturbed evaluations + FD
+        launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.P, w.st, ST_NEED_JAC);
+        launch_fd(h, nprob, m, n, w.P, dfvec, dx, w.J, w.st, ST_NEED_JAC);
+        hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_NEED_JAC,
+                           o->factor_policy == NLH_FACTOR_QR ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
+        if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec))) return rc;
+        // trial residual (:297-299)
+        launch_dq_residual(h, nprob, m, n, dA, db, gamma, w.v.wa2, w.wa4, w.part, w.st, ST_TRIAL_READY);
+        hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_TRIAL_READY,
+                           (int)ST_TRIAL_DONE, 0);
+        lm_update(h, o, nprob, m, n, w, dx, dfvec);
+        hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, h->stream, nprob, w.st, d_active);
+        HIPCHK(h, hipMemcpyAsync(h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (*h_active == 0) break;
+    }
+    HIPCHK(h, hipMemcpyAsync(h_state, w.st, sizeof(LmState) * (size_t)nprob, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    for (int p = 0; p < nprob; ++p) {
+        if (ib) fill_ib(h_state[p], &ib[p]);
+        if (status) status[p] = (h_state[p].flag != 0 || h_state[p].stage != ST_DONE) ? NLH_CONVERGENCE_ERROR : 0;  // :388-390
+    }
+    return 0;
+}
+
+// ===========================================================================
+// Host-callback LM: the same kernels with nprob = 1; residuals come from fcn.
+// ===========================================================================
+int nlh_lm_solve(nlh_handle *h, const nlh_options *o, int32_t m, int32_t n, nlh_vecfcn fcn,
+                 nlh_jacfcn jacfcn, void *ctx, double *x, double *fvec, nlh_iteration_behavior *ib)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (ib) memset(ib, 0, sizeof *ib);                          // :177-185
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :188
+    int rc = check_opts_lm(o, m, n);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    LmWs w;
+    if ((rc = lm_workspace(h, 1, m, n, w, true))) return rc;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
+    if ((rc = ensure(h, h->fdev, sizeof(double) * m))) return rc;
+    const size_t pin_bytes = 256 + sizeof(double) * ((size_t)m * n + 2 * (size_t)m + 2 * (size_t)n);
+    if ((rc = ensure_pinned(h, pin_bytes))) return rc;
+    LmState *hs = (LmState *)h->pinned;
+    double *hP = (double *)((char *)h->pinned + 256);   // m*n panel / Jacobian staging
+    double *hf = hP + (size_t)m * n;                     // m
+    double *hx = hf + m;                                 // n
+    double *dx = (double *)h->xdev.p, *dfvec = (double *)h->fdev.p;
+    hipStream_t s = h->stream;
+
+    fcn(ctx, n, x, m, fvec);                                    // :211
+    HIPCHK(h, hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(dfvec, fvec, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sumsq_part<RB>, dim3(w.nblk, 1), dim3(RB), 0, s, m, n, dfvec, w.part);
+    hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, s, 1, w.nblk, w.part, w.st, (int)ST_NEED_JAC);
+    HIPCHK(h, hipStreamSynchronize(s));
+
+    const int max_rounds = o->max_evals + 8;
+    int last_printed_iter = -1;
+    for (int round = 0; round < max_rounds; ++round) {
+        HIPCHK(h, hipMemcpyAsync(hs, w.st, sizeof(LmState), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (hs->stage == ST_DONE) break;
+        if (hs->stage == ST_NEED_JAC) {
+            if (round > 0 && o->print_status && hs->iter != last_printed_iter) {   // :372-374
+                print_status(hs->iter, hs->neval, hs->njac, hs->xnorm, hs->fnorm);
+                last_printed_iter = hs->iter;
+            }
+            // vfh_jac_fcn (:221).  x and fvec on the host are kept equal to the device copies.
+            if (jacfcn) {
+                jacfcn(ctx, n, x, m, hP);
+                HIPCHK(h, hipMemcpyAsync(w.J, hP, sizeof(double) * (size_t)m * n, hipMemcpyHostToDevice, s));
+            } else {
+                for (int j = 0; j < n; ++j) {                   // src/nonlin_multi_eqn_mult_var.f90:267-273
+                    const double temp = x[j];
+                    double hh = NLH_SQRT_EPS * fabs(temp);
+                    if (hh == 0.0) hh = NLH_SQRT_EPS;
+                    x[j] = temp + hh;
+                    fcn(ctx, n, x, m, hP + (size_t)j * m);
+                    x[j] = temp;
+                }
+                HIPCHK(h, hipMemcpyAsync(w.P, hP, sizeof(double) * (size_t)m * n, hipMemcpyHostToDevice, s));
+                launch_fd(h, 1, m, n, w.P, dfvec, dx, w.J, nullptr, -1);      // :274
+            }
+            hipLaunchKernelGGL(k_stage_advance, dim3(1), dim3(64), 0, s, 1, w.st, (int)ST_NEED_JAC,
+                               o->factor_policy == NLH_FACTOR_QR ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
+        }
+        if ((rc = lm_factor_and_step(h, o, 1, m, n, w, dx, dfvec))) return rc;
+        HIPCHK(h, hipMemcpyAsync(hs, w.st, sizeof(LmState), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(hx, w.v.wa2, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (hs->stage == ST_DONE) break;                       // gradient convergence (:270-273)
+        if (hs->stage != ST_TRIAL_READY) { h->err = "lm: unexpected stage"; return NLH_ERR_HIP; }
+        fcn(ctx, n, hx, m, hf);                                 // :297
+        HIPCHK(h, hipMemcpyAsync(w.wa4, hf, sizeof(double) * m, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_sumsq_part<RB>, dim3(w.nblk, 1), dim3(RB), 0, s, m, n, w.wa4, w.part);
+        hipLaunchKernelGGL(k_stage_advance, dim3(1), dim3(64), 0, s, 1, w.st, (int)ST_TRIAL_READY, (int)ST_TRIAL_DONE, 0);
+        const int iter_before = hs->iter;
+        lm_update(h, o, 1, m, n, w, dx, dfvec);
+        HIPCHK(h, hipMemcpyAsync(hs, w.st, sizeof(LmState), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (hs->iter != iter_before) {                          // accepted: mirror x, fvec on the host (:341-345)
+            memcpy(x, hx, sizeof(double) * n);
+            memcpy(fvec, hf, sizeof(double) * m);
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(hs, w.st, sizeof(LmState), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    if (ib) fill_ib(*hs, ib);
+    return (hs->flag != 0 || hs->stage != ST_DONE) ? NLH_CONVERGENCE_ERROR : 0;
+}
+
+// ===========================================================================
+// vecfcn_helper%jacobian for host callbacks.
+// ===========================================================================
+int nlh_fd_jacobian(nlh_handle *h, int32_t m, int32_t n, nlh_vecfcn fcn, nlh_jacfcn jacfcn, void *ctx,
+                    double *x, const double *fv, double *jac)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :240
+    if (jacfcn) { jacfcn(ctx, n, x, m, jac); return 0; }       // :241-243
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t mn = (size_t)m * n;
+    if ((rc = ensure(h, h->J, sizeof(double) * mn))) return rc;
+    if ((rc = ensure(h, h->P, sizeof(double) * mn))) return rc;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
+    if ((rc = ensure(h, h->fdev, sizeof(double) * m))) return rc;
+    if ((rc = ensure_pinned(h, sizeof(double) * (mn + m)))) return rc;
+    double *hP = (double *)h->pinned, *hf0 = hP + mn;
+    if (fv) memcpy(hf0, fv, sizeof(double) * m);
+    else fcn(ctx, n, x, m, hf0);                                // :257-259
+    for (int j = 0; j < n; ++j) {                               // :267-273
+        const double temp = x[j];
+        double hh = NLH_SQRT_EPS * fabs(temp);
+        if (hh == 0.0) hh = NLH_SQRT_EPS;
+        x[j] = temp + hh;
+        fcn(ctx, n, x, m, hP + (size_t)j * m);
+        x[j] = temp;
+    }
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->P.p, hP, sizeof(double) * mn, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->fdev.p, hf0, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->xdev.p, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    launch_fd(h, 1, m, n, (const double *)h->P.p, (const double *)h->fdev.p, (const double *)h->xdev.p,
+              (double *)h->J.p, nullptr, -1);
+    HIPCHK(h, hipMemcpyAsync(jac, h->J.p, sizeof(double) * mn, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// Newton: ns_solve as a host loop; Jacobian, gradient, LU on the device.
+// The O(n) line-search and convergence arithmetic stays on the host in the
+// reference's exact order (sequential dot products), so given the same search
+// direction every accept/backtrack decision matches the CPU path.
+// ===========================================================================
+struct NewtonEval {
+    // evaluate F at host x -> host f (device copy of f kept in dfvec when keep_dev)
+    std::function<int(const double *x, double *f)> fcn;
+    // Jacobian at host x (device copy of f0 in dfvec) -> device J (n x n)
+    std::function<int(double *x, const double *f0_host, double *dJ)> jac;
+};
+
+static double h_dot(int n, const double *a, const double *b)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s = s + a[i] * b[i];
+    return s;
+}
+
+// NORM2 as the flang runtime evaluates it (processor-dependent intrinsic); the host-side
+// Newton logic uses it only for stpmax and limit_search_vector.
+static double h_norm2(int n, const double *x)
+{
+    double mx = 0.0, s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double a = fabs(x[i]);
+        if (mx == 0.0) mx = a;
+        else if (a > mx) { const double t = mx / a, tsq = t * t; s = s * tsq; s = s + tsq; mx = a; }
+        else if (a != 0.0) { const double t = a / mx; s = s + t * t; }
+    }
+    return mx * sqrt(1.0 + s);
+}
+
+// min_backtrack_search, src/nonlin_linesearch.f90:495-551
+static double min_backtrack_search(int mode, double f0, double f, double f1, double alam, double alam1, double slope)
+{
+    double lam;
+    if (mode == 1) {
+        lam = -slope / (2.0 * (f - f0 - slope));
+    } else {
+        const double rhs1 = f - f0 - alam * slope;
+        const double rhs2 = f1 - f0 - alam1 * slope;
+        const double a = (rhs1 / (alam * alam) - rhs2 / (alam1 * alam1)) / (alam - alam1);
+        const double b = (-alam1 * rhs1 / (alam * alam) + alam * rhs2 / (alam1 * alam1)) / (alam - alam1);
+        if (a == 0.0) {
+            lam = -slope / (2.0 * b);
+        } else {
+            const double disc = b * b - 3.0 * a * slope;
+            if (disc < 0.0) lam = 0.5 * alam;
+            else if (b <= 0.0) lam = (-b + sqrt(disc)) / (3.0 * a);
+            else lam = -slope / (b + sqrt(disc));
+        }
+        if (lam > 0.5 * alam) lam = 0.5 * alam;
+    }
+    return lam;
+}
+
+// ls_search_mimo, src/nonlin_linesearch.f90:152-326
+static int line_search(const nlh_options *o, NewtonEval &ev, int n, const double *xold, const double *grad,
+                       const double *dir, double *x, double *fvec, double fold, double *fx, int *fcn_count)
+{
+    const double tolx = 2.0 * DBL_EPSILON, alpha = o->ls_alpha, lambdamin = o->ls_factor;
+    const int maxeval = o->ls_max_evals;
+    int neval = 0, niter = 0, flag = 0, rc = 0;
+    double alam, alam1 = 0.0, alamin, f1 = 0.0, slope, test, tmplam = 0.0, f = 0.0;
+    *fcn_count = 0;
+    slope = h_dot(n, grad, dir);                                // :249-253
+    if (slope >= 0.0) return NLH_DIVERGENT_BEHAVIOR_ERROR;
+    test = 0.0;                                                 // :256-262
+    for (int i = 0; i < n; ++i) {
+        const double t = fabs(dir[i]) / fmax(fabs(xold[i]), 1.0);
+        if (t > test) test = t;
+    }
+    alamin = tolx / test;
+    alam = 1.0;
+    for (;;) {                                                  // :266-310
+        for (int i = 0; i < n; ++i) x[i] = xold[i] + alam * dir[i];
+        if ((rc = ev.fcn(x, fvec))) return rc;
+        f = 0.5 * h_dot(n, fvec, fvec);
+        neval += 1;
+        niter += 1;
+        if (alam < alamin) {                                    // :275-287
+            double sq = 0.0;
+            for (int i = 0; i < n; ++i) { const double d = x[i] - xold[i]; sq = sq + d * d; }
+            if (sqrt(sq) == 0.0) { rc = NLH_CONVERGENCE_ERROR; break; }
+            for (int i = 0; i < n; ++i) x[i] = xold[i];
+            break;
+        } else if (f <= fold + alpha * alam * slope) {          // :288-291
+            break;
+        } else {
+            tmplam = min_backtrack_search(niter, fold, f, f1, alam, alam1, slope);
+        }
+        alam1 = alam;                                           // :300-302
+        f1 = f;
+        alam = fmax(tmplam, lambdamin * alam);
+        if (neval >= maxeval) { flag = 1; break; }              // :305-309
+    }
+    *fx = f;
+    *fcn_count = neval;
+    if (rc) return rc;
+    return flag ? NLH_CONVERGENCE_ERROR : 0;
+}
+
+static int newton_core(nlh_handle *h, const nlh_options *o, int n, NewtonEval &ev, double *x, double *fvec,
+                       nlh_iteration_behavior *ib)
+{
+    int rc;
+    const size_t nn = (size_t)n * n;
+    if ((rc = ensure(h, h->J, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->lu, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->gvec, sizeof(double) * 2 * n))) return rc;
+    if ((rc = ensure(h, h->ipvt, sizeof(int32_t) * n))) return rc;
+    if ((rc = ensure(h, h->fdev, sizeof(double) * n))) return rc;
+    double *dJ = (double *)h->J.p, *dLU = (double *)h->lu.p, *dgrad = (double *)h->gvec.p, *drhs = dgrad + n;
+    double *dfvec = (double *)h->fdev.p;
+    int32_t *dipvt = (int32_t *)h->ipvt.p;
+    hipStream_t s = h->stream;
+    std::vector<double> dir(n), grad(n), xold(n), rhs(n);
+    int xcnvrg = 0, fcnvrg = 0, gcnvrg = 0, neval = 0, iter = 0, njac = 0, flag = 0;
+    double f, fold, stpmax, xnorm = 0, fnorm = 0, test;
+    rc = 0;
+
+    // :535  Jacobian requested before fvec is defined; result discarded, not counted.
+    if ((rc = ev.jac(x, fvec, dJ))) return rc;
+
+    if ((rc = ev.fcn(x, fvec))) return rc;                      // :538-547
+    f = 0.5 * h_dot(n, fvec, fvec);
+    neval += 1;
+    test = 0.0;
+    for (int i = 0; i < n; ++i) test = fmax(fabs(fvec[i]), test);
+    if (test < o->ftol) fcnvrg = 1;
+
+    if (!fcnvrg) {
+        stpmax = 100.0 * fmax(h_norm2(n, x), (double)n);        // :553
+        for (;;) {                                              // :556-620
+            iter += 1;
+            if ((rc = ev.jac(x, fvec, dJ))) break;              // :561-562
+            njac += 1;
+            // grad(i) = dot(jac(:,i), fvec)  (:565-567), wave per column on the device
+            HIPCHK(h, hipMemcpyAsync(dfvec, fvec, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            {
+                Timed t(h, NLH_K_JTF);
+                hipLaunchKernelGGL(k_jtf, dim3((n + 3) / 4, 1), dim3(256), 0, s, n, n, dJ, dfvec, dgrad,
+                                   (const LmState *)nullptr, -1);
+            }
+            // LU of a copy (:570) and solve for -fvec (:577)
+            HIPCHK(h, hipMemcpyAsync(dLU, dJ, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
+            {
+                Timed t(h, NLH_K_LU);
+                hipLaunchKernelGGL(k_lu_factor, dim3(1), dim3(n >= 96 ? 1024 : 256), 0, s, n, dLU, dipvt, (int32_t *)nullptr);
+            }
+            for (int i = 0; i < n; ++i) rhs[i] = -fvec[i];
+            HIPCHK(h, hipMemcpyAsync(drhs, rhs.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, s, n, dLU, dipvt, drhs);
+            HIPCHK(h, hipMemcpyAsync(dir.data(), drhs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpyAsync(grad.data(), dgrad, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+
+            memcpy(xold.data(), x, sizeof(double) * n);         // :573-574
+            fold = f;
+
+            if (o->use_line_search) {                           // :580-589
+                const double temp = h_dot(n, dir.data(), dir.data());
+                if (temp > stpmax) {
+                    const double sc = stpmax / temp;
+                    for (int i = 0; i < n; ++i) dir[i] = dir[i] * sc;
+                }
+                const double mag = h_norm2(n, dir.data());      // limit_search_vector, linesearch.f90:554-572
+                if (mag != 0.0 && mag > stpmax) {
+                    const double sc = stpmax / mag;
+                    for (int i = 0; i < n; ++i) dir[i] = sc * dir[i];
+                }
+                int lcount = 0;
+                rc = line_search(o, ev, n, xold.data(), grad.data(), dir.data(), x, fvec, fold, &f, &lcount);
+                neval += lcount;
+                if (rc) break;
+            } else {                                            // :591-595
+                for (int i = 0; i < n; ++i) x[i] = x[i] + dir[i];
+                if ((rc = ev.fcn(x, fvec))) break;
+                f = 0.5 * h_dot(n, fvec, fvec);
+                neval += 1;
+            }
+
+            // test_convergence, src/nonlin_helper.f90:36-124
+            int check = 0;
+            xcnvrg = fcnvrg = gcnvrg = 0;
+            {
+                const double fc = 0.5 * h_dot(n, fvec, fvec);
+                fnorm = 0.0; xnorm = 0.0;
+                for (int i = 0; i < n; ++i) fnorm = fmax(fabs(fvec[i]), fnorm);
+                if (fnorm < o->ftol) { fcnvrg = 1; check = 1; }
+                else {
+                    for (int i = 0; i < n; ++i) {
+                        const double t = fabs(x[i] - xold[i]) / fmax(fabs(x[i]), 1.0);
+                        xnorm = fmax(t, xnorm);
+                    }
+                    if (xnorm < o->xtol) { xcnvrg = 1; check = 1; }
+                    else {
+                        double tg = 0.0;
+                        const double den = fmax(fc, 0.5 * (double)n);
+                        for (int i = 0; i < n; ++i) tg = fmax(tg, fabs(grad[i]) * fmax(fabs(x[i]), 1.0) / den);
+                        if (tg < o->gtol) gcnvrg = 1;
+                    }
+                }
+            }
+            if (check) break;
+            if (gcnvrg) { rc = NLH_SPURIOUS_CONVERGENCE_ERROR; break; }     // :604-608
+            if (o->print_status) print_status(iter, neval, njac, xnorm, fnorm);   // :611-613
+            if (neval >= o->max_evals) { flag = 1; break; }     // :616-619
+        }
+    }
+    if (ib) {                                                   // :624-632
+        ib->iter_count = iter; ib->fcn_count = neval; ib->jacobian_count = njac; ib->gradient_count = 0;
+        ib->converge_on_fcn = fcnvrg; ib->converge_on_chng = xcnvrg; ib->converge_on_zero_diff = gcnvrg;
+    }
+    if (rc) return rc;
+    return flag ? NLH_CONVERGENCE_ERROR : 0;
+}
+
+extern "C" {
+
+int nlh_newton_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_vecfcn fcn, nlh_jacfcn jacfcn,
+                     void *ctx, double *x, double *fvec, nlh_iteration_behavior *ib)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (ib) memset(ib, 0, sizeof *ib);
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :518
+    if (!o || n < 1) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t nn = (size_t)n * n;
+    if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
+    if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
+    if ((rc = ensure_pinned(h, sizeof(double) * (nn + n)))) return rc;
+    double *hP = (double *)h->pinned;
+    hipStream_t s = h->stream;
+    NewtonEval ev;
+    ev.fcn = [&](const double *xx, double *ff) -> int { fcn(ctx, n, xx, n, ff); return 0; };
+    ev.jac = [&](double *xx, const double *f0, double *dJ) -> int {
+        if (jacfcn) {
+            jacfcn(ctx, n, xx, n, hP);
+            HIPCHK(h, hipMemcpyAsync(dJ, hP, sizeof(double) * nn, hipMemcpyHostToDevice, s));
+            return 0;
+        }
+        for (int j = 0; j < n; ++j) {                           // vfh_jac_fcn :267-273
+            const double temp = xx[j];
+            double hh = NLH_SQRT_EPS * fabs(temp);
+            if (hh == 0.0) hh = NLH_SQRT_EPS;
+            xx[j] = temp + hh;
+            fcn(ctx, n, xx, n, hP + (size_t)j * n);
+            xx[j] = temp;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->P.p, hP, sizeof(double) * nn, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->wa4.p, f0, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->xdev.p, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        launch_fd(h, 1, n, n, (const double *)h->P.p, (const double *)h->wa4.p, (const double *)h->xdev.p, dJ, nullptr, -1);
+        HIPCHK(h, hipStreamSynchronize(s));   // hP is reused by the next call
+        return 0;
+    };
+    rc = newton_core(h, o, n, ev, x, fvec, ib);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return NLH_ERR_HIP; }
+    return rc;
+}
+
+int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t n, const double *dA,
+                              const double *db, double gamma, int32_t analytic, double *dx, double *dfvec,
+                              nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!o || n < 1) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t nn = (size_t)n * n;
+    if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
+    if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
+    hipStream_t s = h->stream;
+    std::vector<double> x(n), f(n);
+    // Problems are independent and solved one after another (ns_solve is a host loop).
+    for (int p = 0; p < nprob; ++p) {
+        const double *A = dA + (size_t)p * nn, *b = db + (size_t)p * n;
+        double *dxp = dx + (size_t)p * n, *dfp = dfvec + (size_t)p * n;
+        double *dxs = (double *)h->xdev.p, *dfs = (double *)h->wa4.p;
+        HIPCHK(h, hipMemcpyAsync(x.data(), dxp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        NewtonEval ev;
+        ev.fcn = [&](const double *xx, double *ff) -> int {
+            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            launch_dq_residual(h, 1, n, n, A, b, gamma, dxs, dfs, nullptr, nullptr, -1);
+            HIPCHK(h, hipMemcpyAsync(ff, dfs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            return 0;
+        };
+        ev.jac = [&](double *xx, const double *f0, double *dJ) -> int {
+            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            if (analytic) {
+                Timed t(h, NLH_K_DQ_JACOBIAN);
+                hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((n + RB - 1) / RB, 1), dim3(RB), sizeof(double) * n, s,
+                                   n, n, A, gamma, dxs, dJ);
+            } else {
+                HIPCHK(h, hipMemcpyAsync(dfs, f0, sizeof(double) * n, hipMemcpyHostToDevice, s));
+                launch_dq_panel(h, 1, n, n, A, b, gamma, dxs, (double *)h->P.p, nullptr, -1);
+                launch_fd(h, 1, n, n, (const double *)h->P.p, dfs, dxs, dJ, nullptr, -1);
+            }
+            return 0;
+        };
+        nlh_iteration_behavior lib;
+        memset(&lib, 0, sizeof lib);
+        rc = newton_core(h, o, n, ev, x.data(), f.data(), &lib);
+        if (rc < 0) return rc;
+        if (ib) ib[p] = lib;
+        if (status) status[p] = rc;
+        HIPCHK(h, hipMemcpyAsync(dxp, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(dfp, f.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// ===========================================================================
+// Synthetic inputs + stage-level entry points
+// ===========================================================================
+int nlh_dq_generate(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, uint64_t seed0, uint64_t seed_stride, double gamma,
+                    double sigma, double spread, int32_t square_shift, double *dA, double *db,
+                    double *dxtrue, double *dx0)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t mn = (size_t)m * n;
+    unsigned gx = (unsigned)((mn + n + 255) / 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_gen_A, dim3(gx, nprob), dim3(256), 0, h->stream, m, n, seed0, seed_stride, square_shift, dA, dxtrue);
+    HIPCHK(h, hipMemsetAsync(db, 0, sizeof(double) * (size_t)nprob * m, h->stream));
+    launch_dq_residual(h, nprob, m, n, dA, db, gamma, dxtrue, db, nullptr, nullptr, -1);   // b = model(x_true) - 0
+    unsigned gb = (unsigned)(((size_t)m + n + 255) / 256);
+    hipLaunchKernelGGL(k_gen_bx, dim3(gb, nprob), dim3(256), 0, h->stream, m, n, seed0, seed_stride, sigma, spread, db, dxtrue, dx0);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_dq_residual(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dA, const double *db,
+                    double gamma, const double *dx, double *df)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_dq_residual(h, nprob, m, n, dA, db, gamma, dx, df, nullptr, nullptr, -1);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_dq_fd_panel(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dA, const double *db,
+                    double gamma, const double *dx, double *dP)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, dP, nullptr, -1);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_fd_jacobian_panel(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dP,
+                          const double *df0, const double *dx, double *dJ)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_fd(h, nprob, m, n, dP, df0, dx, dJ, nullptr, -1);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_dq_jacobian(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dA, double gamma,
+                    const double *dx, double *dJ)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    {
+        Timed t(h, NLH_K_DQ_JACOBIAN);
+        hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((m + RB - 1) / RB, nprob), dim3(RB), sizeof(double) * n, h->stream,
+                           m, n, dA, gamma, dx, dJ);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_gram(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dJ, const double *df, double *dG,
+             double *dg)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = launch_gram(h, nprob, m, n, dJ, df, dG, df ? dg : nullptr, nullptr, -1);
+    if (rc) return rc;
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_chol_factor(nlh_handle *h, int32_t nprob, int32_t n, double *dG, const double *dg, int32_t *dipvt,
+                    double *dacnorm, double *dqtf, int32_t *dinfo)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    LmVecs v;
+    memset(&v, 0, sizeof v);
+    v.ipvt = dipvt; v.acnorm = dacnorm; v.qtf = dqtf;
+    nlh_options o;
+    nlh_default_options(&o);
+    {
+        Timed t(h, NLH_K_CHOL);
+        size_t sh = sizeof(double) * (size_t)(2 * n + 64);
+        hipLaunchKernelGGL(k_chol_factor, dim3(nprob), dim3(factor_threads(n)), sh, h->stream, n, dG, dg, v,
+                           (const double *)nullptr, (LmState *)nullptr, dinfo, o.factor, o.gtol, 0.0, 1);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_qr_factor(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, double *dJ, const double *df,
+                  int32_t *dipvt, double *drdiag, double *dacnorm, double *dqtf, double *dwa4)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->G, sizeof(double) * (size_t)nprob * n * n))) return rc;
+    LmVecs v;
+    memset(&v, 0, sizeof v);
+    v.ipvt = dipvt; v.acnorm = dacnorm; v.qtf = dqtf; v.rdiag = drdiag;
+    {
+        Timed t(h, NLH_K_QR);
+        size_t sh = sizeof(double) * (size_t)(3 * n + 64);
+        hipLaunchKernelGGL(k_qr_factor, dim3(nprob), dim3(1024), sh, h->stream, m, n, dJ, df, (double *)h->G.p, v,
+                           dwa4, dwa4, (const double *)nullptr, (LmState *)nullptr, 100.0, 0.0, 1);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// lmpar on caller-supplied factors (parity tests): wraps lmpar_dev.
+}  // extern "C"
+
+__global__ void __launch_bounds__(1024)
+k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const double *diag_all,
+                   const double *qtf_all, const double *delta_all, const double *tailsq_all, double *par_all,
+                   double *x_all, double *sdiag_all)
+{
+    extern __shared__ double smem[];
+    const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    double *xs = smem, *sdiag = smem + n, *wa1 = smem + 2 * n, *wa2n = smem + 3 * n, *z = smem + 4 * n;
+    double *red = smem + 5 * n;
+    double par = par_all[p];
+    lmpar_dev(n, Rall + (size_t)p * ldr * n, ldr, ipvt_all + (size_t)p * n, diag_all + (size_t)p * n,
+              qtf_all + (size_t)p * n, delta_all[p], &par, tailsq_all[p], xs, sdiag, wa1, wa2n, z, red, 0);
+    __syncthreads();
+    for (int j = tid; j < n; j += BS) {
+        x_all[(size_t)p * n + j] = xs[j];
+        sdiag_all[(size_t)p * n + j] = sdiag[j];
+    }
+    if (tid == 0) par_all[p] = par;
+}
+
+extern "C" {
+
+int nlh_lmpar(nlh_handle *h, int32_t nprob, int32_t n, double *dR, int32_t ldr, const int32_t *dipvt,
+              const double *ddiag, const double *dqtf, const double *ddelta, const double *dtailsq,
+              double *dpar, double *dxstep, double *dsdiag)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    {
+        Timed t(h, NLH_K_LMPAR);
+        size_t sh = sizeof(double) * (size_t)(5 * n + 64);
+        hipLaunchKernelGGL(k_lmpar_standalone, dim3(nprob), dim3(factor_threads(n)), sh, h->stream, n, dR, ldr, dipvt,
+                           ddiag, dqtf, ddelta, dtailsq, dpar, dxstep, dsdiag);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_lu_factor(nlh_handle *h, int32_t nprob, int32_t n, double *dA, int32_t *dipvt, int32_t *dinfo)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    {
+        Timed t(h, NLH_K_LU);
+        hipLaunchKernelGGL(k_lu_factor, dim3(nprob), dim3(n >= 96 ? 1024 : 256), 0, h->stream, n, dA, dipvt, dinfo);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_lu_solve(nlh_handle *h, int32_t nprob, int32_t n, const double *dLU, const int32_t *dipvt, double *db)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, h->stream, n, dLU, dipvt, db);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+// nlh_kernels_gram.h -- G = J^T J with v_mfma_f64_16x16x4_f64 and g = J^T f.
+//
+// Replaces the O(m n^2) part of lmfactor (src/nonlin_least_squares.f90:569-667) and the
+// Q^T f sweep (:241-253) on the normal-equations path: with P^T G P = R^T R,
+// R equals lmfactor's R up to row signs and qtf = R^-T P^T g.
+//
+// Layout: J column-major m-by-n, so a G entry contracts two contiguous columns.  A
+// workgroup owns one 64x64 block of the lower block-triangle of G and one K-split of the
+// rows; J tiles (32 rows x 64 columns) are read column-coalesced and staged in LDS with a
+// 34-double column pitch (34 = 2 mod 32), which makes the MFMA
+// operand reads (ds_read_b64, lanes 0-15 = 16 columns, lane>>4 = k) bank-conflict-free.
+// Split-K partials go to a slab and are summed in a fixed order: bitwise reproducible.
+#pragma once
+#include "nlh_common.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define GRAM_BT 64          // block edge in columns of J
+#define GRAM_KT 32          // rows of J per LDS tile
+#define GRAM_LD (GRAM_KT + 2)
+
+__device__ __forceinline__ void gram_block_index(int idx, int &bi, int &bj)
+{
+    // idx enumerates the lower block triangle row by row: (0,0),(1,0),(1,1),(2,0)...
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= idx) ++r;
+    bi = r;
+    bj = idx - r * (r + 1) / 2;
+}
+
+__global__ void __launch_bounds__(256)
+k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
+            double *__restrict__ Gpart /* [nprob][nsplit][n*n] */,
+            const LmState *__restrict__ st, int want_stage)
+{
+    __shared__ double tA[GRAM_BT * GRAM_LD];
+    __shared__ double tB[GRAM_BT * GRAM_LD];
+    const int p = blockIdx.z;
+    if (st && st[p].stage != want_stage) return;
+    int bi, bj;
+    gram_block_index(blockIdx.x, bi, bj);
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int kbeg = split * rows_per_split;
+    const int kend = min(m, kbeg + rows_per_split);
+    const double *Jp = J + (size_t)p * m * n;
+    const bool diag = (bi == bj);
+    const double *tBp = diag ? tA : tB;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;          // 2x2 waves, 32x32 outputs each
+    const int lr = tid % GRAM_KT, lc0 = tid / GRAM_KT;   // tile loader: row lr, columns lc0 + LSTEP*cc
+    constexpr int LSTEP = 256 / GRAM_KT;
+
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const int arow = (wr * 32 + (lane & 15)) * GRAM_LD + (lane >> 4);
+    const int brow = (wc * 32 + (lane & 15)) * GRAM_LD + (lane >> 4);
+
+    for (int k0 = kbeg; k0 < kend; k0 += GRAM_KT) {
+        const int row = k0 + lr;
+        const bool rok = row < kend;
+#pragma unroll 4
+        for (int cc = 0; cc < GRAM_BT / LSTEP; ++cc) {
+            const int col = lc0 + LSTEP * cc;
+            const int ja = bi * GRAM_BT + col;
+            tA[col * GRAM_LD + lr] = (rok && ja < n) ? Jp[(size_t)ja * m + row] : 0.0;
+            if (!diag) {
+                const int jb = bj * GRAM_BT + col;
+                tB[col * GRAM_LD + lr] = (rok && jb < n) ? Jp[(size_t)jb * m + row] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < GRAM_KT / 4; ++ks) {
+            const double a0 = tA[arow + ks * 4];
+            const double a1 = tA[arow + 16 * GRAM_LD + ks * 4];
+            const double b0 = tBp[brow + ks * 4];
+            const double b1 = tBp[brow + 16 * GRAM_LD + ks * 4];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // f64 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
+    double *Gp = Gpart + ((size_t)p * nsplit + split) * (size_t)n * n;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = bi * GRAM_BT + wr * 32 + a * 16 + (lane >> 4) + 4 * r;   // A-side column of J
+                const int gc = bj * GRAM_BT + wc * 32 + c * 16 + (lane & 15);           // B-side column of J
+                if (gr < n && gc < n) Gp[(size_t)gc * n + gr] = acc[a][c][r];
+            }
+}
+
+// Sum the K-split partials in split order and mirror the lower block triangle.
+__global__ void __launch_bounds__(256)
+k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__restrict__ G,
+              const LmState *__restrict__ st, int want_stage)
+{
+    const int p = blockIdx.y;
+    if (st && st[p].stage != want_stage) return;
+    const size_t nn = (size_t)n * n;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nn) return;
+    const int r = (int)(e % n), c = (int)(e / n);
+    const bool lower = (r / GRAM_BT) >= (c / GRAM_BT);
+    const size_t src = lower ? ((size_t)c * n + r) : ((size_t)r * n + c);
+    const double *gp = Gpart + (size_t)p * nsplit * nn + src;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s = s + gp[(size_t)k * nn];
+    G[(size_t)p * nn + e] = s;
+}
+
+// g = J^T f: one wave per column, lanes stride the rows (coalesced), shuffle reduction.
+__global__ void __launch_bounds__(256)
+k_jtf(int m, int n, const double *__restrict__ J, const double *__restrict__ f,
+      double *__restrict__ g, const LmState *__restrict__ st, int want_stage)
+{
+    const int p = blockIdx.y;
+    if (st && st[p].stage != want_stage) return;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const double *col = J + (size_t)p * m * n + (size_t)j * m;
+    const double *fp = f + (size_t)p * m;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = lane;
+    for (; i + 192 < m; i += 256) {
+        s0 = s0 + col[i] * fp[i];
+        s1 = s1 + col[i + 64] * fp[i + 64];
+        s2 = s2 + col[i + 128] * fp[i + 128];
+        s3 = s3 + col[i + 192] * fp[i + 192];
+    }
+    for (; i < m; i += 64) s0 = s0 + col[i] * fp[i];
+    double s = wave_reduce_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) g[(size_t)p * n + j] = s;
+}

@@ -1,0 +1,185 @@
+// nlh_kernels_model.h -- residual ("vecfcn") evaluation of the dense-quadratic device
+// model, the n perturbed evaluations of the forward-difference Jacobian, and the
+// forward-difference column write itself.
+//
+// Reference: vfh_jac_fcn, src/nonlin_multi_eqn_mult_var.f90:198-277.
+// Bit-parity rule: every residual value must equal the CPU path's bit for bit, so a
+// row's sum runs over j ascending with a separate multiply and add (the translation
+// unit is built with -ffp-contract=off) and r = (u + (gamma*u)*u) - b.
+#pragma once
+#include "nlh_common.h"
+
+// f = F(x) for one x per problem.  One thread per residual row: lanes read a column
+// of A contiguously (column-coalesced), x is broadcast from LDS.
+// part (optional): per-block partial sums {sum f^2, sum_{i>=n} f^2} in fixed order.
+template <int BS>
+__global__ void __launch_bounds__(BS)
+k_dq_residual(int m, int n, const double *__restrict__ A, const double *__restrict__ b,
+              double gamma, const double *__restrict__ xsrc, double *__restrict__ fout,
+              double *__restrict__ part, const LmState *__restrict__ st, int want_stage)
+{
+    extern __shared__ double smem[];
+    const int p = blockIdx.y;
+    if (st && st[p].stage != want_stage) return;
+    double *xs = smem;            // n
+    double *red = smem + n;       // BS/64 + 1
+    const double *Ap = A + (size_t)p * m * n;
+    const double *xp = xsrc + (size_t)p * n;
+    for (int k = threadIdx.x; k < n; k += BS) xs[k] = xp[k];
+    __syncthreads();
+
+    const int i = blockIdx.x * BS + threadIdx.x;
+    double r = 0.0;
+    if (i < m) {
+        double u = 0.0;
+        const double *a = Ap + i;
+        int k = 0;
+        for (; k + 4 <= n; k += 4) {
+            double a0 = a[(size_t)(k + 0) * m], a1 = a[(size_t)(k + 1) * m];
+            double a2 = a[(size_t)(k + 2) * m], a3 = a[(size_t)(k + 3) * m];
+            u = u + a0 * xs[k + 0];
+            u = u + a1 * xs[k + 1];
+            u = u + a2 * xs[k + 2];
+            u = u + a3 * xs[k + 3];
+        }
+        for (; k < n; ++k) u = u + a[(size_t)k * m] * xs[k];
+        r = (u + (gamma * u) * u) - b[(size_t)p * m + i];
+        fout[(size_t)p * m + i] = r;
+    }
+    if (part) {
+        double sq = (i < m) ? r * r : 0.0;
+        double tq = (i < m && i >= n) ? sq : 0.0;
+        double s = block_reduce_sum(sq, red);
+        double t = block_reduce_sum(tq, red);
+        if (threadIdx.x == 0) {
+            part[((size_t)p * gridDim.x + blockIdx.x) * 2 + 0] = s;
+            part[((size_t)p * gridDim.x + blockIdx.x) * 2 + 1] = t;
+        }
+    }
+}
+
+// The n perturbed evaluations of vfh_jac_fcn (:267-273), all at once:
+// P(i,j) = F_i(x + h_j e_j).  One thread per row, JT columns of the panel per thread.
+// The sequential row sum of column j equals the unperturbed prefix for k < j, so a tile
+// [j0, j0+JT) shares one prefix accumulator, forks inside the tile and then adds the same
+// product to every accumulator: ~n^2/2 adds per row instead of n^2, still bit-identical
+// to n independent evaluations.
+template <int BS, int JT>
+__global__ void __launch_bounds__(BS)
+k_dq_panel(int m, int n, const double *__restrict__ A, const double *__restrict__ b,
+           double gamma, const double *__restrict__ x, double *__restrict__ P,
+           const LmState *__restrict__ st, int want_stage)
+{
+    extern __shared__ double smem[];
+    const int p = blockIdx.z;
+    if (st && st[p].stage != want_stage) return;
+    double *xs = smem;                 // n
+    const double *Ap = A + (size_t)p * m * n;
+    const double *xp = x + (size_t)p * n;
+    for (int k = threadIdx.x; k < n; k += BS) xs[k] = xp[k];
+    __syncthreads();
+
+    const int j0 = blockIdx.y * JT;
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i >= m) return;
+    const int jt = min(JT, n - j0);    // valid columns in this tile
+    const double *a = Ap + i;
+
+    double base = 0.0;
+    for (int k = 0; k < j0; ++k) base = base + a[(size_t)k * m] * xs[k];
+
+    double acc[JT];
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) acc[jj] = base;
+
+#pragma unroll
+    for (int kk = 0; kk < JT; ++kk) {
+        if (kk < jt) {
+            const int k = j0 + kk;
+            const double av = a[(size_t)k * m];
+            const double xk = xs[k];
+            const double pr = av * xk;
+            const double pp = av * (xk + fd_step(xk));   // x(j) = temp + h, :271
+#pragma unroll
+            for (int jj = 0; jj < JT; ++jj) acc[jj] = acc[jj] + (jj == kk ? pp : pr);
+        }
+    }
+    for (int k = j0 + JT; k < n; ++k) {
+        const double pr = a[(size_t)k * m] * xs[k];
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) acc[jj] = acc[jj] + pr;
+    }
+    const double bi = b[(size_t)p * m + i];
+    double *Pp = P + (size_t)p * m * n + i;
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) {
+        if (jj < jt) {
+            const double u = acc[jj];
+            Pp[(size_t)(j0 + jj) * m] = (u + (gamma * u) * u) - bi;
+        }
+    }
+}
+
+// The forward-difference column write (:274): J(:,j) = (P(:,j) - f0) / h_j with a true
+// division.  Pure streaming: reads the panel once, writes J once; f0 is held in
+// registers across CJ columns.  Two rows per lane (16-byte accesses) when m is even.
+template <int BS, int CJ, bool VEC2>
+__global__ void __launch_bounds__(BS)
+k_fd_jacobian(int m, int n, const double *__restrict__ P, const double *__restrict__ f0,
+              const double *__restrict__ x, double *__restrict__ J,
+              const LmState *__restrict__ st, int want_stage)
+{
+    const int p = blockIdx.z;
+    if (st && st[p].stage != want_stage) return;
+    const double *Pp = P + (size_t)p * m * n;
+    double *Jp = J + (size_t)p * m * n;
+    const double *fp = f0 + (size_t)p * m;
+    const double *xp = x + (size_t)p * n;
+    const int jbeg = blockIdx.y * CJ;
+    const int jend = min(n, jbeg + CJ);
+    if (VEC2) {
+        const int i = (blockIdx.x * BS + threadIdx.x) * 2;
+        if (i >= m) return;              // m even => i+1 < m
+        const double2 f = *reinterpret_cast<const double2 *>(fp + i);
+#pragma unroll 4
+        for (int j = jbeg; j < jend; ++j) {
+            const double h = fd_step(xp[j]);
+            const double2 v = *reinterpret_cast<const double2 *>(Pp + (size_t)j * m + i);
+            double2 o;
+            o.x = (v.x - f.x) / h;
+            o.y = (v.y - f.y) / h;
+            *reinterpret_cast<double2 *>(Jp + (size_t)j * m + i) = o;
+        }
+    } else {
+        const int i = blockIdx.x * BS + threadIdx.x;
+        if (i >= m) return;
+        const double f = fp[i];
+        for (int j = jbeg; j < jend; ++j) {
+            const double h = fd_step(xp[j]);
+            Jp[(size_t)j * m + i] = (Pp[(size_t)j * m + i] - f) / h;
+        }
+    }
+}
+
+// Analytic jacobianfcn of the model: J(i,j) = (1 + 2 gamma u_i) A(i,j).
+template <int BS>
+__global__ void __launch_bounds__(BS)
+k_dq_jacobian(int m, int n, const double *__restrict__ A, double gamma,
+              const double *__restrict__ x, double *__restrict__ J)
+{
+    extern __shared__ double smem[];
+    const int p = blockIdx.y;
+    double *xs = smem;
+    const double *Ap = A + (size_t)p * m * n;
+    const double *xp = x + (size_t)p * n;
+    for (int k = threadIdx.x; k < n; k += BS) xs[k] = xp[k];
+    __syncthreads();
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i >= m) return;
+    const double *a = Ap + i;
+    double u = 0.0;
+    for (int k = 0; k < n; ++k) u = u + a[(size_t)k * m] * xs[k];
+    const double s = 1.0 + 2.0 * gamma * u;
+    double *Jp = J + (size_t)p * m * n + i;
+    for (int k = 0; k < n; ++k) Jp[(size_t)k * m] = s * a[(size_t)k * m];
+}

@@ -1,0 +1,179 @@
+"""Device-model ("mode D") front end: batches of independent dense-quadratic problems
+resident in HBM, solved by the batched entry points of include/nonlin_hip.h.
+
+torch is plumbing only (device memory, streams); every computation is a call into
+libnonlin_hip.so.  Layout: A [nprob, n, m] (each problem column-major m-by-n, i.e.
+A[p, j, i] = A_p(i, j)), b/fvec [nprob, m], x [nprob, n], all float64 on the GPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _chk(t, shape, name):
+    if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
+        raise ValueError(f"{name}: expected contiguous float64 GPU tensor of shape {tuple(shape)}, "
+                         f"got {t.dtype} {tuple(t.shape)} cuda={t.is_cuda}")
+
+
+class DeviceSolver:
+    """Owns an nlh handle bound to torch's current stream on `device`."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise _lib.NonlinHipUnavailable("no GPU visible: nonlin_amd has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.h = _lib.Handle(device, stream)
+        self.lib = self.h.lib
+
+    # -- inputs -------------------------------------------------------------
+    def generate(self, nprob, m, n, seed0=12345, gamma=0.5, sigma=1e-3, spread=0.3, square_shift=False,
+                 seed_stride=1):
+        """SURVEY.md 8(d) generator, on the device; problem p uses seed0 + p*seed_stride.
+        Returns (A, b, x_true, x0)."""
+        dev = self.device
+        A = torch.empty((nprob, n, m), dtype=torch.float64, device=dev)
+        b = torch.empty((nprob, m), dtype=torch.float64, device=dev)
+        xt = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        x0 = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        rc = self.lib.nlh_dq_generate(self.h.ptr, nprob, m, n, seed0, seed_stride, gamma, sigma, spread, int(square_shift),
+                                      A.data_ptr(), b.data_ptr(), xt.data_ptr(), x0.data_ptr())
+        self.h.check(rc, "nlh_dq_generate")
+        return A, b, xt, x0
+
+    # -- solvers ------------------------------------------------------------
+    def options(self, **kw):
+        o = _lib.default_options()
+        for k, v in kw.items():
+            if k == "factor":      # lss_set_factor clamp, src/nonlin_least_squares.f90:108-114
+                v = min(max(float(v), 0.1), 100.0)
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        return o
+
+    def lm_solve_batch(self, A, b, gamma, x, opts=None):
+        """least_squares_solver%solve for every problem.  x is updated in place.
+        Returns (fvec, ib_list, status_list)."""
+        nprob, n, m = A.shape
+        _chk(A, (nprob, n, m), "A"); _chk(b, (nprob, m), "b"); _chk(x, (nprob, n), "x")
+        fvec = torch.empty((nprob, m), dtype=torch.float64, device=A.device)
+        ib = (_lib.IterationBehavior * nprob)()
+        status = (C.c_int32 * nprob)()
+        o = opts or self.options()
+        rc = self.lib.nlh_dq_lm_solve_batch(self.h.ptr, C.byref(o), nprob, m, n, A.data_ptr(), b.data_ptr(),
+                                            float(gamma), x.data_ptr(), fvec.data_ptr(), ib, status)
+        self.h.check(rc, "nlh_dq_lm_solve_batch")
+        if rc:
+            raise RuntimeError(f"nlh_dq_lm_solve_batch returned {rc}")
+        return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
+
+    def newton_solve_batch(self, A, b, gamma, x, analytic=True, opts=None):
+        """newton_solver%solve for every (square) problem.  x is updated in place."""
+        nprob, n, m = A.shape
+        assert m == n
+        _chk(A, (nprob, n, n), "A"); _chk(b, (nprob, n), "b"); _chk(x, (nprob, n), "x")
+        fvec = torch.empty((nprob, n), dtype=torch.float64, device=A.device)
+        ib = (_lib.IterationBehavior * nprob)()
+        status = (C.c_int32 * nprob)()
+        o = opts or self.options()
+        rc = self.lib.nlh_dq_newton_solve_batch(self.h.ptr, C.byref(o), nprob, n, A.data_ptr(), b.data_ptr(),
+                                                float(gamma), int(analytic), x.data_ptr(), fvec.data_ptr(),
+                                                ib, status)
+        self.h.check(rc, "nlh_dq_newton_solve_batch")
+        if rc:
+            raise RuntimeError(f"nlh_dq_newton_solve_batch returned {rc}")
+        return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
+
+    # -- stage-level kernels (parity tests, roofline) --------------------------
+    def residual(self, A, b, gamma, x):
+        nprob, n, m = A.shape
+        f = torch.empty((nprob, m), dtype=torch.float64, device=A.device)
+        self.h.check(self.lib.nlh_dq_residual(self.h.ptr, nprob, m, n, A.data_ptr(), b.data_ptr(), float(gamma),
+                                              x.data_ptr(), f.data_ptr()), "nlh_dq_residual")
+        return f
+
+    def fd_panel(self, A, b, gamma, x):
+        nprob, n, m = A.shape
+        P = torch.empty((nprob, n, m), dtype=torch.float64, device=A.device)
+        self.h.check(self.lib.nlh_dq_fd_panel(self.h.ptr, nprob, m, n, A.data_ptr(), b.data_ptr(), float(gamma),
+                                              x.data_ptr(), P.data_ptr()), "nlh_dq_fd_panel")
+        return P
+
+    def fd_jacobian_panel(self, P, f0, x, out=None):
+        nprob, n, m = P.shape
+        J = out if out is not None else torch.empty_like(P)
+        self.h.check(self.lib.nlh_fd_jacobian_panel(self.h.ptr, nprob, m, n, P.data_ptr(), f0.data_ptr(),
+                                                    x.data_ptr(), J.data_ptr()), "nlh_fd_jacobian_panel")
+        return J
+
+    def jacobian(self, A, gamma, x):
+        nprob, n, m = A.shape
+        J = torch.empty_like(A)
+        self.h.check(self.lib.nlh_dq_jacobian(self.h.ptr, nprob, m, n, A.data_ptr(), float(gamma), x.data_ptr(),
+                                              J.data_ptr()), "nlh_dq_jacobian")
+        return J
+
+    def gram(self, J, f):
+        nprob, n, m = J.shape
+        G = torch.empty((nprob, n, n), dtype=torch.float64, device=J.device)
+        g = torch.empty((nprob, n), dtype=torch.float64, device=J.device)
+        self.h.check(self.lib.nlh_gram(self.h.ptr, nprob, m, n, J.data_ptr(), f.data_ptr(), G.data_ptr(),
+                                       g.data_ptr()), "nlh_gram")
+        return G, g
+
+    def chol_factor(self, G, g):
+        """Overwrites G's upper triangle (G[p, c, r], r <= c) with R.  Returns (ipvt0, acnorm, qtf, info)."""
+        nprob, n, _ = G.shape
+        dev = G.device
+        ipvt = torch.empty((nprob, n), dtype=torch.int32, device=dev)
+        acnorm = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        qtf = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        info = torch.empty((nprob,), dtype=torch.int32, device=dev)
+        self.h.check(self.lib.nlh_chol_factor(self.h.ptr, nprob, n, G.data_ptr(), g.data_ptr(), ipvt.data_ptr(),
+                                              acnorm.data_ptr(), qtf.data_ptr(), info.data_ptr()), "nlh_chol_factor")
+        return ipvt, acnorm, qtf, info
+
+    def qr_factor(self, J, f):
+        """lmfactor + Q^T f.  J [nprob, n, m] is overwritten.  Returns (ipvt0, rdiag, acnorm, qtf, wa4)."""
+        nprob, n, m = J.shape
+        dev = J.device
+        ipvt = torch.empty((nprob, n), dtype=torch.int32, device=dev)
+        rdiag = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        acnorm = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        qtf = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        wa4 = torch.empty((nprob, m), dtype=torch.float64, device=dev)
+        self.h.check(self.lib.nlh_qr_factor(self.h.ptr, nprob, m, n, J.data_ptr(), f.data_ptr(), ipvt.data_ptr(),
+                                            rdiag.data_ptr(), acnorm.data_ptr(), qtf.data_ptr(), wa4.data_ptr()),
+                     "nlh_qr_factor")
+        return ipvt, rdiag, acnorm, qtf, wa4
+
+    def lmpar(self, R, ipvt, diag, qtf, delta, tailsq, par):
+        """R [nprob, n, ldr] column-major n-by-n blocks with leading dimension ldr."""
+        nprob, n, ldr = R.shape
+        dev = R.device
+        x = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        sdiag = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        par = par.clone()
+        self.h.check(self.lib.nlh_lmpar(self.h.ptr, nprob, n, R.data_ptr(), ldr, ipvt.data_ptr(), diag.data_ptr(),
+                                        qtf.data_ptr(), delta.data_ptr(), tailsq.data_ptr(), par.data_ptr(),
+                                        x.data_ptr(), sdiag.data_ptr()), "nlh_lmpar")
+        return par, x, sdiag
+
+    def lu_factor(self, A):
+        nprob, n, _ = A.shape
+        ipvt = torch.empty((nprob, n), dtype=torch.int32, device=A.device)
+        info = torch.empty((nprob,), dtype=torch.int32, device=A.device)
+        self.h.check(self.lib.nlh_lu_factor(self.h.ptr, nprob, n, A.data_ptr(), ipvt.data_ptr(), info.data_ptr()),
+                     "nlh_lu_factor")
+        return ipvt, info
+
+    def lu_solve(self, LU, ipvt, b):
+        nprob, n, _ = LU.shape
+        self.h.check(self.lib.nlh_lu_solve(self.h.ptr, nprob, n, LU.data_ptr(), ipvt.data_ptr(), b.data_ptr()),
+                     "nlh_lu_solve")
+        return b

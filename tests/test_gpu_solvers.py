@@ -1,0 +1,294 @@
+"""End-to-end GPU parity tests: least_squares_solver / newton_solver through the C ABI against
+the CPU oracle on identical inputs.  Bar (BASELINE.json north_star): iteration / evaluation /
+Jacobian counts and convergence flags exact, x within 1e-10 relative (written below)."""
+import numpy as np
+import pytest
+import torch
+
+import problems_ref as P
+
+pytestmark = pytest.mark.gpu
+
+RTOL_X = 1e-10     # north_star: "within 1e-10 relative for fp64"
+COUNT_KEYS = ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn", "converge_on_chng",
+              "converge_on_zero_diff")
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _check_batch(ds, oracle, nprob, m, n, seed0, gen_kw, opt_kw, expect_qr=None):
+    gamma = gen_kw.get("gamma", 0.5)
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=seed0, **gen_kw)
+    x = x0.clone()
+    fvec, ibs, status = ds.lm_solve_batch(A, b, gamma, x, ds.options(**opt_kw))
+    worst = 0.0
+    for p in range(nprob):
+        Ah = np.asfortranarray(A[p].cpu().numpy().T)
+        okw = {k: v for k, v in opt_kw.items() if k in ("max_evals", "factor", "ftol", "xtol", "gtol")}
+        rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(Ah, b[p].cpu().numpy(), gamma, x0[p].cpu().numpy(),
+                                                   opts=oracle.default_options(**okw))
+        assert status[p] == rc, (p, status[p], rc)
+        for k in COUNT_KEYS:
+            assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
+        r = _rel(x[p].cpu().numpy(), xo)
+        worst = max(worst, r)
+        assert r <= RTOL_X, (p, r)
+        assert _rel(fvec[p].cpu().numpy(), fo) <= 1e-8      # residual at the solution
+    return worst
+
+
+@pytest.mark.parametrize("m,n,nprob", [(512, 64, 6), (2048, 128, 4), (300, 37, 5), (64, 16, 8)])
+def test_lm_batch_default_regime(ds, oracle, m, n, nprob):
+    """Default synthetic family (Gauss-Newton step accepted: Gram + pivoted-Cholesky path)."""
+    _check_batch(ds, oracle, nprob, m, n, 12345, {}, dict(max_evals=500))
+
+
+def test_lm_batch_c2_single_problem(ds, oracle):
+    """BASELINE config 2: one 4096 x 256 problem, seed 12345 (reference: 5 / 5 / 4)."""
+    A, b, xt, x0 = ds.generate(1, 4096, 256, seed0=12345)
+    x = x0.clone()
+    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500))
+    assert (ibs[0]["iter_count"], ibs[0]["fcn_count"], ibs[0]["jacobian_count"]) == (5, 5, 4)
+    rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), 0.5,
+                                               x0[0].cpu().numpy(), opts=oracle.default_options(max_evals=500))
+    assert _rel(x[0].cpu().numpy(), xo) <= RTOL_X
+
+
+@pytest.mark.parametrize("m,n,gen,opt", [
+    (512, 64, dict(gamma=2.0, sigma=0.1, spread=5.0), dict(factor=0.1)),
+    (512, 64, dict(gamma=2.0, sigma=0.1, spread=5.0), dict()),
+    (256, 32, dict(gamma=10.0, sigma=1.0, spread=50.0), dict(factor=0.1)),
+    (256, 32, dict(gamma=10.0, sigma=1.0, spread=50.0), dict()),
+])
+def test_lm_batch_hard_regime(ds, oracle, m, n, gen, opt):
+    """Trust region binding: the lmpar loop with both deviations from MINPACK is exercised
+    (normal-equations path falls back to the faithful Householder QR + Givens lmsolve)."""
+    _check_batch(ds, oracle, 3, m, n, 12345, gen, dict(max_evals=500, **opt))
+
+
+@pytest.mark.parametrize("m,n", [(512, 64), (64, 16)])
+def test_lm_batch_always_qr(ds, oracle, m, n):
+    _check_batch(ds, oracle, 3, m, n, 2024, {}, dict(max_evals=500, factor_policy=1))
+
+
+def test_lm_batch_zero_residual(ds, oracle):
+    _check_batch(ds, oracle, 4, 256, 32, 7, dict(sigma=0.0), dict(max_evals=500))
+
+
+def test_lm_batch_max_evals_error(ds, oracle):
+    """Too few evaluations: status NL_CONVERGENCE_ERROR for every problem, counts still exact."""
+    _check_batch(ds, oracle, 2, 256, 32, 12345, dict(gamma=10.0, sigma=1.0, spread=50.0), dict(max_evals=5))
+
+
+def test_lm_linearity_property_full_size(ds):
+    """Size-independent property at BASELINE size 4096 x 256: with gamma = 0 the model is linear,
+    so LM must land on the least-squares solution: J^T r = 0 to rounding."""
+    A, b, xt, x0 = ds.generate(2, 4096, 256, seed0=99, gamma=0.0, sigma=1e-3)
+    x = x0.clone()
+    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.0, x, ds.options(max_evals=100))
+    assert status == [0, 0]
+    grad = torch.matmul(A, fvec.unsqueeze(-1)).squeeze(-1)      # A^T r per problem
+    assert float(grad.abs().max()) <= 1e-9 * float(fvec.norm(dim=1).max())
+
+
+# ---------------------------------------------------------------------------
+# host-callback drop-in API on the reference's own test problems
+# ---------------------------------------------------------------------------
+def _solve_lm_host(fcn, m, n, x0, jac=None, policy=0, **opts):
+    import nonlin_amd as nl
+    obj = nl.vecfcn_helper()
+    obj.set_fcn(fcn, m, n)
+    if jac is not None:
+        obj.set_jacobian(jac)
+    s = nl.least_squares_solver()
+    s.factor_policy = policy
+    if "max_evals" in opts:
+        s.set_max_fcn_evals(opts["max_evals"])
+    if "factor" in opts:
+        s.set_step_scaling_factor(opts["factor"])
+    x = np.array(x0, dtype=np.float64)
+    f = np.zeros(m)
+    ib = nl.iteration_behavior()
+    s.solve(obj, x, f, ib)
+    return x, f, ib
+
+
+def test_host_lm_readme_example_2(oracle):
+    """BASELINE config 1 / README Example 2 / test_least_squares_3 through the drop-in API."""
+    x, f, ib = _solve_lm_host(P.lsfcn1, 21, 4, [1.0] * 4)
+    rc, xo, fo, ibo = oracle.lm_solve(lambda xx, ff: P.lsfcn1(xx, ff, None), 21, 4, [1.0] * 4)
+    assert (ib.iter_count, ib.fcn_count, ib.jacobian_count) == (2, 3, 2)
+    assert ib.converge_on_fcn and not ib.converge_on_chng and not ib.converge_on_zero_diff
+    assert _rel(x, xo) <= RTOL_X
+    # README.md:165-171, ten printed digits
+    np.testing.assert_allclose(x, [1.0647627571, -0.1223202909, 0.4466134462, 1.1866142244], rtol=0, atol=6e-11)
+    assert abs(np.abs(f).max() - 0.50636) < 5e-6
+
+
+@pytest.mark.parametrize("ic", [(0.5, 0.5), (1.0, 1.0)])
+@pytest.mark.parametrize("analytic", [True, False])
+def test_host_lm_fcn1(oracle, ic, analytic):
+    """test_least_squares_1 / test_least_squares_4 (tests/nonlin_test_solve.f90:537-584, 657-726)."""
+    jac = P.jac1 if analytic else None
+    x, f, ib = _solve_lm_host(P.fcn1, 2, 2, ic, jac=jac)
+    rc, xo, fo, ibo = oracle.lm_solve(lambda xx, ff: P.fcn1(xx, ff, None), 2, 2, ic,
+                                      jac=(lambda xx, JJ: P.jac1(xx, JJ, None)) if analytic else None)
+    assert abs(abs(x[0]) - 5.0) <= 1e-6 and abs(abs(x[1]) - 3.0) <= 1e-6      # is_ans_1
+    for k in COUNT_KEYS:
+        assert getattr(ib, k) == ibo[k], (k, ib.as_dict(), ibo)
+    assert _rel(x, xo) <= RTOL_X
+
+
+@pytest.mark.parametrize("ic", [(0.5, 0.5), (1.0, 1.0)])
+def test_host_lm_fcn2_badly_scaled(oracle, ic):
+    """test_least_squares_2 (:587-634): ill-conditioned Gram matrix => Householder QR path."""
+    x, f, ib = _solve_lm_host(P.fcn2, 2, 2, ic, max_evals=1000)
+    rc, xo, fo, ibo = oracle.lm_solve(lambda xx, ff: P.fcn2(xx, ff, None), 2, 2, ic,
+                                      opts=oracle.default_options(max_evals=1000))
+    assert abs(abs(x[0]) - 5.0e3) <= 1e-6 and abs(abs(x[1]) - 10.0) <= 1e-6    # is_ans_2
+    for k in COUNT_KEYS:
+        assert getattr(ib, k) == ibo[k], (k, ib.as_dict(), ibo)
+    assert _rel(x, xo) <= RTOL_X
+
+
+def test_host_lm_args_passthrough():
+    """class(*) args reaches the callback untouched (tests/nonlin_test_solve.f90:54-57)."""
+    import nonlin_amd as nl
+    obj = nl.vecfcn_helper()
+    obj.set_fcn(P.fcn1a, 2, 2)
+    s = nl.least_squares_solver()
+    x = np.array([1.0, 1.0])
+    f = np.zeros(2)
+    s.solve(obj, x, f, args=2.0)
+    assert abs(abs(x[0]) - 5.0) <= 1e-6 and abs(abs(x[1]) - 3.0) <= 1e-6
+
+
+def test_host_errors():
+    import nonlin_amd as nl
+    s = nl.least_squares_solver()
+    obj = nl.vecfcn_helper()
+    with pytest.raises(nl.NonlinError) as e:
+        s.solve(obj, np.zeros(2), np.zeros(2))
+    assert e.value.code == nl.NL_UNDEFINED_FUNCTION_ERROR            # :188
+    obj.set_fcn(P.fcn1, 2, 3)
+    with pytest.raises(nl.NonlinError) as e:
+        s.solve(obj, np.zeros(3), np.zeros(2))
+    assert e.value.code == nl.NL_UNDERDEFINED_PROBLEM_ERROR           # :189
+    obj.set_fcn(P.fcn1, 2, 2)
+    with pytest.raises(nl.NonlinError) as e:
+        s.solve(obj, np.zeros(3), np.zeros(2))
+    assert e.value.code == 3                                          # :191-192
+    ns = nl.newton_solver()
+    obj.set_fcn(P.lsfcn1, 21, 4)
+    with pytest.raises(nl.NonlinError) as e:
+        ns.solve(obj, np.zeros(4), np.zeros(21))
+    assert e.value.code == nl.NL_INVALID_INPUT_ERROR                  # src/nonlin_solve.f90:519
+
+
+@pytest.mark.parametrize("x", [(0.0, 0.0), (1.0, 0.0), (0.0, 1.0), (0.5, -0.5)])
+def test_host_fd_jacobian_polar(oracle, x):
+    """test_jacobian_1 (tests/nonlin_test_jacobian.f90:89-177): FD vs exact within 1e-4, and
+    bit-identical to the oracle's vfh_jac_fcn."""
+    import nonlin_amd as nl
+    obj = nl.vecfcn_helper()
+    obj.set_fcn(P.polar, 2, 2)
+    xx = np.array(x, dtype=np.float64)
+    J = np.zeros((2, 2), order="F")
+    obj.jacobian(xx, J)
+    exact = np.zeros((2, 2), order="F")
+    P.polar_jac(xx, exact, None)
+    assert np.abs(J - exact).max() <= 1e-4
+    Jo = oracle.fd_jacobian(lambda a, f: P.polar(a, f, None), 2, 2, x)
+    assert np.array_equal(J, Jo)
+    assert np.array_equal(xx, np.array(x))          # x restored (:273)
+
+
+def test_host_fd_jacobian_args(oracle):
+    """test_jacobian_2 (:180-269): scalar args multiplies the model."""
+    import nonlin_amd as nl
+    obj = nl.vecfcn_helper()
+    obj.set_fcn(P.polar_scaled, 2, 2)
+    xx = np.array([0.5, -0.5])
+    J = np.zeros((2, 2), order="F")
+    obj.jacobian(xx, J, args=0.37)
+    exact = np.zeros((2, 2), order="F")
+    P.polar_scaled_jac(xx, exact, 0.37)
+    assert np.abs(J - exact).max() <= 1e-4
+
+
+def _solve_newton_host(fcn, n, x0, jac=None, use_ls=True, **opts):
+    import nonlin_amd as nl
+    obj = nl.vecfcn_helper()
+    obj.set_fcn(fcn, n, n)
+    if jac is not None:
+        obj.set_jacobian(jac)
+    s = nl.newton_solver()
+    s.set_use_line_search(use_ls)
+    x = np.array(x0, dtype=np.float64)
+    f = np.zeros(n)
+    ib = nl.iteration_behavior()
+    s.solve(obj, x, f, ib, args=opts.get("args"))
+    return x, f, ib
+
+
+@pytest.mark.parametrize("ic", [(0.5, 0.5), (1.0, 1.0)])
+def test_host_newton_1(oracle, ic):
+    """test_newton_1 (:362-409); (1,1) reproduces the recorded reference counts 6 / 9 / 6."""
+    x, f, ib = _solve_newton_host(P.fcn1, 2, ic, jac=P.jac1)
+    rc, xo, fo, ibo = oracle.newton_solve(lambda a, b: P.fcn1(a, b, None), 2, ic, jac=lambda a, b: P.jac1(a, b, None))
+    assert abs(abs(x[0]) - 5.0) <= 1e-6 and abs(abs(x[1]) - 3.0) <= 1e-6
+    for k in COUNT_KEYS:
+        assert getattr(ib, k) == ibo[k], (k, ib.as_dict(), ibo)
+    assert np.array_equal(x, xo)          # LU, line search and model are bit-identical to the CPU path
+    if ic == (1.0, 1.0):
+        assert (ib.iter_count, ib.fcn_count, ib.jacobian_count) == (6, 9, 6)
+
+
+@pytest.mark.parametrize("ic", [(0.5, 0.5), (1.0, 1.0)])
+def test_host_newton_2_fd_no_linesearch(oracle, ic):
+    """test_newton_2 (:412-462): badly scaled, FD Jacobian, line search off."""
+    x, f, ib = _solve_newton_host(P.fcn2, 2, ic, use_ls=False)
+    rc, xo, fo, ibo = oracle.newton_solve(lambda a, b: P.fcn2(a, b, None), 2, ic,
+                                          opts=oracle.default_options(use_line_search=0))
+    assert abs(abs(x[0]) - 5.0e3) <= 1e-6 and abs(abs(x[1]) - 10.0) <= 1e-6
+    for k in COUNT_KEYS:
+        assert getattr(ib, k) == ibo[k]
+    assert np.array_equal(x, xo)
+
+
+def test_host_newton_4_powell(oracle):
+    """test_newton_4 (:806-848): Powell badly scaled, analytic Jacobian, tol 1e-5."""
+    x, f, ib = _solve_newton_host(P.powell, 2, [0.0, 1.0], jac=P.powell_jac)
+    assert abs(x[0] - 1.098159e-5) <= 1e-5 and abs(x[1] - 9.106146) <= 1e-5
+    rc, xo, fo, ibo = oracle.newton_solve(lambda a, b: P.powell(a, b, None), 2, [0.0, 1.0],
+                                          jac=lambda a, b: P.powell_jac(a, b, None))
+    for k in COUNT_KEYS:
+        assert getattr(ib, k) == ibo[k]
+    assert np.array_equal(x, xo)
+
+
+def test_host_newton_fsolve_example(oracle):
+    """examples/nonlin_newton_solve_jacobian.f90: 2x1 - x2 = exp(-x1), -x1 + 2x2 = exp(-x2)."""
+    x, f, ib = _solve_newton_host(P.misc01, 2, [1.0, 1.0], jac=P.misc01_jac)
+    assert np.abs(x - 0.5671432904097838).max() <= 1e-7
+    rc, xo, fo, ibo = oracle.newton_solve(lambda a, b: P.misc01(a, b, None), 2, [1.0, 1.0],
+                                          jac=lambda a, b: P.misc01_jac(a, b, None))
+    assert np.array_equal(x, xo)
+
+
+@pytest.mark.parametrize("n,analytic", [(64, True), (64, False), (200, True)])
+def test_dq_newton_batch(ds, oracle, n, analytic):
+    """BASELINE config 3 family at test size: square dense-quadratic system, A <- 2I + A."""
+    A, b, xt, x0 = ds.generate(2, n, n, seed0=12345, sigma=0.0, square_shift=True)
+    x = x0.clone()
+    fvec, ibs, status = ds.newton_solve_batch(A, b, 0.5, x, analytic=analytic, opts=ds.options(max_evals=500))
+    for p in range(2):
+        Ah = np.asfortranarray(A[p].cpu().numpy().T)
+        rc, xo, fo, ibo, _ = oracle.dq_newton_solve(Ah, b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(), analytic=analytic,
+                                                    opts=oracle.default_options(max_evals=500))
+        assert status[p] == rc == 0
+        for k in COUNT_KEYS:
+            assert ibs[p][k] == ibo[k], (k, ibs[p], ibo)
+        assert _rel(x[p].cpu().numpy(), xo) <= RTOL_X

@@ -1,0 +1,194 @@
+"""GPU parity tests, one kernel family at a time, against the CPU oracle on the same seeded
+inputs.  Everything goes through the C ABI (nonlin_amd.device -> libnonlin_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_problem(oracle, seed, m, n, **kw):
+    A, b, xt, x0 = oracle.dq_generate(seed, m, n, **kw)
+    return A, b, xt, x0
+
+
+def _to_dev(A_list, dev):
+    # oracle A is Fortran-order m x n; device layout is [nprob, n, m] (column-major per problem)
+    return torch.tensor(np.stack([np.ascontiguousarray(A.T) for A in A_list]), device=dev)
+
+
+@pytest.mark.parametrize("m,n", [(21, 4), (512, 64), (300, 37), (2048, 128), (64, 64)])
+def test_generator_matches_oracle_bitwise(ds, oracle, m, n):
+    nprob = 3
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=777, gamma=0.5, sigma=1e-3, spread=0.3,
+                               square_shift=(m == n))
+    for p in range(nprob):
+        Ah, bh, xth, x0h = oracle.dq_generate(777 + p, m, n, square_shift=(m == n))
+        assert np.array_equal(A[p].cpu().numpy().T, Ah)
+        assert np.array_equal(xt[p].cpu().numpy(), xth)
+        assert np.array_equal(x0[p].cpu().numpy(), x0h)
+        assert np.array_equal(b[p].cpu().numpy(), bh)      # needs the bit-exact residual kernel
+
+
+@pytest.mark.parametrize("m,n", [(21, 4), (512, 64), (300, 37), (4096, 256), (1, 1)])
+def test_residual_bit_exact(ds, oracle, m, n):
+    """vecfcn of the device model: every residual equals the CPU value bit for bit."""
+    nprob = 2
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=4242)
+    f = ds.residual(A, b, 0.5, x0)
+    for p in range(nprob):
+        fo = oracle.dq_residual(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5,
+                                x0[p].cpu().numpy())
+        assert np.array_equal(f[p].cpu().numpy(), fo)
+
+
+@pytest.mark.parametrize("m,n", [(21, 4), (512, 64), (300, 37), (2048, 128), (130, 130)])
+def test_fd_jacobian_bit_exact(ds, oracle, m, n):
+    """vfh_jac_fcn: the n perturbed evaluations and the (f1 - f0)/h column write, bit for bit;
+    includes an exactly-zero x_j (h = sqrt(eps) branch)."""
+    nprob = 2
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=99)
+    x0[:, 0] = 0.0
+    f0 = ds.residual(A, b, 0.5, x0)
+    P = ds.fd_panel(A, b, 0.5, x0)
+    J = ds.fd_jacobian_panel(P, f0, x0)
+    for p in range(nprob):
+        Ah = np.asfortranarray(A[p].cpu().numpy().T)
+        Jo = oracle.dq_fd_jacobian(Ah, b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(), fv=f0[p].cpu().numpy())
+        assert np.array_equal(J[p].cpu().numpy().T, Jo)
+
+
+def test_analytic_jacobian_bit_exact(ds, oracle):
+    A, b, xt, x0 = ds.generate(2, 96, 96, seed0=5, square_shift=True)
+    J = ds.jacobian(A, 0.5, x0)
+    for p in range(2):
+        Jo = oracle.dq_jacobian(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy())
+        assert np.array_equal(J[p].cpu().numpy().T, Jo)
+
+
+@pytest.mark.parametrize("m,n", [(21, 4), (512, 64), (300, 37), (4096, 256), (1000, 130)])
+def test_gram_mfma(ds, m, n):
+    """J^T J and J^T f (fp64 MFMA, split-K) against a float64 reference; exact symmetry and
+    run-to-run reproducibility.  Asymmetric random J catches a transposed C/D map."""
+    g = torch.Generator(device="cpu").manual_seed(1)
+    J = torch.randn((2, n, m), dtype=torch.float64, generator=g).cuda()
+    f = torch.randn((2, m), dtype=torch.float64, generator=g).cuda()
+    G, gv = ds.gram(J, f)
+    G2, gv2 = ds.gram(J, f)
+    Gref = torch.matmul(J, J.transpose(1, 2))          # [p, a, b] = sum_i J(i,a) J(i,b)
+    gref = torch.matmul(J, f.unsqueeze(-1)).squeeze(-1)
+    scale = float(Gref.abs().max())
+    assert float((G - Gref).abs().max()) <= 1e-13 * scale * np.sqrt(m)
+    assert float((gv - gref).abs().max()) <= 1e-13 * float(gref.abs().max()) * np.sqrt(m)
+    assert torch.equal(G, G.transpose(1, 2))
+    assert torch.equal(G, G2) and torch.equal(gv, gv2)
+
+
+@pytest.mark.parametrize("m,n", [(21, 4), (512, 64), (300, 37), (2048, 128)])
+def test_chol_factor_matches_lmfactor(ds, oracle, m, n):
+    """Pivoted Cholesky of J^T J reproduces lmfactor's pivot order, |R|, acnorm and |qtf|
+    (rows of R and entries of qtf are defined up to a common sign)."""
+    A, b, xt, x0 = ds.generate(1, m, n, seed0=31)
+    f0 = ds.residual(A, b, 0.5, x0)
+    J = ds.fd_jacobian_panel(ds.fd_panel(A, b, 0.5, x0), f0, x0)
+    G, g = ds.gram(J, f0)
+    ipvt, acnorm, qtf, info = ds.chol_factor(G, g)
+    assert int(info[0]) == 0
+    Jh = np.asfortranarray(J[0].cpu().numpy().T)
+    a, ip, rdiag, acn = oracle.lmfactor(Jh)
+    assert np.array_equal(ipvt[0].cpu().numpy(), ip)
+    np.testing.assert_allclose(acnorm[0].cpu().numpy(), acn, rtol=1e-13)
+    R = np.triu(G[0].cpu().numpy().T)                   # G[p, c, r] -> R(r, c)
+    Ro = np.triu(a[:n, :n], 1) + np.diag(rdiag)
+    sgn = np.sign(rdiag)
+    np.testing.assert_allclose(R, sgn[:, None] * Ro, rtol=0, atol=1e-11 * np.abs(Ro).max())
+    # qtf: apply the reflectors to f on the host
+    w = f0[0].cpu().numpy().copy()
+    a2 = a.copy()
+    for j in range(n):
+        if a2[j, j] != 0.0:
+            t = -np.dot(a2[j:, j], w[j:]) / a2[j, j]
+            w[j:] += a2[j:, j] * t
+    np.testing.assert_allclose(qtf[0].cpu().numpy(), sgn * w[:n], rtol=0, atol=1e-11 * np.abs(w).max())
+
+
+@pytest.mark.parametrize("m,n", [(21, 4), (512, 64), (300, 37), (64, 64)])
+def test_qr_factor_matches_lmfactor(ds, oracle, m, n):
+    """The faithful lmfactor + Q^T f kernel against the oracle (same algorithm; only the
+    reduction order of norms and dot products differs)."""
+    A, b, xt, x0 = ds.generate(1, m, n, seed0=57, square_shift=(m == n))
+    f0 = ds.residual(A, b, 0.5, x0)
+    J = ds.fd_jacobian_panel(ds.fd_panel(A, b, 0.5, x0), f0, x0)
+    Jh = np.asfortranarray(J[0].cpu().numpy().T)
+    ipvt, rdiag, acnorm, qtf, wa4 = ds.qr_factor(J, f0)
+    a, ip, rd, acn = oracle.lmfactor(Jh)
+    assert np.array_equal(ipvt[0].cpu().numpy(), ip)
+    np.testing.assert_allclose(rdiag[0].cpu().numpy(), rd, rtol=1e-12)
+    np.testing.assert_allclose(acnorm[0].cpu().numpy(), acn, rtol=1e-13)
+    Jg = J[0].cpu().numpy().T
+    sc = np.abs(a).max()
+    # below/above the diagonal the factored matrices agree; the diagonal was reset to rdiag (:251)
+    mask = ~np.eye(m, n, dtype=bool)
+    np.testing.assert_allclose(Jg[mask], a[mask], rtol=0, atol=1e-12 * sc)
+    w = f0[0].cpu().numpy().copy()
+    for j in range(n):
+        if a[j, j] != 0.0:
+            t = -np.dot(a[j:, j], w[j:]) / a[j, j]
+            w[j:] += a[j:, j] * t
+    np.testing.assert_allclose(qtf[0].cpu().numpy(), w[:n], rtol=0, atol=1e-12 * np.abs(w).max())
+    np.testing.assert_allclose(wa4[0].cpu().numpy(), w, rtol=0, atol=1e-12 * np.abs(w).max())
+
+
+@pytest.mark.parametrize("m,n,delta_scale", [(64, 16, 0.05), (512, 64, 0.01), (300, 37, 0.3), (64, 64, 0.02)])
+def test_lmpar_binding_trust_region(ds, oracle, m, n, delta_scale):
+    """lmpar with a binding trust region (forces the secular-equation loop, lmsolve and both
+    deviations from MINPACK) on real QR factors, against the oracle."""
+    A, b, xt, x0 = ds.generate(1, m, n, seed0=11, gamma=2.0, sigma=0.1, spread=2.0, square_shift=(m == n))
+    f0 = ds.residual(A, b, 2.0, x0)
+    J = ds.fd_jacobian_panel(ds.fd_panel(A, b, 2.0, x0), f0, x0)
+    Jh = np.asfortranarray(J[0].cpu().numpy().T)
+    a, ip, rd, acn = oracle.lmfactor(Jh)
+    w = f0[0].cpu().numpy().copy()
+    for j in range(n):
+        if a[j, j] != 0.0:
+            t = -np.dot(a[j:, j], w[j:]) / a[j, j]
+            w[j:] += a[j:, j] * t
+        a[j, j] = rd[j]
+    qtf = w[:n].copy()
+    diag = np.where(acn == 0.0, 1.0, acn)
+    delta = delta_scale * np.linalg.norm(diag * x0[0].cpu().numpy())
+    par_o, x_o, sdiag_o, _ = oracle.lmpar(a, ip, diag, qtf, delta, 0.0, w)
+    assert par_o > 0.0            # the loop really ran
+    R = torch.tensor(np.ascontiguousarray(a[:n, :n].T), device="cuda").unsqueeze(0)    # [1, n(col), n(row)]
+    dev = "cuda"
+    par, x, sdiag = ds.lmpar(R, torch.tensor(ip, dtype=torch.int32, device=dev).unsqueeze(0),
+                             torch.tensor(diag, device=dev).unsqueeze(0), torch.tensor(qtf, device=dev).unsqueeze(0),
+                             torch.tensor([delta], device=dev), torch.tensor([float(np.sum(w[n:] ** 2))], device=dev),
+                             torch.tensor([0.0], device=dev))
+    assert abs(float(par[0]) - par_o) <= 1e-10 * par_o
+    np.testing.assert_allclose(x[0].cpu().numpy(), x_o, rtol=0, atol=1e-10 * np.abs(x_o).max())
+    np.testing.assert_allclose(sdiag[0].cpu().numpy(), sdiag_o, rtol=1e-10)
+
+
+@pytest.mark.parametrize("n", [2, 37, 130, 300])
+def test_lu_bit_exact(ds, oracle, n):
+    """lu_factor / solve_lu stand-ins: same pivots, bit-identical factors and solution."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    Ah = np.asfortranarray(rng.standard_normal((n, n)))
+    bh = rng.standard_normal(n)
+    lu = Ah.copy(order="F")
+    ipo = np.zeros(n, dtype=np.int32)
+    L = oracle.lib()
+    L.nlo_lu_factor(n, lu.ctypes.data_as(C.POINTER(C.c_double)), n, ipo.ctypes.data_as(C.POINTER(C.c_int32)))
+    xo = bh.copy()
+    L.nlo_lu_solve(n, lu.ctypes.data_as(C.POINTER(C.c_double)), n, ipo.ctypes.data_as(C.POINTER(C.c_int32)),
+                   xo.ctypes.data_as(C.POINTER(C.c_double)))
+    Ad = torch.tensor(np.ascontiguousarray(Ah.T), device="cuda").unsqueeze(0)
+    bd = torch.tensor(bh, device="cuda").unsqueeze(0)
+    ipvt, info = ds.lu_factor(Ad)
+    ds.lu_solve(Ad, ipvt, bd)
+    assert int(info[0]) == 0
+    assert np.array_equal(ipvt[0].cpu().numpy(), ipo)
+    assert np.array_equal(Ad[0].cpu().numpy().T, lu)
+    assert np.array_equal(bd[0].cpu().numpy(), xo)
