@@ -91,7 +91,7 @@ typedef void (*nlh_jacfcn)(void *ctx, int32_t n, const double *x, int32_t m, dou
 /* ---- handle: owns a HIP stream reference, device workspaces (cached per shape)
  * and per-kernel HIP-event timers.  Not thread-safe; use one per thread. ---- */
 typedef struct nlh_handle nlh_handle;
-int  nlh_create(nlh_handle **h, int32_t device, void *hip_stream /* NULL => own stream */);
+int  nlh_create(nlh_handle **h, int32_t device, void *hip_stream /* NULL => the default (null) stream */);
 void nlh_destroy(nlh_handle *h);
 int  nlh_device_count(void);             /* 0 when no GPU is visible */
 const char *nlh_last_error(const nlh_handle *h);

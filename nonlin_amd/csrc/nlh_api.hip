@@ -166,12 +166,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     if (hipSetDevice(device) != hipSuccess) return NLH_ERR_NO_DEVICE;
     nlh_handle *h = new nlh_handle();
     h->device = device;
-    if (hip_stream) {
-        h->stream = (hipStream_t)hip_stream;
-    } else {
-        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return NLH_ERR_HIP; }
-        h->own_stream = true;
-    }
+    h->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
     // allow the single-workgroup kernels their full dynamic LDS (n-vectors live there)
     const int lds_max = 160 * 1024 - 2048;
     hipFuncSetAttribute((const void *)k_chol_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);

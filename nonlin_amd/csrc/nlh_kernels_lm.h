@@ -181,6 +181,11 @@ __device__ int lmpar_dev(int n, double *r, int ldr, const int32_t *ipvt, const d
         dxnorm = sqrt(sq + tailsq);                            // :531 deviation A: norm over all m entries
         temp = fp;
         fp = dxnorm - delta;
+#ifdef NLH_DEBUG_LMPAR
+        if (tid == 0 && blockIdx.x == 0)
+            printf("[gpu lmpar] iter=%d par=%.17g parl=%.6g paru=%.6g dxnorm=%.17g fp=%.6g delta=%.6g tailsq=%.6g\n",
+                   iter, par, parl, paru, dxnorm, fp, delta, tailsq);
+#endif
         if (fabs(fp) <= p1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
 
         __syncthreads();

@@ -156,6 +156,9 @@ class DeviceSolver:
         """R [nprob, n, ldr] column-major n-by-n blocks with leading dimension ldr."""
         nprob, n, ldr = R.shape
         dev = R.device
+        for t, nm in ((R, "R"), (diag, "diag"), (qtf, "qtf"), (delta, "delta"), (tailsq, "tailsq"), (par, "par")):
+            if t.dtype != torch.float64 or not t.is_cuda:
+                raise ValueError(f"{nm} must be a float64 GPU tensor")
         x = torch.empty((nprob, n), dtype=torch.float64, device=dev)
         sdiag = torch.empty((nprob, n), dtype=torch.float64, device=dev)
         par = par.clone()

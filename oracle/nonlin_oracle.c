@@ -326,6 +326,9 @@ void nlo_lmpar(int32_t m, int32_t n, double *r, int32_t ldr, const int32_t *ipvt
         dxnorm = nlo_norm2(m, wa2);                          /* :531 deviation A */
         temp = fp;
         fp = dxnorm - delta;
+        if (getenv("NLO_DEBUG_LMPAR"))
+            fprintf(stderr, "[lmpar] iter=%d par=%.17g parl=%.6g paru=%.6g dxnorm=%.17g fp=%.6g delta=%.6g\n",
+                    iter, *par, parl, paru, dxnorm, fp, delta);
 
         if (fabs(fp) <= p1 * delta ||
             (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;  /* :538-540 */
