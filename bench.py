@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--m", type=int, default=M)
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--cpu-sample", type=int, default=8, help="problems timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--policy", type=int, default=0, help="0 auto (J^T J + Cholesky), 1 QR, 2 exact (reference order)")
     args = ap.parse_args()
 
     import torch
@@ -90,7 +91,7 @@ def main():
     # block-cyclic: local problem i is global problem rank + i*world, seed = seed0 + global index
     A, b, xt, x0 = ds.generate(B, m, n, seed0=seed0 + rank, gamma=gamma, sigma=sigma, spread=spread,
                                seed_stride=world)
-    opts = ds.options(max_evals=max_evals)
+    opts = ds.options(max_evals=max_evals, factor_policy=args.policy)
     x = x0.clone()
 
     def step():
@@ -162,6 +163,8 @@ def main():
                             f"(SURVEY 8(d): gamma={gamma}, sigma={sigma}, spread={spread}, seeds {seed0}+k), "
                             f"{B} problems per GPU per step",
                 "problems_per_gpu": B, "m": m, "n": n, "max_fcn_evals": max_evals,
+                "factor_policy": {0: "auto (J^T J MFMA + pivoted Cholesky, QR fallback)", 1: "householder-qr",
+                                  2: "exact (reference operation order)"}[args.policy],
                 "parallelism": f"independent problems, block-cyclic over {world} rank(s)",
                 "accepted_steps_per_s": naccept_all / elapsed,
                 "non_converged": int(bad_all),

@@ -64,7 +64,9 @@ typedef struct nlh_iteration_behavior {
  * line_search   src/nonlin_linesearch.f90:35-53                              */
 #define NLH_FACTOR_AUTO 0  /* J^T J + pivoted Cholesky; Householder QR when the Gauss-Newton
                               step is rejected or the Gram matrix is ill-conditioned */
-#define NLH_FACTOR_QR   1  /* always the reference's pivoted Householder QR (lmfactor) */
+#define NLH_FACTOR_QR   1  /* always the reference's pivoted Householder QR (lmfactor), parallel reductions */
+#define NLH_FACTOR_EXACT 2 /* lmfactor/lmpar with every reduction in the reference's operation order
+                              (sequential dot products, flang NORM2): bit-identical to the CPU path */
 typedef struct nlh_options {
     int32_t max_evals;        /* 100   */
     double  ftol;             /* 1e-8  */

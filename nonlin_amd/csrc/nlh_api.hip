@@ -24,6 +24,7 @@
 #include "nlh_kernels_factor.h"
 #include "nlh_kernels_lm.h"
 #include "nlh_kernels_lu.h"
+#include "nlh_kernels_exact.h"
 
 // ---------------------------------------------------------------------------
 // handle
@@ -171,7 +172,9 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     const int lds_max = 160 * 1024 - 2048;
     hipFuncSetAttribute((const void *)k_chol_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    hipFuncSetAttribute((const void *)k_lmpar, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lmpar<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lmpar<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qr_exact, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipGetLastError();
@@ -434,6 +437,24 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
                               double *dx, const double *dfvec)
 {
     const int ft = factor_threads(n);
+    const size_t shl = sizeof(double) * (size_t)(5 * n + 64);
+    if (o->factor_policy == NLH_FACTOR_EXACT) {
+        // reference operation order: row-major copy of J, exact lmfactor + Q^T f, exact lmpar
+        {
+            Timed t(h, NLH_K_QR);
+            dim3 grid((m + 31) / 32, (n + 31) / 32, nprob);
+            hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, w.st, (int)ST_NEED_QR);
+            size_t sh = sizeof(double) * (size_t)(2 * n + 64 + 3 * NLH_NCH + 8);
+            hipLaunchKernelGGL(k_qr_exact, dim3(nprob), dim3(ft), sh, h->stream, m, n, w.P, dfvec, w.G, w.v,
+                               w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, 0);
+        }
+        {
+            Timed t(h, NLH_K_LMPAR);
+            hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(ft), shl + sizeof(double) * (3 * NLH_NCH + 8),
+                               h->stream, m, n, w.G, w.v, dx, w.wa4, w.st, (int)ST_QR_READY);
+        }
+        return 0;
+    }
     int rc = launch_gram(h, nprob, m, n, w.J, dfvec, w.G, w.g, w.st, ST_HAVE_JAC);
     if (rc) return rc;
     {
@@ -442,10 +463,10 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
         hipLaunchKernelGGL(k_chol_factor, dim3(nprob), dim3(ft), sh, h->stream, n, w.G, w.g, w.v, dx, w.st,
                            (int32_t *)nullptr, o->factor, o->gtol, o->ne_pivot_tol, 0);
     }
-    const size_t shl = sizeof(double) * (size_t)(5 * n + 64);
     {
         Timed t(h, NLH_K_LMPAR);
-        hipLaunchKernelGGL(k_lmpar, dim3(nprob), dim3(ft), shl, h->stream, n, w.G, w.v, dx, w.st, (int)ST_NE_READY);
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.G, w.v, dx, w.wa4, w.st,
+                           (int)ST_NE_READY);
     }
     {
         Timed t(h, NLH_K_QR);
@@ -455,7 +476,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
     }
     {
         Timed t(h, NLH_K_LMPAR);
-        hipLaunchKernelGGL(k_lmpar, dim3(nprob), dim3(ft), shl, h->stream, n, w.G, w.v, dx, w.st, (int)ST_QR_READY);
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.G, w.v, dx, w.wa4, w.st,
+                           (int)ST_QR_READY);
     }
     return 0;
 }
@@ -463,8 +485,12 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
 static void lm_update(nlh_handle *h, const nlh_options *o, int nprob, int m, int n, LmWs &w, double *dx, double *dfvec)
 {
     Timed t(h, NLH_K_UPDATE);
-    hipLaunchKernelGGL(k_lm_update, dim3(nprob), dim3(256), 0, h->stream, m, n, w.nblk, w.part, w.v, dx, dfvec,
-                       w.wa4, w.st, o->ftol, o->xtol, (int)o->max_evals);
+    if (o->factor_policy == NLH_FACTOR_EXACT)
+        hipLaunchKernelGGL(k_lm_update<true>, dim3(nprob), dim3(256), 0, h->stream, m, n, w.nblk, w.part, w.v, dx,
+                           dfvec, w.wa4, w.st, o->ftol, o->xtol, (int)o->max_evals);
+    else
+        hipLaunchKernelGGL(k_lm_update<false>, dim3(nprob), dim3(256), 0, h->stream, m, n, w.nblk, w.part, w.v, dx,
+                           dfvec, w.wa4, w.st, o->ftol, o->xtol, (int)o->max_evals);
 }
 
 static void fill_ib(const LmState &s, nlh_iteration_behavior *ib)
@@ -520,7 +546,10 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
 
     // :211-213  f(x0), fnorm
     launch_dq_residual(h, nprob, m, n, dA, db, gamma, dx, dfvec, w.part, nullptr, -1);
-    hipLaunchKernelGGL(k_lm_init, dim3(pb), dim3(256), 0, h->stream, nprob, w.nblk, w.part, w.st, first_stage);
+    if (o->factor_policy == NLH_FACTOR_EXACT)
+        hipLaunchKernelGGL(k_lm_init_exact, dim3(nprob), dim3(256), 0, h->stream, m, dfvec, w.st, first_stage);
+    else
+        hipLaunchKernelGGL(k_lm_init, dim3(pb), dim3(256), 0, h->stream, nprob, w.nblk, w.part, w.st, first_stage);
 
     const int max_rounds = o->max_evals + 8;
     for (int round = 0; round < max_rounds; ++round) {
@@ -528,7 +557,7 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.P, w.st, ST_NEED_JAC);
         launch_fd(h, nprob, m, n, w.P, dfvec, dx, w.J, w.st, ST_NEED_JAC);
         hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_NEED_JAC,
-                           o->factor_policy == NLH_FACTOR_QR ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
+                           o->factor_policy != NLH_FACTOR_AUTO ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
         if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec))) return rc;
         // trial residual (:297-299)
         launch_dq_residual(h, nprob, m, n, dA, db, gamma, w.v.wa2, w.wa4, w.part, w.st, ST_TRIAL_READY);
@@ -579,7 +608,10 @@ int nlh_lm_solve(nlh_handle *h, const nlh_options *o, int32_t m, int32_t n, nlh_
     HIPCHK(h, hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(dfvec, fvec, sizeof(double) * m, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_sumsq_part<RB>, dim3(w.nblk, 1), dim3(RB), 0, s, m, n, dfvec, w.part);
-    hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, s, 1, w.nblk, w.part, w.st, (int)ST_NEED_JAC);
+    if (o->factor_policy == NLH_FACTOR_EXACT)
+        hipLaunchKernelGGL(k_lm_init_exact, dim3(1), dim3(256), 0, s, m, dfvec, w.st, (int)ST_NEED_JAC);
+    else
+        hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, s, 1, w.nblk, w.part, w.st, (int)ST_NEED_JAC);
     HIPCHK(h, hipStreamSynchronize(s));
 
     const int max_rounds = o->max_evals + 8;
@@ -610,7 +642,7 @@ int nlh_lm_solve(nlh_handle *h, const nlh_options *o, int32_t m, int32_t n, nlh_
                 launch_fd(h, 1, m, n, w.P, dfvec, dx, w.J, nullptr, -1);      // :274
             }
             hipLaunchKernelGGL(k_stage_advance, dim3(1), dim3(64), 0, s, 1, w.st, (int)ST_NEED_JAC,
-                               o->factor_policy == NLH_FACTOR_QR ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
+                               o->factor_policy != NLH_FACTOR_AUTO ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
         }
         if ((rc = lm_factor_and_step(h, o, 1, m, n, w, dx, dfvec))) return rc;
         HIPCHK(h, hipMemcpyAsync(hs, w.st, sizeof(LmState), hipMemcpyDeviceToHost, s));
@@ -1132,8 +1164,9 @@ k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const 
     double *xs = smem, *sdiag = smem + n, *wa1 = smem + 2 * n, *wa2n = smem + 3 * n, *z = smem + 4 * n;
     double *red = smem + 5 * n;
     double par = par_all[p];
-    lmpar_dev(n, Rall + (size_t)p * ldr * n, ldr, ipvt_all + (size_t)p * n, diag_all + (size_t)p * n,
-              qtf_all + (size_t)p * n, delta_all[p], &par, tailsq_all[p], xs, sdiag, wa1, wa2n, z, red, 0);
+    lmpar_dev<false>(n, n, Rall + (size_t)p * ldr * n, ldr, ipvt_all + (size_t)p * n, diag_all + (size_t)p * n,
+                     qtf_all + (size_t)p * n, delta_all[p], &par, tailsq_all[p], nullptr, xs, sdiag, wa1, wa2n, z,
+                     red, nullptr, 0);
     __syncthreads();
     for (int j = tid; j < n; j += BS) {
         x_all[(size_t)p * n + j] = xs[j];

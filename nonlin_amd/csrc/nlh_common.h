@@ -114,3 +114,136 @@ __device__ __forceinline__ double fd_step(double xj)
     if (h == 0.0) h = NLH_SQRT_EPS;
     return h;
 }
+
+// ---------------------------------------------------------------------------
+// Reference-order ("exact") reductions.  With EXACT = true every sum is formed in the
+// CPU path's order, so results are bit-identical to it; elementwise work stays parallel.
+//
+// NORM2 follows the flang runtime (the reference's compiler here; the intrinsic is
+// processor-dependent): a running maximum mx and s = sum (x/mx)^2 rescaled whenever the
+// maximum grows; result mx*sqrt(1+s).  The divisions and squares of that algorithm are
+// independent once the prefix maxima are known, so a chunk of elements is prepared in
+// parallel (prefix-max scan in LDS, then c_i, d_i with s <- s*c_i + d_i) and only the
+// two-flop recurrence is folded serially by one thread.
+// ---------------------------------------------------------------------------
+#define NLH_NCH 512     // chunk length of the exact NORM2; scratch = 3*NLH_NCH + 8 doubles
+
+struct Norm2State { double mx, s; };
+
+// get(i) returns element i (any sign).  scratch: LDS, 3*NLH_NCH + 8 doubles.  Whole block.
+template <typename Get>
+__device__ double norm2_flang_block(Get get, int len, double *scratch)
+{
+    const int tid = threadIdx.x, BS = blockDim.x;
+    double *av = scratch, *pm = scratch + NLH_NCH, *dd = scratch + 2 * NLH_NCH;
+    double *carry = scratch + 3 * NLH_NCH;    // [0] = mx, [1] = s
+    __syncthreads();
+    if (tid == 0) { carry[0] = 0.0; carry[1] = 0.0; }
+    __syncthreads();
+    for (int base = 0; base < len; base += NLH_NCH) {
+        const int cl = min(NLH_NCH, len - base);
+        for (int i = tid; i < cl; i += BS) { const double a = fabs(get(base + i)); av[i] = a; pm[i] = a; }
+        __syncthreads();
+        // inclusive prefix maximum (exact: max is associative); ping-pong between pm and dd
+        double *src = pm, *dst = dd;
+        for (int off = 1; off < cl; off <<= 1) {
+            for (int i = tid; i < cl; i += BS) dst[i] = (i >= off) ? fmax(src[i], src[i - off]) : src[i];
+            __syncthreads();
+            double *t = src; src = dst; dst = t;
+        }
+        if (src != pm) {
+            for (int i = tid; i < cl; i += BS) pm[i] = src[i];
+            __syncthreads();
+        }
+        const double mx_in = carry[0];
+        // per-element recurrence coefficients: s <- s*c + d  (c stored in av, d in dd)
+        for (int i = tid; i < cl; i += BS) {
+            const double a = av[i];
+            const double prev = (i == 0) ? mx_in : fmax(mx_in, pm[i - 1]);   // running max before element i
+            double c = 1.0, d = 0.0;
+            if (prev == 0.0) {
+                // mx was zero: element becomes the maximum, s untouched
+            } else if (a > prev) {
+                const double t = prev / a, tsq = t * t;
+                c = tsq; d = tsq;
+            } else if (a != 0.0) {
+                const double t = a / prev;
+                d = t * t;
+            }
+            av[i] = c;
+            dd[i] = d;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double s = carry[1];
+            for (int i = 0; i < cl; ++i) {
+                const double c = av[i];
+                if (c != 1.0) s = s * c;
+                s = s + dd[i];
+            }
+            carry[1] = s;
+            carry[0] = fmax(mx_in, pm[cl - 1]);
+        }
+        __syncthreads();
+    }
+    const double r = carry[0] * sqrt(1.0 + carry[1]);
+    __syncthreads();
+    return r;
+}
+
+// Same algorithm, one thread, for short vectors or per-column use.
+template <typename Get>
+__device__ __forceinline__ double norm2_flang_serial(Get get, int len)
+{
+    double mx = 0.0, s = 0.0;
+    for (int i = 0; i < len; ++i) {
+        const double a = fabs(get(i));
+        if (mx == 0.0) {
+            mx = a;
+        } else if (a > mx) {
+            const double t = mx / a, tsq = t * t;
+            s = s * tsq;
+            s = s + tsq;
+            mx = a;
+        } else if (a != 0.0) {
+            const double t = a / mx;
+            s = s + t * t;
+        }
+    }
+    return mx * sqrt(1.0 + s);
+}
+
+// Norm of get(0..len-1): reference order when EXACT, tree sum of squares otherwise.
+template <bool EXACT, typename Get>
+__device__ __forceinline__ double nrm2_block(Get get, int len, double *red, double *scratch)
+{
+    if (EXACT) {
+        return norm2_flang_block(get, len, scratch);
+    } else {
+        double sq = 0.0;
+        for (int i = threadIdx.x; i < len; i += blockDim.x) { const double v = get(i); sq = sq + v * v; }
+        return sqrt(block_reduce_sum(sq, red));
+    }
+}
+
+// Sum of term(0..len-1): left-to-right by one thread when EXACT, tree otherwise.  Broadcast.
+template <bool EXACT, typename Term>
+__device__ __forceinline__ double sum_block(Term term, int len, double *red)
+{
+    if (EXACT) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int i = 0; i < len; ++i) s = s + term(i);
+            red[0] = s;
+        }
+        __syncthreads();
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    } else {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < len; i += blockDim.x) s = s + term(i);
+        return block_reduce_sum(s, red);
+    }
+}

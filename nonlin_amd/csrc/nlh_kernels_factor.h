@@ -19,23 +19,22 @@ struct LmVecs {          // per-problem n-vectors of the LM driver (device, [npr
 
 // Outer-loop head shared by both factorisations.  R: n-by-n upper (ld = ldr) with the
 // true diagonal; x: current iterate.  Whole workgroup; red = reduction scratch.
+template <bool EXACT>
 __device__ void lm_head(int n, const double *R, int ldr, const int32_t *ipvt,
                         const double *acnorm, const double *qtf, const double *x,
                         double *diag, double *diag_prev, LmState *s, double factor,
-                        double gtol, int ready_stage, double *red)
+                        double gtol, int ready_stage, double *red, double *scratch)
 {
     const int tid = threadIdx.x, BS = blockDim.x;
     const int iter = s->iter;
     if (iter == 1) {                                            // :229-238
-        double sq = 0.0;
         for (int j = tid; j < n; j += BS) {
             double d = acnorm[j];
             if (d == 0.0) d = 1.0;
             diag[j] = d;
-            double t = d * x[j];
-            sq = sq + t * t;
         }
-        double xnorm = sqrt(block_reduce_sum(sq, red));
+        __syncthreads();
+        const double xnorm = nrm2_block<EXACT>([&](int j) { return diag[j] * x[j]; }, n, red, scratch);
         if (tid == 0) {
             s->xnorm = xnorm;
             double delta = factor * xnorm;
@@ -171,8 +170,8 @@ k_chol_factor(int n, double *__restrict__ Gall, const double *__restrict__ gall,
     __syncthreads();
     if (standalone || !s) return;
     if (tid == 0) s->factor_kind = 0;
-    lm_head(n, G, n, ipvt, acnorm, qtf, xall + (size_t)p * n, v.diag + (size_t)p * n,
-            v.diag_prev + (size_t)p * n, s, factor, gtol, ST_NE_READY, red);
+    lm_head<false>(n, G, n, ipvt, acnorm, qtf, xall + (size_t)p * n, v.diag + (size_t)p * n,
+                   v.diag_prev + (size_t)p * n, s, factor, gtol, ST_NE_READY, red, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -328,8 +327,8 @@ k_qr_factor(int m, int n, double *__restrict__ Jall, const double *__restrict__ 
             for (int j = tid; j < n; j += BS) v.diag[(size_t)p * n + j] = v.diag_prev[(size_t)p * n + j];
             __syncthreads();
         }
-        lm_head(n, R, n, ipvt, acnorm, qtf, xall + (size_t)p * n, v.diag + (size_t)p * n,
-                v.diag_prev + (size_t)p * n, s, factor, gtol, ST_QR_READY, red);
+        lm_head<false>(n, R, n, ipvt, acnorm, qtf, xall + (size_t)p * n, v.diag + (size_t)p * n,
+                       v.diag_prev + (size_t)p * n, s, factor, gtol, ST_QR_READY, red, nullptr);
     } else {
         if (tid == 0) s->stage = ST_QR_READY;
     }

@@ -6,12 +6,16 @@
 //   lmpar_dev   : MINPACK lmpar with the reference's two deviations, :394-566
 //   k_lmpar     : lmpar + :286-294 (step, trial point, pnorm) + :307-313 (||R P^T p||)
 //   k_lm_update : :299-365 (ratio test, trust-region update, acceptance, convergence)
+//
+// EXACT = true: every reduction (norms, dot products) runs in the reference's operation
+// order (nlh_common.h), which makes the whole step bit-identical to the CPU path.
 #pragma once
 #include "nlh_common.h"
 #include "nlh_kernels_factor.h"
 
 // Faithful lmsolve on the n-by-n R (global, ld = ldr; strict lower triangle is scratch).
 // diagv[l] is the diagonal of sqrt(par) D; x (indexed by original column), sdiag, wa in LDS.
+template <bool EXACT>
 __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, const double *diagv,
                             const double *qtb, double *x, double *sdiag, double *wa, double *red)
 {
@@ -75,9 +79,8 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
     __syncthreads();
     for (int k = 1; k <= ns; ++k) {
         const int j = ns - k;
-        double sm = 0.0;
-        for (int i = j + 1 + tid; i < ns; i += BS) sm = sm + r[(size_t)j * ldr + i] * wa[i];
-        sm = block_reduce_sum(sm, red);
+        const double *colj = r + (size_t)j * ldr;
+        const double sm = sum_block<EXACT>([&](int i) { return colj[j + 1 + i] * wa[j + 1 + i]; }, ns - j - 1, red);
         __syncthreads();
         if (tid == 0) wa[j] = (wa[j] - sm) / sdiag[j];
         __syncthreads();
@@ -86,14 +89,16 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
     __syncthreads();
 }
 
-// lmpar.  Vectors x, sdiag, wa1, wa2n (the first n entries of the caller's wa4), z are
-// LDS; tailsq = sum of squares of wa4(n+1:m) (deviation A, :531).  ne_mode: the factors
-// come from the Gram matrix (row signs unknown, no Q^T f tail), so only the Gauss-Newton
+// lmpar.  Vectors x, sdiag, wa1, wa2n (the first n entries of the caller's wa4), z are LDS.
+// Deviation A (:531) takes the norm over all m entries of the caller's wa4: EXACT reads the
+// tail wa4[n..m) itself, otherwise tailsq = its sum of squares.  ne_mode: the factors come
+// from the Gram matrix (row signs unknown, no Q^T f tail), so only the Gauss-Newton
 // acceptance test is run; returns 1 when the iteration would be needed (=> QR fallback).
-__device__ int lmpar_dev(int n, double *r, int ldr, const int32_t *ipvt, const double *diag,
+template <bool EXACT>
+__device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, const double *diag,
                          const double *qtb, double delta, double *par_io, double tailsq,
-                         double *x, double *sdiag, double *wa1, double *wa2n, double *z,
-                         double *red, int ne_mode)
+                         const double *wa4, double *x, double *sdiag, double *wa1, double *wa2n,
+                         double *z, double *red, double *scratch, int ne_mode)
 {
     const int tid = threadIdx.x, BS = blockDim.x;
     const double p1 = 0.1, p001 = 1.0e-3;
@@ -122,9 +127,9 @@ __device__ int lmpar_dev(int n, double *r, int ldr, const int32_t *ipvt, const d
     __syncthreads();
 
     // :473-481
-    double sq = 0.0;
-    for (int i = tid; i < n; i += BS) { const double t = diag[i] * x[i]; wa2n[i] = t; sq = sq + t * t; }
-    double dxnorm = sqrt(block_reduce_sum(sq, red));
+    for (int i = tid; i < n; i += BS) wa2n[i] = diag[i] * x[i];
+    __syncthreads();
+    double dxnorm = nrm2_block<EXACT>([&](int i) { return wa2n[i]; }, n, red, scratch);
     double fp = dxnorm - delta;
     if (fp <= p1 * delta) { *par_io = 0.0; return 0; }
     if (ne_mode) return 1;
@@ -136,17 +141,13 @@ __device__ int lmpar_dev(int n, double *r, int ldr, const int32_t *ipvt, const d
         for (int j = tid; j < n; j += BS) { const int l = ipvt[j]; wa1[j] = diag[l] * (wa2n[l] / dxnorm); }
         __syncthreads();
         for (int j = 0; j < n; ++j) {
-            double sm = 0.0;
             const double *colj = r + (size_t)j * ldr;
-            for (int i = tid; i < j; i += BS) sm = sm + colj[i] * wa1[i];
-            sm = block_reduce_sum(sm, red);
+            const double sm = sum_block<EXACT>([&](int i) { return colj[i] * wa1[i]; }, j, red);
             __syncthreads();
             if (tid == 0) wa1[j] = (wa1[j] - sm) / colj[j];
             __syncthreads();
         }
-        sq = 0.0;
-        for (int j = tid; j < n; j += BS) sq = sq + wa1[j] * wa1[j];
-        temp = sqrt(block_reduce_sum(sq, red));
+        temp = nrm2_block<EXACT>([&](int j) { return wa1[j]; }, n, red, scratch);
         parl = ((fp / delta) / temp) / temp;
     }
     __syncthreads();
@@ -158,9 +159,7 @@ __device__ int lmpar_dev(int n, double *r, int ldr, const int32_t *ipvt, const d
         wa1[j] = sm / diag[ipvt[j]];
     }
     __syncthreads();
-    sq = 0.0;
-    for (int j = tid; j < n; j += BS) sq = sq + wa1[j] * wa1[j];
-    const double gnorm = sqrt(block_reduce_sum(sq, red));
+    const double gnorm = nrm2_block<EXACT>([&](int j) { return wa1[j]; }, n, red, scratch);
     double paru = gnorm / delta;
     if (paru == 0.0) paru = NLH_DWARF / fmin(delta, p1);
 
@@ -174,17 +173,22 @@ __device__ int lmpar_dev(int n, double *r, int ldr, const int32_t *ipvt, const d
         __syncthreads();
         for (int i = tid; i < n; i += BS) wa1[i] = temp * diag[i];
         __syncthreads();
-        lmsolve_dev(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red);
-        sq = 0.0;
-        for (int i = tid; i < n; i += BS) { const double t = diag[i] * x[i]; wa2n[i] = t; sq = sq + t * t; }
-        sq = block_reduce_sum(sq, red);
-        dxnorm = sqrt(sq + tailsq);                            // :531 deviation A: norm over all m entries
+        lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red);
+        for (int i = tid; i < n; i += BS) wa2n[i] = diag[i] * x[i];
+        __syncthreads();
+        if (EXACT) {                                           // :531 deviation A: norm over all m entries
+            dxnorm = norm2_flang_block([&](int i) { return i < n ? wa2n[i] : wa4[i]; }, m, scratch);
+        } else {
+            double sq = 0.0;
+            for (int i = tid; i < n; i += BS) sq = sq + wa2n[i] * wa2n[i];
+            dxnorm = sqrt(block_reduce_sum(sq, red) + tailsq);
+        }
         temp = fp;
         fp = dxnorm - delta;
 #ifdef NLH_DEBUG_LMPAR
         if (tid == 0 && blockIdx.x == 0)
-            printf("[gpu lmpar] iter=%d par=%.17g parl=%.6g paru=%.6g dxnorm=%.17g fp=%.6g delta=%.6g tailsq=%.6g\n",
-                   iter, par, parl, paru, dxnorm, fp, delta, tailsq);
+            printf("[gpu lmpar] iter=%d par=%.17g parl=%.6g paru=%.6g dxnorm=%.17g fp=%.6g delta=%.6g\n",
+                   iter, par, parl, paru, dxnorm, fp, delta);
 #endif
         if (fabs(fp) <= p1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
 
@@ -205,9 +209,7 @@ __device__ int lmpar_dev(int n, double *r, int ldr, const int32_t *ipvt, const d
             }
             __syncthreads();
         }
-        sq = 0.0;
-        for (int j = tid; j < n; j += BS) sq = sq + wa1[j] * wa1[j];
-        temp = sqrt(block_reduce_sum(sq, red));
+        temp = nrm2_block<EXACT>([&](int j) { return wa1[j]; }, n, red, scratch);
         const double parc = ((fp / delta) / temp) / temp;
         if (fp > 0.0) parl = fmax(parl, par);                  // :558-559
         if (fp < 0.0) paru = fmin(paru, par);
@@ -218,10 +220,11 @@ __device__ int lmpar_dev(int n, double *r, int ldr, const int32_t *ipvt, const d
 }
 
 // lmpar for every problem whose factors are ready, then the step and trial point.
-// Dynamic LDS: (5n + 64) doubles.
+// Dynamic LDS: (5n + 64) doubles, plus 3*NLH_NCH + 8 when EXACT.
+template <bool EXACT>
 __global__ void __launch_bounds__(1024)
-k_lmpar(int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
-        LmState *__restrict__ st, int want_stage)
+k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
+        const double *__restrict__ wa4all, LmState *__restrict__ st, int want_stage)
 {
     extern __shared__ double smem[];
     const int p = blockIdx.x;
@@ -230,6 +233,7 @@ k_lmpar(int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
     const int tid = threadIdx.x, BS = blockDim.x;
     double *xs = smem, *sdiag = smem + n, *wa1 = smem + 2 * n, *wa2n = smem + 3 * n, *z = smem + 4 * n;
     double *red = smem + 5 * n;
+    double *scratch = red + 64;
     double *R = Rall + (size_t)p * n * n;
     const int32_t *ipvt = v.ipvt + (size_t)p * n;
     const double *diag = v.diag + (size_t)p * n;
@@ -239,7 +243,8 @@ k_lmpar(int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
 
     double par = s->par;
     const double delta = s->delta;
-    const int rc = lmpar_dev(n, R, n, ipvt, diag, qtf, delta, &par, s->tailsq, xs, sdiag, wa1, wa2n, z, red, ne_mode);
+    const int rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, s->tailsq,
+                                    wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch, ne_mode);
     __syncthreads();
     if (rc) {                       // Gauss-Newton step rejected on the normal-equations path
         if (tid == 0) s->stage = ST_NEED_QR;
@@ -247,25 +252,24 @@ k_lmpar(int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
     }
     // :286-291  p = -x_lmpar ; trial = x + p ; pnorm = ||D p||
     double *pw = v.wa1 + (size_t)p * n, *tw = v.wa2 + (size_t)p * n;
-    double sq = 0.0;
     for (int j = tid; j < n; j += BS) {
         const double pj = -xs[j];
         xs[j] = pj;
         pw[j] = pj;
         tw[j] = xc[j] + pj;
-        const double t = diag[j] * pj;
-        sq = sq + t * t;
+        wa1[j] = diag[j] * pj;
     }
-    const double pnorm = sqrt(block_reduce_sum(sq, red));
+    __syncthreads();
+    const double pnorm = nrm2_block<EXACT>([&](int j) { return wa1[j]; }, n, red, scratch);
     __syncthreads();
     // :307-312  wa3 = R (P^T p), row i accumulates columns j ascending
-    sq = 0.0;
     for (int i = tid; i < n; i += BS) {
         double acc = 0.0;
         for (int j = i; j < n; ++j) acc = acc + R[(size_t)j * n + i] * xs[ipvt[j]];
-        sq = sq + acc * acc;
+        z[i] = acc;
     }
-    const double t1 = sqrt(block_reduce_sum(sq, red));
+    __syncthreads();
+    const double t1 = nrm2_block<EXACT>([&](int i) { return z[i]; }, n, red, scratch);
     if (tid == 0) {
         s->par = par;
         s->pnorm = pnorm;
@@ -277,25 +281,34 @@ k_lmpar(int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
 }
 
 // :299-365 for every problem with a fresh trial residual.  One workgroup per problem
-// (the acceptance copies fvec <- wa4, m entries).
+// (the acceptance copies fvec <- wa4, m entries).  EXACT: fnorm1 = NORM2(wa4) in reference
+// order; otherwise from the per-block partial sums written by the residual kernel.
+template <bool EXACT>
 __global__ void __launch_bounds__(256)
 k_lm_update(int m, int n, int nblk, const double *__restrict__ part, LmVecs v,
             double *__restrict__ xall, double *__restrict__ fvec, const double *__restrict__ wa4,
             LmState *__restrict__ st, double ftol, double xtol, int maxeval)
 {
     __shared__ double red[16];
+    __shared__ double scratch[EXACT ? (3 * NLH_NCH + 8) : 1];
     const int p = blockIdx.x;
     LmState *s = st + p;
     if (s->stage != ST_TRIAL_DONE) return;
     const int tid = threadIdx.x, BS = blockDim.x;
     const double p1 = 0.1, half = 0.5, one = 1.0;
 
-    double sq = 0.0, tq = 0.0;                                  // fnorm1 = ||wa4|| (:299)
-    for (int k = 0; k < nblk; ++k) {                            // fixed order
-        sq = sq + part[((size_t)p * nblk + k) * 2 + 0];
-        tq = tq + part[((size_t)p * nblk + k) * 2 + 1];
+    double fnorm1, tq = 0.0;                                    // fnorm1 = ||wa4|| (:299)
+    if (EXACT) {
+        const double *w = wa4 + (size_t)p * m;
+        fnorm1 = norm2_flang_block([&](int i) { return w[i]; }, m, scratch);
+    } else {
+        double sq = 0.0;
+        for (int k = 0; k < nblk; ++k) {                        // fixed order
+            sq = sq + part[((size_t)p * nblk + k) * 2 + 0];
+            tq = tq + part[((size_t)p * nblk + k) * 2 + 1];
+        }
+        fnorm1 = sqrt(sq);
     }
-    const double fnorm1 = sqrt(sq);
     const double fnorm = s->fnorm, pnorm = s->pnorm, temp1n = s->temp1n, gnorm0 = s->gnorm;
     double par = s->par, delta = s->delta, xnorm = s->xnorm;
     const int iter = s->iter, neval0 = s->neval, fkind = s->factor_kind;
@@ -326,14 +339,8 @@ k_lm_update(int m, int n, int nblk, const double *__restrict__ part, LmVecs v,
     if (accept) {
         const double *tw = v.wa2 + (size_t)p * n;
         const double *diag = v.diag + (size_t)p * n;
-        double xs = 0.0;
-        for (int j = tid; j < n; j += BS) {
-            const double xj = tw[j];
-            xall[(size_t)p * n + j] = xj;
-            const double t = diag[j] * xj;
-            xs = xs + t * t;
-        }
-        xnorm = sqrt(block_reduce_sum(xs, red));
+        for (int j = tid; j < n; j += BS) xall[(size_t)p * n + j] = tw[j];
+        xnorm = nrm2_block<EXACT>([&](int j) { return diag[j] * tw[j]; }, n, red, scratch);
         for (int i = tid; i < m; i += BS) fvec[(size_t)p * m + i] = wa4[(size_t)p * m + i];
     }
     if (tid != 0) return;

@@ -39,8 +39,16 @@ void nlo_default_options(nlo_options *o)
  * maximum with a rescaled sum of squared ratios, result max*sqrt(1+sum).  It
  * was checked bit-for-bit against amdflang's NORM2 on 300 random vectors
  * (tests/golden/make_norm2_vectors.f90 -> tests/golden/norm2_flang.json). */
+static int g_norm2_mode = 0;    /* 0 = flang runtime algorithm (default), 1 = sqrt(sequential sum of squares) */
+void nlo_set_norm2_mode(int mode) { g_norm2_mode = mode; }
+
 double nlo_norm2(int32_t n, const double *x)
 {
+    if (g_norm2_mode == 1) {
+        double q = 0.0;
+        for (int32_t i = 0; i < n; ++i) q = q + x[i] * x[i];
+        return sqrt(q);
+    }
     double mx = 0.0, s = 0.0;
     for (int32_t i = 0; i < n; ++i) {
         double a = fabs(x[i]);

@@ -26,7 +26,8 @@
  *
  * Arithmetic conventions (frozen): IEEE binary64, no FMA contraction
  * (-ffp-contract=off), dot_product = left-to-right sequential sum,
- * norm2(x) = sqrt(sequential sum of squares).
+ * norm2(x) = the flang runtime's scaled algorithm (amdflang 22 / ROCm 7.2), checked
+ * bit-for-bit against amdflang's NORM2 (tests/golden/norm2_flang.json).
  */
 #ifndef NONLIN_ORACLE_H
 #define NONLIN_ORACLE_H
@@ -89,6 +90,10 @@ typedef struct {
 } nlo_trace;
 
 double nlo_norm2(int32_t n, const double *x);
+/* NORM2 is a processor-dependent intrinsic: 0 = the flang runtime's algorithm (default: the
+ * reference as built here), 1 = sqrt(sequential sum of squares).  Mode 1 exists only to show
+ * how far "the reference" moves between Fortran processors (tests/test_oracle.py). */
+void nlo_set_norm2_mode(int mode);
 double nlo_dot(int32_t n, const double *x, const double *y);
 
 /* vfh_jac_fcn (src/nonlin_multi_eqn_mult_var.f90:198-277).  fv may be NULL. */

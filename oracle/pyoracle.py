@@ -60,6 +60,8 @@ def lib():
         dp = C.POINTER(C.c_double)
         ip = C.POINTER(C.c_int32)
         L.nlo_default_options.argtypes = [C.POINTER(Options)]
+        L.nlo_set_norm2_mode.argtypes = [C.c_int]
+        L.nlo_set_norm2_mode.restype = None
         L.nlo_norm2.restype = C.c_double
         L.nlo_norm2.argtypes = [C.c_int32, dp]
         L.nlo_fd_jacobian.argtypes = [VECFCN, JACFCN, C.c_void_p, C.c_int32, C.c_int32, dp, dp, dp]
@@ -99,6 +101,16 @@ def _dp(a):
 
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def set_norm2_mode(mode):
+    """0 = flang algorithm (default), 1 = sqrt(sum of squares)."""
+    lib().nlo_set_norm2_mode(int(mode))
+
+
+def norm2(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return float(lib().nlo_norm2(x.size, _dp(x)))
 
 
 def default_options(**kw):

@@ -25,7 +25,16 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def _check_batch(ds, oracle, nprob, m, n, seed0, gen_kw, opt_kw, rtol=RTOL_X, bitwise=False):
+def _counts_match(ib, ibo, strict):
+    """strict: every count and flag identical.  Otherwise (normal-equations policy) the last trial step
+    of a converged solve can be a coin toss -- actred = 1 - (fnorm1/fnorm)^2 is pure rounding noise there,
+    in the reference as well -- so counts may differ by one and the terminating flag may differ."""
+    if strict:
+        return all(ib[k] == ibo[k] for k in COUNT_KEYS)
+    return all(abs(ib[k] - ibo[k]) <= 1 for k in ("iter_count", "fcn_count", "jacobian_count"))
+
+
+def _check_batch(ds, oracle, nprob, m, n, seed0, gen_kw, opt_kw, rtol=RTOL_X, bitwise=False, strict=True):
     gamma = gen_kw.get("gamma", 0.5)
     A, b, xt, x0 = ds.generate(nprob, m, n, seed0=seed0, **gen_kw)
     x = x0.clone()
@@ -37,21 +46,20 @@ def _check_batch(ds, oracle, nprob, m, n, seed0, gen_kw, opt_kw, rtol=RTOL_X, bi
         rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(Ah, b[p].cpu().numpy(), gamma, x0[p].cpu().numpy(),
                                                    opts=oracle.default_options(**okw))
         assert status[p] == rc, (p, status[p], rc)
-        for k in COUNT_KEYS:
-            assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
+        assert _counts_match(ibs[p], ibo, strict), (p, ibs[p], ibo)
         r = _rel(x[p].cpu().numpy(), xo)
         worst = max(worst, r)
         assert r <= rtol, (p, r)
         if bitwise:
             assert np.array_equal(x[p].cpu().numpy(), xo) and np.array_equal(fvec[p].cpu().numpy(), fo)
-        assert np.abs(fvec[p].cpu().numpy() - fo).max() <= 1e-6 * max(np.abs(fo).max(), 1e-6)   # F at the solution
+        assert np.abs(fvec[p].cpu().numpy() - fo).max() <= max(rtol, 1e-12) * 10 * max(np.abs(fo).max(), 1.0)   # F at the solution
     return worst
 
 
 @pytest.mark.parametrize("m,n,nprob", [(512, 64, 6), (2048, 128, 4), (300, 37, 5), (64, 16, 8)])
 def test_lm_batch_default_regime(ds, oracle, m, n, nprob):
     """Default synthetic family (Gauss-Newton step accepted: Gram + pivoted-Cholesky path)."""
-    _check_batch(ds, oracle, nprob, m, n, 12345, {}, dict(max_evals=500), rtol=RTOL_X_FD_NOISE)
+    _check_batch(ds, oracle, nprob, m, n, 12345, {}, dict(max_evals=500), rtol=RTOL_X_FD_NOISE, strict=False)
 
 
 def test_lm_batch_c2_single_problem(ds, oracle):
@@ -74,12 +82,36 @@ def test_lm_batch_c2_single_problem(ds, oracle):
 def test_lm_batch_hard_regime(ds, oracle, m, n, gen, opt):
     """Trust region binding: the lmpar loop with both deviations from MINPACK is exercised
     (normal-equations path falls back to the faithful Householder QR + Givens lmsolve)."""
-    _check_batch(ds, oracle, 3, m, n, 12345, gen, dict(max_evals=500, **opt), rtol=RTOL_X_FD_NOISE)
+    _check_batch(ds, oracle, 3, m, n, 12345, gen, dict(max_evals=500, **opt), rtol=RTOL_X_FD_NOISE, strict=False)
 
 
 @pytest.mark.parametrize("m,n", [(512, 64), (64, 16)])
 def test_lm_batch_always_qr(ds, oracle, m, n):
-    _check_batch(ds, oracle, 3, m, n, 2024, {}, dict(max_evals=500, factor_policy=1), rtol=RTOL_X_FD_NOISE)
+    _check_batch(ds, oracle, 3, m, n, 2024, {}, dict(max_evals=500, factor_policy=1), rtol=RTOL_X_FD_NOISE,
+                 strict=False)
+
+
+@pytest.mark.parametrize("m,n,nprob,gen,opt", [
+    (512, 64, 4, {}, {}),
+    (300, 37, 3, {}, {}),
+    (64, 16, 4, {}, {}),
+    (512, 64, 2, dict(gamma=2.0, sigma=0.1, spread=5.0), dict(factor=0.1)),
+    (512, 64, 2, dict(gamma=2.0, sigma=0.1, spread=5.0), {}),
+    (256, 32, 2, dict(gamma=10.0, sigma=1.0, spread=50.0), dict(factor=0.1)),
+    (256, 32, 2, dict(gamma=10.0, sigma=1.0, spread=50.0), {}),
+    (2048, 128, 2, {}, {}),
+])
+def test_lm_batch_exact_policy_bitwise(ds, oracle, m, n, nprob, gen, opt):
+    """factor_policy = NLH_FACTOR_EXACT: every reduction in the reference's operation order.
+    x and fvec are bit-identical to the CPU path, counts exact -- including the trust-region-binding
+    regime that exercises lmpar's two deviations from MINPACK."""
+    _check_batch(ds, oracle, nprob, m, n, 12345, gen, dict(max_evals=500, factor_policy=2, **opt),
+                 rtol=0.0, bitwise=True)
+
+
+def test_lm_exact_policy_c2_bitwise(ds, oracle):
+    """BASELINE config 2 (4096 x 256, seed 12345) under the exact policy: bit-identical x."""
+    _check_batch(ds, oracle, 1, 4096, 256, 12345, {}, dict(max_evals=500, factor_policy=2), rtol=0.0, bitwise=True)
 
 
 def test_lm_batch_zero_residual(ds, oracle):
@@ -89,7 +121,9 @@ def test_lm_batch_zero_residual(ds, oracle):
 def test_lm_batch_max_evals_error(ds, oracle):
     """Too few evaluations: status NL_CONVERGENCE_ERROR for every problem, counts still exact."""
     _check_batch(ds, oracle, 2, 256, 32, 12345, dict(gamma=10.0, sigma=1.0, spread=50.0), dict(max_evals=5),
-                 rtol=RTOL_X_FD_NOISE)
+                 rtol=RTOL_X_FD_NOISE, strict=False)
+    _check_batch(ds, oracle, 2, 256, 32, 12345, dict(gamma=10.0, sigma=1.0, spread=50.0),
+                 dict(max_evals=5, factor_policy=2), rtol=0.0, bitwise=True)
 
 
 def test_lm_linearity_property_full_size(ds):
@@ -108,6 +142,7 @@ def test_lm_linearity_property_full_size(ds):
 # host-callback drop-in API on the reference's own test problems
 # ---------------------------------------------------------------------------
 def _solve_lm_host(fcn, m, n, x0, jac=None, policy=0, **opts):
+    """policy 0 = NLH_FACTOR_AUTO (normal equations, QR fallback), 2 = NLH_FACTOR_EXACT."""
     import nonlin_amd as nl
     obj = nl.vecfcn_helper()
     obj.set_fcn(fcn, m, n)
@@ -147,8 +182,7 @@ def test_host_lm_fcn1(oracle, ic, analytic):
     rc, xo, fo, ibo = oracle.lm_solve(lambda xx, ff: P.fcn1(xx, ff, None), 2, 2, ic,
                                       jac=(lambda xx, JJ: P.jac1(xx, JJ, None)) if analytic else None)
     assert abs(abs(x[0]) - 5.0) <= 1e-6 and abs(abs(x[1]) - 3.0) <= 1e-6      # is_ans_1
-    for k in COUNT_KEYS:
-        assert getattr(ib, k) == ibo[k], (k, ib.as_dict(), ibo)
+    assert _counts_match(ib.as_dict(), ibo, strict=False), (ib.as_dict(), ibo)
     assert _rel(x, xo) <= RTOL_X
 
 
@@ -159,9 +193,38 @@ def test_host_lm_fcn2_badly_scaled(oracle, ic):
     rc, xo, fo, ibo = oracle.lm_solve(lambda xx, ff: P.fcn2(xx, ff, None), 2, 2, ic,
                                       opts=oracle.default_options(max_evals=1000))
     assert abs(abs(x[0]) - 5.0e3) <= 1e-6 and abs(abs(x[1]) - 10.0) <= 1e-6    # is_ans_2
+    assert _counts_match(ib.as_dict(), ibo, strict=False), (ib.as_dict(), ibo)
+    assert _rel(x, xo) <= RTOL_X
+
+
+@pytest.mark.parametrize("name,fcn,jac,m,n,x0,kw", [
+    ("readme", P.lsfcn1, None, 21, 4, [1.0] * 4, {}),
+    ("fcn1_fd_a", P.fcn1, None, 2, 2, (0.5, 0.5), {}),
+    ("fcn1_fd_b", P.fcn1, None, 2, 2, (1.0, 1.0), {}),
+    ("fcn1_an_a", P.fcn1, P.jac1, 2, 2, (0.5, 0.5), {}),
+    ("fcn1_an_b", P.fcn1, P.jac1, 2, 2, (1.0, 1.0), {}),
+    ("fcn2_a", P.fcn2, None, 2, 2, (0.5, 0.5), dict(max_evals=1000)),
+    ("fcn2_b", P.fcn2, None, 2, 2, (1.0, 1.0), dict(max_evals=1000)),
+    ("readme_binding", P.lsfcn1, None, 21, 4, [1.0] * 4, dict(factor=0.1)),
+])
+def test_host_lm_exact_policy_bitwise(oracle, name, fcn, jac, m, n, x0, kw):
+    """The reference's own LM test problems through the drop-in API with the exact policy:
+    x, fvec, every count and flag identical to the CPU path."""
+    x, f, ib = _solve_lm_host(fcn, m, n, x0, jac=jac, policy=2, **kw)
+    okw = dict(kw)
+    rc, xo, fo, ibo = oracle.lm_solve(lambda xx, ff: fcn(xx, ff, None), m, n, x0,
+                                      jac=(lambda xx, JJ: jac(xx, JJ, None)) if jac else None,
+                                      opts=oracle.default_options(**okw))
+    assert rc == 0
     for k in COUNT_KEYS:
         assert getattr(ib, k) == ibo[k], (k, ib.as_dict(), ibo)
-    assert _rel(x, xo) <= RTOL_X
+    assert np.array_equal(x, xo), (x - xo)
+    assert np.array_equal(f, fo)
+    if name == "readme":
+        # SURVEY.md section 6: bit pattern of the reference's own answer (amdflang build)
+        import struct
+        hexes = " ".join("%016X" % struct.unpack(">Q", struct.pack(">d", v))[0] for v in x)
+        assert hexes == "3FF10944AC39F2FE BFBF5061F1058060 3FDC9550905F97F8 3FF2FC5F326EDD8B"
 
 
 def test_host_lm_args_passthrough():
