@@ -47,7 +47,7 @@ struct nlh_handle {
     int64_t launches[NLH_K_COUNT] = {0};
     std::vector<DevBuf *> bufs;       // every workspace buffer, for destroy
     // named workspace buffers (grown on demand, reused across calls)
-    DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev;
+    DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
 };
@@ -130,7 +130,7 @@ struct Timed {
 
 __global__ void k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const double *diag_all,
                                    const double *qtf_all, const double *delta_all, const double *tailsq_all,
-                                   double *par_all, double *x_all, double *sdiag_all);
+                                   double *par_all, double *x_all, double *sdiag_all, double *Wall);
 
 extern "C" {
 
@@ -397,7 +397,7 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
 static int factor_threads(int n) { return n >= 96 ? 1024 : 256; }
 
 struct LmWs {
-    double *J, *P, *wa4, *scratch, *G, *g, *part;
+    double *J, *P, *wa4, *scratch, *G, *g, *part, *W2;
     LmVecs v;
     LmState *st;
     int32_t *info;
@@ -413,6 +413,7 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
     if ((rc = ensure(h, h->wa4, sizeof(double) * pm))) return rc;
     if ((rc = ensure(h, h->scratch, sizeof(double) * pm))) return rc;
     if ((rc = ensure(h, h->G, sizeof(double) * (size_t)nprob * n * n))) return rc;
+    if ((rc = ensure(h, h->W2, sizeof(double) * (size_t)nprob * n * n))) return rc;
     if ((rc = ensure(h, h->vecs, sizeof(double) * pn * 10))) return rc;
     if ((rc = ensure(h, h->ipvt, sizeof(int32_t) * pn))) return rc;
     if ((rc = ensure(h, h->gvec, sizeof(double) * pn))) return rc;
@@ -423,6 +424,7 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
     w.J = (double *)h->J.p; w.P = (double *)h->P.p; w.wa4 = (double *)h->wa4.p;
     w.scratch = (double *)h->scratch.p; w.G = (double *)h->G.p; w.g = (double *)h->gvec.p;
     w.part = (double *)h->part.p; w.st = (LmState *)h->state.p; w.info = (int32_t *)h->info.p;
+    w.W2 = (double *)h->W2.p;
     double *vb = (double *)h->vecs.p;
     w.v.diag = vb; w.v.diag_prev = vb + pn; w.v.qtf = vb + 2 * pn; w.v.acnorm = vb + 3 * pn;
     w.v.rdiag = vb + 4 * pn; w.v.g = vb + 5 * pn; w.v.wa1 = vb + 6 * pn; w.v.wa2 = vb + 7 * pn;
@@ -451,7 +453,7 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
         {
             Timed t(h, NLH_K_LMPAR);
             hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(ft), shl + sizeof(double) * (3 * NLH_NCH + 8),
-                               h->stream, m, n, w.G, w.v, dx, w.wa4, w.st, (int)ST_QR_READY);
+                               h->stream, m, n, w.G, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY);
         }
         return 0;
     }
@@ -465,8 +467,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
     }
     {
         Timed t(h, NLH_K_LMPAR);
-        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.G, w.v, dx, w.wa4, w.st,
-                           (int)ST_NE_READY);
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.G, w.v, dx, w.wa4, w.P,
+                           w.J, w.W2, w.st, (int)ST_NE_READY);
     }
     {
         Timed t(h, NLH_K_QR);
@@ -476,8 +478,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
     }
     {
         Timed t(h, NLH_K_LMPAR);
-        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.G, w.v, dx, w.wa4, w.st,
-                           (int)ST_QR_READY);
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.G, w.v, dx, w.wa4, w.P,
+                           w.J, w.W2, w.st, (int)ST_QR_READY);
     }
     return 0;
 }
@@ -1157,7 +1159,7 @@ int nlh_qr_factor(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, double *dJ
 __global__ void __launch_bounds__(1024)
 k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const double *diag_all,
                    const double *qtf_all, const double *delta_all, const double *tailsq_all, double *par_all,
-                   double *x_all, double *sdiag_all)
+                   double *x_all, double *sdiag_all, double *Wall)
 {
     extern __shared__ double smem[];
     const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
@@ -1166,7 +1168,7 @@ k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const 
     double par = par_all[p];
     lmpar_dev<false>(n, n, Rall + (size_t)p * ldr * n, ldr, ipvt_all + (size_t)p * n, diag_all + (size_t)p * n,
                      qtf_all + (size_t)p * n, delta_all[p], &par, tailsq_all[p], nullptr, xs, sdiag, wa1, wa2n, z,
-                     red, nullptr, 0);
+                     red, nullptr, Wall + (size_t)p * n * n, 0);
     __syncthreads();
     for (int j = tid; j < n; j += BS) {
         x_all[(size_t)p * n + j] = xs[j];
@@ -1183,11 +1185,13 @@ int nlh_lmpar(nlh_handle *h, int32_t nprob, int32_t n, double *dR, int32_t ldr, 
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
     HIPCHK(h, hipSetDevice(h->device));
+    int rc = ensure(h, h->misc, sizeof(double) * (size_t)nprob * n * n);
+    if (rc) return rc;
     {
         Timed t(h, NLH_K_LMPAR);
         size_t sh = sizeof(double) * (size_t)(5 * n + 64);
         hipLaunchKernelGGL(k_lmpar_standalone, dim3(nprob), dim3(factor_threads(n)), sh, h->stream, n, dR, ldr, dipvt,
-                           ddiag, dqtf, ddelta, dtailsq, dpar, dxstep, dsdiag);
+                           ddiag, dqtf, ddelta, dtailsq, dpar, dxstep, dsdiag, (double *)h->misc.p);
     }
     HIPCHK(h, hipGetLastError());
     return 0;

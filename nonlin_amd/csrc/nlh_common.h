@@ -30,6 +30,8 @@ struct LmState {
     int32_t flag;          // NL_* failure flag (:358-363)
     int32_t qr_count;      // diagnostics: how many QR fallbacks happened
     int32_t head_done;     // the outer-loop head already ran in this outer iteration
+    int32_t signs_done;    // normal-equations factors already carry lmfactor's row signs
+    int32_t pad0;
 };
 
 __device__ __forceinline__ double wave_reduce_sum(double v)

@@ -130,28 +130,55 @@ k_qr_exact(int m, int n, double *__restrict__ Jt_all, const double *__restrict__
             const double ajj = a[(size_t)j * n + j];
             // trailing columns (:652-662) and the residual (column index n, :241-253)
             for (int k = j + 1 + tid; k <= n; k += BS) {
+                // column k of the row-major matrix, or the residual vector when k == n
+                double *ck = (k < n) ? (a + k) : w4;
+                const size_t sk = (k < n) ? (size_t)n : 1;
+                const double *cj = a + j;
+                // dot product over rows j..m-1 in ascending order; loads are issued 8 rows ahead
+                // of the (serial) additions so memory latency overlaps the recurrence
+                double sm = 0.0;
+                int i = j;
+                for (; i + 8 <= m; i += 8) {
+                    double vv[8], av[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { vv[u] = cj[(size_t)(i + u) * n]; av[u] = ck[(size_t)(i + u) * sk]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sm = sm + vv[u] * av[u];
+                }
+                for (; i < m; ++i) sm = sm + cj[(size_t)i * n] * ck[(size_t)i * sk];
                 if (k < n) {
-                    double sm = 0.0;
-                    for (int i = j; i < m; ++i) sm = sm + a[(size_t)i * n + j] * a[(size_t)i * n + k];
                     const double temp = sm / ajj;
-                    for (int i = j; i < m; ++i)
-                        a[(size_t)i * n + k] = a[(size_t)i * n + k] - temp * a[(size_t)i * n + j];
+                    i = j;
+                    for (; i + 8 <= m; i += 8) {
+                        double vv[8], av[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { vv[u] = cj[(size_t)(i + u) * n]; av[u] = ck[(size_t)(i + u) * sk]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) ck[(size_t)(i + u) * sk] = av[u] - temp * vv[u];
+                    }
+                    for (; i < m; ++i) ck[(size_t)i * sk] = ck[(size_t)i * sk] - temp * cj[(size_t)i * n];
                     double rk = rdiag[k];
                     if (rk != 0.0) {
                         const double t2 = a[(size_t)j * n + k] / rk;
                         rk = rk * sqrt(fmax(0.0, 1.0 - t2 * t2));
                         const double q = rk / wa[k];
                         if (!(p05 * (q * q) > NLH_EPS)) {
-                            rk = norm2_flang_serial([&](int i) { return a[(size_t)(j + 1 + i) * n + k]; }, m - j - 1);
+                            rk = norm2_flang_serial([&](int i2) { return a[(size_t)(j + 1 + i2) * n + k]; }, m - j - 1);
                             wa[k] = rk;
                         }
                         rdiag[k] = rk;
                     }
                 } else {
-                    double sm = 0.0;
-                    for (int i = j; i < m; ++i) sm = sm + a[(size_t)i * n + j] * w4[i];
-                    const double temp = -sm / ajj;
-                    for (int i = j; i < m; ++i) w4[i] = w4[i] + a[(size_t)i * n + j] * temp;
+                    const double temp = -sm / ajj;                 // :248
+                    i = j;
+                    for (; i + 8 <= m; i += 8) {
+                        double vv[8], av[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { vv[u] = cj[(size_t)(i + u) * n]; av[u] = ck[(size_t)(i + u) * sk]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) ck[(size_t)(i + u) * sk] = av[u] + vv[u] * temp;
+                    }
+                    for (; i < m; ++i) ck[(size_t)i * sk] = ck[(size_t)i * sk] + cj[(size_t)i * n] * temp;
                 }
             }
         }

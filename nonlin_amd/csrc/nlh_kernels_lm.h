@@ -15,28 +15,40 @@
 
 // Faithful lmsolve on the n-by-n R (global, ld = ldr; strict lower triangle is scratch).
 // diagv[l] is the diagonal of sqrt(par) D; x (indexed by original column), sdiag, wa in LDS.
+//
+// The Givens sweeps (:717-765) are run as a wavefront: rotation (j,k) -- elimination of row j
+// of D against column k -- depends only on (j,k-1) and (j-1,k), so all rotations with j + k = t
+// are independent and touch disjoint data (column k of r, working row j).  Time step t runs
+// them concurrently, one wave per rotation, one barrier per step: 2n-1 steps instead of
+// n(n+1)/2 serial rotations.  Every datum still sees exactly the reference's sequence of
+// operations, so the result is bit-identical to the serial sweep.
+// Wrows: n*n doubles of global scratch (working row of elimination j at Wrows + j*n);
+// qtbp: n doubles (LDS), the running qtbpj of each elimination.
 template <bool EXACT>
 __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, const double *diagv,
-                            const double *qtb, double *x, double *sdiag, double *wa, double *red)
+                            const double *qtb, double *x, double *sdiag, double *wa, double *red,
+                            double *Wrows, double *qtbp)
 {
-    const int tid = threadIdx.x, BS = blockDim.x;
+    const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
     for (int j = 0; j < n; ++j) {                              // :710-714
         for (int i = j + tid; i < n; i += BS) r[(size_t)j * ldr + i] = r[(size_t)i * ldr + j];
     }
-    for (int j = tid; j < n; j += BS) { x[j] = r[(size_t)j * ldr + j]; wa[j] = qtb[j]; }
+    for (int j = tid; j < n; j += BS) { x[j] = r[(size_t)j * ldr + j]; wa[j] = qtb[j]; qtbp[j] = 0.0; }
+    for (int e = tid; e < n * n; e += BS) Wrows[e] = 0.0;       // sdiag(j:n) = zero, per elimination (:722)
+    __syncthreads();
+    for (int j = tid; j < n; j += BS) Wrows[(size_t)j * n + j] = diagv[ipvt[j]];   // sdiag(j) = diag(l) (:723)
     __syncthreads();
 
-    for (int j = 0; j < n; ++j) {                              // :717-765
-        const int l = ipvt[j];
-        const double dl = diagv[l];
-        if (dl != 0.0) {
-            for (int k = j + tid; k < n; k += BS) sdiag[k] = (k == j) ? dl : 0.0;
-            __syncthreads();
-            double qtbpj = 0.0;
-            for (int k = j; k < n; ++k) {
-                const double sk = sdiag[k];
-                if (sk == 0.0) continue;                       // uniform
-                const double rkk = r[(size_t)k * ldr + k];
+    for (int t = 0; t <= 2 * (n - 1); ++t) {                   // :717-765 as a wavefront
+        const int jlo = t - (n - 1) > 0 ? t - (n - 1) : 0, jhi = t >> 1;
+        for (int j = jlo + wid; j <= jhi; j += nw) {
+            const int k = t - j;
+            double *Wj = Wrows + (size_t)j * n;
+            double *colk = r + (size_t)k * ldr;
+            const bool act = diagv[ipvt[j]] != 0.0;            // :721
+            const double sk = Wj[k];
+            if (act && sk != 0.0) {                            // :732
+                const double rkk = colk[k];
                 double cs, sn;
                 if (fabs(rkk) < fabs(sk)) {                    // :733-741
                     const double ctan = rkk / sk;
@@ -47,24 +59,22 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
                     cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
                     sn = cs * tn;
                 }
-                const double wk = wa[k];
-                const double temp = cs * wk + sn * qtbpj;
-                qtbpj = -sn * wk + cs * qtbpj;
-                __syncthreads();                               // all have read sdiag[k], wa[k], r(k,k)
-                if (tid == 0) { r[(size_t)k * ldr + k] = cs * rkk + sn * sk; wa[k] = temp; }
-                double *colk = r + (size_t)k * ldr;
-                for (int i = k + 1 + tid; i < n; i += BS) {    // :753-757
-                    const double rik = colk[i], si = sdiag[i];
+                const double wk = wa[k], qj = qtbp[j];
+                for (int i = k + 1 + lane; i < n; i += 64) {   // :753-757
+                    const double rik = colk[i], si = Wj[i];
                     colk[i] = cs * rik + sn * si;
-                    sdiag[i] = -sn * rik + cs * si;
+                    Wj[i] = -sn * rik + cs * si;
                 }
-                __syncthreads();
+                if (lane == 0) {
+                    colk[k] = cs * rkk + sn * sk;              // :745
+                    wa[k] = cs * wk + sn * qj;                 // :746-748
+                    qtbp[j] = -sn * wk + cs * qj;
+                }
             }
-        }
-        __syncthreads();
-        if (tid == 0) {                                        // :763-764
-            sdiag[j] = r[(size_t)j * ldr + j];
-            r[(size_t)j * ldr + j] = x[j];
+            if (k == j && lane == 0) {                         // :763-764 (column j is final after (j,j))
+                sdiag[j] = (act && sk != 0.0) ? colk[j] : r[(size_t)j * ldr + j];
+                colk[j] = x[j];
+            }
         }
         __syncthreads();
     }
@@ -98,7 +108,7 @@ template <bool EXACT>
 __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, const double *diag,
                          const double *qtb, double delta, double *par_io, double tailsq,
                          const double *wa4, double *x, double *sdiag, double *wa1, double *wa2n,
-                         double *z, double *red, double *scratch, int ne_mode)
+                         double *z, double *red, double *scratch, double *Wrows, int ne_mode)
 {
     const int tid = threadIdx.x, BS = blockDim.x;
     const double p1 = 0.1, p001 = 1.0e-3;
@@ -173,7 +183,7 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
         __syncthreads();
         for (int i = tid; i < n; i += BS) wa1[i] = temp * diag[i];
         __syncthreads();
-        lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red);
+        lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red, Wrows, z);
         for (int i = tid; i < n; i += BS) wa2n[i] = diag[i] * x[i];
         __syncthreads();
         if (EXACT) {                                           // :531 deviation A: norm over all m entries
@@ -219,12 +229,60 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
     return 0;
 }
 
+// Normal-equations path, trust region binding.  lmpar's iteration is not invariant under the
+// row signs of R (its deviation B mixes rows of R with rows of S, :552), so the Cholesky factor
+// R~ (positive diagonal) has to be given lmfactor's signs: R = S R~, qtf = S qtf~ with
+// s_j = -sign of the j-th pivot entry Householder sees.  Those signs follow from the top n-by-n
+// block of the positive thin Q, W = (J P)(1:n,:) R~^-1, by a sign-tracking LU of W - S
+// (Householder reconstruction): s_j = -sgn(W_jj) after j-1 elimination steps, pivot W_jj - s_j.
+// O(n^3) on n-by-n data instead of an O(m n^2) QR.  W: n*n global scratch; sg, rowj, lcol: LDS n.
+__device__ void ne_recover_signs(int m, int n, const double *J, const int32_t *ipvt, double *R,
+                                 double *qtf, double *W, double *sg, double *rowj, double *lcol)
+{
+    const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
+    for (int i = tid; i < n; i += BS) {                         // row i of W = (row i of J P) R~^-1
+        for (int c = 0; c < n; ++c) {
+            double acc = J[(size_t)ipvt[c] * m + i];
+            const double *Rc = R + (size_t)c * n;
+            for (int k = 0; k < c; ++k) acc = acc - W[(size_t)k * n + i] * Rc[k];
+            W[(size_t)c * n + i] = acc / Rc[c];
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double wjj = W[(size_t)j * n + j];
+        const double sj = (wjj < 0.0) ? 1.0 : -1.0;             // lmfactor :644 / :665
+        const double piv = wjj - sj;
+        for (int c = j + 1 + tid; c < n; c += BS) {
+            rowj[c] = W[(size_t)c * n + j];
+            lcol[c] = W[(size_t)j * n + c] / piv;
+        }
+        if (tid == 0) sg[j] = sj;
+        __syncthreads();
+        for (int c = j + 1 + wid; c < n; c += nw) {
+            const double rc = rowj[c];
+            double *col = W + (size_t)c * n;
+            for (int i = j + 1 + lane; i < n; i += 64) col[i] = col[i] - lcol[i] * rc;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += BS) {                     // R = S R~ (upper triangle), qtf = S qtf~
+        const int i = e % n, c = e / n;
+        if (i <= c && sg[i] < 0.0) R[e] = -R[e];
+    }
+    for (int j = tid; j < n; j += BS)
+        if (sg[j] < 0.0) qtf[j] = -qtf[j];
+    __syncthreads();
+}
+
 // lmpar for every problem whose factors are ready, then the step and trial point.
 // Dynamic LDS: (5n + 64) doubles, plus 3*NLH_NCH + 8 when EXACT.
 template <bool EXACT>
 __global__ void __launch_bounds__(1024)
 k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
-        const double *__restrict__ wa4all, LmState *__restrict__ st, int want_stage)
+        const double *__restrict__ wa4all, double *__restrict__ Wall /* [nprob][m*n] scratch */,
+        const double *__restrict__ Jall, double *__restrict__ W2all /* [nprob][n*n] scratch */,
+        LmState *__restrict__ st, int want_stage)
 {
     extern __shared__ double smem[];
     const int p = blockIdx.x;
@@ -243,12 +301,33 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
 
     double par = s->par;
     const double delta = s->delta;
-    const int rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, s->tailsq,
-                                    wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch, ne_mode);
+    int rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, s->tailsq,
+                              wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
+                              Wall + (size_t)p * m * n, ne_mode);
     __syncthreads();
-    if (rc) {                       // Gauss-Newton step rejected on the normal-equations path
-        if (tid == 0) s->stage = ST_NEED_QR;
-        return;
+    if (rc) {
+        // Gauss-Newton step rejected on the normal-equations path: give the factors lmfactor's
+        // signs, reconstruct ||(Q^T f)(n+1:m)||^2 = ||f||^2 - ||qtf||^2 for deviation A on the
+        // first inner pass (later passes use the rejected trial residual's tail), run full lmpar.
+        double tailsq = s->tailsq;
+        double *qtfw = v.qtf + (size_t)p * n;
+        if (!s->signs_done) {
+            ne_recover_signs(m, n, Jall + (size_t)p * m * n, ipvt, R, qtfw, W2all + (size_t)p * n * n, xs, sdiag, wa1);
+        }
+        if (s->inner_pass == 0) {
+            double q2 = 0.0;
+            for (int j = tid; j < n; j += BS) q2 = q2 + qtfw[j] * qtfw[j];
+            q2 = block_reduce_sum(q2, red);
+            const double f2 = s->fnorm * s->fnorm;
+            tailsq = f2 > q2 ? f2 - q2 : 0.0;
+        }
+        __syncthreads();
+        if (tid == 0) { s->signs_done = 1; s->tailsq = tailsq; }
+        par = s->par;
+        rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, tailsq,
+                              wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
+                              Wall + (size_t)p * m * n, 0);
+        __syncthreads();
     }
     // :286-291  p = -x_lmpar ; trial = x + p ; pnorm = ||D p||
     double *pw = v.wa1 + (size_t)p * n, *tw = v.wa2 + (size_t)p * n;
@@ -369,6 +448,6 @@ k_lm_update(int m, int n, int nblk, const double *__restrict__ part, LmVecs v,
     s->xcnvrg = xcnvrg;
     s->flag = flag;
     if (fcnvrg || xcnvrg || flag) s->stage = ST_DONE;
-    else if (accept) { s->stage = ST_NEED_JAC; s->inner_pass = 0; s->head_done = 0; }
+    else if (accept) { s->stage = ST_NEED_JAC; s->inner_pass = 0; s->head_done = 0; s->signs_done = 0; }
     else s->stage = (fkind == 1) ? ST_QR_READY : ST_NE_READY;   // inner loop again
 }
