@@ -1,0 +1,95 @@
+! nonlin_hip_c.f90 -- ISO_C_BINDING view of include/nonlin_hip.h (libnonlin_hip.so).
+! One interface body per C entry point the Fortran shim uses; struct layouts mirror the header.
+module nonlin_hip_c
+    use, intrinsic :: iso_c_binding
+    implicit none
+    public
+
+    type, bind(C) :: nlh_iteration_behavior
+        integer(c_int32_t) :: iter_count, fcn_count, jacobian_count, gradient_count
+        integer(c_int32_t) :: converge_on_fcn, converge_on_chng, converge_on_zero_diff
+    end type
+
+    type, bind(C) :: nlh_options
+        integer(c_int32_t) :: max_evals
+        real(c_double) :: ftol, xtol, gtol
+        integer(c_int32_t) :: print_status
+        real(c_double) :: factor
+        integer(c_int32_t) :: use_line_search, ls_max_evals
+        real(c_double) :: ls_alpha, ls_factor
+        integer(c_int32_t) :: factor_policy
+        real(c_double) :: ne_pivot_tol
+    end type
+
+    integer(c_int32_t), parameter :: NLH_FACTOR_AUTO = 0, NLH_FACTOR_QR = 1, NLH_FACTOR_EXACT = 2
+
+    interface
+        subroutine nlh_default_options(opts) bind(C, name="nlh_default_options")
+            import :: nlh_options
+            type(nlh_options), intent(out) :: opts
+        end subroutine
+        function nlh_create(h, device, stream) bind(C, name="nlh_create") result(rc)
+            import :: c_ptr, c_int, c_int32_t
+            type(c_ptr), intent(out) :: h
+            integer(c_int32_t), value :: device
+            type(c_ptr), value :: stream
+            integer(c_int) :: rc
+        end function
+        subroutine nlh_destroy(h) bind(C, name="nlh_destroy")
+            import :: c_ptr
+            type(c_ptr), value :: h
+        end subroutine
+        function nlh_fd_jacobian(h, m, n, fcn, jacfcn, ctx, x, fv, jac) bind(C, name="nlh_fd_jacobian") result(rc)
+            import :: c_ptr, c_funptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: h
+            integer(c_int32_t), value :: m, n
+            type(c_funptr), value :: fcn, jacfcn
+            type(c_ptr), value :: ctx
+            real(c_double), intent(inout) :: x(*)
+            type(c_ptr), value :: fv
+            real(c_double), intent(out) :: jac(*)
+            integer(c_int) :: rc
+        end function
+        function nlh_lm_solve(h, opts, m, n, fcn, jacfcn, ctx, x, fvec, ib) bind(C, name="nlh_lm_solve") result(rc)
+            import :: c_ptr, c_funptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h
+            type(nlh_options), intent(in) :: opts
+            integer(c_int32_t), value :: m, n
+            type(c_funptr), value :: fcn, jacfcn
+            type(c_ptr), value :: ctx
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fvec(*)
+            type(nlh_iteration_behavior), intent(out) :: ib
+            integer(c_int) :: rc
+        end function
+        function nlh_newton_solve(h, opts, n, fcn, jacfcn, ctx, x, fvec, ib) bind(C, name="nlh_newton_solve") result(rc)
+            import :: c_ptr, c_funptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h
+            type(nlh_options), intent(in) :: opts
+            integer(c_int32_t), value :: n
+            type(c_funptr), value :: fcn, jacfcn
+            type(c_ptr), value :: ctx
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fvec(*)
+            type(nlh_iteration_behavior), intent(out) :: ib
+            integer(c_int) :: rc
+        end function
+    end interface
+
+    type(c_ptr), save, private :: default_handle = c_null_ptr
+
+contains
+    !> Lazily created process-wide handle on device 0, default stream.
+    function nlh_default_handle() result(h)
+        type(c_ptr) :: h
+        integer(c_int) :: rc
+        if (.not.c_associated(default_handle)) then
+            rc = nlh_create(default_handle, 0_c_int32_t, c_null_ptr)
+            if (rc /= 0) then
+                print '(A,I0)', "nonlin_hip: no usable HIP device (nlh_create returned ", rc
+                error stop 1
+            end if
+        end if
+        h = default_handle
+    end function
+end module

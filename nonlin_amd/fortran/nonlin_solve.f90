@@ -1,0 +1,140 @@
+! line_search_solver and newton_solver with the reference's public interface
+! (src/nonlin_solve.f90:20-41, 60-67, 92-151); solve marshals to nlh_newton_solve (ns_solve, :452-638).
+module nonlin_solve
+    use iso_fortran_env
+    use, intrinsic :: iso_c_binding
+    use nonlin_error_handling
+    use nonlin_multi_eqn_mult_var
+    use nonlin_linesearch
+    use nonlin_types
+    use nonlin_hip_c
+    implicit none
+    private
+    public :: line_search_solver
+    public :: newton_solver
+
+    type, abstract, extends(equation_solver) :: line_search_solver
+        class(line_search), private, allocatable :: m_lineSearch
+        logical, private :: m_useLineSearch = .true.
+    contains
+        procedure, public :: get_line_search => lss_get_line_search
+        procedure, public :: set_line_search => lss_set_line_search
+        procedure, public :: set_default_line_search => lss_set_default
+        procedure, public :: is_line_search_defined => lss_is_line_search_defined
+        procedure, public :: get_use_line_search => lss_get_use_search
+        procedure, public :: set_use_line_search => lss_set_use_search
+    end type
+
+    type, extends(line_search_solver) :: newton_solver
+    contains
+        procedure, public :: solve => ns_solve
+    end type
+
+contains
+    subroutine lss_get_line_search(this, ls)
+        class(line_search_solver), intent(in) :: this
+        class(line_search), intent(out), allocatable :: ls
+        if (allocated(this%m_lineSearch)) allocate(ls, source = this%m_lineSearch)
+    end subroutine
+
+    subroutine lss_set_line_search(this, ls)
+        class(line_search_solver), intent(inout) :: this
+        class(line_search), intent(in) :: ls
+        if (allocated(this%m_lineSearch)) deallocate(this%m_lineSearch)
+        allocate(this%m_lineSearch, source = ls)
+    end subroutine
+
+    subroutine lss_set_default(this)
+        class(line_search_solver), intent(inout) :: this
+        type(line_search) :: ls
+        call this%set_line_search(ls)
+    end subroutine
+
+    pure function lss_is_line_search_defined(this) result(x)
+        class(line_search_solver), intent(in) :: this
+        logical :: x
+        x = allocated(this%m_lineSearch)
+    end function
+
+    pure function lss_get_use_search(this) result(x)
+        class(line_search_solver), intent(in) :: this
+        logical :: x
+        x = this%m_useLineSearch
+    end function
+
+    subroutine lss_set_use_search(this, x)
+        class(line_search_solver), intent(inout) :: this
+        logical, intent(in) :: x
+        this%m_useLineSearch = x
+    end subroutine
+
+    subroutine ns_solve(this, fcn, x, fvec, ib, args)
+        class(newton_solver), intent(inout) :: this
+        class(vecfcn_helper), intent(in), target :: fcn
+        real(real64), intent(inout), dimension(:) :: x
+        real(real64), intent(out), dimension(:) :: fvec
+        type(iteration_behavior), optional :: ib
+        class(*), intent(inout), optional, target :: args
+
+        integer(int32) :: neqn, nvar, flag
+        integer(c_int) :: rc
+        type(nlh_options) :: opts
+        type(nlh_iteration_behavior) :: cib
+        type(nlh_callback_ctx), target :: ctx
+        type(c_funptr) :: cjac
+        real(c_double), allocatable :: xc(:), fc(:)
+        class(line_search), allocatable :: ls
+
+        neqn = fcn%get_equation_count()
+        nvar = fcn%get_variable_count()
+        if (present(ib)) then           ! :502-510
+            ib%iter_count = 0; ib%fcn_count = 0; ib%jacobian_count = 0; ib%gradient_count = 0
+            ib%converge_on_fcn = .false.; ib%converge_on_chng = .false.; ib%converge_on_zero_diff = .false.
+        end if
+        call nlh_default_options(opts)
+        if (this%get_use_line_search()) then        ! :511-515
+            if (.not.this%is_line_search_defined()) call this%set_default_line_search()
+            call this%get_line_search(ls)
+            opts%ls_max_evals = ls%get_max_fcn_evals()
+            opts%ls_alpha = ls%get_scaling_factor()
+            opts%ls_factor = ls%get_distance_factor()
+        end if
+        if (.not.fcn%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR    ! :518
+        if (nvar /= neqn) error stop NL_INVALID_INPUT_ERROR                      ! :519
+        flag = 0
+        if (size(x) /= nvar) then
+            flag = 3
+        else if (size(fvec) /= neqn) then
+            flag = 4
+        end if
+        if (flag /= 0) error stop flag
+
+        opts%max_evals = this%get_max_fcn_evals()
+        opts%ftol = this%get_fcn_tolerance()
+        opts%xtol = this%get_var_tolerance()
+        opts%gtol = this%get_gradient_tolerance()
+        opts%print_status = merge(1, 0, this%get_print_status())
+        opts%use_line_search = merge(1, 0, this%get_use_line_search())
+
+        ctx%helper => fcn
+        if (present(args)) ctx%args => args
+        cjac = c_null_funptr
+        if (fcn%is_jacobian_defined()) cjac = c_funloc(nlh_jacfcn_trampoline)
+        allocate(xc(nvar), fc(neqn))
+        xc = x
+        rc = nlh_newton_solve(nlh_default_handle(), opts, nvar, c_funloc(nlh_vecfcn_trampoline), cjac, &
+            c_loc(ctx), xc, fc, cib)
+        x = xc
+        fvec = fc
+        if (present(ib)) then           ! :624-632
+            ib%iter_count = cib%iter_count
+            ib%fcn_count = cib%fcn_count
+            ib%jacobian_count = cib%jacobian_count
+            ib%gradient_count = 0
+            ib%converge_on_fcn = cib%converge_on_fcn /= 0
+            ib%converge_on_chng = cib%converge_on_chng /= 0
+            ib%converge_on_zero_diff = cib%converge_on_zero_diff /= 0
+        end if
+        if (rc /= 0) error stop rc      ! :635-637, :604-608, line-search stops
+    end subroutine
+end module

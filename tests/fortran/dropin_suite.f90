@@ -1,0 +1,191 @@
+! Drop-in check of the Fortran shim: user code written against nonlin's API (use nonlin;
+! vecfcn_helper / least_squares_solver / newton_solver / iteration_behavior) runs unchanged on
+! the GPU library.  Problems are the reference's own test problems (tests/nonlin_test_solve.f90,
+! tests/nonlin_test_jacobian.f90, README Example 2).  Every result is printed as
+!   <case> <iter> <fcn> <jac> <cf> <cx> <cg> <hex x...>
+! and compared with the CPU oracle by tests/test_gpu_fortran.py.
+module dropin_problems
+    use iso_fortran_env
+    implicit none
+contains
+    subroutine fcn1(x, f, args)
+        real(real64), intent(in), dimension(:) :: x
+        real(real64), intent(out), dimension(:) :: f
+        class(*), intent(inout), optional :: args
+        f(1) = x(1)**2 + x(2)**2 - 34.0d0
+        f(2) = x(1)**2 - 2.0d0 * x(2)**2 - 7.0d0
+    end subroutine
+
+    subroutine jac1(x, j, args)
+        real(real64), intent(in), dimension(:) :: x
+        real(real64), intent(out), dimension(:,:) :: j
+        class(*), intent(inout), optional :: args
+        j(1,1) = 2.0d0 * x(1)
+        j(2,1) = 2.0d0 * x(1)
+        j(1,2) = 2.0d0 * x(2)
+        j(2,2) = 2.0d0 * (-2.0d0 * x(2))
+    end subroutine
+
+    subroutine fcn1a(x, f, args)
+        real(real64), intent(in), dimension(:) :: x
+        real(real64), intent(out), dimension(:) :: f
+        class(*), intent(inout), optional :: args
+        real(real64) :: a
+        a = 0.0d0
+        select type (args)
+        type is (real(real64))
+            a = args
+        end select
+        f(1) = x(1)**2 + x(2)**2 - 34.0d0
+        f(2) = x(1)**2 - a * x(2)**2 - 7.0d0
+    end subroutine
+
+    subroutine fcn2(x, f, args)
+        real(real64), intent(in), dimension(:) :: x
+        real(real64), intent(out), dimension(:) :: f
+        class(*), intent(inout), optional :: args
+        f(1) = x(2) - 10.0d0
+        f(2) = x(1) * x(2) - 5.0d4
+    end subroutine
+
+    subroutine cubicfit(x, f, args)
+        real(real64), intent(in), dimension(:) :: x
+        real(real64), intent(out), dimension(:) :: f
+        class(*), intent(inout), optional :: args
+        real(real64), dimension(21) :: xp, yp
+        xp = [0.0d0, 0.1d0, 0.2d0, 0.3d0, 0.4d0, 0.5d0, 0.6d0, 0.7d0, 0.8d0, &
+            0.9d0, 1.0d0, 1.1d0, 1.2d0, 1.3d0, 1.4d0, 1.5d0, 1.6d0, 1.7d0, &
+            1.8d0, 1.9d0, 2.0d0]
+        yp = [1.216737514d0, 1.250032542d0, 1.305579195d0, 1.040182335d0, &
+            1.751867738d0, 1.109716707d0, 2.018141531d0, 1.992418729d0, &
+            1.807916923d0, 2.078806005d0, 2.698801324d0, 2.644662712d0, &
+            3.412756702d0, 4.406137221d0, 4.567156645d0, 4.999550779d0, &
+            5.652854194d0, 6.784320119d0, 8.307936836d0, 8.395126494d0, &
+            10.30252404d0]
+        f = x(1) * xp**3 + x(2) * xp**2 + x(3) * xp + x(4) - yp
+    end subroutine
+
+    subroutine polar(x, f, args)
+        real(real64), intent(in), dimension(:) :: x
+        real(real64), intent(out), dimension(:) :: f
+        class(*), intent(inout), optional :: args
+        f(1) = x(1) * cos(x(2))
+        f(2) = x(1) * sin(x(2))
+    end subroutine
+end module
+
+program dropin_suite
+    use iso_fortran_env
+    use nonlin
+    use dropin_problems
+    implicit none
+
+    type(vecfcn_helper) :: obj
+    procedure(vecfcn), pointer :: fcn
+    procedure(jacobianfcn), pointer :: jac
+    type(least_squares_solver) :: lm
+    type(newton_solver) :: nt
+    type(iteration_behavior) :: ib
+    real(real64) :: x2(2), f2(2), x4(4), f21(21), a, numjac(2,2), ics(2)
+    integer :: k
+
+    ! README Example 2 (BASELINE config 1)
+    fcn => cubicfit
+    call obj%set_fcn(fcn, 21, 4)
+    x4 = 1.0d0
+    call lm%solve(obj, x4, f21, ib)
+    call report("lm_readme", ib, x4)
+    print '(A,F12.10)', "# c0: ", x4(4)
+    print '(A,F7.5)', "# Max Residual: ", maxval(abs(f21))
+
+    ! test_least_squares_1 / _4: fcn1, FD then analytic, two starts
+    ics = [0.5d0, 1.0d0]
+    fcn => fcn1
+    do k = 1, 2
+        call set_plain(obj, fcn)
+        x2 = ics(k)
+        call lm%solve(obj, x2, f2, ib)
+        call report("lm_fcn1_fd", ib, x2)
+    end do
+    jac => jac1
+    call obj%set_jacobian(jac)
+    do k = 1, 2
+        x2 = ics(k)
+        call lm%solve(obj, x2, f2, ib)
+        call report("lm_fcn1_an", ib, x2)
+    end do
+
+    ! test_least_squares_2: badly scaled, 1000 evaluations allowed
+    block
+        type(vecfcn_helper) :: o2
+        type(least_squares_solver) :: lm2
+        fcn => fcn2
+        call o2%set_fcn(fcn, 2, 2)
+        call lm2%set_max_fcn_evals(1000)
+        do k = 1, 2
+            x2 = ics(k)
+            call lm2%solve(o2, x2, f2, ib)
+            call report("lm_fcn2", ib, x2)
+        end do
+    end block
+
+    ! args pass-through (class(*) -> real64), Newton with FD Jacobian (test_newton_3a)
+    block
+        type(vecfcn_helper) :: o3
+        fcn => fcn1a
+        call o3%set_fcn(fcn, 2, 2)
+        a = 2.0d0
+        x2 = 1.0d0
+        call nt%solve(o3, x2, f2, ib, args = a)
+        call report("newton_fcn1a_fd", ib, x2)
+    end block
+
+    ! test_newton_1: analytic Jacobian, line search on
+    block
+        type(vecfcn_helper) :: o4
+        fcn => fcn1
+        jac => jac1
+        call o4%set_fcn(fcn, 2, 2)
+        call o4%set_jacobian(jac)
+        x2 = 1.0d0
+        call nt%solve(o4, x2, f2, ib)
+        call report("newton_fcn1_an", ib, x2)
+    end block
+
+    ! test_newton_2: line search off, FD Jacobian
+    block
+        type(vecfcn_helper) :: o5
+        type(newton_solver) :: nt2
+        fcn => fcn2
+        call o5%set_fcn(fcn, 2, 2)
+        call nt2%set_use_line_search(.false.)
+        x2 = 0.5d0
+        call nt2%solve(o5, x2, f2, ib)
+        call report("newton_fcn2_nols", ib, x2)
+    end block
+
+    ! test_jacobian_1: vecfcn_helper%jacobian (no fv)
+    block
+        type(vecfcn_helper) :: o6
+        fcn => polar
+        call o6%set_fcn(fcn, 2, 2)
+        x2 = [0.5d0, -0.5d0]
+        call o6%jacobian(x2, numjac)
+        print '(A,4(1X,Z16.16))', "jac_polar 0 0 0 0 0 0", numjac(1,1), numjac(2,1), numjac(1,2), numjac(2,2)
+    end block
+
+contains
+    subroutine set_plain(o, f)
+        type(vecfcn_helper), intent(out) :: o
+        procedure(vecfcn), pointer, intent(in) :: f
+        call o%set_fcn(f, 2, 2)
+    end subroutine
+
+    subroutine report(name, b, x)
+        character(len=*), intent(in) :: name
+        type(iteration_behavior), intent(in) :: b
+        real(real64), intent(in) :: x(:)
+        print '(A,3(1X,I0),3(1X,L1),*(1X,Z16.16))', name, b%iter_count, b%fcn_count, b%jacobian_count, &
+            b%converge_on_fcn, b%converge_on_chng, b%converge_on_zero_diff, x
+    end subroutine
+end program

@@ -12,9 +12,11 @@ import math
 import numpy as np
 
 
+# Fortran evaluates x**2 as x*x; Python's ** goes through pow(), which is not guaranteed to be
+# correctly rounded, so squares are written as products here.
 def fcn1(x, f, args=None):
-    f[0] = x[0] ** 2 + x[1] ** 2 - 34.0
-    f[1] = x[0] ** 2 - 2.0 * x[1] ** 2 - 7.0
+    f[0] = x[0] * x[0] + x[1] * x[1] - 34.0
+    f[1] = x[0] * x[0] - 2.0 * (x[1] * x[1]) - 7.0
 
 
 def jac1(x, J, args=None):
@@ -26,8 +28,8 @@ def jac1(x, J, args=None):
 
 def fcn1a(x, f, args=None):
     a = float(args)
-    f[0] = x[0] ** 2 + x[1] ** 2 - 34.0
-    f[1] = x[0] ** 2 - a * x[1] ** 2 - 7.0
+    f[0] = x[0] * x[0] + x[1] * x[1] - 34.0
+    f[1] = x[0] * x[0] - a * (x[1] * x[1]) - 7.0
 
 
 def jac1a(x, J, args=None):

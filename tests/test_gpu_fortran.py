@@ -1,0 +1,86 @@
+"""GPU test of the Fortran drop-in layer: a program written against nonlin's own API
+(`use nonlin`, vecfcn_helper, least_squares_solver, newton_solver, iteration_behavior) linked with
+nonlin_amd/fortran (ISO_C_BINDING shim) + libnonlin_hip.so, compared with the CPU oracle.
+The shim's default factor policy is NLH_FACTOR_EXACT, so x is compared bit for bit."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import problems_ref as P
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+EXE = os.path.join(HERE, "fortran", "build", "dropin_suite")
+
+
+def _unhex(h):
+    return struct.unpack(">d", bytes.fromhex(h))[0]
+
+
+@pytest.fixture(scope="module")
+def results():
+    if not os.path.exists(EXE):
+        if not (shutil.which("amdflang") or os.path.exists("/opt/rocm/bin/amdflang")):
+            pytest.skip("no Fortran compiler and no prebuilt tests/fortran/build/dropin_suite")
+        root = os.path.dirname(HERE)
+        subprocess.check_call(["make", "-C", os.path.join(root, "nonlin_amd", "fortran"), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "fortran"), "-s"])
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    res = {}
+    for line in out.stdout.splitlines():
+        t = line.split()
+        if not t or t[0].startswith("#"):
+            continue
+        res.setdefault(t[0], []).append({
+            "counts": (int(t[1]), int(t[2]), int(t[3])), "flags": tuple(t[4:7]),
+            "x": np.array([_unhex(h) for h in t[7:]])})
+    res["_stdout"] = out.stdout
+    return res
+
+
+def _cmp(r, rc, xo, ibo):
+    assert rc == 0
+    assert r["counts"] == (ibo["iter_count"], ibo["fcn_count"], ibo["jacobian_count"]), (r, ibo)
+    assert r["flags"] == tuple("T" if ibo[k] else "F" for k in ("converge_on_fcn", "converge_on_chng", "converge_on_zero_diff"))
+    assert np.array_equal(r["x"], xo), (r["x"], xo)
+
+
+def test_readme_example_2(results, oracle):
+    rc, xo, fo, ibo = oracle.lm_solve(lambda x, f: P.lsfcn1(x, f, None), 21, 4, [1.0] * 4)
+    _cmp(results["lm_readme"][0], rc, xo, ibo)
+    assert "# c0: 1.1866142244" in results["_stdout"]            # README.md:165-171
+    assert "# Max Residual: 0.50636" in results["_stdout"]
+
+
+def test_least_squares_problems(results, oracle):
+    for k, ic in enumerate([(0.5, 0.5), (1.0, 1.0)]):
+        rc, xo, fo, ibo = oracle.lm_solve(lambda x, f: P.fcn1(x, f, None), 2, 2, ic)
+        _cmp(results["lm_fcn1_fd"][k], rc, xo, ibo)
+        rc, xo, fo, ibo = oracle.lm_solve(lambda x, f: P.fcn1(x, f, None), 2, 2, ic, jac=lambda x, J: P.jac1(x, J, None))
+        _cmp(results["lm_fcn1_an"][k], rc, xo, ibo)
+        rc, xo, fo, ibo = oracle.lm_solve(lambda x, f: P.fcn2(x, f, None), 2, 2, ic, opts=oracle.default_options(max_evals=1000))
+        _cmp(results["lm_fcn2"][k], rc, xo, ibo)
+        assert abs(abs(xo[0]) - 5.0e3) <= 1e-6 and abs(abs(xo[1]) - 10.0) <= 1e-6
+
+
+def test_newton_problems(results, oracle):
+    rc, xo, fo, ibo = oracle.newton_solve(lambda x, f: P.fcn1a(x, f, 2.0), 2, [1.0, 1.0])
+    _cmp(results["newton_fcn1a_fd"][0], rc, xo, ibo)                 # class(*) args reached the callback
+    rc, xo, fo, ibo = oracle.newton_solve(lambda x, f: P.fcn1(x, f, None), 2, [1.0, 1.0], jac=lambda x, J: P.jac1(x, J, None))
+    _cmp(results["newton_fcn1_an"][0], rc, xo, ibo)
+    assert results["newton_fcn1_an"][0]["counts"] == (6, 9, 6)       # recorded reference counts
+    rc, xo, fo, ibo = oracle.newton_solve(lambda x, f: P.fcn2(x, f, None), 2, [0.5, 0.5],
+                                          opts=oracle.default_options(use_line_search=0))
+    _cmp(results["newton_fcn2_nols"][0], rc, xo, ibo)
+
+
+def test_fd_jacobian(results):
+    J = results["jac_polar"][0]["x"].reshape(2, 2).T                  # printed column by column
+    E = np.zeros((2, 2), order="F")
+    P.polar_jac(np.array([0.5, -0.5]), E, None)
+    assert np.abs(J - E).max() <= 1e-4                                # tests/nonlin_test_jacobian.f90 tolerance
