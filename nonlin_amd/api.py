@@ -166,7 +166,9 @@ class equation_solver:
         self._gtol = 1.0e-12
         self._print_status = False
         self.handle = None
-        self.factor_policy = 0        # extension: NLH_FACTOR_AUTO / NLH_FACTOR_QR
+        # extension: 2 = NLH_FACTOR_EXACT (default: reference operation order, bit-identical results),
+        # 0 = NLH_FACTOR_AUTO (J^T J + Cholesky), 1 = NLH_FACTOR_QR
+        self.factor_policy = 2
 
     def get_max_fcn_evals(self): return self._max_eval
     def set_max_fcn_evals(self, n): self._max_eval = int(n)
