@@ -47,7 +47,7 @@ struct nlh_handle {
     int64_t launches[NLH_K_COUNT] = {0};
     std::vector<DevBuf *> bufs;       // every workspace buffer, for destroy
     // named workspace buffers (grown on demand, reused across calls)
-    DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2;
+    DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2, R;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
 };
@@ -171,6 +171,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     // allow the single-workgroup kernels their full dynamic LDS (n-vectors live there)
     const int lds_max = 160 * 1024 - 2048;
     hipFuncSetAttribute((const void *)k_chol_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_chol_nopiv<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -397,7 +398,7 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
 static int factor_threads(int n) { return n >= 96 ? 1024 : 256; }
 
 struct LmWs {
-    double *J, *P, *wa4, *scratch, *G, *g, *part, *W2;
+    double *J, *P, *wa4, *scratch, *G, *g, *part, *W2, *R;
     LmVecs v;
     LmState *st;
     int32_t *info;
@@ -414,6 +415,7 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
     if ((rc = ensure(h, h->scratch, sizeof(double) * pm))) return rc;
     if ((rc = ensure(h, h->G, sizeof(double) * (size_t)nprob * n * n))) return rc;
     if ((rc = ensure(h, h->W2, sizeof(double) * (size_t)nprob * n * n))) return rc;
+    if ((rc = ensure(h, h->R, sizeof(double) * (size_t)nprob * n * n))) return rc;
     if ((rc = ensure(h, h->vecs, sizeof(double) * pn * 10))) return rc;
     if ((rc = ensure(h, h->ipvt, sizeof(int32_t) * pn))) return rc;
     if ((rc = ensure(h, h->gvec, sizeof(double) * pn))) return rc;
@@ -425,6 +427,7 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
     w.scratch = (double *)h->scratch.p; w.G = (double *)h->G.p; w.g = (double *)h->gvec.p;
     w.part = (double *)h->part.p; w.st = (LmState *)h->state.p; w.info = (int32_t *)h->info.p;
     w.W2 = (double *)h->W2.p;
+    w.R = (double *)h->R.p;
     double *vb = (double *)h->vecs.p;
     w.v.diag = vb; w.v.diag_prev = vb + pn; w.v.qtf = vb + 2 * pn; w.v.acnorm = vb + 3 * pn;
     w.v.rdiag = vb + 4 * pn; w.v.g = vb + 5 * pn; w.v.wa1 = vb + 6 * pn; w.v.wa2 = vb + 7 * pn;
@@ -439,7 +442,7 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
                               double *dx, const double *dfvec)
 {
     const int ft = factor_threads(n);
-    const size_t shl = sizeof(double) * (size_t)(5 * n + 64);
+    const size_t shl = sizeof(double) * (size_t)(6 * n + 72);
     if (o->factor_policy == NLH_FACTOR_EXACT) {
         // reference operation order: row-major copy of J, exact lmfactor + Q^T f, exact lmpar
         {
@@ -447,38 +450,56 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
             dim3 grid((m + 31) / 32, (n + 31) / 32, nprob);
             hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, w.st, (int)ST_NEED_QR);
             size_t sh = sizeof(double) * (size_t)(2 * n + 64 + 3 * NLH_NCH + 8);
-            hipLaunchKernelGGL(k_qr_exact, dim3(nprob), dim3(ft), sh, h->stream, m, n, w.P, dfvec, w.G, w.v,
+            hipLaunchKernelGGL(k_qr_exact, dim3(nprob), dim3(ft), sh, h->stream, m, n, w.P, dfvec, w.R, w.v,
                                w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, 0);
         }
         {
             Timed t(h, NLH_K_LMPAR);
             hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(ft), shl + sizeof(double) * (3 * NLH_NCH + 8),
-                               h->stream, m, n, w.G, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY);
+                               h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY);
         }
         return 0;
     }
     int rc = launch_gram(h, nprob, m, n, w.J, dfvec, w.G, w.g, w.st, ST_HAVE_JAC);
     if (rc) return rc;
-    {
+    constexpr int NB = 16;
+    {   // fast path: blocked Cholesky in natural order, G -> R
         Timed t(h, NLH_K_CHOL);
-        size_t sh = sizeof(double) * (size_t)(2 * n + 64);
-        hipLaunchKernelGGL(k_chol_factor, dim3(nprob), dim3(ft), sh, h->stream, n, w.G, w.g, w.v, dx, w.st,
-                           (int32_t *)nullptr, o->factor, o->gtol, o->ne_pivot_tol, 0);
+        size_t sh = sizeof(double) * ((size_t)NB * n + NB * NB + n + NB + 64);
+        if (sh <= 150 * 1024) {
+            hipLaunchKernelGGL(k_chol_nopiv<NB>, dim3(nprob), dim3(ft), sh, h->stream, n, w.G, w.g, w.R, w.v, dx, w.st,
+                               o->factor, o->gtol, o->ne_pivot_tol);
+        } else {    // panel does not fit LDS: go straight to the pivoted (unblocked) factorisation
+            size_t sh2 = sizeof(double) * (size_t)(3 * n + 64);
+            hipLaunchKernelGGL(k_chol_factor, dim3(nprob), dim3(ft), sh2, h->stream, n, w.R, w.G, w.g, w.v, dx, w.st,
+                               (int32_t *)nullptr, o->factor, o->gtol, o->ne_pivot_tol, 0, (int)ST_HAVE_JAC);
+        }
     }
     {
         Timed t(h, NLH_K_LMPAR);
-        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.G, w.v, dx, w.wa4, w.P,
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.R, w.v, dx, w.wa4, w.P,
+                           w.J, w.W2, w.st, (int)ST_NE_READY);
+    }
+    {   // problems whose lmpar iteration needs lmfactor's pivot order (or with a weak pivot)
+        Timed t(h, NLH_K_CHOL);
+        size_t sh = sizeof(double) * (size_t)(3 * n + 64);
+        hipLaunchKernelGGL(k_chol_factor, dim3(nprob), dim3(ft), sh, h->stream, n, w.R, w.G, w.g, w.v, dx, w.st,
+                           (int32_t *)nullptr, o->factor, o->gtol, o->ne_pivot_tol, 0, (int)ST_NEED_PCHOL);
+    }
+    {
+        Timed t(h, NLH_K_LMPAR);
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.R, w.v, dx, w.wa4, w.P,
                            w.J, w.W2, w.st, (int)ST_NE_READY);
     }
     {
         Timed t(h, NLH_K_QR);
         size_t sh = sizeof(double) * (size_t)(3 * n + 64);
-        hipLaunchKernelGGL(k_qr_factor, dim3(nprob), dim3(1024), sh, h->stream, m, n, w.J, dfvec, w.G, w.v,
+        hipLaunchKernelGGL(k_qr_factor, dim3(nprob), dim3(1024), sh, h->stream, m, n, w.J, dfvec, w.R, w.v,
                            w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, 0);
     }
     {
         Timed t(h, NLH_K_LMPAR);
-        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.G, w.v, dx, w.wa4, w.P,
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.R, w.v, dx, w.wa4, w.P,
                            w.J, w.W2, w.st, (int)ST_QR_READY);
     }
     return 0;
@@ -1125,9 +1146,10 @@ int nlh_chol_factor(nlh_handle *h, int32_t nprob, int32_t n, double *dG, const d
     nlh_default_options(&o);
     {
         Timed t(h, NLH_K_CHOL);
-        size_t sh = sizeof(double) * (size_t)(2 * n + 64);
-        hipLaunchKernelGGL(k_chol_factor, dim3(nprob), dim3(factor_threads(n)), sh, h->stream, n, dG, dg, v,
-                           (const double *)nullptr, (LmState *)nullptr, dinfo, o.factor, o.gtol, 0.0, 1);
+        size_t sh = sizeof(double) * (size_t)(3 * n + 64);
+        hipLaunchKernelGGL(k_chol_factor, dim3(nprob), dim3(factor_threads(n)), sh, h->stream, n, dG,
+                           (const double *)nullptr, dg, v, (const double *)nullptr, (LmState *)nullptr, dinfo,
+                           o.factor, o.gtol, 0.0, 1, -1);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1165,10 +1187,11 @@ k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const 
     const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
     double *xs = smem, *sdiag = smem + n, *wa1 = smem + 2 * n, *wa2n = smem + 3 * n, *z = smem + 4 * n;
     double *red = smem + 5 * n;
+    double *rot = red + 64;
     double par = par_all[p];
     lmpar_dev<false>(n, n, Rall + (size_t)p * ldr * n, ldr, ipvt_all + (size_t)p * n, diag_all + (size_t)p * n,
                      qtf_all + (size_t)p * n, delta_all[p], &par, tailsq_all[p], nullptr, xs, sdiag, wa1, wa2n, z,
-                     red, nullptr, Wall + (size_t)p * n * n, 0);
+                     red, nullptr, Wall + (size_t)p * n * n, rot, 0);
     __syncthreads();
     for (int j = tid; j < n; j += BS) {
         x_all[(size_t)p * n + j] = xs[j];
@@ -1189,7 +1212,7 @@ int nlh_lmpar(nlh_handle *h, int32_t nprob, int32_t n, double *dR, int32_t ldr, 
     if (rc) return rc;
     {
         Timed t(h, NLH_K_LMPAR);
-        size_t sh = sizeof(double) * (size_t)(5 * n + 64);
+        size_t sh = sizeof(double) * (size_t)(6 * n + 72);
         hipLaunchKernelGGL(k_lmpar_standalone, dim3(nprob), dim3(factor_threads(n)), sh, h->stream, n, dR, ldr, dipvt,
                            ddiag, dqtf, ddelta, dtailsq, dpar, dxstep, dsdiag, (double *)h->misc.p);
     }

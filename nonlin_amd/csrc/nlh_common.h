@@ -15,7 +15,8 @@ enum NlhStage : int32_t {
     ST_QR_READY = 4,   // QR factors valid, lmpar due
     ST_TRIAL_READY = 5,// trial point in wa2, residual evaluation due
     ST_TRIAL_DONE = 6, // residual at trial point in wa4, update due
-    ST_DONE = 7
+    ST_DONE = 7,
+    ST_NEED_PCHOL = 8  // Gram factors with lmfactor's pivot order due (lmpar iteration or weak pivot)
 };
 
 struct LmState {
@@ -31,7 +32,7 @@ struct LmState {
     int32_t qr_count;      // diagnostics: how many QR fallbacks happened
     int32_t head_done;     // the outer-loop head already ran in this outer iteration
     int32_t signs_done;    // normal-equations factors already carry lmfactor's row signs
-    int32_t pad0;
+    int32_t pivoted;       // normal-equations factors use lmfactor's pivot order (else natural order)
 };
 
 __device__ __forceinline__ double wave_reduce_sum(double v)

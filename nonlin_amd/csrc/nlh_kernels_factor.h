@@ -66,36 +66,50 @@ __device__ void lm_head(int n, const double *R, int ldr, const int32_t *ipvt,
 }
 
 // ---------------------------------------------------------------------------
-// Pivoted Cholesky, one workgroup per problem, G (n-by-n, column-major, symmetric,
-// both triangles valid on entry) in global memory/L2; the upper triangle is overwritten
-// by R.  Row j of R is staged in LDS each step so the rank-1 update reads it as a
-// broadcast; columns are updated wave-per-column (contiguous, coalesced).
-// Dynamic LDS: (2n + 64) doubles + 64 ints.
+// Pivoted Cholesky, one workgroup per problem, G (n-by-n, column-major, symmetric, both
+// triangles valid on entry) in global memory/L2; the upper triangle is overwritten by R.
+//
+// Left-looking: step j forms row j of R from the untouched entries G(j,k) and the rows above,
+//   R(j,k) = (G(j,k) - sum_{i<j} R(i,j) R(i,k)) / R(j,j),   one wave per column k,
+// so a step has no trailing-matrix update and only two dependent L2 round trips (the column
+// interchange and the dot products).  Everything a step decides on lives in LDS: the Schur
+// diagonal d (pivot search = "largest remaining column norm", lmfactor :622-625), column j
+// of R (broadcast operand of the dots) and the permuted gradient (qtf is carried as an extra
+// column: qtf(j) = (g_j - sum_i R(i,j) qtf(i)) / R(j,j)).
+// Dynamic LDS: (3n + 64) doubles.
 // standalone != 0: only factor (stage-level entry point nlh_chol_factor).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-k_chol_factor(int n, double *__restrict__ Gall, const double *__restrict__ gall,
+k_chol_factor(int n, double *__restrict__ Gall, const double *__restrict__ Gsrc_all,
+              const double *__restrict__ gall,
               LmVecs v, const double *__restrict__ xall, LmState *__restrict__ st,
               int32_t *__restrict__ info, double factor, double gtol, double pivot_tol,
-              int standalone)
+              int standalone, int want_stage)
 {
     extern __shared__ double smem[];
     const int p = blockIdx.x;
     LmState *s = st ? st + p : nullptr;
-    if (s && s->stage != ST_HAVE_JAC) return;
+    if (s && s->stage != want_stage) return;
     const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
-    double *rowj = smem;            // n   : row j of R
+    double *colj = smem;            // n   : R(0:j, j)
     double *gp = smem + n;          // n   : permuted gradient -> qtf
-    double *red = smem + 2 * n;     // 64
+    double *d = smem + 2 * n;       // n   : Schur diagonal
+    double *red = smem + 3 * n;     // 64
     int *redi = reinterpret_cast<int *>(red + 32);
     double *G = Gall + (size_t)p * n * n;
     int32_t *ipvt = v.ipvt + (size_t)p * n;
     double *acnorm = v.acnorm + (size_t)p * n;
     double *qtf = v.qtf + (size_t)p * n;
 
+    if (Gsrc_all) {                             // factor a copy: the Gram matrix itself is preserved
+        const double *Gs = Gsrc_all + (size_t)p * n * n;
+        for (int e = tid; e < n * n; e += BS) G[e] = Gs[e];
+        __syncthreads();
+    }
     for (int k = tid; k < n; k += BS) {
-        const double d = G[(size_t)k * n + k];
-        acnorm[k] = sqrt(fmax(d, 0.0));        // ||J(:,k)||, lmfactor :611-616
+        const double dk = G[(size_t)k * n + k];
+        d[k] = dk;
+        acnorm[k] = sqrt(fmax(dk, 0.0));        // ||J(:,k)||, lmfactor :611-616
         ipvt[k] = k;
         gp[k] = gall[(size_t)p * n + k];
     }
@@ -107,55 +121,77 @@ k_chol_factor(int n, double *__restrict__ Gall, const double *__restrict__ gall,
         double bv = 0.0;
         int bk = 0x7fffffff;
         for (int k = j + tid; k < n; k += BS) {
-            const double d = G[(size_t)k * n + k];
-            if (bk == 0x7fffffff || d > bv) { bv = d; bk = k; }
+            const double dk = d[k];
+            if (bk == 0x7fffffff || dk > bv) { bv = dk; bk = k; }
         }
         const int q = block_argmax_first(bv, bk, red, redi);
         if (q != j) {                           // symmetric interchange j <-> q (upper storage)
-            for (int r = tid; r < j; r += BS) {
+            for (int r = tid; r < j; r += BS) {                 // rows of R above
                 double t = G[(size_t)j * n + r];
                 G[(size_t)j * n + r] = G[(size_t)q * n + r];
                 G[(size_t)q * n + r] = t;
             }
-            for (int r = j + 1 + tid; r < q; r += BS) {
+            for (int r = j + 1 + tid; r < q; r += BS) {         // untouched entries between j and q
                 double t = G[(size_t)r * n + j];
                 G[(size_t)r * n + j] = G[(size_t)q * n + r];
                 G[(size_t)q * n + r] = t;
             }
-            for (int c = q + 1 + tid; c < n; c += BS) {
+            for (int c = q + 1 + tid; c < n; c += BS) {         // untouched entries right of q
                 double t = G[(size_t)c * n + j];
                 G[(size_t)c * n + j] = G[(size_t)c * n + q];
                 G[(size_t)c * n + q] = t;
             }
             if (tid == 0) {
-                double t = G[(size_t)j * n + j];
-                G[(size_t)j * n + j] = G[(size_t)q * n + q];
-                G[(size_t)q * n + q] = t;
+                double t = d[j]; d[j] = d[q]; d[q] = t;
                 int32_t ti = ipvt[j]; ipvt[j] = ipvt[q]; ipvt[q] = ti;
                 double tg = gp[j]; gp[j] = gp[q]; gp[q] = tg;
             }
             __syncthreads();
         }
-        const double dj = G[(size_t)j * n + j];
+        const double dj = d[j];
         const double an = acnorm[ipvt[j]];
         if (!(dj > pivot_tol * an * an) || !(dj > 0.0)) { bad = j + 1; break; }   // uniform
         const double rjj = sqrt(dj);
-        const double yj = gp[j] / rjj;          // qtf(j)
-        // row j of R
-        for (int c = j + 1 + tid; c < n; c += BS) {
-            const double r = G[(size_t)c * n + j] / rjj;
-            G[(size_t)c * n + j] = r;
-            rowj[c] = r;
-            gp[c] = gp[c] - r * yj;
-        }
+        for (int i = tid; i < j; i += BS) colj[i] = G[(size_t)j * n + i];         // R(0:j, j)
         __syncthreads();
-        if (tid == 0) { G[(size_t)j * n + j] = rjj; gp[j] = yj; }
-        // trailing update of the upper triangle: G(r,c) -= R(j,r) R(j,c), j < r <= c
-        for (int c = j + 1 + wid; c < n; c += nw) {
-            const double rc = rowj[c];
-            double *col = G + (size_t)c * n;
-            for (int r = j + 1 + lane; r <= c; r += 64) col[r] = col[r] - rowj[r] * rc;
+        // row j of R: a wave takes CW columns k > j at a time (independent loads in flight before
+        // the shuffle reductions); column index n is the gradient, i.e. qtf
+        constexpr int CW = 8;
+        for (int k0 = j + 1 + wid * CW; k0 <= n; k0 += nw * CW) {
+            double sm[CW], g0[CW];
+#pragma unroll
+            for (int u = 0; u < CW; ++u) {
+                sm[u] = 0.0;
+                g0[u] = (k0 + u < n) ? G[(size_t)(k0 + u) * n + j] : 0.0;   // untouched G(j,k), loaded up front
+            }
+            for (int i = lane; i < j; i += 64) {
+                const double cj = colj[i];
+                double v[CW];
+#pragma unroll
+                for (int u = 0; u < CW; ++u) {
+                    const int k = k0 + u;
+                    v[u] = (k < n) ? G[(size_t)k * n + i] : ((k == n) ? gp[i] : 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < CW; ++u) sm[u] = sm[u] + cj * v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < CW; ++u) sm[u] = wave_reduce_sum(sm[u]);
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < CW; ++u) {
+                    const int k = k0 + u;
+                    if (k < n) {
+                        const double r = (g0[u] - sm[u]) / rjj;
+                        G[(size_t)k * n + j] = r;
+                        d[k] = d[k] - r * r;
+                    } else if (k == n) {
+                        gp[j] = (gp[j] - sm[u]) / rjj;          // qtf(j)
+                    }
+                }
+            }
         }
+        if (tid == 0) G[(size_t)j * n + j] = rjj;
         __syncthreads();
     }
     if (bad) {
@@ -169,8 +205,160 @@ k_chol_factor(int n, double *__restrict__ Gall, const double *__restrict__ gall,
     if (tid == 0 && info) info[p] = 0;
     __syncthreads();
     if (standalone || !s) return;
-    if (tid == 0) s->factor_kind = 0;
+    if (tid == 0) { s->factor_kind = 0; s->pivoted = 1; }
+    if (s->head_done) {                         // re-factorisation inside an outer iteration: head already ran
+        __syncthreads();
+        if (tid == 0) s->stage = ST_NE_READY;
+        return;
+    }
     lm_head<false>(n, G, n, ipvt, acnorm, qtf, xall + (size_t)p * n, v.diag + (size_t)p * n,
+                   v.diag_prev + (size_t)p * n, s, factor, gtol, ST_NE_READY, red, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// Blocked Cholesky in natural column order (no pivoting): the fast path.
+// When the Gauss-Newton step is accepted (the common case) the step, the scaled gradient norm
+// and the predicted reduction do not depend on lmfactor's pivot order, only on J^T J itself; the
+// pivoted kernel above is run afterwards only for problems that need lmfactor's R (lmpar
+// iteration, weak pivots).  Right-looking with NB-wide panels: the diagonal block is factored
+// in LDS, the block row is a per-column triangular solve (thread per column), and the trailing
+// update is one pass with the panel broadcast from LDS -- n/NB dependent global round trips
+// instead of n.  The gradient rides along as column n (qtf = R^-T g).
+// Dynamic LDS: NB*n + NB*NB + n + NB + 64 doubles.
+// ---------------------------------------------------------------------------
+template <int NB>
+__global__ void __launch_bounds__(1024)
+k_chol_nopiv(int n, const double *__restrict__ Gall, const double *__restrict__ gall,
+             double *__restrict__ Rall, LmVecs v, const double *__restrict__ xall,
+             LmState *__restrict__ st, double factor, double gtol, double pivot_tol)
+{
+    extern __shared__ double smem[];
+    const int p = blockIdx.x;
+    LmState *s = st + p;
+    if (s->stage != ST_HAVE_JAC) return;
+    const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
+    double *panel = smem;                   // NB x n  : rows of R of the current block, panel[i*n + k]
+    double *r11 = panel + (size_t)NB * n;   // NB x NB : diagonal block, r11[i + c*NB] (upper)
+    double *gp = r11 + NB * NB;             // n       : gradient -> qtf
+    double *yb = gp + n;                    // NB      : qtf entries of the current block
+    double *red = yb + NB;                  // 64
+    __shared__ int bad_sh;
+    const double *G = Gall + (size_t)p * n * n;
+    double *R = Rall + (size_t)p * n * n;
+    int32_t *ipvt = v.ipvt + (size_t)p * n;
+    double *acnorm = v.acnorm + (size_t)p * n;
+    double *qtf = v.qtf + (size_t)p * n;
+
+    for (int e = tid; e < n * n; e += BS) R[e] = G[e];
+    for (int k = tid; k < n; k += BS) {
+        acnorm[k] = sqrt(fmax(G[(size_t)k * n + k], 0.0));
+        ipvt[k] = k;
+        gp[k] = gall[(size_t)p * n + k];
+    }
+    if (tid == 0) bad_sh = 0;
+    __syncthreads();
+
+    for (int jb = 0; jb < n; jb += NB) {
+        const int nbk = min(NB, n - jb);
+        // diagonal block -> LDS
+        for (int e = tid; e < NB * NB; e += BS) {
+            const int i = e % NB, c = e / NB;
+            r11[e] = (i <= c && c < nbk) ? R[(size_t)(jb + c) * n + jb + i] : 0.0;
+        }
+        __syncthreads();
+        // factor it: nbk small steps, lanes = columns of the block
+        for (int j = 0; j < nbk; ++j) {
+            const double dj = r11[j + j * NB];
+            const double an = acnorm[jb + j];
+            if (!(dj > pivot_tol * an * an) || !(dj > 0.0)) { if (tid == 0) bad_sh = jb + j + 1; }
+            const double rjj = sqrt(fmax(dj, 1e-300));
+            __syncthreads();
+            if (tid > j && tid < nbk) {
+                const int c = tid;
+                const double rjc = r11[j + c * NB] / rjj;
+                r11[j + c * NB] = rjc;
+            }
+            if (tid == j) r11[j + j * NB] = rjj;
+            __syncthreads();
+            if (tid > j && tid < nbk) {
+                const int c = tid;
+                const double rjc = r11[j + c * NB];
+                for (int i = j + 1; i <= c; ++i) r11[i + c * NB] = r11[i + c * NB] - r11[j + i * NB] * rjc;
+            }
+            __syncthreads();
+        }
+        if (bad_sh) break;                                      // uniform
+        // write the factored diagonal block back
+        for (int e = tid; e < NB * NB; e += BS) {
+            const int i = e % NB, c = e / NB;
+            if (i <= c && c < nbk) R[(size_t)(jb + c) * n + jb + i] = r11[e];
+        }
+        // block row: R12 = R11^-T A12, one thread per column k >= jb + nbk; k == n is the gradient
+        for (int k = jb + nbk + tid; k <= n; k += BS) {
+            double a[NB];
+            if (k < n) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) a[i] = (i < nbk) ? R[(size_t)k * n + jb + i] : 0.0;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) a[i] = (i < nbk) ? gp[jb + i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (i < nbk) {
+                    double acc = a[i];
+#pragma unroll
+                    for (int l = 0; l < NB; ++l)
+                        if (l < i) acc = acc - r11[l + i * NB] * a[l];
+                    a[i] = acc / r11[i + i * NB];
+                }
+            }
+            if (k < n) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (i < nbk) { R[(size_t)k * n + jb + i] = a[i]; panel[(size_t)i * n + k] = a[i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (i < nbk) { gp[jb + i] = a[i]; yb[i] = a[i]; }
+            }
+        }
+        __syncthreads();
+        // trailing update: A22(r,c) -= sum_i R12(i,r) R12(i,c), jb+nbk <= r <= c; gradient likewise
+        const int t0 = jb + nbk;
+        for (int c = t0 + wid; c <= n; c += nw) {
+            if (c < n) {
+                double pc[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) pc[i] = (i < nbk) ? panel[(size_t)i * n + c] : 0.0;
+                double *col = R + (size_t)c * n;
+                for (int r = t0 + lane; r <= c; r += 64) {
+                    double acc = col[r];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i)
+                        if (i < nbk) acc = acc - panel[(size_t)i * n + r] * pc[i];
+                    col[r] = acc;
+                }
+            } else {
+                for (int r = t0 + lane; r < n; r += 64) {
+                    double acc = gp[r];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i)
+                        if (i < nbk) acc = acc - panel[(size_t)i * n + r] * yb[i];
+                    gp[r] = acc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (bad_sh) {
+        if (tid == 0) s->stage = ST_NEED_PCHOL;                 // let the pivoted kernel decide (it may ask for QR)
+        return;
+    }
+    for (int k = tid; k < n; k += BS) qtf[k] = gp[k];
+    __syncthreads();
+    if (tid == 0) { s->factor_kind = 0; s->pivoted = 0; }
+    lm_head<false>(n, R, n, ipvt, acnorm, qtf, xall + (size_t)p * n, v.diag + (size_t)p * n,
                    v.diag_prev + (size_t)p * n, s, factor, gtol, ST_NE_READY, red, nullptr);
 }
 

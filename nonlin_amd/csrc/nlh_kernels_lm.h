@@ -27,7 +27,7 @@
 template <bool EXACT>
 __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, const double *diagv,
                             const double *qtb, double *x, double *sdiag, double *wa, double *red,
-                            double *Wrows, double *qtbp)
+                            double *Wrows, double *qtbp, double *rot /* LDS, n + 8 doubles */)
 {
     const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
     for (int j = 0; j < n; ++j) {                              // :710-714
@@ -41,15 +41,17 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
 
     for (int t = 0; t <= 2 * (n - 1); ++t) {                   // :717-765 as a wavefront
         const int jlo = t - (n - 1) > 0 ? t - (n - 1) : 0, jhi = t >> 1;
-        for (int j = jlo + wid; j <= jhi; j += nw) {
-            const int k = t - j;
+        const int nrot = jhi - jlo + 1;
+        // phase A: one thread per rotation forms (cs, sn) and the scalar updates (:733-748)
+        for (int q = tid; q < nrot; q += BS) {
+            const int j = jlo + q, k = t - j;
             double *Wj = Wrows + (size_t)j * n;
             double *colk = r + (size_t)k * ldr;
             const bool act = diagv[ipvt[j]] != 0.0;            // :721
             const double sk = Wj[k];
+            double cs = 1.0, sn = 0.0;
             if (act && sk != 0.0) {                            // :732
                 const double rkk = colk[k];
-                double cs, sn;
                 if (fabs(rkk) < fabs(sk)) {                    // :733-741
                     const double ctan = rkk / sk;
                     sn = 0.5 / sqrt(0.25 + 0.25 * (ctan * ctan));
@@ -60,20 +62,58 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
                     sn = cs * tn;
                 }
                 const double wk = wa[k], qj = qtbp[j];
-                for (int i = k + 1 + lane; i < n; i += 64) {   // :753-757
-                    const double rik = colk[i], si = Wj[i];
-                    colk[i] = cs * rik + sn * si;
-                    Wj[i] = -sn * rik + cs * si;
-                }
-                if (lane == 0) {
-                    colk[k] = cs * rkk + sn * sk;              // :745
-                    wa[k] = cs * wk + sn * qj;                 // :746-748
-                    qtbp[j] = -sn * wk + cs * qj;
-                }
+                colk[k] = cs * rkk + sn * sk;                  // :745
+                wa[k] = cs * wk + sn * qj;                     // :746-748
+                qtbp[j] = -sn * wk + cs * qj;
+                rot[2 * q] = cs;
+                rot[2 * q + 1] = sn;
+            } else {
+                rot[2 * q] = 2.0;                              // marker: rotation skipped (:732 cycle)
+                rot[2 * q + 1] = 0.0;
             }
-            if (k == j && lane == 0) {                         // :763-764 (column j is final after (j,j))
-                sdiag[j] = (act && sk != 0.0) ? colk[j] : r[(size_t)j * ldr + j];
+            if (k == j) {                                      // :763-764 (column j is final after (j,j))
+                sdiag[j] = colk[j];
                 colk[j] = x[j];
+            }
+        }
+        __syncthreads();
+        // phase B: apply the rotations to the rest of column k and working row j (:753-757);
+        // a wave takes RG rotations at a time so their loads are in flight together
+        constexpr int RG = 4;
+        for (int q0 = wid * RG; q0 < nrot; q0 += nw * RG) {
+            double cs[RG], sn[RG];
+            int kk[RG];
+            double *cp[RG], *wp[RG];
+            int imax = 0;
+#pragma unroll
+            for (int u = 0; u < RG; ++u) {
+                const int q = q0 + u;
+                const bool ok = q < nrot && rot[2 * (q < nrot ? q : 0)] != 2.0;
+                const int j = jlo + (q < nrot ? q : 0), k = t - j;
+                cs[u] = ok ? rot[2 * q] : 1.0;
+                sn[u] = ok ? rot[2 * q + 1] : 0.0;
+                kk[u] = ok ? k : n;                             // n => no elements
+                cp[u] = r + (size_t)k * ldr;
+                wp[u] = Wrows + (size_t)j * n;
+                if (ok && n - k - 1 > imax) imax = n - k - 1;
+            }
+            for (int e = lane; e < imax; e += 64) {
+                double rv[RG], sv[RG];
+#pragma unroll
+                for (int u = 0; u < RG; ++u) {
+                    const int i = kk[u] + 1 + e;
+                    const bool in = i < n;
+                    rv[u] = in ? cp[u][i] : 0.0;
+                    sv[u] = in ? wp[u][i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < RG; ++u) {
+                    const int i = kk[u] + 1 + e;
+                    if (i < n) {
+                        cp[u][i] = cs[u] * rv[u] + sn[u] * sv[u];
+                        wp[u][i] = -sn[u] * rv[u] + cs[u] * sv[u];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -108,7 +148,7 @@ template <bool EXACT>
 __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, const double *diag,
                          const double *qtb, double delta, double *par_io, double tailsq,
                          const double *wa4, double *x, double *sdiag, double *wa1, double *wa2n,
-                         double *z, double *red, double *scratch, double *Wrows, int ne_mode)
+                         double *z, double *red, double *scratch, double *Wrows, double *rot, int ne_mode)
 {
     const int tid = threadIdx.x, BS = blockDim.x;
     const double p1 = 0.1, p001 = 1.0e-3;
@@ -183,7 +223,7 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
         __syncthreads();
         for (int i = tid; i < n; i += BS) wa1[i] = temp * diag[i];
         __syncthreads();
-        lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red, Wrows, z);
+        lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red, Wrows, z, rot);
         for (int i = tid; i < n; i += BS) wa2n[i] = diag[i] * x[i];
         __syncthreads();
         if (EXACT) {                                           // :531 deviation A: norm over all m entries
@@ -244,7 +284,15 @@ __device__ void ne_recover_signs(int m, int n, const double *J, const int32_t *i
         for (int c = 0; c < n; ++c) {
             double acc = J[(size_t)ipvt[c] * m + i];
             const double *Rc = R + (size_t)c * n;
-            for (int k = 0; k < c; ++k) acc = acc - W[(size_t)k * n + i] * Rc[k];
+            int k = 0;
+            for (; k + 8 <= c; k += 8) {
+                double wv[8], rv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { wv[u] = W[(size_t)(k + u) * n + i]; rv[u] = Rc[k + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = acc - wv[u] * rv[u];
+            }
+            for (; k < c; ++k) acc = acc - W[(size_t)k * n + i] * Rc[k];
             W[(size_t)c * n + i] = acc / Rc[c];
         }
     }
@@ -259,10 +307,17 @@ __device__ void ne_recover_signs(int m, int n, const double *J, const int32_t *i
         }
         if (tid == 0) sg[j] = sj;
         __syncthreads();
-        for (int c = j + 1 + wid; c < n; c += nw) {
-            const double rc = rowj[c];
-            double *col = W + (size_t)c * n;
-            for (int i = j + 1 + lane; i < n; i += 64) col[i] = col[i] - lcol[i] * rc;
+        constexpr int CG = 4;
+        for (int c0 = j + 1 + wid * CG; c0 < n; c0 += nw * CG) {
+            for (int i = j + 1 + lane; i < n; i += 64) {
+                const double li = lcol[i];
+                double wv[CG];
+#pragma unroll
+                for (int u = 0; u < CG; ++u) wv[u] = (c0 + u < n) ? W[(size_t)(c0 + u) * n + i] : 0.0;
+#pragma unroll
+                for (int u = 0; u < CG; ++u)
+                    if (c0 + u < n) W[(size_t)(c0 + u) * n + i] = wv[u] - li * rowj[c0 + u];
+            }
         }
         __syncthreads();
     }
@@ -276,7 +331,7 @@ __device__ void ne_recover_signs(int m, int n, const double *J, const int32_t *i
 }
 
 // lmpar for every problem whose factors are ready, then the step and trial point.
-// Dynamic LDS: (5n + 64) doubles, plus 3*NLH_NCH + 8 when EXACT.
+// Dynamic LDS: (6n + 72) doubles, plus 3*NLH_NCH + 8 when EXACT.
 template <bool EXACT>
 __global__ void __launch_bounds__(1024)
 k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
@@ -291,7 +346,8 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
     const int tid = threadIdx.x, BS = blockDim.x;
     double *xs = smem, *sdiag = smem + n, *wa1 = smem + 2 * n, *wa2n = smem + 3 * n, *z = smem + 4 * n;
     double *red = smem + 5 * n;
-    double *scratch = red + 64;
+    double *rot = red + 64;             // n + 8
+    double *scratch = rot + n + 8;
     double *R = Rall + (size_t)p * n * n;
     const int32_t *ipvt = v.ipvt + (size_t)p * n;
     const double *diag = v.diag + (size_t)p * n;
@@ -303,17 +359,28 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
     const double delta = s->delta;
     int rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, s->tailsq,
                               wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
-                              Wall + (size_t)p * m * n, ne_mode);
+                              Wall + (size_t)p * m * n, rot, ne_mode);
     __syncthreads();
+    if (rc && !s->pivoted) {
+        // the lmpar iteration needs lmfactor's pivot order: ask for the pivoted factorisation
+        if (tid == 0) s->stage = ST_NEED_PCHOL;
+        return;
+    }
     if (rc) {
         // Gauss-Newton step rejected on the normal-equations path: give the factors lmfactor's
         // signs, reconstruct ||(Q^T f)(n+1:m)||^2 = ||f||^2 - ||qtf||^2 for deviation A on the
         // first inner pass (later passes use the rejected trial residual's tail), run full lmpar.
         double tailsq = s->tailsq;
         double *qtfw = v.qtf + (size_t)p * n;
+#ifdef NLH_DEBUG_TIMING
+        const unsigned long long tt0 = wall_clock64();
+#endif
         if (!s->signs_done) {
             ne_recover_signs(m, n, Jall + (size_t)p * m * n, ipvt, R, qtfw, W2all + (size_t)p * n * n, xs, sdiag, wa1);
         }
+#ifdef NLH_DEBUG_TIMING
+        const unsigned long long tt1 = wall_clock64();
+#endif
         if (s->inner_pass == 0) {
             double q2 = 0.0;
             for (int j = tid; j < n; j += BS) q2 = q2 + qtfw[j] * qtfw[j];
@@ -326,8 +393,12 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
         par = s->par;
         rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, tailsq,
                               wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
-                              Wall + (size_t)p * m * n, 0);
+                              Wall + (size_t)p * m * n, rot, 0);
         __syncthreads();
+#ifdef NLH_DEBUG_TIMING
+        if (tid == 0) printf("[lmpar p=%d] signs %.3f ms, full lmpar %.3f ms, par=%g\n", p, (tt1 - tt0) * 1e-5,
+                             (wall_clock64() - tt1) * 1e-5, par);
+#endif
     }
     // :286-291  p = -x_lmpar ; trial = x + p ; pnorm = ||D p||
     double *pw = v.wa1 + (size_t)p * n, *tw = v.wa2 + (size_t)p * n;
@@ -448,6 +519,6 @@ k_lm_update(int m, int n, int nblk, const double *__restrict__ part, LmVecs v,
     s->xcnvrg = xcnvrg;
     s->flag = flag;
     if (fcnvrg || xcnvrg || flag) s->stage = ST_DONE;
-    else if (accept) { s->stage = ST_NEED_JAC; s->inner_pass = 0; s->head_done = 0; s->signs_done = 0; }
+    else if (accept) { s->stage = ST_NEED_JAC; s->inner_pass = 0; s->head_done = 0; s->signs_done = 0; s->pivoted = 0; }
     else s->stage = (fkind == 1) ? ST_QR_READY : ST_NE_READY;   // inner loop again
 }
