@@ -361,6 +361,31 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
                               wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
                               Wall + (size_t)p * m * n, rot, ne_mode);
     __syncthreads();
+    bool blowup = false;
+    if (rc && !EXACT) {
+        // Deviation A (:531) adds ||wa4(n+1:m)|| to ||D x|| inside the loop.  If that tail alone exceeds
+        // 1.1*delta the exit test |fp| <= 0.1*delta can never pass for any par: the reference runs its ten
+        // iterations with par growing super-exponentially to +Inf and returns x = 0 (the solve then ends
+        // with converge_on_chng because delta becomes 0).  Produce that outcome directly instead of ten
+        // lmsolve sweeps; the exact policy does not take this shortcut.
+        double tq = s->tailsq;
+        if (s->inner_pass == 0) {
+            const double *qt = v.qtf + (size_t)p * n;
+            double q2 = 0.0;
+            for (int j = tid; j < n; j += BS) q2 = q2 + qt[j] * qt[j];
+            q2 = block_reduce_sum(q2, red);
+            const double f2 = s->fnorm * s->fnorm;
+            tq = f2 > q2 ? f2 - q2 : 0.0;
+        }
+        if (sqrt(tq) > 1.1 * delta * (1.0 + 1.0e-6)) {
+            blowup = true;
+            __syncthreads();
+            for (int j = tid; j < n; j += BS) xs[j] = 0.0;
+            par = __builtin_inf();
+            rc = 0;
+            __syncthreads();
+        }
+    }
     if (rc && !s->pivoted) {
         // the lmpar iteration needs lmfactor's pivot order: ask for the pivoted factorisation
         if (tid == 0) s->stage = ST_NEED_PCHOL;
