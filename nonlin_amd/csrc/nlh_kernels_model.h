@@ -34,13 +34,12 @@ k_dq_residual(int m, int n, const double *__restrict__ A, const double *__restri
         double u = 0.0;
         const double *a = Ap + i;
         int k = 0;
-        for (; k + 4 <= n; k += 4) {
-            double a0 = a[(size_t)(k + 0) * m], a1 = a[(size_t)(k + 1) * m];
-            double a2 = a[(size_t)(k + 2) * m], a3 = a[(size_t)(k + 3) * m];
-            u = u + a0 * xs[k + 0];
-            u = u + a1 * xs[k + 1];
-            u = u + a2 * xs[k + 2];
-            u = u + a3 * xs[k + 3];
+        for (; k + 16 <= n; k += 16) {
+            double av[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) av[q] = a[(size_t)(k + q) * m];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) u = u + av[q] * xs[k + q];
         }
         for (; k < n; ++k) u = u + a[(size_t)k * m] * xs[k];
         r = (u + (gamma * u) * u) - b[(size_t)p * m + i];
@@ -85,8 +84,21 @@ k_dq_panel(int m, int n, const double *__restrict__ A, const double *__restrict_
     const int jt = min(JT, n - j0);    // valid columns in this tile
     const double *a = Ap + i;
 
+    // Loads are issued PF rows ahead of their use: the row sums are serial recurrences, so without
+    // this every iteration would wait out a full memory round trip.
+    constexpr int PF = 8;
     double base = 0.0;
-    for (int k = 0; k < j0; ++k) base = base + a[(size_t)k * m] * xs[k];
+    {
+        int k = 0;
+        for (; k + PF <= j0; k += PF) {
+            double av[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) av[u] = a[(size_t)(k + u) * m];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) base = base + av[u] * xs[k + u];
+        }
+        for (; k < j0; ++k) base = base + a[(size_t)k * m] * xs[k];
+    }
 
     double acc[JT];
 #pragma unroll
@@ -104,10 +116,24 @@ k_dq_panel(int m, int n, const double *__restrict__ A, const double *__restrict_
             for (int jj = 0; jj < JT; ++jj) acc[jj] = acc[jj] + (jj == kk ? pp : pr);
         }
     }
-    for (int k = j0 + JT; k < n; ++k) {
-        const double pr = a[(size_t)k * m] * xs[k];
+    {
+        int k = j0 + JT;
+        for (; k + PF <= n; k += PF) {
+            double av[PF];
 #pragma unroll
-        for (int jj = 0; jj < JT; ++jj) acc[jj] = acc[jj] + pr;
+            for (int u = 0; u < PF; ++u) av[u] = a[(size_t)(k + u) * m];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const double pr = av[u] * xs[k + u];
+#pragma unroll
+                for (int jj = 0; jj < JT; ++jj) acc[jj] = acc[jj] + pr;
+            }
+        }
+        for (; k < n; ++k) {
+            const double pr = a[(size_t)k * m] * xs[k];
+#pragma unroll
+            for (int jj = 0; jj < JT; ++jj) acc[jj] = acc[jj] + pr;
+        }
     }
     const double bi = b[(size_t)p * m + i];
     double *Pp = P + (size_t)p * m * n + i;
