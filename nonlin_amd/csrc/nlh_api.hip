@@ -376,21 +376,20 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
     const int ns = gram_splits(nprob, m, n);
     int rps = (m + ns - 1) / ns;
     rps = ((rps + GRAM_KT - 1) / GRAM_KT) * GRAM_KT;
-    int rc = ensure(h, h->Gpart, sizeof(double) * (size_t)nprob * ns * n * n);
+    int rc = ensure(h, h->Gpart, sizeof(double) * ((size_t)nprob * ns * n * n + (size_t)nprob * ns * n));
     if (rc) return rc;
+    double *Gp = (double *)h->Gpart.p;
+    double *gp = Gp + (size_t)nprob * ns * n * n;
     {
         Timed t(h, NLH_K_GRAM);
-        hipLaunchKernelGGL(k_gram_mfma, dim3(nblk, ns, nprob), dim3(256), 0, h->stream, m, n, rps, J,
-                           (double *)h->Gpart.p, st, want);
+        hipLaunchKernelGGL(k_gram_mfma, dim3(nblk, ns, nprob), dim3(256), 0, h->stream, m, n, rps, J, Gp,
+                           g ? f : (const double *)nullptr, gp, st, want);
     }
     {
         Timed t(h, NLH_K_GRAM_REDUCE);
         dim3 grid((unsigned)(((size_t)n * n + 255) / 256), nprob);
-        hipLaunchKernelGGL(k_gram_reduce, grid, dim3(256), 0, h->stream, n, ns, (const double *)h->Gpart.p, G, st, want);
-    }
-    if (g) {
-        Timed t(h, NLH_K_JTF);
-        hipLaunchKernelGGL(k_jtf, dim3((n + 3) / 4, nprob), dim3(256), 0, h->stream, m, n, J, f, g, st, want);
+        hipLaunchKernelGGL(k_gram_reduce, grid, dim3(256), 0, h->stream, n, ns, (const double *)Gp, G,
+                           (const double *)gp, g, st, want);
     }
     return 0;
 }

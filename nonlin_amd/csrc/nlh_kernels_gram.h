@@ -31,10 +31,13 @@ __device__ __forceinline__ void gram_block_index(int idx, int &bi, int &bj)
 __global__ void __launch_bounds__(256)
 k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
             double *__restrict__ Gpart /* [nprob][nsplit][n*n] */,
+            const double *__restrict__ f /* [nprob][m] or null */,
+            double *__restrict__ gpart /* [nprob][nsplit][n] */,
             const LmState *__restrict__ st, int want_stage)
 {
     __shared__ double tA[GRAM_BT * GRAM_LD];
     __shared__ double tB[GRAM_BT * GRAM_LD];
+    __shared__ double fs[GRAM_KT];
     const int p = blockIdx.z;
     if (st && st[p].stage != want_stage) return;
     int bi, bj;
@@ -60,20 +63,45 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
     const int arow = (wr * 32 + (lane & 15)) * GRAM_LD + (lane >> 4);
     const int brow = (wc * 32 + (lane & 15)) * GRAM_LD + (lane >> 4);
 
-    for (int k0 = kbeg; k0 < kend; k0 += GRAM_KT) {
+    // Software pipeline: the global loads of tile t+1 are issued into registers right after the
+    // barrier that publishes tile t in LDS, so their latency overlaps the MFMA phase of tile t.
+    constexpr int NLD = GRAM_BT / LSTEP;        // loads per thread per tile
+    double ra[NLD], rb[NLD];
+    auto load_tile = [&](int k0) {
         const int row = k0 + lr;
         const bool rok = row < kend;
-#pragma unroll 4
-        for (int cc = 0; cc < GRAM_BT / LSTEP; ++cc) {
+#pragma unroll
+        for (int cc = 0; cc < NLD; ++cc) {
             const int col = lc0 + LSTEP * cc;
             const int ja = bi * GRAM_BT + col;
-            tA[col * GRAM_LD + lr] = (rok && ja < n) ? Jp[(size_t)ja * m + row] : 0.0;
+            ra[cc] = (rok && ja < n) ? Jp[(size_t)ja * m + row] : 0.0;
             if (!diag) {
                 const int jb = bj * GRAM_BT + col;
-                tB[col * GRAM_LD + lr] = (rok && jb < n) ? Jp[(size_t)jb * m + row] : 0.0;
+                rb[cc] = (rok && jb < n) ? Jp[(size_t)jb * m + row] : 0.0;
             }
         }
+    };
+    // g = J^T f rides along in the diagonal blocks (VALU beside the MFMA pipe): thread (column
+    // tid & 63, k-quarter tid >> 6) accumulates its share of every tile; fixed-order combine at the end.
+    const bool dog = diag && f != nullptr;
+    const double *fp = dog ? f + (size_t)p * m : nullptr;
+    double gacc = 0.0;
+    if (kbeg < kend) load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GRAM_KT) {
+#pragma unroll
+        for (int cc = 0; cc < NLD; ++cc) {
+            const int col = lc0 + LSTEP * cc;
+            tA[col * GRAM_LD + lr] = ra[cc];
+            if (!diag) tB[col * GRAM_LD + lr] = rb[cc];
+        }
+        if (dog && tid < GRAM_KT) fs[tid] = (k0 + tid < kend) ? fp[k0 + tid] : 0.0;
         __syncthreads();
+        if (k0 + GRAM_KT < kend) load_tile(k0 + GRAM_KT);
+        if (dog) {
+            const int gc = tid & 63, gq = (tid >> 6) * (GRAM_KT / 4);
+#pragma unroll
+            for (int i = 0; i < GRAM_KT / 4; ++i) gacc = gacc + tA[gc * GRAM_LD + gq + i] * fs[gq + i];
+        }
 #pragma unroll 4
         for (int ks = 0; ks < GRAM_KT / 4; ++ks) {
             const double a0 = tA[arow + ks * 4];
@@ -88,6 +116,15 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
         __syncthreads();
     }
 
+    if (dog) {                                  // tB is unused by diagonal blocks: combine the four k-quarters
+        tB[tid] = gacc;
+        __syncthreads();
+        if (tid < 64) {
+            const int jg = bi * GRAM_BT + tid;
+            if (jg < n)
+                gpart[((size_t)p * nsplit + split) * n + jg] = ((tB[tid] + tB[tid + 64]) + tB[tid + 128]) + tB[tid + 192];
+        }
+    }
     // f64 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
     double *Gp = Gpart + ((size_t)p * nsplit + split) * (size_t)n * n;
 #pragma unroll
@@ -105,12 +142,18 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
 // Sum the K-split partials in split order and mirror the lower block triangle.
 __global__ void __launch_bounds__(256)
 k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__restrict__ G,
+              const double *__restrict__ gpart, double *__restrict__ g,
               const LmState *__restrict__ st, int want_stage)
 {
     const int p = blockIdx.y;
     if (st && st[p].stage != want_stage) return;
     const size_t nn = (size_t)n * n;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g && e < (size_t)n) {
+        double sg = 0.0;
+        for (int k = 0; k < nsplit; ++k) sg = sg + gpart[((size_t)p * nsplit + k) * n + e];
+        g[(size_t)p * n + e] = sg;
+    }
     if (e >= nn) return;
     const int r = (int)(e % n), c = (int)(e / n);
     const bool lower = (r / GRAM_BT) >= (c / GRAM_BT);
