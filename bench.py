@@ -58,11 +58,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("NLH_BENCH_BATCH", "128")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("NLH_BENCH_BATCH", "256")),
                     help="problems per GPU per step")
     ap.add_argument("--m", type=int, default=M)
     ap.add_argument("--n", type=int, default=N_VAR)
-    ap.add_argument("--cpu-sample", type=int, default=8, help="problems timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="problems timed on the CPU oracle (0 = skip)")
     ap.add_argument("--policy", type=int, default=0, help="0 auto (J^T J + Cholesky), 1 QR, 2 exact (reference order)")
     args = ap.parse_args()
 

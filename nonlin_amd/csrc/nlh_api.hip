@@ -396,6 +396,29 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
 
 static int factor_threads(int n) { return n >= 96 ? 1024 : 256; }
 
+// lu_factor: unblocked single-workgroup kernel for small n, blocked multi-kernel path otherwise.
+static void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipvt, int32_t *dinfo)
+{
+    Timed t(h, NLH_K_LU);
+    if (n < 128) {
+        hipLaunchKernelGGL(k_lu_factor, dim3(nprob), dim3(n >= 96 ? 1024 : 256), 0, h->stream, n, dA, dipvt, dinfo);
+        return;
+    }
+    if (dinfo) hipMemsetAsync(dinfo, 0, sizeof(int32_t) * (size_t)nprob, h->stream);
+    for (int jb = 0; jb < n; jb += LU_NB) {
+        const int nb = (n - jb < LU_NB) ? (n - jb) : LU_NB;
+        hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
+        if (n - nb > 0)
+            hipLaunchKernelGGL(k_lu_swap, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
+                               (const int32_t *)dipvt, jb, nb);
+        const int nt = n - jb - nb;
+        if (nt > 0) {
+            hipLaunchKernelGGL(k_lu_trsm, dim3((nt + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA, jb, nb);
+            hipLaunchKernelGGL(k_lu_gemm, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, h->stream, n, dA, jb, nb);
+        }
+    }
+}
+
 struct LmWs {
     double *J, *P, *wa4, *scratch, *G, *g, *part, *W2, *R;
     LmVecs v;
@@ -882,10 +905,7 @@ static int newton_core(nlh_handle *h, const nlh_options *o, int n, NewtonEval &e
             }
             // LU of a copy (:570) and solve for -fvec (:577)
             HIPCHK(h, hipMemcpyAsync(dLU, dJ, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
-            {
-                Timed t(h, NLH_K_LU);
-                hipLaunchKernelGGL(k_lu_factor, dim3(1), dim3(n >= 96 ? 1024 : 256), 0, s, n, dLU, dipvt, (int32_t *)nullptr);
-            }
+            launch_lu_factor(h, 1, n, dLU, dipvt, (int32_t *)nullptr);
             for (int i = 0; i < n; ++i) rhs[i] = -fvec[i];
             HIPCHK(h, hipMemcpyAsync(drhs, rhs.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, s, n, dLU, dipvt, drhs);
@@ -1223,10 +1243,7 @@ int nlh_lu_factor(nlh_handle *h, int32_t nprob, int32_t n, double *dA, int32_t *
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
     HIPCHK(h, hipSetDevice(h->device));
-    {
-        Timed t(h, NLH_K_LU);
-        hipLaunchKernelGGL(k_lu_factor, dim3(nprob), dim3(n >= 96 ? 1024 : 256), 0, h->stream, n, dA, dipvt, dinfo);
-    }
+    launch_lu_factor(h, nprob, n, dA, dipvt, dinfo);
     HIPCHK(h, hipGetLastError());
     return 0;
 }

@@ -372,3 +372,41 @@ def test_dq_newton_batch(ds, oracle, n, analytic):
         for k in COUNT_KEYS:
             assert ibs[p][k] == ibo[k], (k, ibs[p], ibo)
         assert _rel(x[p].cpu().numpy(), xo) <= RTOL_X
+
+
+def test_dq_newton_c3_full_size(ds, oracle):
+    """BASELINE config 3 at full size: newton_solver on an n = 1024 square dense-quadratic system with
+    the analytic Jacobian, line search on.  The blocked LU keeps the reference's operation order, so x,
+    fvec and every count are bit-identical to the CPU path."""
+    n = 1024
+    A, b, xt, x0 = ds.generate(1, n, n, seed0=12345, sigma=0.0, square_shift=True)
+    x = x0.clone()
+    fvec, ibs, status = ds.newton_solve_batch(A, b, 0.5, x, analytic=True, opts=ds.options(max_evals=500))
+    Ah = np.asfortranarray(A[0].cpu().numpy().T)
+    rc, xo, fo, ibo, _ = oracle.dq_newton_solve(Ah, b[0].cpu().numpy(), 0.5, x0[0].cpu().numpy(), analytic=True,
+                                                opts=oracle.default_options(max_evals=500))
+    assert status[0] == rc == 0
+    for k in COUNT_KEYS:
+        assert ibs[0][k] == ibo[k], (k, ibs[0], ibo)
+    assert np.array_equal(x[0].cpu().numpy(), xo)
+    assert np.array_equal(fvec[0].cpu().numpy(), fo)
+    assert np.abs(fo).max() < 1e-8
+
+
+def test_lm_c4_batch_property_and_spot_parity(ds, oracle):
+    """BASELINE config 4 shape (2048 x 128 problems, 256 of them here): every problem converges, counts
+    are in the recorded range, and a spot check of three problems against the oracle holds the FD-noise bound."""
+    nprob, m, n = 256, 2048, 128
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=12345)
+    x = x0.clone()
+    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500))
+    assert all(s == 0 for s in status)
+    assert all(3 <= ib["jacobian_count"] <= 8 for ib in ibs)
+    # residual norm at the solution ~ sigma * sqrt(m/3): the noise floor of the generator
+    fn = fvec.norm(dim=1).cpu().numpy()
+    assert np.all(fn < 3 * 1e-3 * np.sqrt(m / 3.0)) and np.all(fn > 0.3 * 1e-3 * np.sqrt(m / 3.0))
+    for p in (0, 101, 255):
+        rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5,
+                                                   x0[p].cpu().numpy(), opts=oracle.default_options(max_evals=500))
+        assert rc == 0 and _counts_match(ibs[p], ibo, strict=False)
+        assert _rel(x[p].cpu().numpy(), xo) <= RTOL_X_FD_NOISE
