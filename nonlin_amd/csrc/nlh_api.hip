@@ -471,7 +471,7 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
             Timed t(h, NLH_K_QR);
             dim3 grid((m + 31) / 32, (n + 31) / 32, nprob);
             hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, w.st, (int)ST_NEED_QR);
-            size_t sh = sizeof(double) * (size_t)(2 * n + 64 + 3 * NLH_NCH + 8);
+            size_t sh = sizeof(double) * (size_t)(2 * n + 64 + 3 * NLH_NCH + 8 + QX_VC);
             hipLaunchKernelGGL(k_qr_exact, dim3(nprob), dim3(ft), sh, h->stream, m, n, w.P, dfvec, w.R, w.v,
                                w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, 0);
         }

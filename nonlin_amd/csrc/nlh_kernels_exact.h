@@ -59,7 +59,10 @@ k_lm_init_exact(int m, const double *__restrict__ fvec, LmState *__restrict__ st
     }
 }
 
-// Dynamic LDS: (2n + 64) doubles + 3*NLH_NCH + 8.
+#define QX_VC 2048     // rows of the reflector staged in LDS at a time
+#define QX_PF 16       // loads each column thread keeps in flight
+
+// Dynamic LDS: (2n + 64) doubles + 3*NLH_NCH + 8 + QX_VC.
 __global__ void __launch_bounds__(1024)
 k_qr_exact(int m, int n, double *__restrict__ Jt_all, const double *__restrict__ fall,
            double *__restrict__ Rall, LmVecs v, double *__restrict__ wa4all,
@@ -76,6 +79,7 @@ k_qr_exact(int m, int n, double *__restrict__ Jt_all, const double *__restrict__
     double *red = smem + 2 * n;     // 64
     int *redi = reinterpret_cast<int *>(red + 32);
     double *scratch = red + 64;     // 3*NLH_NCH + 8
+    double *vcol = scratch + 3 * NLH_NCH + 8;   // QX_VC
     double *a = Jt_all + (size_t)p * m * n;
     int32_t *ipvt = v.ipvt + (size_t)p * n;
     double *acnorm = v.acnorm + (size_t)p * n;
@@ -128,35 +132,61 @@ k_qr_exact(int m, int n, double *__restrict__ Jt_all, const double *__restrict__
             }
             __syncthreads();
             const double ajj = a[(size_t)j * n + j];
-            // trailing columns (:652-662) and the residual (column index n, :241-253)
-            for (int k = j + 1 + tid; k <= n; k += BS) {
-                // column k of the row-major matrix, or the residual vector when k == n
-                double *ck = (k < n) ? (a + k) : w4;
-                const size_t sk = (k < n) ? (size_t)n : 1;
-                const double *cj = a + j;
-                // dot product over rows j..m-1 in ascending order; loads are issued 8 rows ahead
-                // of the (serial) additions so memory latency overlaps the recurrence
+            // trailing columns (:652-662) and the residual (column index n, :241-253): one thread per
+            // column.  The reflector is staged through LDS in chunks of QX_VC rows (shared by all
+            // columns); each thread keeps QX_PF of its own loads in flight ahead of the serial recurrence.
+            for (int kbase = j + 1; kbase <= n; kbase += BS) {
+                const int k = kbase + tid;
+                const bool act = k <= n, isf = (k == n);
+                double *ck = isf ? w4 : (a + (act ? k : 0));
+                const size_t sk = isf ? 1 : (size_t)n;
                 double sm = 0.0;
-                int i = j;
-                for (; i + 8 <= m; i += 8) {
-                    double vv[8], av[8];
+                for (int c0 = j; c0 < m; c0 += QX_VC) {             // pass 1: dot product, rows ascending
+                    const int cl = min(QX_VC, m - c0);
+                    __syncthreads();
+                    for (int i = tid; i < cl; i += BS) vcol[i] = a[(size_t)(c0 + i) * n + j];
+                    __syncthreads();
+                    if (act) {
+                        const double *cp = ck + (size_t)c0 * sk;
+                        int i = 0;
+                        for (; i + QX_PF <= cl; i += QX_PF) {
+                            double av[QX_PF];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { vv[u] = cj[(size_t)(i + u) * n]; av[u] = ck[(size_t)(i + u) * sk]; }
+                            for (int u = 0; u < QX_PF; ++u) av[u] = cp[(size_t)(i + u) * sk];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) sm = sm + vv[u] * av[u];
-                }
-                for (; i < m; ++i) sm = sm + cj[(size_t)i * n] * ck[(size_t)i * sk];
-                if (k < n) {
-                    const double temp = sm / ajj;
-                    i = j;
-                    for (; i + 8 <= m; i += 8) {
-                        double vv[8], av[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { vv[u] = cj[(size_t)(i + u) * n]; av[u] = ck[(size_t)(i + u) * sk]; }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) ck[(size_t)(i + u) * sk] = av[u] - temp * vv[u];
+                            for (int u = 0; u < QX_PF; ++u) sm = sm + vcol[i + u] * av[u];
+                        }
+                        for (; i < cl; ++i) sm = sm + vcol[i] * cp[(size_t)i * sk];
                     }
-                    for (; i < m; ++i) ck[(size_t)i * sk] = ck[(size_t)i * sk] - temp * cj[(size_t)i * n];
+                }
+                const double temp = isf ? (-sm / ajj) : (sm / ajj);     // :654 / :248
+                for (int c0 = j; c0 < m; c0 += QX_VC) {             // pass 2: axpy
+                    const int cl = min(QX_VC, m - c0);
+                    __syncthreads();
+                    for (int i = tid; i < cl; i += BS) vcol[i] = a[(size_t)(c0 + i) * n + j];
+                    __syncthreads();
+                    if (act) {
+                        double *cp = ck + (size_t)c0 * sk;
+                        int i = 0;
+                        for (; i + QX_PF <= cl; i += QX_PF) {
+                            double av[QX_PF];
+#pragma unroll
+                            for (int u = 0; u < QX_PF; ++u) av[u] = cp[(size_t)(i + u) * sk];
+                            if (isf) {
+#pragma unroll
+                                for (int u = 0; u < QX_PF; ++u) cp[(size_t)(i + u) * sk] = av[u] + vcol[i + u] * temp;
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < QX_PF; ++u) cp[(size_t)(i + u) * sk] = av[u] - temp * vcol[i + u];
+                            }
+                        }
+                        for (; i < cl; ++i) {
+                            if (isf) cp[(size_t)i * sk] = cp[(size_t)i * sk] + vcol[i] * temp;
+                            else cp[(size_t)i * sk] = cp[(size_t)i * sk] - temp * vcol[i];
+                        }
+                    }
+                }
+                if (act && !isf) {
                     double rk = rdiag[k];
                     if (rk != 0.0) {
                         const double t2 = a[(size_t)j * n + k] / rk;
@@ -168,17 +198,6 @@ k_qr_exact(int m, int n, double *__restrict__ Jt_all, const double *__restrict__
                         }
                         rdiag[k] = rk;
                     }
-                } else {
-                    const double temp = -sm / ajj;                 // :248
-                    i = j;
-                    for (; i + 8 <= m; i += 8) {
-                        double vv[8], av[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { vv[u] = cj[(size_t)(i + u) * n]; av[u] = ck[(size_t)(i + u) * sk]; }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) ck[(size_t)(i + u) * sk] = av[u] + vv[u] * temp;
-                    }
-                    for (; i < m; ++i) ck[(size_t)i * sk] = ck[(size_t)i * sk] + cj[(size_t)i * n] * temp;
                 }
             }
         }
