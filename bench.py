@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--m", type=int, default=M)
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--cpu-sample", type=int, default=24, help="problems timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--exact-sample", type=int, default=64, help="problems for the exact-policy figure (0 = skip)")
     ap.add_argument("--policy", type=int, default=0, help="0 auto (J^T J + Cholesky), 1 QR, 2 exact (reference order)")
     args = ap.parse_args()
 
@@ -190,6 +191,21 @@ def main():
             },
             "kernel_ms_per_step": {k: v / args.steps for k, v in kernel_ms.items()},
         }
+        if world == 1 and args.policy == 0 and args.exact_sample > 0:
+            # the same workload under the exact factor policy (reference operation order: x, fvec and all
+            # counts bit-identical to the CPU path, tests/test_gpu_solvers.py), one untimed + one timed pass
+            Be = min(B, args.exact_sample)
+            oe = ds.options(max_evals=max_evals, factor_policy=2)
+            xe = x0[:Be].clone()
+            ds.lm_solve_batch(A[:Be], b[:Be], gamma, xe, oe)
+            xe.copy_(x0[:Be])
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            _, ibe, _ = ds.lm_solve_batch(A[:Be], b[:Be], gamma, xe, oe)
+            torch.cuda.synchronize()
+            te = time.perf_counter() - te
+            out["exact_policy"] = {"value": sum(i["jacobian_count"] for i in ibe) / te, "unit": "LM iterations/s",
+                                   "problems": Be, "note": "NLH_FACTOR_EXACT: bit-identical to the CPU path"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, m, n)
         print(json.dumps(out))

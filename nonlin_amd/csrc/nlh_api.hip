@@ -382,8 +382,10 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
     double *gp = Gp + (size_t)nprob * ns * n * n;
     {
         Timed t(h, NLH_K_GRAM);
-        hipLaunchKernelGGL(k_gram_mfma, dim3(nblk, ns, nprob), dim3(256), 0, h->stream, m, n, rps, J, Gp,
-                           g ? f : (const double *)nullptr, gp, st, want);
+        const long items = (long)ns * nprob;
+        const long groups = (items + 7) / 8;
+        hipLaunchKernelGGL(k_gram_mfma, dim3((unsigned)(groups * 8 * nblk)), dim3(256), 0, h->stream, m, n, rps, J, Gp,
+                           g ? f : (const double *)nullptr, gp, st, want, nblk, ns, nprob);
     }
     {
         Timed t(h, NLH_K_GRAM_REDUCE);

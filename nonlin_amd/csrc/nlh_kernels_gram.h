@@ -33,16 +33,28 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
             double *__restrict__ Gpart /* [nprob][nsplit][n*n] */,
             const double *__restrict__ f /* [nprob][m] or null */,
             double *__restrict__ gpart /* [nprob][nsplit][n] */,
-            const LmState *__restrict__ st, int want_stage)
+            const LmState *__restrict__ st, int want_stage, int nblk_arg, int nsplit_arg, int nprob_arg)
 {
     __shared__ double tA[GRAM_BT * GRAM_LD];
     __shared__ double tB[GRAM_BT * GRAM_LD];
     __shared__ double fs[GRAM_KT];
-    const int p = blockIdx.z;
+    // XCD-aware mapping.  Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with
+    // its own L2.  The nblk blocks of one (problem, K-split) item read the same rows of J, so they
+    // are given ids  g*8*nblk + blk*8 + xcd  (item = g*8 + xcd): same XCD, adjacent in dispatch
+    // order, and J comes from HBM once per item instead of once per block.  Placement is a
+    // performance hint only; results do not depend on it.
+    const int nblk = nblk_arg, nsplit = nsplit_arg;
+    const long L = blockIdx.x;
+    const long grp = L / (8L * nblk);
+    const int within = (int)(L % (8L * nblk));
+    const long item = grp * 8 + (within & 7);
+    const int blk = within >> 3;
+    if (item >= (long)nsplit * nprob_arg) return;
+    const int p = (int)(item / nsplit);
+    const int split = (int)(item % nsplit);
     if (st && st[p].stage != want_stage) return;
     int bi, bj;
-    gram_block_index(blockIdx.x, bi, bj);
-    const int split = blockIdx.y, nsplit = gridDim.y;
+    gram_block_index(blk, bi, bj);
     const int kbeg = split * rows_per_split;
     const int kend = min(m, kbeg + rows_per_split);
     const double *Jp = J + (size_t)p * m * n;
