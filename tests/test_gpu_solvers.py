@@ -410,3 +410,43 @@ def test_lm_c4_batch_property_and_spot_parity(ds, oracle):
                                                    x0[p].cpu().numpy(), opts=oracle.default_options(max_evals=500))
         assert rc == 0 and _counts_match(ibs[p], ibo, strict=False)
         assert _rel(x[p].cpu().numpy(), xo) <= RTOL_X_FD_NOISE
+
+
+@pytest.mark.parametrize("m,n", [(1024, 300), (700, 513)])
+def test_lm_wide_problems_both_policies(ds, oracle, m, n):
+    """n > 256 (several Gram blocks per row, multi-panel blocked Cholesky, n + 1 > 256 column threads):
+    exact policy bit-identical, normal-equations policy within the FD-noise bound."""
+    _check_batch(ds, oracle, 2, m, n, 4321, {}, dict(max_evals=500, factor_policy=2), rtol=0.0, bitwise=True)
+    _check_batch(ds, oracle, 2, m, n, 4321, {}, dict(max_evals=500), rtol=RTOL_X_FD_NOISE, strict=False)
+
+
+def test_host_lm_callback_medium_problem(oracle):
+    """Host-callback mode at a size where the panel upload, the 16-byte FD path and the MFMA Gram kernel all
+    matter: the dense-quadratic residual evaluated by a numpy callback in the oracle's operation order."""
+    import nonlin_amd as nl
+    m, n, gamma = 512, 64, 0.5
+    A, b, xt, x0 = oracle.dq_generate(2468, m, n)
+
+    def fcn(x, f, args=None):
+        u = np.zeros(m)
+        for j in range(n):                 # column sweep: each row accumulates j ascending, mul then add
+            u = u + A[:, j] * x[j]
+        f[:] = (u + (gamma * u) * u) - b
+
+    for policy, bitwise in ((2, True), (0, False)):
+        obj = nl.vecfcn_helper()
+        obj.set_fcn(fcn, m, n)
+        s = nl.least_squares_solver()
+        s.factor_policy = policy
+        s.set_max_fcn_evals(500)
+        x = x0.copy()
+        f = np.zeros(m)
+        ib = nl.iteration_behavior()
+        s.solve(obj, x, f, ib)
+        rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(A, b, gamma, x0, opts=oracle.default_options(max_evals=500))
+        assert rc == 0
+        assert _counts_match(ib.as_dict(), ibo, strict=bitwise), (ib.as_dict(), ibo)
+        if bitwise:
+            assert np.array_equal(x, xo) and np.array_equal(f, fo)
+        else:
+            assert _rel(x, xo) <= RTOL_X_FD_NOISE

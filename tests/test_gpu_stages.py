@@ -7,16 +7,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _host_problem(oracle, seed, m, n, **kw):
-    A, b, xt, x0 = oracle.dq_generate(seed, m, n, **kw)
-    return A, b, xt, x0
-
-
-def _to_dev(A_list, dev):
-    # oracle A is Fortran-order m x n; device layout is [nprob, n, m] (column-major per problem)
-    return torch.tensor(np.stack([np.ascontiguousarray(A.T) for A in A_list]), device=dev)
-
-
 @pytest.mark.parametrize("m,n", [(21, 4), (512, 64), (300, 37), (2048, 128), (64, 64)])
 def test_generator_matches_oracle_bitwise(ds, oracle, m, n):
     nprob = 3
