@@ -150,7 +150,7 @@ def main():
         # corrections applied), committed under profiles/; scaled to the average launch of this run.
         traffic = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             if (prof["m"], prof["n"]) == (m, n):
                 per_problem = prof["kernels"]["k_fd_jacobian<256, 8, true>"]["hbm_bytes_per_problem"]
                 traffic = per_problem * njac / max(fd_launches, 1)
@@ -184,7 +184,7 @@ def main():
             "roofline": {
                 "kernel": "k_fd_jacobian", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), bytes per average launch",
+                "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), bytes per average launch",
                 "algorithmic_bytes_per_launch": fd_bytes(m, n) * njac / max(fd_launches, 1),
                 "bytes_per_unit": fd_bytes(m, n), "units": "problem-Jacobians", "launches": int(fd_launches),
                 "avg_launch_ms": fd_ms / max(fd_launches, 1),
