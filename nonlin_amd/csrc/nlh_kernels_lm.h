@@ -361,7 +361,6 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
                               wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
                               Wall + (size_t)p * m * n, rot, ne_mode);
     __syncthreads();
-    bool blowup = false;
     if (rc && !EXACT) {
         // Deviation A (:531) adds ||wa4(n+1:m)|| to ||D x|| inside the loop.  If that tail alone exceeds
         // 1.1*delta the exit test |fp| <= 0.1*delta can never pass for any par: the reference runs its ten
@@ -378,7 +377,6 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
             tq = f2 > q2 ? f2 - q2 : 0.0;
         }
         if (sqrt(tq) > 1.1 * delta * (1.0 + 1.0e-6)) {
-            blowup = true;
             __syncthreads();
             for (int j = tid; j < n; j += BS) xs[j] = 0.0;
             par = __builtin_inf();

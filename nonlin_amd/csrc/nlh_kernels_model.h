@@ -170,11 +170,13 @@ k_fd_jacobian(int m, int n, const double *__restrict__ P, const double *__restri
 #pragma unroll 4
         for (int j = jbeg; j < jend; ++j) {
             const double h = fd_step(xp[j]);
-            const double2 v = *reinterpret_cast<const double2 *>(Pp + (size_t)j * m + i);
-            double2 o;
+            // streamed once: non-temporal so the panel and J do not displace A in L2 / Infinity Cache
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Pp + (size_t)j * m + i));
+            v2d o;
             o.x = (v.x - f.x) / h;
             o.y = (v.y - f.y) / h;
-            *reinterpret_cast<double2 *>(Jp + (size_t)j * m + i) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<v2d *>(Jp + (size_t)j * m + i));
         }
     } else {
         const int i = blockIdx.x * BS + threadIdx.x;
