@@ -191,6 +191,18 @@ def main():
             },
             "kernel_ms_per_step": {k: v / args.steps for k, v in kernel_ms.items()},
         }
+        if world == 1:
+            # latency of BASELINE config 2 taken literally: ONE 4096 x 256 problem (seed 12345), warm handle
+            x1 = x0[:1].clone()
+            ds.lm_solve_batch(A[:1], b[:1], gamma, x1, opts)
+            x1.copy_(x0[:1])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, ib1, _ = ds.lm_solve_batch(A[:1], b[:1], gamma, x1, opts)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter() - t1
+            out["single_problem"] = {"ms": 1e3 * t1, "lm_iterations": ib1[0]["jacobian_count"],
+                                     "lm_iterations_per_s": ib1[0]["jacobian_count"] / t1}
         if world == 1 and args.policy == 0 and args.exact_sample > 0:
             # the same workload under the exact factor policy (reference operation order: x, fvec and all
             # counts bit-identical to the CPU path, tests/test_gpu_solvers.py), one untimed + one timed pass

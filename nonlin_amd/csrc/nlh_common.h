@@ -51,6 +51,30 @@ __device__ __forceinline__ double wave_reduce_max(double v)
 
 // Deterministic block-wide sum; result broadcast to all threads.
 // sh must hold at least blockDim.x/64 + 1 doubles.  Two barriers.
+// Value of v in lane l (l uniform; cheapest with a compile-time l): two v_readlane_b32.
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// sqrt(x) and 1/sqrt(x) together from the hardware estimate plus two coupled Goldschmidt steps
+// (a short dependent chain; the IEEE sqrt and divide sequences are several times longer).
+// Only used on the non-exact factor policies.  x must be a positive normal number.
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &r)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    s = g; r = 2.0 * h;
+}
+
 __device__ __forceinline__ double block_reduce_sum(double v, double *sh)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

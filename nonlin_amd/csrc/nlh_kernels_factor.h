@@ -243,6 +243,7 @@ k_chol_nopiv(int n, const double *__restrict__ Gall, const double *__restrict__ 
     double *yb = gp + n;                    // NB      : qtf entries of the current block
     double *red = yb + NB;                  // 64
     __shared__ int bad_sh;
+    __shared__ double dinv[NB];             // 1 / diag of the current diagonal block
     const double *G = Gall + (size_t)p * n * n;
     double *R = Rall + (size_t)p * n * n;
     int32_t *ipvt = v.ipvt + (size_t)p * n;
@@ -258,36 +259,60 @@ k_chol_nopiv(int n, const double *__restrict__ Gall, const double *__restrict__ 
     if (tid == 0) bad_sh = 0;
     __syncthreads();
 
+#ifdef NLH_DEBUG_TIMING
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tq = wall_clock64();
+#define TPH(i) { __syncthreads(); unsigned long long t_ = wall_clock64(); tph[i] += t_ - tq; tq = t_; }
+#else
+#define TPH(i)
+#endif
     for (int jb = 0; jb < n; jb += NB) {
         const int nbk = min(NB, n - jb);
+        TPH(4)
         // diagonal block -> LDS
         for (int e = tid; e < NB * NB; e += BS) {
             const int i = e % NB, c = e / NB;
             r11[e] = (i <= c && c < nbk) ? R[(size_t)(jb + c) * n + jb + i] : 0.0;
         }
         __syncthreads();
-        // factor it: nbk small steps, lanes = columns of the block
-        for (int j = 0; j < nbk; ++j) {
-            const double dj = r11[j + j * NB];
-            const double an = acnorm[jb + j];
-            if (!(dj > pivot_tol * an * an) || !(dj > 0.0)) { if (tid == 0) bad_sh = jb + j + 1; }
-            const double rjj = sqrt(fmax(dj, 1e-300));
-            __syncthreads();
-            if (tid > j && tid < nbk) {
-                const int c = tid;
-                const double rjc = r11[j + c * NB] / rjj;
-                r11[j + c * NB] = rjc;
+        TPH(5)
+        // factor it inside wave 0: lane c keeps column c of the block in registers and row j is
+        // broadcast with v_readlane (compile-time lane numbers), so the 16 steps need neither LDS
+        // round trips nor barriers.
+        if (wid == 0) {
+            double col[NB];                                     // lane c: col[i] = A(i, c), i <= c
+#pragma unroll
+            for (int i = 0; i < NB; ++i) col[i] = (lane < nbk && i <= lane) ? r11[i + lane * NB] : 0.0;
+            const double an_l = (lane < nbk) ? acnorm[jb + lane] : 0.0;
+            const double thr_l = pivot_tol * an_l * an_l;       // weak-pivot threshold of column `lane`
+            double myinv = 0.0;
+            int bad = 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j < nbk) {                                  // uniform
+                    const double dj = readlane_f64(col[j], j);
+                    const double tj = readlane_f64(thr_l, j);
+                    if ((!(dj > tj) || !(dj > 0.0)) && bad == 0) bad = jb + j + 1;
+                    double rjj, rinv;
+                    sqrt_rsqrt(fmax(dj, 1e-300), rjj, rinv);
+                    const double rjc = (lane > j) ? col[j] * rinv : 0.0;    // row j, entry `lane`
+                    if (lane == j) { col[j] = rjj; myinv = rinv; }
+                    else if (lane > j) col[j] = rjc;
+                    // entries i > lane of col are never read, so the update needs no predicate
+#pragma unroll
+                    for (int i = j + 1; i < NB; ++i) col[i] = col[i] - readlane_f64(rjc, i) * rjc;
+                }
             }
-            if (tid == j) r11[j + j * NB] = rjj;
-            __syncthreads();
-            if (tid > j && tid < nbk) {
-                const int c = tid;
-                const double rjc = r11[j + c * NB];
-                for (int i = j + 1; i <= c; ++i) r11[i + c * NB] = r11[i + c * NB] - r11[j + i * NB] * rjc;
-            }
-            __syncthreads();
+            if (bad && lane == 0) bad_sh = bad;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                if (lane < nbk && i <= lane) r11[i + lane * NB] = col[i];
+            if (lane < NB) dinv[lane] = myinv;                  // reciprocal diagonal for the block row
         }
+        TPH(6)
+        __syncthreads();
         if (bad_sh) break;                                      // uniform
+        TPH(0)
         // write the factored diagonal block back
         for (int e = tid; e < NB * NB; e += BS) {
             const int i = e % NB, c = e / NB;
@@ -304,13 +329,12 @@ k_chol_nopiv(int n, const double *__restrict__ Gall, const double *__restrict__ 
                 for (int i = 0; i < NB; ++i) a[i] = (i < nbk) ? gp[jb + i] : 0.0;
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                if (i < nbk) {
-                    double acc = a[i];
+            for (int l = 0; l < NB; ++l) {                      // forward substitution, axpy form
+                if (l < nbk) {
+                    const double al = a[l] * dinv[l];
+                    a[l] = al;
 #pragma unroll
-                    for (int l = 0; l < NB; ++l)
-                        if (l < i) acc = acc - r11[l + i * NB] * a[l];
-                    a[i] = acc / r11[i + i * NB];
+                    for (int i = l + 1; i < NB; ++i) a[i] = a[i] - r11[l + i * NB] * al;
                 }
             }
             if (k < n) {
@@ -324,22 +348,46 @@ k_chol_nopiv(int n, const double *__restrict__ Gall, const double *__restrict__ 
             }
         }
         __syncthreads();
-        // trailing update: A22(r,c) -= sum_i R12(i,r) R12(i,c), jb+nbk <= r <= c; gradient likewise
+        TPH(1)
+        // trailing update: A22(r,c) -= sum_i R12(i,r) R12(i,c), jb+nbk <= r <= c; gradient likewise.
+        // A wave walks its columns in 64-row pieces and handles TU pieces at a time: all global loads
+        // of a group are issued before any store, so the read-modify-write round trips overlap.
         const int t0 = jb + nbk;
-        for (int c = t0 + wid; c <= n; c += nw) {
-            if (c < n) {
-                double pc[NB];
+        {
+            // 16x16 tiles of the upper triangle with v_mfma_f64_16x16x4_f64: T = C - P_c^T P_r computed as
+            // D[c][r] so that lanes & 15 run along r (contiguous in the column-major R).  Operand maps (f64):
+            // A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15], D row = (l >> 4) + 4*reg, col = l & 15.
+            typedef double v4d_t __attribute__((ext_vector_type(4)));
+            const int nt = (n - t0 + 15) / 16;                     // tiles per side
+            const int ntile = nt * (nt + 1) / 2;
+            for (int tix = wid; tix < ntile; tix += nw) {
+                int tc = (int)((sqrtf(8.0f * (float)tix + 1.0f) - 1.0f) * 0.5f);   // tile column block, row block tr <= tc
+                while ((tc + 1) * (tc + 2) / 2 <= tix) ++tc;
+                while (tc * (tc + 1) / 2 > tix) --tc;
+                const int tr = tix - tc * (tc + 1) / 2;
+                const int cb = t0 + tc * 16, rb = t0 + tr * 16;
+                const int crow = cb + (lane >> 4), rcol = rb + (lane & 15);
+                v4d_t acc;
 #pragma unroll
-                for (int i = 0; i < NB; ++i) pc[i] = (i < nbk) ? panel[(size_t)i * n + c] : 0.0;
-                double *col = R + (size_t)c * n;
-                for (int r = t0 + lane; r <= c; r += 64) {
-                    double acc = col[r];
-#pragma unroll
-                    for (int i = 0; i < NB; ++i)
-                        if (i < nbk) acc = acc - panel[(size_t)i * n + r] * pc[i];
-                    col[r] = acc;
+                for (int q = 0; q < 4; ++q) {
+                    const int c = crow + 4 * q;
+                    acc[q] = (c < n && rcol <= c) ? R[(size_t)c * n + rcol] : 0.0;
                 }
-            } else {
+                const int ca = cb + (lane & 15);
+#pragma unroll
+                for (int kk = 0; kk < NB / 4; ++kk) {
+                    const int k = kk * 4 + (lane >> 4);
+                    const double av = (k < nbk && ca < n) ? -panel[(size_t)k * n + ca] : 0.0;      // A[c][k] = -P(k, c)
+                    const double bv = (k < nbk && rcol < n) ? panel[(size_t)k * n + rcol] : 0.0;   // B[k][r] =  P(k, r)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = crow + 4 * q;
+                    if (c < n && rcol <= c) R[(size_t)c * n + rcol] = acc[q];
+                }
+            }
+            if (wid == nw - 1) {                            // gradient "column"
                 for (int r = t0 + lane; r < n; r += 64) {
                     double acc = gp[r];
 #pragma unroll
@@ -350,7 +398,13 @@ k_chol_nopiv(int n, const double *__restrict__ Gall, const double *__restrict__ 
             }
         }
         __syncthreads();
+        TPH(2)
     }
+#ifdef NLH_DEBUG_TIMING
+    if (tid == 0 && p == 0) printf("[chol_nopiv] diag %.1f us, blockrow %.1f us, trailing %.1f us, other %.1f us\n",
+                                   tph[0] * 1e-2, tph[1] * 1e-2, tph[2] * 1e-2, tph[4] * 1e-2);
+    if (tid == 0 && p == 0) printf("[chol_nopiv]   diag: load %.1f us, factor %.1f us\n", tph[5] * 1e-2, tph[6] * 1e-2);
+#endif
     if (bad_sh) {
         if (tid == 0) s->stage = ST_NEED_PCHOL;                 // let the pivoted kernel decide (it may ask for QR)
         return;
