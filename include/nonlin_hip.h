@@ -121,6 +121,13 @@ int nlh_newton_solve(nlh_handle *h, const nlh_options *opts, int32_t n,
                      nlh_vecfcn fcn, nlh_jacfcn jacfcn, void *ctx,
                      double *x, double *fvec, nlh_iteration_behavior *ib);
 
+/* quasi_newton_solver%solve -- qns_solve, src/nonlin_solve.f90:156-427 (Broyden's method; QR of the
+ * Jacobian at :289, rank-one QR update at :307, triangular solve at :327).  jdelta =
+ * quasi_newton_solver%m_jDelta (get/set_jacobian_interval, :429-447; default 5, :51). */
+int nlh_quasi_newton_solve(nlh_handle *h, const nlh_options *opts, int32_t jdelta, int32_t n,
+                           nlh_vecfcn fcn, nlh_jacfcn jacfcn, void *ctx,
+                           double *x, double *fvec, nlh_iteration_behavior *ib);
+
 /* ===========================================================================
  * Device-model ("mode D") batched entry points: DEVICE pointers.
  * Residual family "dense-quadratic" (SURVEY.md 8(d)), evaluated on the GPU with
@@ -140,6 +147,12 @@ int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *opts, int32_t np
                               int32_t n, const double *dA, const double *db, double gamma,
                               int32_t analytic_jacobian, double *dx, double *dfvec,
                               nlh_iteration_behavior *ib, int32_t *status);
+
+int nlh_dq_quasi_newton_solve_batch(nlh_handle *h, const nlh_options *opts, int32_t jdelta,
+                                    int32_t nprob, int32_t n, const double *dA, const double *db,
+                                    double gamma, int32_t analytic, double *dx, double *dfvec,
+                                    nlh_iteration_behavior *ib /* host, [nprob] */,
+                                    int32_t *status /* host, [nprob] */);
 
 /* Synthetic problem generator of SURVEY.md 8(d) (bench/test inputs, not part of the
  * reference): counter-based splitmix64, U_k = mix(seed + (k+1)*0x9E3779B97F4A7C15),
@@ -193,6 +206,14 @@ int nlh_lu_factor(nlh_handle *h, int32_t nprob, int32_t n, double *dA, int32_t *
                   int32_t *dinfo);
 int nlh_lu_solve(nlh_handle *h, int32_t nprob, int32_t n, const double *dLU,
                  const int32_t *dipvt, double *db);
+/* qr_factor(b, q = q, r = r), qr_rank1_update(q, r, u, v) and solve_triangular_system stand-ins
+ * (call sites src/nonlin_solve.f90:289, 307, 327; third-party linalg in the reference).
+ * dB, dQ: [nprob][n][n] column-major.  dRt: R stored ROW-major.  Q1 R1 = Q R + u v^T. */
+int nlh_qr_factor_full(nlh_handle *h, int32_t nprob, int32_t n, const double *dB, double *dQ,
+                       double *dRt);
+int nlh_qr_rank1_update(nlh_handle *h, int32_t nprob, int32_t n, double *dQ, double *dRt,
+                        const double *du, const double *dv);
+int nlh_solve_upper(nlh_handle *h, int32_t nprob, int32_t n, const double *dRt, double *dx);
 
 /* ---- per-kernel timing (HIP events on the handle's stream) ------------------ */
 #define NLH_K_DQ_RESIDUAL   0

@@ -49,12 +49,17 @@ SYMBOLS = {
                                c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
     "nlh_newton_solve": (C.c_int, [_H, C.POINTER(Options), C.c_int32, VECFCN, JACFCN, C.c_void_p,
                                    c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
+    "nlh_quasi_newton_solve": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, VECFCN, JACFCN, C.c_void_p,
+                                         c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
     "nlh_dq_lm_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                         C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_dq_newton_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_dq_quasi_newton_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                                  C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
+                                                  C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_dq_generate": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_double, C.c_double,
                                   C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_dq_residual": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
@@ -74,6 +79,9 @@ SYMBOLS = {
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_lu_factor": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_lu_solve": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlh_qr_factor_full": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlh_qr_rank1_update": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlh_solve_upper": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "nlh_timing_enable": (None, [_H, C.c_int32]),
     "nlh_timing_reset": (None, [_H]),
     "nlh_timing_get": (C.c_int, [_H, C.c_int32, c_double_p, C.POINTER(C.c_int64)]),

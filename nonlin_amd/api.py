@@ -290,6 +290,48 @@ class line_search_solver(equation_solver):
     def set_use_line_search(self, x): self._use_line_search = bool(x)
 
 
+class quasi_newton_solver(line_search_solver):
+    """src/nonlin_solve.f90:43-58."""
+
+    def __init__(self):
+        super().__init__()
+        self._jdelta = 5                                      # m_jDelta, :51
+
+    def get_jacobian_interval(self): return self._jdelta      # :429-436
+    def set_jacobian_interval(self, n): self._jdelta = int(n)  # :439-447
+
+    def solve(self, fcn, x, fvec, ib=None, args=None):
+        """qns_solve (:156-427)."""
+        _check_xf(fcn, x, fvec)
+        if self.get_use_line_search() and not self.is_line_search_defined():
+            self.set_default_line_search()        # :233-237
+        if not fcn.is_fcn_defined():
+            raise NonlinError(NL_UNDEFINED_FUNCTION_ERROR)   # :240
+        m, n = fcn.get_equation_count(), fcn.get_variable_count()
+        if n != m:
+            raise NonlinError(NL_INVALID_INPUT_ERROR)        # :241
+        if x.shape != (n,):
+            raise NonlinError(3)
+        if fvec.shape != (m,):
+            raise NonlinError(4)
+        o = self._options()
+        o.use_line_search = 1 if self._use_line_search else 0
+        if self._line_search is not None:
+            o.ls_max_evals = self._line_search._max_eval
+            o.ls_alpha = self._line_search._alpha
+            o.ls_factor = self._line_search._factor
+        h = self._handle()
+        cib = _lib.IterationBehavior()
+        cf, cj = fcn._c_fcn(args), fcn._c_jac(args)
+        rc = h.lib.nlh_quasi_newton_solve(h.ptr, C.byref(o), self._jdelta, n, cf, cj, None, _dp(x), _dp(fvec),
+                                          C.byref(cib))
+        h.check(rc, "nlh_quasi_newton_solve")
+        if ib is not None:
+            ib._fill(cib)
+        if rc:
+            raise NonlinError(rc)
+
+
 class newton_solver(line_search_solver):
     """src/nonlin_solve.f90:60-67."""
 

@@ -24,6 +24,7 @@
 #include "nlh_kernels_factor.h"
 #include "nlh_kernels_lm.h"
 #include "nlh_kernels_lu.h"
+#include "nlh_kernels_broyden.h"
 #include "nlh_kernels_exact.h"
 
 // ---------------------------------------------------------------------------
@@ -47,7 +48,8 @@ struct nlh_handle {
     int64_t launches[NLH_K_COUNT] = {0};
     std::vector<DevBuf *> bufs;       // every workspace buffer, for destroy
     // named workspace buffers (grown on demand, reused across calls)
-    DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2, R;
+    DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2, R,
+           qnQ, qnR, qnV;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
 };
@@ -178,6 +180,13 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_qr_exact, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_house_dot, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_rot_q, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_hess_r, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_retri<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_retri<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_solve_upper, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_resid, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipGetLastError();
     *out = h;
     return 0;
@@ -979,6 +988,189 @@ static int newton_core(nlh_handle *h, const nlh_options *o, int n, NewtonEval &e
     return flag ? NLH_CONVERGENCE_ERROR : 0;
 }
 
+
+// ===========================================================================
+// Quasi-Newton (Broyden): qns_solve as a host loop; B, Q, R live on the device.
+// Same division of labour as Newton: O(n) vector logic on the host in the reference's order,
+// every O(n^2)/O(n^3) operation in the kernels of nlh_kernels_broyden.h.
+// ===========================================================================
+static const int QN_MAX_N = 4096;      // k_qn_retri: 4 columns per thread at most
+
+// B (column-major) -> Q, R: Householder QR with Q formed (qr_factor(b, q = q, r = r), :289)
+static void launch_qn_qr(nlh_handle *h, int nprob, int n, const double *dB, double *dQ, double *dRt, double *dvb)
+{
+    // dvb: per problem 2n (reflector column, two slots) + 2n (w) + 4 (tau, scal, beta)
+    hipStream_t s = h->stream;
+    double *vbuf = dvb, *wbuf = dvb + (size_t)nprob * 2 * n, *st = wbuf + (size_t)nprob * 2 * n;
+    {
+        dim3 grid((n + 31) / 32, (n + 31) / 32, nprob);
+        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, n, n, dB, dRt, (const LmState *)nullptr, -1);
+    }
+    hipLaunchKernelGGL(k_qn_qr_init, dim3(std::min(1024, (n * n + 255) / 256), nprob), dim3(256), 0, s, n, dRt, dQ, vbuf);
+    for (int j = 0; j + 1 < n; ++j) {
+        hipLaunchKernelGGL(k_qn_house_dot, dim3((2 * n + QN_DOT_BS - 1) / QN_DOT_BS, nprob), dim3(QN_DOT_BS),
+                           sizeof(double) * n, s, n, j, dRt, dQ, vbuf, wbuf, st);
+        hipLaunchKernelGGL(k_qn_house_apply, dim3((2 * n + 255) / 256, (n - j + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
+                           n, j, dRt, dQ, vbuf, wbuf, st);
+    }
+}
+
+// Q1 R1 = Q R + u v^T (qr_rank1_update(q, r, s, dx), :307).  dwcs: 3n doubles per problem of scratch.
+static void launch_qn_update(nlh_handle *h, int nprob, int n, double *dQ, double *dRt, const double *du,
+                             const double *dv, double *dwcs)
+{
+    hipStream_t s = h->stream;
+    double *dw = dwcs, *dc = dwcs + (size_t)nprob * n, *dsn = dc + (size_t)nprob * n;
+    hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, nprob), dim3(64), 0, s, n, dQ, du, dw, 1.0);
+    hipLaunchKernelGGL(k_qn_fold, dim3(nprob), dim3(64), 0, s, n, dw, dc, dsn);
+    const dim3 g1((n + 255) / 256, nprob);
+    hipLaunchKernelGGL(k_qn_rot_q, g1, dim3(256), sizeof(double) * 2 * n, s, n, dQ, dc, dsn, 1);
+    hipLaunchKernelGGL(k_qn_hess_r, g1, dim3(256), sizeof(double) * 2 * n, s, n, dRt, dc, dsn, dw, dv);
+    if (n <= 1024) {
+        const int bs = std::min(1024, ((n + 63) / 64) * 64);
+        hipLaunchKernelGGL(k_qn_retri<1>, dim3(nprob), dim3(bs), sizeof(double) * 2 * n, s, n, dRt, dc, dsn);
+    } else {
+        hipLaunchKernelGGL(k_qn_retri<4>, dim3(nprob), dim3(1024), sizeof(double) * 2 * n, s, n, dRt, dc, dsn);
+    }
+    hipLaunchKernelGGL(k_qn_rot_q, g1, dim3(256), sizeof(double) * 2 * n, s, n, dQ, dc, dsn, 0);
+}
+
+static int quasi_newton_core(nlh_handle *h, const nlh_options *o, int jdelta, int n, NewtonEval &ev, double *x,
+                             double *fvec, nlh_iteration_behavior *ib)
+{
+    int rc;
+    const size_t nn = (size_t)n * n;
+    if (n > QN_MAX_N) return NLH_ARRAY_SIZE_ERROR;
+    if ((rc = ensure(h, h->J, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->qnQ, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->qnR, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->qnV, sizeof(double) * ((size_t)16 * n + 8)))) return rc;
+    double *dB = (double *)h->J.p, *dQ = (double *)h->qnQ.p, *dRt = (double *)h->qnR.p;
+    double *dv = (double *)h->qnV.p;
+    double *ddx = dv, *ddf = dv + n, *dsv = dv + 2 * n, *dwcs = dv + 3 * n /* 3n */, *dgrad = dv + 6 * n,
+           *dstep = dv + 7 * n, *dfv = dv + 8 * n, *dvb = dv + 9 * n /* 4n + 4 */;
+    hipStream_t s = h->stream;
+    std::vector<double> dx(n), df(n), fvold(n), xold(n);
+    int restart = 1, xcnvrg = 0, fcnvrg = 0, gcnvrg = 0, neval = 0, iter = 0, njac = 0, flag = 0, jcount = 0;
+    int ls_zero_diff = 0;                                       // lib%converge_on_zero_diff: .false. after every search (:318 of linesearch)
+    double f, fold, stpmax, xnorm = 0, fnorm = 0, test;
+    rc = 0;
+
+    if ((rc = ev.fcn(x, fvec))) return rc;                      // :261-270
+    f = 0.5 * h_dot(n, fvec, fvec);
+    neval += 1;
+    test = 0.0;
+    for (int i = 0; i < n; ++i) test = fmax(fabs(fvec[i]), test);
+    if (test < o->ftol) fcnvrg = 1;
+
+    if (!fcnvrg) {
+        stpmax = 100.0 * fmax(h_norm2(n, x), (double)n);        // :276
+        for (;;) {                                              // :279-411
+            iter += 1;
+            if (restart) {                                      // :284-292
+                if ((rc = ev.jac(x, fvec, dB))) break;
+                njac += 1;
+                launch_qn_qr(h, 1, n, dB, dQ, dRt, dvb);
+                jcount = 0;
+            } else {                                            // :294-310
+                for (int i = 0; i < n; ++i) df[i] = fvec[i] - fvold[i];
+                for (int i = 0; i < n; ++i) dx[i] = x[i] - xold[i];
+                const double x2 = h_dot(n, dx.data(), dx.data());
+                HIPCHK(h, hipMemcpyAsync(ddx, dx.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+                HIPCHK(h, hipMemcpyAsync(ddf, df.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_qn_resid, dim3((n + 255) / 256, 1), dim3(256), sizeof(double) * n, s, n, dB, ddx, ddf, x2, dsv);
+                hipLaunchKernelGGL(k_qn_rank1, dim3((n + 255) / 256, n, 1), dim3(256), 0, s, n, dB, dsv, ddx);
+                launch_qn_update(h, 1, n, dQ, dRt, dsv, ddx, dwcs);
+                jcount += 1;
+            }
+            // grad = B^T f (:313), step = -R^-1 Q^T f (:322-328)
+            HIPCHK(h, hipMemcpyAsync(dfv, fvec, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, 1), dim3(64), 0, s, n, dB, dfv, dgrad, 1.0);
+            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, 1), dim3(64), 0, s, n, dQ, dfv, dstep, -1.0);
+            hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dRt, dstep);
+            HIPCHK(h, hipMemcpyAsync(dx.data(), dgrad, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpyAsync(df.data(), dstep, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+
+            memcpy(xold.data(), x, sizeof(double) * n);         // :316-318
+            memcpy(fvold.data(), fvec, sizeof(double) * n);
+            fold = f;
+
+            double temp = h_dot(n, dx.data(), df.data());       // :332-339
+            if (temp >= 0.0) {
+                restart = 1;
+                if (o->print_status) print_status(iter, neval, njac, xnorm, fnorm);
+                if (iter > 10 * o->max_evals + 100) { flag = 1; break; }    // the reference would spin here
+                continue;
+            }
+
+            if (o->use_line_search) {                           // :342-351
+                temp = h_dot(n, df.data(), df.data());
+                if (temp > stpmax) {
+                    const double sc = stpmax / temp;
+                    for (int i = 0; i < n; ++i) df[i] = df[i] * sc;
+                }
+                const double mag = h_norm2(n, df.data());       // limit_search_vector
+                if (mag != 0.0 && mag > stpmax) {
+                    const double sc = stpmax / mag;
+                    for (int i = 0; i < n; ++i) df[i] = sc * df[i];
+                }
+                int lcount = 0;
+                rc = line_search(o, ev, n, xold.data(), dx.data(), df.data(), x, fvec, fold, &f, &lcount);
+                neval += lcount;
+                ls_zero_diff = 0;
+                if (rc) break;
+            } else {                                            // :353-357
+                for (int i = 0; i < n; ++i) x[i] = x[i] + df[i];
+                if ((rc = ev.fcn(x, fvec))) break;
+                f = 0.5 * h_dot(n, fvec, fvec);
+                neval += 1;
+            }
+
+            // test_convergence (:360-367); the gradient test runs only if the search reported a zero slope
+            int check = 0;
+            xcnvrg = fcnvrg = gcnvrg = 0;
+            {
+                const double fc = 0.5 * h_dot(n, fvec, fvec);
+                fnorm = 0.0; xnorm = 0.0;
+                for (int i = 0; i < n; ++i) fnorm = fmax(fabs(fvec[i]), fnorm);
+                if (fnorm < o->ftol) { fcnvrg = 1; check = 1; }
+                else {
+                    for (int i = 0; i < n; ++i) {
+                        const double t = fabs(x[i] - xold[i]) / fmax(fabs(x[i]), 1.0);
+                        xnorm = fmax(t, xnorm);
+                    }
+                    if (xnorm < o->xtol) { xcnvrg = 1; check = 1; }
+                    else if (ls_zero_diff && o->use_line_search) {
+                        double tg = 0.0;
+                        const double den = fmax(fc, 0.5 * (double)n);
+                        for (int i = 0; i < n; ++i) tg = fmax(tg, fabs(dx[i]) * fmax(fabs(x[i]), 1.0) / den);
+                        if (tg < o->gtol) gcnvrg = 1;
+                    }
+                }
+            }
+            if (!check) {                                       // :368-391
+                if (gcnvrg) {
+                    if (restart) { rc = NLH_SPURIOUS_CONVERGENCE_ERROR; break; }
+                    restart = 1;
+                } else {
+                    restart = jcount >= jdelta ? 1 : 0;
+                }
+            } else {
+                break;
+            }
+            if (o->print_status) print_status(iter, neval, njac, xnorm, fnorm);   // :398-400
+            if (neval >= o->max_evals) { flag = 1; break; }     // :403-406
+        }
+    }
+    if (ib) {                                                   // :414-422
+        ib->iter_count = iter; ib->fcn_count = neval; ib->jacobian_count = njac; ib->gradient_count = 0;
+        ib->converge_on_fcn = fcnvrg; ib->converge_on_chng = xcnvrg; ib->converge_on_zero_diff = gcnvrg;
+    }
+    if (rc) return rc;
+    return flag ? NLH_CONVERGENCE_ERROR : 0;
+}
+
 extern "C" {
 
 int nlh_newton_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_vecfcn fcn, nlh_jacfcn jacfcn,
@@ -1071,6 +1263,108 @@ int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob
         nlh_iteration_behavior lib;
         memset(&lib, 0, sizeof lib);
         rc = newton_core(h, o, n, ev, x.data(), f.data(), &lib);
+        if (rc < 0) return rc;
+        if (ib) ib[p] = lib;
+        if (status) status[p] = rc;
+        HIPCHK(h, hipMemcpyAsync(dxp, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(dfp, f.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// quasi_newton_solver%solve -- qns_solve, src/nonlin_solve.f90:156-427
+int nlh_quasi_newton_solve(nlh_handle *h, const nlh_options *o, int32_t jdelta, int32_t n, nlh_vecfcn fcn,
+                           nlh_jacfcn jacfcn, void *ctx, double *x, double *fvec, nlh_iteration_behavior *ib)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (ib) memset(ib, 0, sizeof *ib);
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :240
+    if (!o || n < 1) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t nn = (size_t)n * n;
+    if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
+    if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
+    if ((rc = ensure_pinned(h, sizeof(double) * (nn + n)))) return rc;
+    double *hP = (double *)h->pinned;
+    hipStream_t s = h->stream;
+    NewtonEval ev;
+    ev.fcn = [&](const double *xx, double *ff) -> int { fcn(ctx, n, xx, n, ff); return 0; };
+    ev.jac = [&](double *xx, const double *f0, double *dJ) -> int {
+        if (jacfcn) {
+            jacfcn(ctx, n, xx, n, hP);
+            HIPCHK(h, hipMemcpyAsync(dJ, hP, sizeof(double) * nn, hipMemcpyHostToDevice, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            return 0;
+        }
+        for (int j = 0; j < n; ++j) {                           // vfh_jac_fcn :267-273
+            const double temp = xx[j];
+            double hh = NLH_SQRT_EPS * fabs(temp);
+            if (hh == 0.0) hh = NLH_SQRT_EPS;
+            xx[j] = temp + hh;
+            fcn(ctx, n, xx, n, hP + (size_t)j * n);
+            xx[j] = temp;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->P.p, hP, sizeof(double) * nn, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->wa4.p, f0, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->xdev.p, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        launch_fd(h, 1, n, n, (const double *)h->P.p, (const double *)h->wa4.p, (const double *)h->xdev.p, dJ, nullptr, -1);
+        HIPCHK(h, hipStreamSynchronize(s));
+        return 0;
+    };
+    rc = quasi_newton_core(h, o, jdelta, n, ev, x, fvec, ib);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return NLH_ERR_HIP; }
+    return rc;
+}
+
+int nlh_dq_quasi_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t jdelta, int32_t nprob, int32_t n,
+                                    const double *dA, const double *db, double gamma, int32_t analytic, double *dx,
+                                    double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!o || n < 1) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t nn = (size_t)n * n;
+    if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
+    if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
+    hipStream_t s = h->stream;
+    std::vector<double> x(n), f(n);
+    for (int p = 0; p < nprob; ++p) {                           // independent problems, one after another
+        const double *A = dA + (size_t)p * nn, *b = db + (size_t)p * n;
+        double *dxp = dx + (size_t)p * n, *dfp = dfvec + (size_t)p * n;
+        double *dxs = (double *)h->xdev.p, *dfs = (double *)h->wa4.p;
+        HIPCHK(h, hipMemcpyAsync(x.data(), dxp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        NewtonEval ev;
+        ev.fcn = [&](const double *xx, double *ff) -> int {
+            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            launch_dq_residual(h, 1, n, n, A, b, gamma, dxs, dfs, nullptr, nullptr, -1);
+            HIPCHK(h, hipMemcpyAsync(ff, dfs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            return 0;
+        };
+        ev.jac = [&](double *xx, const double *f0, double *dJ) -> int {
+            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            if (analytic) {
+                Timed t(h, NLH_K_DQ_JACOBIAN);
+                hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((n + RB - 1) / RB, 1), dim3(RB), sizeof(double) * n, s,
+                                   n, n, A, gamma, dxs, dJ);
+            } else {
+                HIPCHK(h, hipMemcpyAsync(dfs, f0, sizeof(double) * n, hipMemcpyHostToDevice, s));
+                launch_dq_panel(h, 1, n, n, A, b, gamma, dxs, (double *)h->P.p, nullptr, -1);
+                launch_fd(h, 1, n, n, (const double *)h->P.p, dfs, dxs, dJ, nullptr, -1);
+            }
+            return 0;
+        };
+        nlh_iteration_behavior lib;
+        memset(&lib, 0, sizeof lib);
+        rc = quasi_newton_core(h, o, jdelta, n, ev, x.data(), f.data(), &lib);
         if (rc < 0) return rc;
         if (ib) ib[p] = lib;
         if (status) status[p] = rc;
@@ -1259,6 +1553,45 @@ int nlh_lu_solve(nlh_handle *h, int32_t nprob, int32_t n, const double *dLU, con
     if (!h) return NLH_ERR_BAD_HANDLE;
     HIPCHK(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, h->stream, n, dLU, dipvt, db);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// qr_factor(b, q = q, r = r) / qr_rank1_update / solve_triangular_system stand-ins (call sites :289, :307, :327).
+// dB, dQ column-major [nprob][n][n]; dRt is R ROW-major.
+int nlh_qr_factor_full(nlh_handle *h, int32_t nprob, int32_t n, const double *dB, double *dQ, double *dRt)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->qnV, sizeof(double) * ((size_t)nprob * (16 * (size_t)n + 8))))) return rc;
+    launch_qn_qr(h, nprob, n, dB, dQ, dRt, (double *)h->qnV.p);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_qr_rank1_update(nlh_handle *h, int32_t nprob, int32_t n, double *dQ, double *dRt, const double *du,
+                        const double *dv)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
+    if (n > QN_MAX_N) return NLH_ARRAY_SIZE_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->qnV, sizeof(double) * ((size_t)nprob * (16 * (size_t)n + 8))))) return rc;
+    launch_qn_update(h, nprob, n, dQ, dRt, du, dv, (double *)h->qnV.p);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int nlh_solve_upper(nlh_handle *h, int32_t nprob, int32_t n, const double *dRt, double *dx)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_qn_solve_upper, dim3(nprob), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n,
+                       h->stream, n, dRt, dx);
     HIPCHK(h, hipGetLastError());
     return 0;
 }

@@ -1,0 +1,362 @@
+// nlh_kernels_broyden.h -- dense kernels of quasi_newton_solver (qns_solve,
+// src/nonlin_solve.f90:156-427): Householder QR with explicit Q (qr_factor, :289), the rank-one
+// Broyden update of B (:301-306) and of its QR factors (qr_rank1_update, :307), B^T f and
+// Q^T f (:313, :322) and the triangular solve (:327).
+//
+// The reference takes all of these from the third-party linalg library (LAPACK / qrupdate,
+// unpinned); the CPU restatement defines them as the published unblocked algorithms with every
+// sum in ascending index order, and the kernels below perform exactly those operations on every
+// matrix element (a sequential sum is owned by one thread; rotations are elementwise), so Q, R, B
+// and every iterate are bit-identical to the CPU path.
+//
+// Layout per problem: B and Q column-major n x n; R ROW-major (Rt[i*n + c]) so that a thread
+// per column reads consecutive addresses across a wave.  The QR work array [A | E] is stored
+// row-major too: A^T-of-B becomes R in place and the transformed identity E = Q^T, read
+// row-major, IS Q column-major -- the factorisation writes both results where they are used.
+#pragma once
+#include "nlh_common.h"
+
+// DLARTG (LAPACK 3.10): c >= 0, r carries the sign of f.
+__device__ __forceinline__ void givens_dev(double f, double g, double &c, double &s, double &r)
+{
+    if (g == 0.0) { c = 1.0; s = 0.0; r = f; return; }
+    if (f == 0.0) { c = 0.0; s = 1.0; r = g; return; }
+    const double d = sqrt(f * f + g * g);
+    c = fabs(f) / d;
+    r = copysign(d, f);
+    s = g / r;
+}
+
+// Q <- I, and the first reflector's column: vbuf[i] = A(i,0).
+__global__ void __launch_bounds__(256)
+k_qn_qr_init(int n, const double *__restrict__ Rt, double *__restrict__ Q, double *__restrict__ vbuf)
+{
+    const int p = blockIdx.y;
+    const size_t nn = (size_t)n * n;
+    double *Qp = Q + p * nn;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nn; e += (size_t)gridDim.x * 256)
+        Qp[e] = (e % n == e / n) ? 1.0 : 0.0;
+    if (blockIdx.x == 0) {
+        const double *A = Rt + p * nn;
+        double *v = vbuf + (size_t)p * 2 * n;
+        for (int i = 1 + threadIdx.x; i < n; i += 256) v[i] = A[(size_t)i * n];
+    }
+}
+
+// Householder step j, first half, on the row-major work array [A | E] (thread k owns column k; k < n: A,
+// k >= n: E): the reflector of column j from the copy the previous step left in vbuf (slot j & 1), then
+// w_k = tau * (T(j,k) + sum_{i>j} v_i T(i,k)) for every column still in play, summed by one thread in
+// ascending i with QN_U loads in flight.  st[p] = {tau, scal, beta} for the second half (tau = 0: H = I).
+#define QN_DOT_BS 128
+#define QN_U 32
+__global__ void __launch_bounds__(QN_DOT_BS)
+k_qn_house_dot(int n, int j, const double *__restrict__ Rt, const double *__restrict__ Q,
+               const double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st)
+{
+    extern __shared__ double vs[];                 // n: reflector, rows j+1 .. n-1
+    __shared__ double sq_sh;
+    const int p = blockIdx.y, tid = threadIdx.x;
+    const size_t nn = (size_t)n * n;
+    const double *A = Rt + p * nn, *E = Q + p * nn;
+    const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * n;
+    for (int i = j + 1 + tid; i < n; i += QN_DOT_BS) vs[i] = vcur[i];
+    __syncthreads();
+    if (tid == 0) {                                // one ordered sum; LDS reads batched 16 at a time
+        double s = 0.0;
+        int i = j + 1;
+        for (; i + 16 <= n; i += 16) {
+            double t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = vs[i + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = s + t[u] * t[u];
+        }
+        for (; i < n; ++i) s = s + vs[i] * vs[i];
+        sq_sh = s;
+    }
+    __syncthreads();
+    const double sq = sq_sh;
+    if (sq == 0.0) {                               // H = I (uniform)
+        if (blockIdx.x == 0 && tid == 0) { st[(size_t)p * 4] = 0.0; st[(size_t)p * 4 + 1] = 0.0; st[(size_t)p * 4 + 2] = 0.0; }
+        return;
+    }
+    const double alpha = A[(size_t)j * n + j];
+    const double beta = -copysign(sqrt(alpha * alpha + sq), alpha);
+    const double tau = (beta - alpha) / beta;
+    const double scal = 1.0 / (alpha - beta);
+    if (blockIdx.x == 0 && tid == 0) { st[(size_t)p * 4] = tau; st[(size_t)p * 4 + 1] = scal; st[(size_t)p * 4 + 2] = beta; }
+    for (int i = j + 1 + tid; i < n; i += QN_DOT_BS) vs[i] = vs[i] * scal;
+    __syncthreads();
+    const int k = blockIdx.x * QN_DOT_BS + tid;
+    if (k >= 2 * n || (k < n && k <= j)) return;
+    const double *T = (k < n) ? A + k : E + (k - n);
+    double w = T[(size_t)j * n];
+    for (int i = j + 1; i < n; i += QN_U) {        // the chain is serial in i; the loads are not
+        double t[QN_U];
+#pragma unroll
+        for (int u = 0; u < QN_U; ++u) t[u] = (i + u < n) ? T[(size_t)(i + u) * n] : 0.0;
+#pragma unroll
+        for (int u = 0; u < QN_U; ++u)
+            if (i + u < n) w = w + vs[i + u] * t[u];
+    }
+    wbuf[(size_t)p * 2 * n + k] = tau * w;
+}
+
+// Second half: T(j,k) -= w_k, T(i,k) -= v_i w_k (elementwise, one thread per column and QN_RC rows),
+// column j becomes (beta, 0, ..., 0), and the updated column j+1 is copied to the other vbuf slot.
+#define QN_RC 16
+__global__ void __launch_bounds__(256)
+k_qn_house_apply(int n, int j, double *__restrict__ Rt, double *__restrict__ Q, double *__restrict__ vbuf,
+                 const double *__restrict__ wbuf, const double *__restrict__ st)
+{
+    const int p = blockIdx.z;
+    const size_t nn = (size_t)n * n;
+    double *A = Rt + p * nn, *E = Q + p * nn;
+    const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * n;
+    double *vnext = vbuf + ((size_t)p * 2 + ((j + 1) & 1)) * n;
+    const double tau = st[(size_t)p * 4], scal = st[(size_t)p * 4 + 1], beta = st[(size_t)p * 4 + 2];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = j + blockIdx.y * QN_RC, i1 = min(n, i0 + QN_RC);
+    if (k >= 2 * n || (k < n && k < j)) return;
+    const bool next_owner = (k == j + 1) && (k < n);
+    double *T = (k < n) ? A + k : E + (k - n);
+    if (tau == 0.0) {
+        if (next_owner)
+            for (int i = max(i0, j + 2); i < i1; ++i) vnext[i] = T[(size_t)i * n];
+        return;
+    }
+    if (k == j) {
+        for (int i = i0; i < i1; ++i) T[(size_t)i * n] = (i == j) ? beta : 0.0;
+        return;
+    }
+    const double w = wbuf[(size_t)p * 2 * n + k];
+    double t[QN_RC];
+#pragma unroll
+    for (int u = 0; u < QN_RC; ++u) t[u] = (i0 + u < i1) ? T[(size_t)(i0 + u) * n] : 0.0;
+#pragma unroll
+    for (int u = 0; u < QN_RC; ++u) {
+        const int i = i0 + u;
+        if (i < i1) {
+            const double a = (i == j) ? t[u] - w : t[u] - (vcur[i] * scal) * w;
+            T[(size_t)i * n] = a;
+            if (next_owner && i >= j + 2) vnext[i] = a;
+        }
+    }
+}
+
+// s = (df - B dx) / x2   (:301-302): thread per row, sum over columns ascending.
+__global__ void __launch_bounds__(256)
+k_qn_resid(int n, const double *__restrict__ B, const double *__restrict__ dx, const double *__restrict__ df,
+           double x2, double *__restrict__ s)
+{
+    extern __shared__ double xs[];
+    const int p = blockIdx.y;
+    for (int k = threadIdx.x; k < n; k += 256) xs[k] = dx[(size_t)p * n + k];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double *b = B + (size_t)p * n * n + i;
+    double t = 0.0;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = b[(size_t)(j + u) * n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t = t + v[u] * xs[j + u];
+    }
+    for (; j < n; ++j) t = t + b[(size_t)j * n] * xs[j];
+    s[(size_t)p * n + i] = (df[(size_t)p * n + i] - t) / x2;
+}
+
+// B += s dx^T  (rank1_update, :306)
+__global__ void __launch_bounds__(256)
+k_qn_rank1(int n, double *__restrict__ B, const double *__restrict__ s, const double *__restrict__ dx)
+{
+    const int p = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= n) return;
+    double *b = B + (size_t)p * n * n + (size_t)j * n + i;
+    *b = *b + s[(size_t)p * n + i] * dx[(size_t)p * n + j];
+}
+
+// out_k = sign * sum_i M(i,k) f_i, M column-major, sum over i ascending (grad = B^T f, -Q^T f, Q^T u).
+// A 64-thread workgroup owns 64 columns; 64x64 tiles are read coalesced and re-read from LDS by column.
+__global__ void __launch_bounds__(64)
+k_qn_colsdot(int n, const double *__restrict__ M, const double *__restrict__ f, double *__restrict__ out,
+             double sign)
+{
+    __shared__ double tile[64 * 65];
+    __shared__ double fs[64];
+    const int p = blockIdx.y, t = threadIdx.x;
+    const int k0 = blockIdx.x * 64;
+    const double *Mp = M + (size_t)p * n * n;
+    const double *fp = f + (size_t)p * n;
+    double acc = 0.0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + t;
+        for (int kk = 0; kk < 64; ++kk)
+            tile[kk * 65 + t] = (i < n && k0 + kk < n) ? Mp[(size_t)(k0 + kk) * n + i] : 0.0;
+        fs[t] = (i < n) ? fp[i] : 0.0;
+        __syncthreads();
+        const int lim = min(64, n - i0);
+        for (int ii = 0; ii < lim; ++ii) acc = acc + tile[t * 65 + ii] * fs[ii];
+        __syncthreads();
+    }
+    if (k0 + t < n) out[(size_t)p * n + k0 + t] = sign * acc;
+}
+
+// DQRTV1: rotations folding w into w(0), generated from the bottom (one thread per problem).
+__global__ void k_qn_fold(int n, double *__restrict__ w, double *__restrict__ c, double *__restrict__ s)
+{
+    const int p = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double *wp = w + (size_t)p * n, *cp = c + (size_t)p * n, *sp = s + (size_t)p * n;
+    double rr = wp[n - 1];
+    for (int i = n - 2; i >= 0; --i) {
+        double ci, si, t;
+        givens_dev(wp[i], rr, ci, si, t);
+        cp[i] = ci; sp[i] = si;
+        rr = t;
+    }
+    wp[0] = rr;
+}
+
+// DQROT: rotations on adjacent columns of Q, thread per row.  backward: pairs n-2 .. 0, else 0 .. n-2.
+__global__ void __launch_bounds__(256)
+k_qn_rot_q(int n, double *__restrict__ Q, const double *__restrict__ c, const double *__restrict__ s, int backward)
+{
+    extern __shared__ double cs[];                 // c[n], s[n]
+    const int p = blockIdx.y;
+    for (int k = threadIdx.x; k < n; k += 256) { cs[k] = c[(size_t)p * n + k]; cs[n + k] = s[(size_t)p * n + k]; }
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n || n < 2) return;
+    double *q = Q + (size_t)p * n * n + row;
+    if (backward) {
+        double y = q[(size_t)(n - 1) * n];
+        for (int i = n - 2; i >= 0; --i) {
+            const double x = q[(size_t)i * n];
+            const double ci = cs[i], si = cs[n + i];
+            q[(size_t)(i + 1) * n] = ci * y - si * x;
+            y = ci * x + si * y;
+        }
+        q[0] = y;
+    } else {
+        double x = q[0];
+        for (int i = 0; i < n - 1; ++i) {
+            const double y = q[(size_t)(i + 1) * n];
+            const double ci = cs[i], si = cs[n + i];
+            q[(size_t)i * n] = ci * x + si * y;
+            x = ci * y - si * x;
+        }
+        q[(size_t)(n - 1) * n] = x;
+    }
+}
+
+// DQRQH + the first-row update: R -> upper Hessenberg, then R(0,:) += w0 v^T.  Thread per column.
+__global__ void __launch_bounds__(256)
+k_qn_hess_r(int n, double *__restrict__ Rt, const double *__restrict__ c, const double *__restrict__ s,
+            const double *__restrict__ w, const double *__restrict__ v)
+{
+    extern __shared__ double cs[];
+    const int p = blockIdx.y;
+    for (int k = threadIdx.x; k < n; k += 256) { cs[k] = c[(size_t)p * n + k]; cs[n + k] = s[(size_t)p * n + k]; }
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= n) return;
+    double *r = Rt + (size_t)p * n * n + col;
+    const int ii = col < n - 2 ? col : n - 2;
+    double top;
+    if (ii >= 0) {
+        double t = r[(size_t)(ii + 1) * n];
+        for (int j = ii; j >= 0; --j) {
+            const double rj = r[(size_t)j * n];
+            const double cj = cs[j], sj = cs[n + j];
+            r[(size_t)(j + 1) * n] = cj * t - sj * rj;
+            t = cj * rj + sj * t;
+        }
+        top = t;
+    } else {
+        top = r[0];
+    }
+    r[0] = top + w[(size_t)p * n] * v[(size_t)p * n + col];
+}
+
+// DQHQR: back to upper triangular.  One workgroup per problem, thread per column (NC columns per thread
+// when n > blockDim): step j, the owner of column j turns (t, R(j+1,j)) into rotation j and publishes it,
+// then every later column applies it.  c, s receive the rotations (dynamic LDS: 2n doubles).
+template <int NC>
+__global__ void __launch_bounds__(1024)
+k_qn_retri(int n, double *__restrict__ Rt, double *__restrict__ c, double *__restrict__ s)
+{
+    extern __shared__ double cs[];
+    const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    double *R = Rt + (size_t)p * n * n;
+    double t[NC], nx[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int col = tid + q * BS;
+        t[q] = (col < n) ? R[col] : 0.0;                          // R(0, col)
+        nx[q] = (col < n && n > 1) ? R[(size_t)n + col] : 0.0;    // R(1, col)
+    }
+    for (int j = 0; j < n - 1; ++j) {
+        const int oq = j / BS, ot = j - oq * BS;                  // owner of column j
+        if (tid == ot) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (q == oq) {
+                    double cj, sj, rd;
+                    givens_dev(t[q], nx[q], cj, sj, rd);
+                    cs[j] = cj; cs[n + j] = sj;
+                    R[(size_t)j * n + j] = rd;
+                    R[(size_t)(j + 1) * n + j] = 0.0;
+                }
+        }
+        __syncthreads();
+        const double cj = cs[j], sj = cs[n + j];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int col = tid + q * BS;
+            if (col > j && col < n) {
+                const double below = nx[q];
+                R[(size_t)j * n + col] = cj * t[q] + sj * below;
+                t[q] = cj * below - sj * t[q];
+                nx[q] = (j + 2 < n) ? R[(size_t)(j + 2) * n + col] : 0.0;
+            }
+        }
+    }
+    {                                                             // last column keeps its carried value
+        const int col = n - 1, oq = col / BS, ot = col - oq * BS;
+        if (tid == ot) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (q == oq) R[(size_t)col * n + col] = t[q];
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += BS) { c[(size_t)p * n + k] = cs[k]; s[(size_t)p * n + k] = cs[n + k]; }
+}
+
+// x <- R^-1 x, column oriented (DTRSV 'U','N','N'); R row-major.  Dynamic LDS: n doubles.
+__global__ void __launch_bounds__(1024)
+k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall)
+{
+    extern __shared__ double bs[];
+    const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    const double *R = Rt + (size_t)p * n * n;
+    double *x = xall + (size_t)p * n;
+    for (int i = tid; i < n; i += BS) bs[i] = x[i];
+    __syncthreads();
+    for (int j = n - 1; j >= 0; --j) {
+        const double bj = bs[j];
+        if (bj != 0.0) {                                          // uniform
+            const double tj = bj / R[(size_t)j * n + j];
+            __syncthreads();
+            for (int i = tid; i < j; i += BS) bs[i] = bs[i] - tj * R[(size_t)i * n + j];
+            if (tid == 0) bs[j] = tj;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += BS) x[i] = bs[i];
+}

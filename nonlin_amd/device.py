@@ -89,6 +89,23 @@ class DeviceSolver:
             raise RuntimeError(f"nlh_dq_newton_solve_batch returned {rc}")
         return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
 
+    def quasi_newton_solve_batch(self, A, b, gamma, x, analytic=True, opts=None, jdelta=5):
+        """quasi_newton_solver%solve for every (square) problem.  x is updated in place."""
+        nprob, n, m = A.shape
+        assert m == n
+        _chk(A, (nprob, n, n), "A"); _chk(b, (nprob, n), "b"); _chk(x, (nprob, n), "x")
+        fvec = torch.empty((nprob, n), dtype=torch.float64, device=A.device)
+        ib = (_lib.IterationBehavior * nprob)()
+        status = (C.c_int32 * nprob)()
+        o = opts or self.options()
+        rc = self.lib.nlh_dq_quasi_newton_solve_batch(self.h.ptr, C.byref(o), int(jdelta), nprob, n, A.data_ptr(),
+                                                      b.data_ptr(), float(gamma), int(analytic), x.data_ptr(),
+                                                      fvec.data_ptr(), ib, status)
+        self.h.check(rc, "nlh_dq_quasi_newton_solve_batch")
+        if rc:
+            raise RuntimeError(f"nlh_dq_quasi_newton_solve_batch returned {rc}")
+        return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
+
     # -- stage-level kernels (parity tests, roofline) --------------------------
     def residual(self, A, b, gamma, x):
         nprob, n, m = A.shape
@@ -174,6 +191,31 @@ class DeviceSolver:
         self.h.check(self.lib.nlh_lu_factor(self.h.ptr, nprob, n, A.data_ptr(), ipvt.data_ptr(), info.data_ptr()),
                      "nlh_lu_factor")
         return ipvt, info
+
+    def qr_factor_full(self, B):
+        """Householder QR with Q formed.  B: [nprob, n, n] column-major problems (B[p].T is the matrix).
+        Returns (Q column-major like B, Rt = R stored row-major, i.e. Rt[p] IS R as a torch matrix)."""
+        nprob, n, _ = B.shape
+        _chk(B, (nprob, n, n), "B")
+        Q = torch.empty_like(B)
+        Rt = torch.empty_like(B)
+        self.h.check(self.lib.nlh_qr_factor_full(self.h.ptr, nprob, n, B.data_ptr(), Q.data_ptr(), Rt.data_ptr()),
+                     "nlh_qr_factor_full")
+        return Q, Rt
+
+    def qr_rank1_update(self, Q, Rt, u, v):
+        """In place: Q1 R1 = Q R + u v^T."""
+        nprob, n, _ = Q.shape
+        _chk(Q, (nprob, n, n), "Q"); _chk(Rt, (nprob, n, n), "Rt"); _chk(u, (nprob, n), "u"); _chk(v, (nprob, n), "v")
+        self.h.check(self.lib.nlh_qr_rank1_update(self.h.ptr, nprob, n, Q.data_ptr(), Rt.data_ptr(), u.data_ptr(),
+                                                  v.data_ptr()), "nlh_qr_rank1_update")
+        return Q, Rt
+
+    def solve_upper(self, Rt, x):
+        nprob, n, _ = Rt.shape
+        _chk(Rt, (nprob, n, n), "Rt"); _chk(x, (nprob, n), "x")
+        self.h.check(self.lib.nlh_solve_upper(self.h.ptr, nprob, n, Rt.data_ptr(), x.data_ptr()), "nlh_solve_upper")
+        return x
 
     def lu_solve(self, LU, ipvt, b):
         nprob, n, _ = LU.shape

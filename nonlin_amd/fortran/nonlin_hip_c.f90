@@ -74,6 +74,19 @@ module nonlin_hip_c
             type(nlh_iteration_behavior), intent(out) :: ib
             integer(c_int) :: rc
         end function
+        function nlh_quasi_newton_solve(h, opts, jdelta, n, fcn, jacfcn, ctx, x, fvec, ib) &
+                bind(C, name="nlh_quasi_newton_solve") result(rc)
+            import :: c_ptr, c_funptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h
+            type(nlh_options), intent(in) :: opts
+            integer(c_int32_t), value :: jdelta, n
+            type(c_funptr), value :: fcn, jacfcn
+            type(c_ptr), value :: ctx
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fvec(*)
+            type(nlh_iteration_behavior), intent(out) :: ib
+            integer(c_int) :: rc
+        end function
     end interface
 
     type(c_ptr), save, private :: default_handle = c_null_ptr

@@ -1,5 +1,6 @@
-! line_search_solver and newton_solver with the reference's public interface
-! (src/nonlin_solve.f90:20-41, 60-67, 92-151); solve marshals to nlh_newton_solve (ns_solve, :452-638).
+! line_search_solver, newton_solver and quasi_newton_solver with the reference's public interface
+! (src/nonlin_solve.f90:20-67, 92-151, 429-447); solve marshals to nlh_newton_solve (ns_solve, :452-638)
+! and nlh_quasi_newton_solve (qns_solve, :156-427).
 module nonlin_solve
     use iso_fortran_env
     use, intrinsic :: iso_c_binding
@@ -12,6 +13,7 @@ module nonlin_solve
     private
     public :: line_search_solver
     public :: newton_solver
+    public :: quasi_newton_solver
 
     type, abstract, extends(equation_solver) :: line_search_solver
         class(line_search), private, allocatable :: m_lineSearch
@@ -28,6 +30,14 @@ module nonlin_solve
     type, extends(line_search_solver) :: newton_solver
     contains
         procedure, public :: solve => ns_solve
+    end type
+
+    type, extends(line_search_solver) :: quasi_newton_solver
+        integer(int32), private :: m_jDelta = 5         ! :51
+    contains
+        procedure, public :: solve => qns_solve
+        procedure, public :: get_jacobian_interval => qns_get_jac_interval
+        procedure, public :: set_jacobian_interval => qns_set_jac_interval
     end type
 
 contains
@@ -136,5 +146,87 @@ contains
             ib%converge_on_zero_diff = cib%converge_on_zero_diff /= 0
         end if
         if (rc /= 0) error stop rc      ! :635-637, :604-608, line-search stops
+    end subroutine
+
+    subroutine qns_solve(this, fcn, x, fvec, ib, args)
+        class(quasi_newton_solver), intent(inout) :: this
+        class(vecfcn_helper), intent(in), target :: fcn
+        real(real64), intent(inout), dimension(:) :: x
+        real(real64), intent(out), dimension(:) :: fvec
+        type(iteration_behavior), optional :: ib
+        class(*), intent(inout), optional, target :: args
+
+        integer(int32) :: neqn, nvar, flag
+        integer(c_int) :: rc
+        type(nlh_options) :: opts
+        type(nlh_iteration_behavior) :: cib
+        type(nlh_callback_ctx), target :: ctx
+        type(c_funptr) :: cjac
+        real(c_double), allocatable :: xc(:), fc(:)
+        class(line_search), allocatable :: ls
+
+        neqn = fcn%get_equation_count()
+        nvar = fcn%get_variable_count()
+        if (present(ib)) then           ! :224-232
+            ib%iter_count = 0; ib%fcn_count = 0; ib%jacobian_count = 0; ib%gradient_count = 0
+            ib%converge_on_fcn = .false.; ib%converge_on_chng = .false.; ib%converge_on_zero_diff = .false.
+        end if
+        call nlh_default_options(opts)
+        if (this%get_use_line_search()) then        ! :233-237
+            if (.not.this%is_line_search_defined()) call this%set_default_line_search()
+            call this%get_line_search(ls)
+            opts%ls_max_evals = ls%get_max_fcn_evals()
+            opts%ls_alpha = ls%get_scaling_factor()
+            opts%ls_factor = ls%get_distance_factor()
+        end if
+        if (.not.fcn%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR    ! :240
+        if (nvar /= neqn) error stop NL_INVALID_INPUT_ERROR                      ! :241
+        flag = 0
+        if (size(x) /= nvar) then
+            flag = 3
+        else if (size(fvec) /= neqn) then
+            flag = 4
+        end if
+        if (flag /= 0) error stop flag
+
+        opts%max_evals = this%get_max_fcn_evals()
+        opts%ftol = this%get_fcn_tolerance()
+        opts%xtol = this%get_var_tolerance()
+        opts%gtol = this%get_gradient_tolerance()
+        opts%print_status = merge(1, 0, this%get_print_status())
+        opts%use_line_search = merge(1, 0, this%get_use_line_search())
+
+        ctx%helper => fcn
+        if (present(args)) ctx%args => args
+        cjac = c_null_funptr
+        if (fcn%is_jacobian_defined()) cjac = c_funloc(nlh_jacfcn_trampoline)
+        allocate(xc(nvar), fc(neqn))
+        xc = x
+        rc = nlh_quasi_newton_solve(nlh_default_handle(), opts, this%m_jDelta, nvar, &
+            c_funloc(nlh_vecfcn_trampoline), cjac, c_loc(ctx), xc, fc, cib)
+        x = xc
+        fvec = fc
+        if (present(ib)) then           ! :414-422
+            ib%iter_count = cib%iter_count
+            ib%fcn_count = cib%fcn_count
+            ib%jacobian_count = cib%jacobian_count
+            ib%gradient_count = 0
+            ib%converge_on_fcn = cib%converge_on_fcn /= 0
+            ib%converge_on_chng = cib%converge_on_chng /= 0
+            ib%converge_on_zero_diff = cib%converge_on_zero_diff /= 0
+        end if
+        if (rc /= 0) error stop rc      ! :425-427, :376, line-search stops
+    end subroutine
+
+    pure function qns_get_jac_interval(this) result(n)      ! :429-436
+        class(quasi_newton_solver), intent(in) :: this
+        integer(int32) :: n
+        n = this%m_jDelta
+    end function
+
+    subroutine qns_set_jac_interval(this, n)                ! :439-447
+        class(quasi_newton_solver), intent(inout) :: this
+        integer(int32), intent(in) :: n
+        this%m_jDelta = n
     end subroutine
 end module

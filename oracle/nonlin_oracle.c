@@ -860,6 +860,272 @@ int nlo_newton_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_n
 }
 
 /* ---------------------------------------------------------------------------
+ * Dense kernels behind qns_solve.  The reference takes these from the third-party
+ * `linalg` library (jchristopherson/linalg, unpinned: fpm.toml:15, src/CMakeLists.txt:26),
+ * which forwards to LAPACK / qrupdate: qr_factor = DGEQRF + DORGQR, qr_rank1_update =
+ * DQR1UP, solve_triangular_system = DTRSV, mtx_mult = DGEMV, rank1_update = DGER,
+ * recip_mult_array = DRSCL.  None of it is under /root/reference, so the published
+ * unblocked algorithms are restated here with every sum in ascending index order
+ * (parity unpinned at this boundary; see header).  Call sites: src/nonlin_solve.f90:286-336.
+ * ------------------------------------------------------------------------- */
+
+/* Plane rotation of LAPACK 3.10 DLARTG: c >= 0, r carries the sign of f. */
+void nlo_givens(double f, double g, double *c, double *s, double *r)
+{
+    if (g == 0.0) { *c = 1.0; *s = 0.0; *r = f; return; }
+    if (f == 0.0) { *c = 0.0; *s = 1.0; *r = g; return; }
+    const double d = sqrt(f * f + g * g);
+    *c = fabs(f) / d;
+    *r = copysign(d, f);
+    *s = g / *r;
+}
+
+/* Householder QR of the n-by-n column-major a (DGEQR2), with Q^T accumulated by applying
+ * every reflector to an identity alongside (instead of DORG2R's backward pass).  On exit
+ * r = R (upper, zeros below), q = Q, both column-major with leading dimension n. */
+void nlo_qr_factor_full(int32_t n, const double *a_in, double *q, double *r)
+{
+    double *a = (double *)malloc(sizeof(double) * (size_t)n * (size_t)n);
+    double *e = (double *)calloc((size_t)n * (size_t)n, sizeof(double));     /* becomes Q^T */
+    double *v = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    memcpy(a, a_in, sizeof(double) * (size_t)n * (size_t)n);
+    for (int32_t i = 0; i < n; ++i) A_(e, n, i, i) = 1.0;
+    for (int32_t j = 0; j < n; ++j) {
+        const double alpha = A_(a, n, j, j);
+        double ssq = 0.0;
+        for (int32_t i = j + 1; i < n; ++i) ssq = ssq + A_(a, n, i, j) * A_(a, n, i, j);
+        if (ssq == 0.0) continue;                                /* H = I (DLARFG with xnorm == 0) */
+        const double beta = -copysign(sqrt(alpha * alpha + ssq), alpha);
+        const double tau = (beta - alpha) / beta;
+        const double scal = 1.0 / (alpha - beta);
+        for (int32_t i = j + 1; i < n; ++i) v[i] = A_(a, n, i, j) * scal;
+        A_(a, n, j, j) = beta;
+        for (int32_t i = j + 1; i < n; ++i) A_(a, n, i, j) = 0.0;
+        for (int32_t pass = 0; pass < 2; ++pass) {
+            double *t = pass == 0 ? a : e;
+            for (int32_t k = (pass == 0 ? j + 1 : 0); k < n; ++k) {
+                double w = A_(t, n, j, k);
+                for (int32_t i = j + 1; i < n; ++i) w = w + v[i] * A_(t, n, i, k);
+                w = tau * w;
+                A_(t, n, j, k) = A_(t, n, j, k) - w;
+                for (int32_t i = j + 1; i < n; ++i) A_(t, n, i, k) = A_(t, n, i, k) - v[i] * w;
+            }
+        }
+    }
+    memcpy(r, a, sizeof(double) * (size_t)n * (size_t)n);
+    for (int32_t i = 0; i < n; ++i)
+        for (int32_t k = 0; k < n; ++k) A_(q, n, k, i) = A_(e, n, i, k);
+    free(a); free(e); free(v);
+}
+
+/* Q1 R1 = Q R + u v^T for square Q, R (qrupdate DQR1UP: DQRTV1, DQROT 'B', DQRQH, the
+ * first-row update, DQHQR, DQROT 'F').  u is overwritten. */
+void nlo_qr_rank1_update(int32_t n, double *q, double *r, double *u, const double *v)
+{
+    if (n < 1) return;
+    double *w = (double *)malloc(sizeof(double) * (size_t)n);
+    double *c = (double *)malloc(sizeof(double) * (size_t)n);
+    double *s = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int32_t k = 0; k < n; ++k) {                            /* w = Q^T u */
+        double t = 0.0;
+        for (int32_t i = 0; i < n; ++i) t = t + A_(q, n, i, k) * u[i];
+        w[k] = t;
+    }
+    /* DQRTV1: rotations that fold w into w(0), generated from the bottom */
+    double rr = w[n - 1];
+    for (int32_t i = n - 2; i >= 0; --i) {
+        double t;
+        nlo_givens(w[i], rr, &c[i], &s[i], &t);
+        rr = t;
+    }
+    w[0] = rr;
+    /* DQROT 'B': the same rotations on the columns of Q, last pair first */
+    for (int32_t i = n - 2; i >= 0; --i)
+        for (int32_t row = 0; row < n; ++row) {
+            const double x = A_(q, n, row, i), y = A_(q, n, row, i + 1);
+            A_(q, n, row, i) = c[i] * x + s[i] * y;
+            A_(q, n, row, i + 1) = c[i] * y - s[i] * x;
+        }
+    /* DQRQH: R -> upper Hessenberg, column by column from the bottom */
+    for (int32_t col = 0; col < n; ++col) {
+        int32_t ii = col < n - 2 ? col : n - 2;
+        if (ii < 0) continue;
+        double t = A_(r, n, ii + 1, col);
+        for (int32_t j = ii; j >= 0; --j) {
+            A_(r, n, j + 1, col) = c[j] * t - s[j] * A_(r, n, j, col);
+            t = c[j] * A_(r, n, j, col) + s[j] * t;
+        }
+        A_(r, n, 0, col) = t;
+    }
+    for (int32_t col = 0; col < n; ++col) A_(r, n, 0, col) = A_(r, n, 0, col) + w[0] * v[col];
+    /* DQHQR: back to upper triangular, rotations generated column by column */
+    for (int32_t col = 0; col < n; ++col) {
+        double t = A_(r, n, 0, col);
+        const int32_t ii = col < n - 1 ? col : n - 1;
+        for (int32_t j = 0; j < ii; ++j) {
+            A_(r, n, j, col) = c[j] * t + s[j] * A_(r, n, j + 1, col);
+            t = c[j] * A_(r, n, j + 1, col) - s[j] * t;
+        }
+        if (col < n - 1) {
+            double rd;
+            nlo_givens(t, A_(r, n, col + 1, col), &c[col], &s[col], &rd);
+            A_(r, n, col, col) = rd;
+            A_(r, n, col + 1, col) = 0.0;
+        } else {
+            A_(r, n, ii, col) = t;
+        }
+    }
+    /* DQROT 'F' */
+    for (int32_t i = 0; i < n - 1; ++i)
+        for (int32_t row = 0; row < n; ++row) {
+            const double x = A_(q, n, row, i), y = A_(q, n, row, i + 1);
+            A_(q, n, row, i) = c[i] * x + s[i] * y;
+            A_(q, n, row, i + 1) = c[i] * y - s[i] * x;
+        }
+    (void)u;
+    free(w); free(c); free(s);
+}
+
+/* x <- R^-1 x, R upper triangular, column oriented (DTRSV 'U','N','N'). */
+void nlo_solve_upper(int32_t n, const double *r, double *x)
+{
+    for (int32_t j = n - 1; j >= 0; --j) {
+        if (x[j] != 0.0) {
+            x[j] = x[j] / A_(r, n, j, j);
+            const double t = x[j];
+            for (int32_t i = j - 1; i >= 0; --i) x[i] = x[i] - t * A_(r, n, i, j);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * qns_solve: src/nonlin_solve.f90:156-427 (Broyden's method with QR rank-1 updates)
+ * ------------------------------------------------------------------------- */
+int nlo_quasi_newton_solve(const nlo_options *opt, int32_t jdelta, nlo_vecfcn fcn,
+                           nlo_jacfcn jac_or_null, void *ctx, int32_t n, double *x,
+                           double *fvec, nlo_iteration_behavior *ib)
+{
+    const double half = 0.5, factor = 1.0e2;
+    int32_t restart = 1, xcnvrg = 0, fcnvrg = 0, gcnvrg = 0, check = 0;
+    int32_t neval = 0, iter = 0, njac = 0, flag = 0, jcount = 0;
+    const double ftol = opt->ftol, xtol = opt->xtol, gtol = opt->gtol;
+    const int32_t maxeval = opt->max_evals;
+    double f, fold, stpmax, xnorm = 0.0, fnorm = 0.0, temp, test, x2;
+    int rc = 0;
+    nlo_iteration_behavior lib;
+    memset(&lib, 0, sizeof lib);              /* :205 `lib` is undefined before the first search; 0 here */
+
+    if (ib) memset(ib, 0, sizeof *ib);                       /* :224-232 */
+    if (!fcn) return NLO_UNDEFINED_FUNCTION_ERROR;           /* :240 */
+
+    const size_t nn = (size_t)n * (size_t)(n > 0 ? n : 1);
+    double *b = (double *)malloc(sizeof(double) * nn);       /* :251-258 */
+    double *q = (double *)malloc(sizeof(double) * nn);
+    double *r = (double *)malloc(sizeof(double) * nn);
+    double *df = (double *)calloc((size_t)(5 * n + 1), sizeof(double));
+    double *fvold = df + n, *xold = fvold + n, *dx = xold + n, *s = dx + n;
+
+    fcn(ctx, n, x, n, fvec);                                 /* :261-270 */
+    f = half * nlo_dot(n, fvec, fvec);
+    neval = neval + 1;
+    test = 0.0;
+    for (int32_t i = 0; i < n; ++i) test = dmax(fabs(fvec[i]), test);
+    if (test < ftol) fcnvrg = 1;
+
+    if (!fcnvrg) {
+        stpmax = factor * dmax(nlo_norm2(n, x), (double)n);  /* :276 */
+        for (;;) {                                           /* :279-411 */
+            iter = iter + 1;
+            if (restart) {                                   /* :284-292 */
+                nlo_fd_jacobian(fcn, jac_or_null, ctx, n, n, x, fvec, b);
+                njac = njac + 1;
+                nlo_qr_factor_full(n, b, q, r);
+                jcount = 0;
+            } else {                                         /* :294-310 */
+                for (int32_t i = 0; i < n; ++i) df[i] = fvec[i] - fvold[i];
+                for (int32_t i = 0; i < n; ++i) dx[i] = x[i] - xold[i];
+                x2 = nlo_dot(n, dx, dx);
+                for (int32_t i = 0; i < n; ++i) {            /* s = (df - matmul(b, dx)) / x2 */
+                    double t = 0.0;
+                    for (int32_t j = 0; j < n; ++j) t = t + A_(b, n, i, j) * dx[j];
+                    s[i] = (df[i] - t) / x2;
+                }
+                for (int32_t j = 0; j < n; ++j)              /* rank1_update: b += s dx^T */
+                    for (int32_t i = 0; i < n; ++i) A_(b, n, i, j) = A_(b, n, i, j) + s[i] * dx[j];
+                nlo_qr_rank1_update(n, q, r, s, dx);
+                jcount = jcount + 1;
+            }
+
+            for (int32_t j = 0; j < n; ++j)                  /* :313 grad = b^T f, kept in dx */
+                dx[j] = nlo_dot(n, &A_(b, n, 0, j), fvec);
+
+            memcpy(xold, x, sizeof(double) * (size_t)n);     /* :316-318 */
+            memcpy(fvold, fvec, sizeof(double) * (size_t)n);
+            fold = f;
+
+            for (int32_t k = 0; k < n; ++k)                  /* :322 df = -q^T f */
+                df[k] = -nlo_dot(n, &A_(q, n, 0, k), fvec);
+            nlo_solve_upper(n, r, df);                       /* :327-328 */
+
+            temp = nlo_dot(n, dx, df);                       /* :332-339 */
+            if (temp >= 0.0) {
+                restart = 1;
+                if (opt->print_status) print_status(iter, neval, njac, xnorm, fnorm);
+                if (iter > 10 * maxeval + 100) { flag = 1; break; }   /* the reference would spin; bounded here */
+                continue;
+            }
+
+            if (opt->use_line_search) {                      /* :342-351 */
+                temp = nlo_dot(n, df, df);
+                if (temp > stpmax) {                         /* squared length vs stpmax: kept */
+                    const double sc = stpmax / temp;
+                    for (int32_t i = 0; i < n; ++i) df[i] = df[i] * sc;
+                }
+                nlo_limit_search_vector(n, df, stpmax);
+                rc = nlo_line_search(opt, fcn, ctx, n, n, xold, dx, df, x, fvec, fold, &f, &lib);
+                neval = neval + lib.fcn_count;
+                if (rc) break;
+            } else {                                         /* :353-357 */
+                for (int32_t i = 0; i < n; ++i) x[i] = x[i] + df[i];
+                fcn(ctx, n, x, n, fvec);
+                f = half * nlo_dot(n, fvec, fvec);
+                neval = neval + 1;
+            }
+
+            nlo_test_convergence(n, n, x, xold, fvec, dx,    /* :360-367 */
+                                 (lib.converge_on_zero_diff && opt->use_line_search) ? 1 : 0,
+                                 xtol, ftol, gtol, &check, &xcnvrg, &fcnvrg, &gcnvrg, &xnorm, &fnorm);
+            if (!check) {                                    /* :368-391 */
+                if (gcnvrg) {
+                    if (restart) { rc = NLO_SPURIOUS_CONVERGENCE_ERROR; break; }
+                    restart = 1;
+                } else {
+                    restart = jcount >= jdelta ? 1 : 0;
+                }
+            } else {
+                break;
+            }
+
+            if (opt->print_status) print_status(iter, neval, njac, xnorm, fnorm);   /* :398-400 */
+            if (neval >= maxeval) { flag = 1; break; }       /* :403-406 */
+        }
+    }
+
+    if (ib) {                                                /* :414-422 */
+        ib->iter_count = iter;
+        ib->fcn_count = neval;
+        ib->jacobian_count = njac;
+        ib->gradient_count = 0;
+        ib->converge_on_fcn = fcnvrg;
+        ib->converge_on_chng = xcnvrg;
+        ib->converge_on_zero_diff = gcnvrg;
+    }
+    free(b); free(q); free(r); free(df);
+    if (rc) return rc;
+    return flag != 0 ? NLO_CONVERGENCE_ERROR : 0;            /* :425-427 */
+}
+
+/* ---------------------------------------------------------------------------
  * Synthetic dense-quadratic family; not reference code.
  * ------------------------------------------------------------------------- */
 static void trace_push(nlo_trace *t, int32_t n, const double *x)
@@ -952,6 +1218,15 @@ int nlo_dq_newton_solve(const nlo_options *opt, const nlo_dq_problem *p, int32_t
 {
     nlo_dq_problem q = *p;
     int rc = nlo_newton_solve(opt, nlo_dq_fcn, analytic ? nlo_dq_jac : NULL, &q, q.n, x, fvec, ib);
+    ((nlo_dq_problem *)p)->ncalls = q.ncalls;
+    return rc;
+}
+
+int nlo_dq_quasi_newton_solve(const nlo_options *opt, int32_t jdelta, const nlo_dq_problem *p,
+                              int32_t analytic, double *x, double *fvec, nlo_iteration_behavior *ib)
+{
+    nlo_dq_problem q = *p;
+    int rc = nlo_quasi_newton_solve(opt, jdelta, nlo_dq_fcn, analytic ? nlo_dq_jac : NULL, &q, q.n, x, fvec, ib);
     ((nlo_dq_problem *)p)->ncalls = q.ncalls;
     return rc;
 }

@@ -141,6 +141,17 @@ int nlo_newton_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_n
                      void *ctx, int32_t n, double *x, double *fvec,
                      nlo_iteration_behavior *ib);
 
+/* Dense kernels behind qns_solve (third-party linalg in the reference; restated, see .c). */
+void nlo_givens(double f, double g, double *c, double *s, double *r);
+void nlo_qr_factor_full(int32_t n, const double *a, double *q, double *r);
+void nlo_qr_rank1_update(int32_t n, double *q, double *r, double *u, const double *v);
+void nlo_solve_upper(int32_t n, const double *r, double *x);
+
+/* qns_solve (src/nonlin_solve.f90:156-427).  jdelta = quasi_newton_solver%m_jDelta (default 5). */
+int nlo_quasi_newton_solve(const nlo_options *opt, int32_t jdelta, nlo_vecfcn fcn,
+                           nlo_jacfcn jac_or_null, void *ctx, int32_t n, double *x,
+                           double *fvec, nlo_iteration_behavior *ib);
+
 /* ---- Synthetic "dense-quadratic" residual family ----
  * u_i = sum_j A(i,j) x_j (j ascending, one multiply + one add per term, no FMA)
  * r_i = (u_i + gamma*u_i*u_i) - b_i ;  J(i,j) = (1 + 2*gamma*u_i) * A(i,j).   */
@@ -168,6 +179,8 @@ int nlo_dq_lm_solve(const nlo_options *opt, const nlo_dq_problem *p, double *x,
                     double *fvec, nlo_iteration_behavior *ib);
 int nlo_dq_newton_solve(const nlo_options *opt, const nlo_dq_problem *p, int32_t analytic,
                         double *x, double *fvec, nlo_iteration_behavior *ib);
+int nlo_dq_quasi_newton_solve(const nlo_options *opt, int32_t jdelta, const nlo_dq_problem *p,
+                              int32_t analytic, double *x, double *fvec, nlo_iteration_behavior *ib);
 
 #ifdef __cplusplus
 }

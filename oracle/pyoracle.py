@@ -91,6 +91,13 @@ def lib():
                                       C.POINTER(IterationBehavior)]
         L.nlo_dq_newton_solve.argtypes = [C.POINTER(Options), C.POINTER(DqProblem), C.c_int32, dp, dp,
                                           C.POINTER(IterationBehavior)]
+        L.nlo_dq_quasi_newton_solve.argtypes = [C.POINTER(Options), C.c_int32, C.POINTER(DqProblem), C.c_int32, dp, dp,
+                                                C.POINTER(IterationBehavior)]
+        L.nlo_quasi_newton_solve.argtypes = [C.POINTER(Options), C.c_int32, VECFCN, JACFCN, C.c_void_p, C.c_int32, dp, dp,
+                                             C.POINTER(IterationBehavior)]
+        L.nlo_qr_factor_full.argtypes = [C.c_int32, dp, dp, dp]
+        L.nlo_qr_rank1_update.argtypes = [C.c_int32, dp, dp, dp, dp]
+        L.nlo_solve_upper.argtypes = [C.c_int32, dp, dp]
         _LIB = L
     return _LIB
 
@@ -177,6 +184,44 @@ def newton_solve(fcn, n, x0, jac=None, opts=None, record=None):
     return rc, x, fvec, ib.as_dict()
 
 
+def quasi_newton_solve(fcn, n, x0, jac=None, opts=None, jdelta=5, record=None):
+    """quasi_newton_solver%solve.  Returns (rc, x, fvec, ib_dict)."""
+    x = np.array(x0, dtype=np.float64)
+    fvec = np.zeros(n)
+    ib = IterationBehavior()
+    o = opts or default_options()
+    cf, cj = _wrap_fcn(fcn, record), _wrap_jac(jac)
+    rc = lib().nlo_quasi_newton_solve(C.byref(o), int(jdelta), cf, cj, None, n, _dp(x), _dp(fvec), C.byref(ib))
+    return rc, x, fvec, ib.as_dict()
+
+
+def qr_factor_full(a):
+    """Householder QR of a square Fortran-order matrix.  Returns (q, r)."""
+    a = np.array(a, dtype=np.float64, order="F")
+    n = a.shape[0]
+    q = np.zeros((n, n), order="F")
+    r = np.zeros((n, n), order="F")
+    lib().nlo_qr_factor_full(n, _dp(a), _dp(q), _dp(r))
+    return q, r
+
+
+def qr_rank1_update(q, r, u, v):
+    """Q1 R1 = Q R + u v^T.  Returns (q1, r1)."""
+    q = np.array(q, dtype=np.float64, order="F")
+    r = np.array(r, dtype=np.float64, order="F")
+    u = np.array(u, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    lib().nlo_qr_rank1_update(q.shape[0], _dp(q), _dp(r), _dp(u), _dp(v))
+    return q, r
+
+
+def solve_upper(r, b):
+    r = np.array(r, dtype=np.float64, order="F")
+    x = np.array(b, dtype=np.float64)
+    lib().nlo_solve_upper(r.shape[0], _dp(r), _dp(x))
+    return x
+
+
 def dq_generate(seed, m, n, gamma=0.5, sigma=1e-3, spread=0.3, square_shift=False):
     """Synthetic dense-quadratic problem.  A is Fortran-order m x n."""
     A = np.zeros((m, n), order="F")
@@ -255,6 +300,19 @@ def dq_newton_solve(A, b, gamma, x0, analytic=True, opts=None):
     ib = IterationBehavior()
     o = opts or default_options()
     rc = lib().nlo_dq_newton_solve(C.byref(o), C.byref(p), int(analytic), _dp(x), _dp(fvec), C.byref(ib))
+    return rc, x, fvec, ib.as_dict(), int(p.ncalls)
+
+
+def dq_quasi_newton_solve(A, b, gamma, x0, analytic=True, opts=None, jdelta=5):
+    m, n = A.shape
+    assert m == n
+    p = _dq_problem(A, b, gamma)
+    x = np.array(x0, dtype=np.float64)
+    fvec = np.zeros(m)
+    ib = IterationBehavior()
+    o = opts or default_options()
+    rc = lib().nlo_dq_quasi_newton_solve(C.byref(o), int(jdelta), C.byref(p), int(analytic), _dp(x), _dp(fvec),
+                                         C.byref(ib))
     return rc, x, fvec, ib.as_dict(), int(p.ncalls)
 
 

@@ -164,6 +164,33 @@ program dropin_suite
         call report("newton_fcn2_nols", ib, x2)
     end block
 
+    ! test_quasinewton_1 (analytic Jacobian), _2 (line search off, FD), _3a (args, FD)
+    block
+        type(vecfcn_helper) :: o7, o8, o9
+        type(quasi_newton_solver) :: qn, qn2
+        fcn => fcn1
+        jac => jac1
+        call o7%set_fcn(fcn, 2, 2)
+        call o7%set_jacobian(jac)
+        x2 = 1.0d0
+        call qn%solve(o7, x2, f2, ib)
+        call report("qn_fcn1_an", ib, x2)
+        fcn => fcn2
+        call o8%set_fcn(fcn, 2, 2)
+        call qn2%set_use_line_search(.false.)
+        x2 = 0.5d0
+        call qn2%solve(o8, x2, f2, ib)
+        call report("qn_fcn2_nols", ib, x2)
+        fcn => fcn1a
+        call o9%set_fcn(fcn, 2, 2)
+        a = 2.0d0
+        x2 = 0.5d0
+        call qn%set_jacobian_interval(3)
+        call qn%solve(o9, x2, f2, ib, args = a)
+        call report("qn_fcn1a_fd_j3", ib, x2)
+        if (qn%get_jacobian_interval() /= 3) error stop 99
+    end block
+
     ! test_jacobian_1: vecfcn_helper%jacobian (no fv)
     block
         type(vecfcn_helper) :: o6

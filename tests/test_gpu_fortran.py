@@ -79,6 +79,19 @@ def test_newton_problems(results, oracle):
     _cmp(results["newton_fcn2_nols"][0], rc, xo, ibo)
 
 
+def test_quasi_newton_problems(results, oracle):
+    """quasi_newton_solver through the Fortran shim (test_quasinewton_1 / 2 / 3a): bit-identical to the CPU path."""
+    rc, xo, fo, ibo = oracle.quasi_newton_solve(lambda x, f: P.fcn1(x, f, None), 2, [1.0, 1.0],
+                                                jac=lambda x, J: P.jac1(x, J, None))
+    _cmp(results["qn_fcn1_an"][0], rc, xo, ibo)
+    assert abs(abs(xo[0]) - 5.0) <= 1e-6 and abs(abs(xo[1]) - 3.0) <= 1e-6
+    rc, xo, fo, ibo = oracle.quasi_newton_solve(lambda x, f: P.fcn2(x, f, None), 2, [0.5, 0.5],
+                                                opts=oracle.default_options(use_line_search=0))
+    _cmp(results["qn_fcn2_nols"][0], rc, xo, ibo)
+    rc, xo, fo, ibo = oracle.quasi_newton_solve(lambda x, f: P.fcn1a(x, f, 2.0), 2, [0.5, 0.5], jdelta=3)
+    _cmp(results["qn_fcn1a_fd_j3"][0], rc, xo, ibo)
+
+
 def test_fd_jacobian(results):
     J = results["jac_polar"][0]["x"].reshape(2, 2).T                  # printed column by column
     E = np.zeros((2, 2), order="F")

@@ -170,3 +170,63 @@ def test_reference_is_compiler_dependent_at_fd_noise_level(oracle):
     assert rc0 == rc1 == 0
     rel = np.abs(xa - xb).max() / np.abs(xa).max()
     assert 1e-10 < rel < 2e-6, rel
+
+
+# ---------------------------------------------------------------------------
+# quasi_newton_solver: qns_solve, src/nonlin_solve.f90:156-427
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 9, 40])
+def test_qr_factor_and_rank1_update_identities(oracle, n):
+    """The restated linalg kernels (qr_factor with Q formed, qr_rank1_update, triangular solve) satisfy
+    their defining identities: Q R = A, Q^T Q = I, R upper; Q1 R1 = Q R + u v^T; R x = b."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n))
+    q, r = oracle.qr_factor_full(A)
+    assert np.abs(q @ r - A).max() <= 1e-13 * n
+    assert np.abs(q.T @ q - np.eye(n)).max() <= 1e-14 * n
+    assert np.array_equal(np.tril(r, -1), np.zeros((n, n)))
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+    q1, r1 = oracle.qr_rank1_update(q, r, u, v)
+    assert np.abs(q1 @ r1 - (A + np.outer(u, v))).max() <= 1e-13 * n
+    assert np.abs(q1.T @ q1 - np.eye(n)).max() <= 1e-14 * n
+    assert np.array_equal(np.tril(r1, -1), np.zeros((n, n)))
+    b = rng.standard_normal(n)
+    assert np.abs(np.triu(r1) @ oracle.solve_upper(r1, b) - b).max() <= 1e-11 * n
+
+
+@pytest.mark.parametrize("ic", [(0.5, 0.5), (1.0, 1.0)])
+@pytest.mark.parametrize("with_jac", [True, False])
+def test_quasinewton_1_and_3(oracle, ic, with_jac):
+    """test_quasinewton_1 / 3 (tests/nonlin_test_solve.f90:187-234, 290-360): |x| -> (5, 3) within 1e-6."""
+    rc, x, f, ib = oracle.quasi_newton_solve(lambda a, b: P.fcn1a(a, b, 2.0), 2, ic,
+                                             jac=(lambda a, b: P.jac1a(a, b, 2.0)) if with_jac else None)
+    assert rc == 0
+    assert abs(abs(x[0]) - 5.0) <= 1e-6 and abs(abs(x[1]) - 3.0) <= 1e-6
+
+
+@pytest.mark.parametrize("ic", [(0.5, 0.5), (1.0, 1.0)])
+def test_quasinewton_2(oracle, ic):
+    """test_quasinewton_2 (:237-287): poorly scaled system, line search off."""
+    rc, x, f, ib = oracle.quasi_newton_solve(lambda a, b: P.fcn2(a, b, None), 2, ic,
+                                             opts=oracle.default_options(use_line_search=0))
+    assert rc == 0
+    assert abs(x[0] - 5.0e3) <= 1e-6 and abs(x[1] - 10.0) <= 1e-6
+
+
+def test_quasinewton_4_powell(oracle):
+    """test_quasinewton_4 (:851-896): Powell badly scaled, line search off, tol 1e-5."""
+    rc, x, f, ib = oracle.quasi_newton_solve(lambda a, b: P.powell(a, b, None), 2, [0.0, 1.0],
+                                             jac=lambda a, b: P.powell_jac(a, b, None),
+                                             opts=oracle.default_options(use_line_search=0))
+    assert rc == 0
+    assert abs(x[0] - 1.098159e-5) <= 1e-5 and abs(x[1] - 9.106146) <= 1e-5
+    assert ib["jacobian_count"] < ib["iter_count"]          # Broyden updates between Jacobians
+
+
+def test_quasinewton_square_dense_quadratic(oracle):
+    """Square device-model system: converges on the residual with Jacobian restarts every m_jDelta updates."""
+    A, b, xt, x0 = oracle.dq_generate(12345, 64, 64, sigma=0.0, spread=0.1, square_shift=True)
+    rc, x, f, ib, ncalls = oracle.dq_quasi_newton_solve(A, b, 0.5, x0, opts=oracle.default_options(max_evals=500))
+    assert rc == 0 and ib["converge_on_fcn"] == 1
+    assert np.abs(f).max() < 1e-8
+    assert 1 < ib["jacobian_count"] < ib["iter_count"]
