@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=24, help="problems timed on the CPU oracle (0 = skip)")
     ap.add_argument("--exact-sample", type=int, default=64, help="problems for the exact-policy figure (0 = skip)")
     ap.add_argument("--policy", type=int, default=0, help="0 auto (J^T J + Cholesky), 1 QR, 2 exact (reference order)")
+    ap.add_argument("--fuse-fd", type=int, default=0,
+                    help="1: form the Jacobian column in the panel kernel's epilogue (k_fd_jacobian is then not launched)")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,7 +118,7 @@ def main():
     # block-cyclic: local problem i is global problem rank + i*world, seed = seed0 + global index
     A, b, xt, x0 = ds.generate(B, m, n, seed0=seed0 + rank, gamma=gamma, sigma=sigma, spread=spread,
                                seed_stride=world)
-    opts = ds.options(max_evals=max_evals, factor_policy=args.policy)
+    opts = ds.options(max_evals=max_evals, factor_policy=args.policy, fuse_fd=args.fuse_fd)
     x = x0.clone()
 
     def step():
@@ -241,6 +243,23 @@ def main():
             t1 = time.perf_counter() - t1
             out["single_problem"] = {"ms": 1e3 * t1, "lm_iterations": ib1[0]["jacobian_count"],
                                      "lm_iterations_per_s": ib1[0]["jacobian_count"] / t1}
+        if world == 1 and not args.fuse_fd:
+            # same batch with the FD column write fused into the panel kernel (bit-identical results, one kernel
+            # and one 8mn-byte round trip less per Jacobian); the headline keeps the stand-alone FD kernel
+            of = ds.options(max_evals=max_evals, factor_policy=args.policy, fuse_fd=1)
+            xf = x0.clone()
+            ds.lm_solve_batch(A, b, gamma, xf, of)
+            tf, nj = 0.0, 0
+            for _ in range(args.steps):
+                xf.copy_(x0)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                _, ibf, _ = ds.lm_solve_batch(A, b, gamma, xf, of)
+                torch.cuda.synchronize()
+                tf += time.perf_counter() - t1
+                nj += sum(i["jacobian_count"] for i in ibf)
+            out["fused_fd"] = {"value": nj / tf, "unit": "LM iterations/s", "identical_x": bool(torch.equal(xf, x)),
+                               "note": "opts.fuse_fd = 1: Jacobian column formed in the panel kernel's epilogue"}
         if world == 1 and args.policy == 0 and args.exact_sample > 0:
             # the same workload under the exact factor policy (reference operation order: x, fvec and all
             # counts bit-identical to the CPU path, tests/test_gpu_solvers.py), one untimed + one timed pass

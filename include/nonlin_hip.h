@@ -80,6 +80,9 @@ typedef struct nlh_options {
     double  ls_factor;        /* 0.1   */
     int32_t factor_policy;    /* NLH_FACTOR_AUTO */
     double  ne_pivot_tol;     /* 1e-4: Cholesky pivot / column-norm^2 below this => QR */
+    int32_t fuse_fd;          /* 0.  Device-model solves only: 1 = the kernel that evaluates the n perturbed
+                                 residuals also forms jac(:,j) = (f_j - f0)/h_j (:274) in its epilogue and the
+                                 residual panel is never written; same operations per element, same bits */
 } nlh_options;
 
 void nlh_default_options(nlh_options *opts);

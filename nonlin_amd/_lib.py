@@ -32,7 +32,7 @@ class Options(C.Structure):
                 ("gtol", C.c_double), ("print_status", C.c_int32), ("factor", C.c_double),
                 ("use_line_search", C.c_int32), ("ls_max_evals", C.c_int32),
                 ("ls_alpha", C.c_double), ("ls_factor", C.c_double),
-                ("factor_policy", C.c_int32), ("ne_pivot_tol", C.c_double)]
+                ("factor_policy", C.c_int32), ("ne_pivot_tol", C.c_double), ("fuse_fd", C.c_int32)]
 
 
 # every symbol include/nonlin_hip.h declares: name -> (restype, argtypes)

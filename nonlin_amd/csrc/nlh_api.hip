@@ -150,6 +150,7 @@ void nlh_default_options(nlh_options *o)
     o->ls_factor = 0.1;          // :46
     o->factor_policy = NLH_FACTOR_AUTO;
     o->ne_pivot_tol = 1.0e-4;
+    o->fuse_fd = 0;
 }
 
 int nlh_device_count(void)
@@ -341,16 +342,21 @@ static void launch_dq_residual(nlh_handle *h, int nprob, int m, int n, const dou
 }
 
 static void launch_dq_panel(nlh_handle *h, int nprob, int m, int n, const double *A, const double *b,
-                            double gamma, const double *x, double *P, const LmState *st, int want)
+                            double gamma, const double *x, double *P, const LmState *st, int want,
+                            const double *f0_fused = nullptr)
 {
     Timed t(h, NLH_K_DQ_PANEL);
     // 32 columns per thread: A is re-read from L2 n/32 times (the kernel is L2->CU bound at 16) and the
     // register budget still leaves 5 waves per SIMD; measured 2.49 ms (16) / 1.97 (32) / 1.95 (48) per
-    // 256 x 4096 x 256 launch.
+    // 256 x 4096 x 256 launch.  f0_fused != null: the epilogue writes the Jacobian column instead of the residual.
     constexpr int JT = 32;
     dim3 grid((m + RB - 1) / RB, (n + JT - 1) / JT, nprob);
     size_t sh = sizeof(double) * (size_t)n;
-    hipLaunchKernelGGL((k_dq_panel<RB, JT>), grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, P, st, want);
+    if (f0_fused)
+        hipLaunchKernelGGL((k_dq_panel<RB, JT, true>), grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, P, f0_fused, st, want);
+    else
+        hipLaunchKernelGGL((k_dq_panel<RB, JT, false>), grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, P,
+                           (const double *)nullptr, st, want);
 }
 
 static void launch_fd(nlh_handle *h, int nprob, int m, int n, const double *P, const double *f0,
@@ -613,8 +619,12 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     const int max_rounds = o->max_evals + 8;
     for (int round = 0; round < max_rounds; ++round) {
         // outer-loop head for problems that need a Jacobian (:221): n perturbed evaluations + FD
-        launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.P, w.st, ST_NEED_JAC);
-        launch_fd(h, nprob, m, n, w.P, dfvec, dx, w.J, w.st, ST_NEED_JAC);
+        if (o->fuse_fd) {
+            launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.J, w.st, ST_NEED_JAC, dfvec);
+        } else {
+            launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.P, w.st, ST_NEED_JAC);
+            launch_fd(h, nprob, m, n, w.P, dfvec, dx, w.J, w.st, ST_NEED_JAC);
+        }
         hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_NEED_JAC,
                            o->factor_policy != NLH_FACTOR_AUTO ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
         if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec))) return rc;

@@ -63,11 +63,13 @@ k_dq_residual(int m, int n, const double *__restrict__ A, const double *__restri
 // [j0, j0+JT) shares one prefix accumulator, forks inside the tile and then adds the same
 // product to every accumulator: ~n^2/2 adds per row instead of n^2, still bit-identical
 // to n independent evaluations.
-template <int BS, int JT>
+// FUSE: the epilogue forms the forward-difference column (:274) itself, J(i,j) = (F_i(x + h_j e_j) - f0_i) / h_j,
+// and writes it to P (which is then the Jacobian); the residual panel never reaches memory.
+template <int BS, int JT, bool FUSE>
 __global__ void __launch_bounds__(BS)
 k_dq_panel(int m, int n, const double *__restrict__ A, const double *__restrict__ b,
            double gamma, const double *__restrict__ x, double *__restrict__ P,
-           const LmState *__restrict__ st, int want_stage)
+           const double *__restrict__ f0, const LmState *__restrict__ st, int want_stage)
 {
     extern __shared__ double smem[];
     const int p = blockIdx.z;
@@ -136,12 +138,15 @@ k_dq_panel(int m, int n, const double *__restrict__ A, const double *__restrict_
         }
     }
     const double bi = b[(size_t)p * m + i];
+    const double f0i = FUSE ? f0[(size_t)p * m + i] : 0.0;
     double *Pp = P + (size_t)p * m * n + i;
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) {
         if (jj < jt) {
             const double u = acc[jj];
-            Pp[(size_t)(j0 + jj) * m] = (u + (gamma * u) * u) - bi;
+            const double r = (u + (gamma * u) * u) - bi;
+            if (FUSE) Pp[(size_t)(j0 + jj) * m] = (r - f0i) / fd_step(xs[j0 + jj]);
+            else Pp[(size_t)(j0 + jj) * m] = r;
         }
     }
 }

@@ -450,3 +450,18 @@ def test_host_lm_callback_medium_problem(oracle):
             assert np.array_equal(x, xo) and np.array_equal(f, fo)
         else:
             assert _rel(x, xo) <= RTOL_X_FD_NOISE
+
+
+@pytest.mark.parametrize("m,n,policy", [(512, 64, 2), (4096, 256, 0), (300, 37, 2)])
+def test_fused_fd_epilogue_is_bitwise_the_two_kernel_path(ds, m, n, policy):
+    """opts.fuse_fd: the panel kernel forms (f_j - f0)/h_j itself; same operations per element, so x, fvec and
+    all counts equal the panel + k_fd_jacobian path bit for bit under every factor policy."""
+    A, b, xt, x0 = ds.generate(3, m, n, seed0=4711)
+    outs = []
+    for fuse in (0, 1):
+        x = x0.clone()
+        fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500, factor_policy=policy, fuse_fd=fuse))
+        outs.append((x.cpu().numpy(), fvec.cpu().numpy(), ibs, status))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
