@@ -28,7 +28,7 @@ __device__ __forceinline__ void gram_block_index(int idx, int &bi, int &bj)
     bj = idx - r * (r + 1) / 2;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
             double *__restrict__ Gpart /* [nprob][nsplit][n*n] */,
             const double *__restrict__ f /* [nprob][m] or null */,
@@ -74,6 +74,17 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
 
     const int arow = (wr * 32 + (lane & 15)) * GRAM_LD + (lane >> 4);
     const int brow = (wc * 32 + (lane & 15)) * GRAM_LD + (lane >> 4);
+    // LDS byte addresses of this lane's first A / B operand (the low 32 bits of a generic LDS pointer)
+    const unsigned aaddr = (unsigned)(size_t)(tA + arow);
+    const unsigned baddr = (unsigned)(size_t)(tBp + brow);
+#define GRAM_LDS_READ4(x0, x1, y0, y1, OFF)                                                          \
+    asm volatile("ds_read_b64 %0, %4 offset:%6\n\tds_read_b64 %1, %4 offset:%7\n\t"                 \
+                 "ds_read_b64 %2, %5 offset:%6\n\tds_read_b64 %3, %5 offset:%7"                      \
+                 : "=&v"(x0), "=&v"(x1), "=&v"(y0), "=&v"(y1)                                       \
+                 : "v"(aaddr), "v"(baddr), "n"(OFF), "n"((OFF) + 16 * GRAM_LD * 8)                  \
+                 : "memory");
+#define GRAM_LDS_WAIT4(x0, x1, y0, y1)                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
 
     // Software pipeline: the global loads of tile t+1 are issued into registers right after the
     // barrier that publishes tile t in LDS, so their latency overlaps the MFMA phase of tile t.
@@ -114,20 +125,32 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
 #pragma unroll
             for (int i = 0; i < GRAM_KT / 4; ++i) gacc = gacc + tA[gc * GRAM_LD + gq + i] * fs[gq + i];
         }
-#pragma unroll 4
+        // Operand reads are issued as ds_read_b64 by hand (two 32-lane groups over 64 banks: conflict-free with
+        // this pitch, 256 B/clk).  Left to the compiler the reads of neighbouring k-steps are paired into
+        // ds_read2_b64, which is serviced in 16-lane groups over 32 banks -- 2-way conflicts here and half the
+        // bandwidth (PMC: 42 % of the LDS cycles were conflict cycles).  The operands of step ks+1 are requested
+        // before the MFMAs of step ks are issued.
+        double a0, a1, b0, b1;
+        GRAM_LDS_READ4(a0, a1, b0, b1, 0)
+        GRAM_LDS_WAIT4(a0, a1, b0, b1)
+#pragma unroll
         for (int ks = 0; ks < GRAM_KT / 4; ++ks) {
-            const double a0 = tA[arow + ks * 4];
-            const double a1 = tA[arow + 16 * GRAM_LD + ks * 4];
-            const double b0 = tBp[brow + ks * 4];
-            const double b1 = tBp[brow + 16 * GRAM_LD + ks * 4];
+            double na0 = 0.0, na1 = 0.0, nb0 = 0.0, nb1 = 0.0;
+            if (ks + 1 < GRAM_KT / 4) GRAM_LDS_READ4(na0, na1, nb0, nb1, (ks + 1) * 32)
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            if (ks + 1 < GRAM_KT / 4) {
+                GRAM_LDS_WAIT4(na0, na1, nb0, nb1)
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+            }
         }
         __syncthreads();
     }
 
+#undef GRAM_LDS_READ4
+#undef GRAM_LDS_WAIT4
     if (dog) {                                  // tB is unused by diagonal blocks: combine the four k-quarters
         tB[tid] = gacc;
         __syncthreads();
