@@ -131,6 +131,16 @@ int nlh_quasi_newton_solve(nlh_handle *h, const nlh_options *opts, int32_t jdelt
                            nlh_vecfcn fcn, nlh_jacfcn jacfcn, void *ctx,
                            double *x, double *fvec, nlh_iteration_behavior *ib);
 
+/* constrained_least_squares_solver%solve -- cls_solve, src/nonlin_least_squares.f90:938-1176 (bounded
+ * trust-region dog-leg: qr_factor :1047, coleman_li_scaling :1050, dogleg :1053/1301-1403, Armijo
+ * fallback :1088-1123).  delta0 = get_trust_region_radius() (default 1, :60), stepscale0 =
+ * get_step_scaling_factor() (default 1, :61); xl / xu = get_lower_limits() / get_upper_limits()
+ * ([n] host arrays, NULL = unbounded, :999-1009). */
+int nlh_cls_solve(nlh_handle *h, const nlh_options *opts, double delta0, double stepscale0,
+                  const double *xl, const double *xu, int32_t m, int32_t n,
+                  nlh_vecfcn fcn, nlh_jacfcn jacfcn, void *ctx,
+                  double *x, double *fvec, nlh_iteration_behavior *ib);
+
 /* ===========================================================================
  * Device-model ("mode D") batched entry points: DEVICE pointers.
  * Residual family "dense-quadratic" (SURVEY.md 8(d)), evaluated on the GPU with
@@ -156,6 +166,13 @@ int nlh_dq_quasi_newton_solve_batch(nlh_handle *h, const nlh_options *opts, int3
                                     double gamma, int32_t analytic, double *dx, double *dfvec,
                                     nlh_iteration_behavior *ib /* host, [nprob] */,
                                     int32_t *status /* host, [nprob] */);
+
+/* xl / xu: [n] host arrays shared by every problem, or NULL. */
+int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *opts, double delta0, double stepscale0,
+                           const double *xl, const double *xu, int32_t nprob, int32_t m, int32_t n,
+                           const double *dA, const double *db, double gamma, double *dx,
+                           double *dfvec, nlh_iteration_behavior *ib /* host, [nprob] */,
+                           int32_t *status /* host, [nprob] */);
 
 /* Synthetic problem generator of SURVEY.md 8(d) (bench/test inputs, not part of the
  * reference): counter-based splitmix64, U_k = mix(seed + (k+1)*0x9E3779B97F4A7C15),

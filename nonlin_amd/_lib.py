@@ -51,6 +51,8 @@ SYMBOLS = {
                                    c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
     "nlh_quasi_newton_solve": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, VECFCN, JACFCN, C.c_void_p,
                                          c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
+    "nlh_cls_solve": (C.c_int, [_H, C.POINTER(Options), C.c_double, C.c_double, c_double_p, c_double_p, C.c_int32, C.c_int32,
+                                VECFCN, JACFCN, C.c_void_p, c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
     "nlh_dq_lm_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                         C.POINTER(IterationBehavior), c_int32_p]),
@@ -60,6 +62,9 @@ SYMBOLS = {
     "nlh_dq_quasi_newton_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                                   C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
                                                   C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_dq_cls_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_double, C.c_double, c_double_p, c_double_p, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_dq_generate": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_double, C.c_double,
                                   C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_dq_residual": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,

@@ -241,6 +241,74 @@ class least_squares_solver(equation_solver):
             raise NonlinError(rc)                 # :388-390
 
 
+class constrained_equation_solver(least_squares_solver):
+    """src/nonlin_least_squares.f90:33-53 (bounds holder)."""
+
+    def __init__(self):
+        super().__init__()
+        self._upper = np.zeros(0)
+        self._lower = np.zeros(0)
+
+    def get_upper_limits(self): return self._upper.copy()                                  # :796-808
+    def set_upper_limits(self, x): self._upper = np.array(x, dtype=np.float64).ravel()      # :811-824
+    def get_lower_limits(self): return self._lower.copy()                                  # :827-839
+    def set_lower_limits(self, x): self._lower = np.array(x, dtype=np.float64).ravel()      # :842-855
+
+    def apply_limits(self, x):                                                             # :858-883
+        nl, nu = min(x.size, self._lower.size), min(x.size, self._upper.size)
+        for i in range(nl):
+            if x[i] < self._lower[i]:
+                x[i] = self._lower[i]
+        for i in range(nu):
+            if x[i] > self._upper[i]:
+                x[i] = self._upper[i]
+
+
+class constrained_least_squares_solver(constrained_equation_solver):
+    """src/nonlin_least_squares.f90:55-74."""
+
+    def __init__(self):
+        super().__init__()
+        self._delta = 1.0                         # :60
+        self._scaling = 1.0                       # :61
+
+    def get_trust_region_radius(self): return self._delta                    # :888-895
+    def set_trust_region_radius(self, x): self._delta = 1.0 if x <= 0.0 else float(x)       # :898-910
+    def get_step_scaling_factor(self): return self._scaling                  # :913-920 (overrides the LM factor)
+    def set_step_scaling_factor(self, x): self._scaling = 1.0 if x <= 0.0 else float(x)     # :923-935
+
+    def solve(self, fcn, x, fvec, ib=None, args=None):
+        """cls_solve (:938-1176)."""
+        _check_xf(fcn, x, fvec)
+        if not fcn.is_fcn_defined():
+            raise NonlinError(NL_UNDEFINED_FUNCTION_ERROR)   # :988
+        m, n = fcn.get_equation_count(), fcn.get_variable_count()
+        if n > m:
+            raise NonlinError(NL_UNDERDEFINED_PROBLEM_ERROR)  # :989
+        if x.shape != (n,):
+            raise NonlinError(3)
+        if fvec.shape != (m,):
+            raise NonlinError(4)
+        big = float(np.finfo(np.float64).max)
+        if self._lower.size != n:                 # :999-1009: wrong-sized limits are replaced (and stored)
+            self.set_lower_limits(np.full(n, -big))
+        if self._upper.size != n:
+            self.set_upper_limits(np.full(n, big))
+        lo = np.ascontiguousarray(self._lower)
+        hi = np.ascontiguousarray(self._upper)
+        o = self._options()
+        h = self._handle()
+        cib = _lib.IterationBehavior()
+        cf, cj = fcn._c_fcn(args), fcn._c_jac(args)
+        rc = h.lib.nlh_cls_solve(h.ptr, C.byref(o), self._delta, self._scaling, _dp(lo), _dp(hi), m, n, cf, cj, None,
+                                 _dp(x), _dp(fvec), C.byref(cib))
+        h.check(rc, "nlh_cls_solve")
+        if ib is not None:
+            ib._fill(cib)
+        if rc:
+            raise NonlinError(rc)                 # :1173-1175
+
+
 class line_search:
     """src/nonlin_linesearch.f90:18-65 (configuration; the search runs inside newton_solver)."""
 

@@ -49,29 +49,31 @@ k_qn_qr_init(int n, const double *__restrict__ Rt, double *__restrict__ Q, doubl
 // ascending i with QN_U loads in flight.  st[p] = {tau, scal, beta} for the second half (tau = 0: H = I).
 #define QN_DOT_BS 128
 #define QN_U 32
+// General shape: `rows` rows, A has ncA columns (row-major, ld ncA), E has ncE columns (row-major, ld ncE).
+// Broyden: rows = ncA = ncE = n (E = Q^T accumulator).  Constrained least squares: rows = m, ncA = n,
+// ncE = 1 (E = the right-hand side f, which becomes Q^T f).
 __global__ void __launch_bounds__(QN_DOT_BS)
-k_qn_house_dot(int n, int j, const double *__restrict__ Rt, const double *__restrict__ Q,
+k_qn_house_dot(int rows, int ncA, int ncE, int j, const double *__restrict__ Aall, const double *__restrict__ Eall,
                const double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st)
 {
-    extern __shared__ double vs[];                 // n: reflector, rows j+1 .. n-1
+    extern __shared__ double vs[];                 // rows: reflector, rows j+1 .. rows-1
     __shared__ double sq_sh;
     const int p = blockIdx.y, tid = threadIdx.x;
-    const size_t nn = (size_t)n * n;
-    const double *A = Rt + p * nn, *E = Q + p * nn;
-    const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * n;
-    for (int i = j + 1 + tid; i < n; i += QN_DOT_BS) vs[i] = vcur[i];
+    const double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
+    const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
+    for (int i = j + 1 + tid; i < rows; i += QN_DOT_BS) vs[i] = vcur[i];
     __syncthreads();
     if (tid == 0) {                                // one ordered sum; LDS reads batched 16 at a time
         double s = 0.0;
         int i = j + 1;
-        for (; i + 16 <= n; i += 16) {
+        for (; i + 16 <= rows; i += 16) {
             double t[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) t[u] = vs[i + u];
 #pragma unroll
             for (int u = 0; u < 16; ++u) s = s + t[u] * t[u];
         }
-        for (; i < n; ++i) s = s + vs[i] * vs[i];
+        for (; i < rows; ++i) s = s + vs[i] * vs[i];
         sq_sh = s;
     }
     __syncthreads();
@@ -80,68 +82,104 @@ k_qn_house_dot(int n, int j, const double *__restrict__ Rt, const double *__rest
         if (blockIdx.x == 0 && tid == 0) { st[(size_t)p * 4] = 0.0; st[(size_t)p * 4 + 1] = 0.0; st[(size_t)p * 4 + 2] = 0.0; }
         return;
     }
-    const double alpha = A[(size_t)j * n + j];
+    const double alpha = A[(size_t)j * ncA + j];
     const double beta = -copysign(sqrt(alpha * alpha + sq), alpha);
     const double tau = (beta - alpha) / beta;
     const double scal = 1.0 / (alpha - beta);
     if (blockIdx.x == 0 && tid == 0) { st[(size_t)p * 4] = tau; st[(size_t)p * 4 + 1] = scal; st[(size_t)p * 4 + 2] = beta; }
-    for (int i = j + 1 + tid; i < n; i += QN_DOT_BS) vs[i] = vs[i] * scal;
+    for (int i = j + 1 + tid; i < rows; i += QN_DOT_BS) vs[i] = vs[i] * scal;
     __syncthreads();
     const int k = blockIdx.x * QN_DOT_BS + tid;
-    if (k >= 2 * n || (k < n && k <= j)) return;
-    const double *T = (k < n) ? A + k : E + (k - n);
-    double w = T[(size_t)j * n];
-    for (int i = j + 1; i < n; i += QN_U) {        // the chain is serial in i; the loads are not
+    if (k >= ncA + ncE || (k < ncA && k <= j)) return;
+    const double *T = (k < ncA) ? A + k : E + (k - ncA);
+    const size_t ld = (k < ncA) ? ncA : ncE;
+    double w = T[(size_t)j * ld];
+    for (int i = j + 1; i < rows; i += QN_U) {     // the chain is serial in i; the loads are not
         double t[QN_U];
 #pragma unroll
-        for (int u = 0; u < QN_U; ++u) t[u] = (i + u < n) ? T[(size_t)(i + u) * n] : 0.0;
+        for (int u = 0; u < QN_U; ++u) t[u] = (i + u < rows) ? T[(size_t)(i + u) * ld] : 0.0;
 #pragma unroll
         for (int u = 0; u < QN_U; ++u)
-            if (i + u < n) w = w + vs[i + u] * t[u];
+            if (i + u < rows) w = w + vs[i + u] * t[u];
     }
-    wbuf[(size_t)p * 2 * n + k] = tau * w;
+    wbuf[(size_t)p * (ncA + ncE) + k] = tau * w;
 }
 
 // Second half: T(j,k) -= w_k, T(i,k) -= v_i w_k (elementwise, one thread per column and QN_RC rows),
 // column j becomes (beta, 0, ..., 0), and the updated column j+1 is copied to the other vbuf slot.
 #define QN_RC 16
 __global__ void __launch_bounds__(256)
-k_qn_house_apply(int n, int j, double *__restrict__ Rt, double *__restrict__ Q, double *__restrict__ vbuf,
-                 const double *__restrict__ wbuf, const double *__restrict__ st)
+k_qn_house_apply(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
+                 double *__restrict__ vbuf, const double *__restrict__ wbuf, const double *__restrict__ st)
 {
     const int p = blockIdx.z;
-    const size_t nn = (size_t)n * n;
-    double *A = Rt + p * nn, *E = Q + p * nn;
-    const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * n;
-    double *vnext = vbuf + ((size_t)p * 2 + ((j + 1) & 1)) * n;
+    double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
+    const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
+    double *vnext = vbuf + ((size_t)p * 2 + ((j + 1) & 1)) * rows;
     const double tau = st[(size_t)p * 4], scal = st[(size_t)p * 4 + 1], beta = st[(size_t)p * 4 + 2];
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const int i0 = j + blockIdx.y * QN_RC, i1 = min(n, i0 + QN_RC);
-    if (k >= 2 * n || (k < n && k < j)) return;
-    const bool next_owner = (k == j + 1) && (k < n);
-    double *T = (k < n) ? A + k : E + (k - n);
+    const int i0 = j + blockIdx.y * QN_RC, i1 = min(rows, i0 + QN_RC);
+    if (k >= ncA + ncE || (k < ncA && k < j)) return;
+    const bool next_owner = (k == j + 1) && (k < ncA);
+    double *T = (k < ncA) ? A + k : E + (k - ncA);
+    const size_t ld = (k < ncA) ? ncA : ncE;
     if (tau == 0.0) {
         if (next_owner)
-            for (int i = max(i0, j + 2); i < i1; ++i) vnext[i] = T[(size_t)i * n];
+            for (int i = max(i0, j + 2); i < i1; ++i) vnext[i] = T[(size_t)i * ld];
         return;
     }
     if (k == j) {
-        for (int i = i0; i < i1; ++i) T[(size_t)i * n] = (i == j) ? beta : 0.0;
+        for (int i = i0; i < i1; ++i) T[(size_t)i * ld] = (i == j) ? beta : 0.0;
         return;
     }
-    const double w = wbuf[(size_t)p * 2 * n + k];
+    const double w = wbuf[(size_t)p * (ncA + ncE) + k];
     double t[QN_RC];
 #pragma unroll
-    for (int u = 0; u < QN_RC; ++u) t[u] = (i0 + u < i1) ? T[(size_t)(i0 + u) * n] : 0.0;
+    for (int u = 0; u < QN_RC; ++u) t[u] = (i0 + u < i1) ? T[(size_t)(i0 + u) * ld] : 0.0;
 #pragma unroll
     for (int u = 0; u < QN_RC; ++u) {
         const int i = i0 + u;
         if (i < i1) {
             const double a = (i == j) ? t[u] - w : t[u] - (vcur[i] * scal) * w;
-            T[(size_t)i * n] = a;
+            T[(size_t)i * ld] = a;
             if (next_owner && i >= j + 2) vnext[i] = a;
         }
     }
+}
+
+// vbuf slot 0 <- column 0 of the row-major A (the first reflector's column).
+__global__ void __launch_bounds__(256)
+k_qn_col0(int rows, int ncA, const double *__restrict__ Aall, double *__restrict__ vbuf)
+{
+    const int p = blockIdx.y;
+    const double *A = Aall + (size_t)p * rows * ncA;
+    double *v = vbuf + (size_t)p * 2 * rows;
+    const int i = 1 + blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) v[i] = A[(size_t)i * ncA];
+}
+
+// out_i = sum_j v_j J(i,j), J column-major m x n, j ascending from an accumulator of zero (DGEMV 'N').
+__global__ void __launch_bounds__(256)
+k_matvec_cm(int m, int n, const double *__restrict__ J, const double *__restrict__ v, double *__restrict__ out)
+{
+    extern __shared__ double xs[];
+    const int p = blockIdx.y;
+    for (int k = threadIdx.x; k < n; k += 256) xs[k] = v[(size_t)p * n + k];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const double *a = J + (size_t)p * m * n + i;
+    double t = 0.0;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        double c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = a[(size_t)(j + u) * m];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t = t + xs[j + u] * c[u];
+    }
+    for (; j < n; ++j) t = t + xs[j] * a[(size_t)j * m];
+    out[(size_t)p * m + i] = t;
 }
 
 // s = (df - B dx) / x2   (:301-302): thread per row, sum over columns ascending.
@@ -180,26 +218,26 @@ k_qn_rank1(int n, double *__restrict__ B, const double *__restrict__ s, const do
     *b = *b + s[(size_t)p * n + i] * dx[(size_t)p * n + j];
 }
 
-// out_k = sign * sum_i M(i,k) f_i, M column-major, sum over i ascending (grad = B^T f, -Q^T f, Q^T u).
+// out_k = sign * sum_i M(i,k) f_i, M column-major m x n, sum over i ascending (grad = B^T f, -Q^T f, Q^T u, J^T f).
 // A 64-thread workgroup owns 64 columns; 64x64 tiles are read coalesced and re-read from LDS by column.
 __global__ void __launch_bounds__(64)
-k_qn_colsdot(int n, const double *__restrict__ M, const double *__restrict__ f, double *__restrict__ out,
+k_qn_colsdot(int m, int n, const double *__restrict__ M, const double *__restrict__ f, double *__restrict__ out,
              double sign)
 {
     __shared__ double tile[64 * 65];
     __shared__ double fs[64];
     const int p = blockIdx.y, t = threadIdx.x;
     const int k0 = blockIdx.x * 64;
-    const double *Mp = M + (size_t)p * n * n;
-    const double *fp = f + (size_t)p * n;
+    const double *Mp = M + (size_t)p * m * n;
+    const double *fp = f + (size_t)p * m;
     double acc = 0.0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
+    for (int i0 = 0; i0 < m; i0 += 64) {
         const int i = i0 + t;
         for (int kk = 0; kk < 64; ++kk)
-            tile[kk * 65 + t] = (i < n && k0 + kk < n) ? Mp[(size_t)(k0 + kk) * n + i] : 0.0;
-        fs[t] = (i < n) ? fp[i] : 0.0;
+            tile[kk * 65 + t] = (i < m && k0 + kk < n) ? Mp[(size_t)(k0 + kk) * m + i] : 0.0;
+        fs[t] = (i < m) ? fp[i] : 0.0;
         __syncthreads();
-        const int lim = min(64, n - i0);
+        const int lim = min(64, m - i0);
         for (int ii = 0; ii < lim; ++ii) acc = acc + tile[t * 65 + ii] * fs[ii];
         __syncthreads();
     }

@@ -106,6 +106,27 @@ class DeviceSolver:
             raise RuntimeError(f"nlh_dq_quasi_newton_solve_batch returned {rc}")
         return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
 
+    def cls_solve_batch(self, A, b, gamma, x, opts=None, lower=None, upper=None, delta=1.0, stepscale=1.0):
+        """constrained_least_squares_solver%solve for every problem (the same bounds for all).  x in place."""
+        import numpy as np
+        nprob, n, m = A.shape
+        _chk(A, (nprob, n, m), "A"); _chk(b, (nprob, m), "b"); _chk(x, (nprob, n), "x")
+        fvec = torch.empty((nprob, m), dtype=torch.float64, device=A.device)
+        ib = (_lib.IterationBehavior * nprob)()
+        status = (C.c_int32 * nprob)()
+        o = opts or self.options()
+        lo = None if lower is None else np.ascontiguousarray(lower, dtype=np.float64)
+        hi = None if upper is None else np.ascontiguousarray(upper, dtype=np.float64)
+        plo = None if lo is None else lo.ctypes.data_as(_lib.c_double_p)
+        phi = None if hi is None else hi.ctypes.data_as(_lib.c_double_p)
+        rc = self.lib.nlh_dq_cls_solve_batch(self.h.ptr, C.byref(o), float(delta), float(stepscale), plo, phi, nprob, m, n,
+                                             A.data_ptr(), b.data_ptr(), float(gamma), x.data_ptr(), fvec.data_ptr(),
+                                             ib, status)
+        self.h.check(rc, "nlh_dq_cls_solve_batch")
+        if rc:
+            raise RuntimeError(f"nlh_dq_cls_solve_batch returned {rc}")
+        return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
+
     # -- stage-level kernels (parity tests, roofline) --------------------------
     def residual(self, A, b, gamma, x):
         nprob, n, m = A.shape

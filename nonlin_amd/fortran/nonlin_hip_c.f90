@@ -75,6 +75,21 @@ module nonlin_hip_c
             type(nlh_iteration_behavior), intent(out) :: ib
             integer(c_int) :: rc
         end function
+        function nlh_cls_solve(h, opts, delta0, stepscale0, xl, xu, m, n, fcn, jacfcn, ctx, x, fvec, ib) &
+                bind(C, name="nlh_cls_solve") result(rc)
+            import :: c_ptr, c_funptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h
+            type(nlh_options), intent(in) :: opts
+            real(c_double), value :: delta0, stepscale0
+            real(c_double), intent(in) :: xl(*), xu(*)
+            integer(c_int32_t), value :: m, n
+            type(c_funptr), value :: fcn, jacfcn
+            type(c_ptr), value :: ctx
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fvec(*)
+            type(nlh_iteration_behavior), intent(out) :: ib
+            integer(c_int) :: rc
+        end function
         function nlh_quasi_newton_solve(h, opts, jdelta, n, fcn, jacfcn, ctx, x, fvec, ib) &
                 bind(C, name="nlh_quasi_newton_solve") result(rc)
             import :: c_ptr, c_funptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior

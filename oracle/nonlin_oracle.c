@@ -1126,6 +1126,289 @@ int nlo_quasi_newton_solve(const nlo_options *opt, int32_t jdelta, nlo_vecfcn fc
 }
 
 /* ---------------------------------------------------------------------------
+ * constrained_least_squares_solver: src/nonlin_least_squares.f90:33-74, 793-1403
+ * (bounded trust-region dog-leg with Coleman-Li scaling and an Armijo fallback).
+ * Third-party pieces restated as for qns_solve: qr_factor(jac, tau, qr) = DGEQR2,
+ * solve_qr = reflectors applied to f (DORM2R) + DTRSM on the top n rows, DGEMV.
+ * ------------------------------------------------------------------------- */
+
+/* Householder QR of the m-by-n column-major a (m >= n) with the same reflectors applied to the
+ * right-hand side f (length m): on exit a holds R in its upper triangle (zeros below), f = Q^T f. */
+void nlo_qr_factor_rhs(int32_t m, int32_t n, double *a, double *f)
+{
+    double *v = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    const int32_t steps = (n < m - 1) ? n : m - 1;
+    for (int32_t j = 0; j < steps; ++j) {
+        const double alpha = A_(a, m, j, j);
+        double ssq = 0.0;
+        for (int32_t i = j + 1; i < m; ++i) ssq = ssq + A_(a, m, i, j) * A_(a, m, i, j);
+        if (ssq == 0.0) continue;
+        const double beta = -copysign(sqrt(alpha * alpha + ssq), alpha);
+        const double tau = (beta - alpha) / beta;
+        const double scal = 1.0 / (alpha - beta);
+        for (int32_t i = j + 1; i < m; ++i) v[i] = A_(a, m, i, j) * scal;
+        A_(a, m, j, j) = beta;
+        for (int32_t i = j + 1; i < m; ++i) A_(a, m, i, j) = 0.0;
+        for (int32_t k = j + 1; k <= n; ++k) {                    /* k == n: the right-hand side */
+            double *t = (k < n) ? &A_(a, m, 0, k) : f;
+            double w = t[j];
+            for (int32_t i = j + 1; i < m; ++i) w = w + v[i] * t[i];
+            w = tau * w;
+            t[j] = t[j] - w;
+            for (int32_t i = j + 1; i < m; ++i) t[i] = t[i] - v[i] * w;
+        }
+    }
+    free(v);
+}
+
+static double cls_scaled_norm(int32_t n, const double *x, const double *s, double *tmp)   /* :1263-1273 */
+{
+    for (int32_t i = 0; i < n; ++i) tmp[i] = x[i] * s[i];
+    return nlo_norm2(n, tmp);
+}
+
+static int cls_is_finite(int32_t n, const double *x)         /* :1276-1298 */
+{
+    for (int32_t i = 0; i < n; ++i) {
+        if (!(x[i] == x[i])) return 0;
+        if (fabs(x[i]) == DBL_MAX) return 0;
+    }
+    return 1;
+}
+
+static void cls_apply_limits(int32_t n, const double *xl, const double *xu, double *x)   /* :858-883 */
+{
+    for (int32_t i = 0; i < n; ++i) if (x[i] < xl[i]) x[i] = xl[i];
+    for (int32_t i = 0; i < n; ++i) if (x[i] > xu[i]) x[i] = xu[i];
+}
+
+double nlo_alpha_box(int32_t n, const double *x, const double *p, const double *xl, const double *xu)   /* :1181-1219 */
+{
+    double rst = DBL_MAX;
+    for (int32_t i = 0; i < n; ++i) {
+        if (p[i] > 0.0) {
+            if (xu[i] < x[i]) return 0.0;
+            const double a = (xu[i] - x[i]) / p[i];
+            if (a < rst) rst = a;
+        } else if (p[i] < 0.0) {
+            if (xl[i] > x[i]) return 0.0;
+            const double a = (xl[i] - x[i]) / p[i];
+            if (a < rst) rst = a;
+        }
+    }
+    if (rst < 0.0) rst = 0.0;
+    return rst;
+}
+
+void nlo_coleman_li_scaling(int32_t n, const double *x, const double *xl, const double *xu, double *s)   /* :1222-1260 */
+{
+    const double min_scale = 1.0e-8, max_scale = 1.0e8, big = DBL_MAX;
+    for (int32_t i = 0; i < n; ++i) {
+        double di;
+        if (xl[i] > -big && xu[i] < big) di = dmin(x[i] - xl[i], xu[i] - x[i]);
+        else if (xl[i] > -big) di = x[i] - xl[i];
+        else if (xu[i] < big) di = xu[i] - x[i];
+        else di = 1.0;
+        di = dmax(di, min_scale);
+        s[i] = 1.0 / di;
+        if (s[i] > max_scale) s[i] = max_scale;
+    }
+}
+
+/* dogleg, :1301-1403.  jac: the Jacobian (m x n); r: R of its QR in the top n rows of an m x n array;
+ * qtf: Q^T f.  Outputs p, g, Jp, prered.  work: 4n + m doubles. */
+void nlo_dogleg(int32_t m, int32_t n, double delta, const double *x, const double *f, const double *jac,
+                const double *r, const double *qtf, const double *s, const double *xl, const double *xu,
+                double *p, double *g, double *Jp, double *prered, double *work)
+{
+    double *pgn = work, *psd = work + n, *u = work + 2 * n, *v = work + 3 * n, *Jg = work + 4 * n;
+    double alpha, pgnnorm, psdnorm, t, c1, c2, a, b, c, arg;
+    for (int32_t j = 0; j < n; ++j) g[j] = nlo_dot(m, &A_(jac, m, 0, j), f);      /* :1331 dgemv 'T' */
+    for (int32_t i = 0; i < n; ++i) u[i] = qtf[i];                                /* :1334 solve_qr */
+    {
+        /* back substitution on the leading n x n block of r (leading dimension m) */
+        for (int32_t j = n - 1; j >= 0; --j) {
+            if (u[j] != 0.0) {
+                u[j] = u[j] / A_(r, m, j, j);
+                const double tj = u[j];
+                for (int32_t i = j - 1; i >= 0; --i) u[i] = u[i] - tj * A_(r, m, i, j);
+            }
+        }
+    }
+    for (int32_t i = 0; i < n; ++i) pgn[i] = -u[i];
+    pgnnorm = cls_scaled_norm(n, pgn, s, v);
+    if (pgnnorm > delta) {                                                         /* :1339 */
+        for (int32_t i = 0; i < m; ++i) Jg[i] = 0.0;                               /* dgemv 'N' */
+        for (int32_t j = 0; j < n; ++j) {
+            const double tj = g[j];
+            for (int32_t i = 0; i < m; ++i) Jg[i] = Jg[i] + tj * A_(jac, m, i, j);
+        }
+        c1 = nlo_dot(n, g, g);
+        c2 = nlo_dot(m, Jg, Jg);
+        alpha = (c2 > 0.0 && c1 > 0.0) ? c1 / c2 : 0.0;
+        for (int32_t i = 0; i < n; ++i) psd[i] = -alpha * g[i];
+        psdnorm = cls_scaled_norm(n, psd, s, v);
+        if (psdnorm >= delta && psdnorm > 0.0) {
+            const double sc = delta / psdnorm;
+            for (int32_t i = 0; i < n; ++i) p[i] = sc * psd[i];
+        } else {
+            for (int32_t i = 0; i < n; ++i) u[i] = pgn[i] - psd[i];
+            for (int32_t i = 0; i < n; ++i) u[i] = s[i] * u[i];
+            for (int32_t i = 0; i < n; ++i) v[i] = s[i] * psd[i];
+            a = nlo_dot(n, u, u);
+            b = 2.0 * nlo_dot(n, u, v);
+            c = nlo_dot(n, v, v) - delta * delta;
+            if (a <= 0.0) {
+                for (int32_t i = 0; i < n; ++i) p[i] = psd[i];
+            } else {
+                arg = dmax(0.0, b * b - 4.0 * a * c);
+                if (arg == 0.0) {
+                    t = -b / (2.0 * a);
+                } else {
+                    t = (-b + sqrt(arg)) / (2.0 * a);
+                    if (t < 0.0 || t > 1.0) t = (-b - sqrt(arg)) / (2.0 * a);
+                }
+                t = dmax(0.0, dmin(1.0, t));
+                for (int32_t i = 0; i < n; ++i) p[i] = psd[i] + t * u[i];          /* u is the SCALED difference: kept */
+            }
+        }
+    } else {
+        for (int32_t i = 0; i < n; ++i) p[i] = pgn[i];
+    }
+    alpha = nlo_alpha_box(n, x, p, xl, xu);                                        /* :1392-1395 */
+    if (alpha < 1.0)
+        for (int32_t i = 0; i < n; ++i) p[i] = alpha * p[i];
+    for (int32_t i = 0; i < m; ++i) Jp[i] = 0.0;                                   /* :1398 */
+    for (int32_t j = 0; j < n; ++j) {
+        const double tj = p[j];
+        for (int32_t i = 0; i < m; ++i) Jp[i] = Jp[i] + tj * A_(jac, m, i, j);
+    }
+    c1 = nlo_dot(n, g, p);
+    c2 = 0.5 * nlo_dot(m, Jp, Jp);
+    *prered = -c1 - c2;
+}
+
+/* cls_solve, :938-1176.  xl / xu may be NULL (unbounded).  delta0 = get_trust_region_radius() (1),
+ * stepscale0 = get_step_scaling_factor() (1). */
+int nlo_cls_solve(const nlo_options *opt, double delta0, double stepscale0, const double *xl_in,
+                  const double *xu_in, nlo_vecfcn fcn, nlo_jacfcn jac_or_null, void *ctx, int32_t m,
+                  int32_t n, double *x, double *fvec, nlo_iteration_behavior *ib)
+{
+    const double delta_max = 1.0e3, eta = 1.0e-1, ls_cl = 1.0e-4, ls_beta = 0.5;
+    const int32_t ls_max_iter = 10;
+    int32_t converged = 0, xcnvrg = 0, fcnvrg = 0, gcnvrg = 0;
+    int32_t neval = 0, iter = 0, njac = 0, k;
+    const double ftol = opt->ftol, xtol = opt->xtol, gtol = opt->gtol;
+    const int32_t maxeval = opt->max_evals;
+    double xnorm, fnorm, gnorm, fnewnorm, actred, prered, rho, delta, stepscale, dderiv;
+
+    if (ib) memset(ib, 0, sizeof *ib);                       /* :977-985 */
+    if (!fcn) return NLO_UNDEFINED_FUNCTION_ERROR;           /* :988 */
+    if (n > m) return NLO_UNDERDEFINED_PROBLEM_ERROR;        /* :989 */
+
+    const size_t mn = (size_t)m * (size_t)n;
+    double *jac = (double *)malloc(sizeof(double) * (mn ? mn : 1));
+    double *qr = (double *)malloc(sizeof(double) * (mn ? mn : 1));
+    double *w = (double *)calloc((size_t)(11 * n + 4 * m + 1), sizeof(double));
+    double *xl = w, *xu = xl + n, *s = xu + n, *g = s + n, *p = g + n, *xnew = p + n, *tmp = xnew + n,
+           *dwork = tmp + n /* 4n + m */, *Jp = dwork + 4 * n + m, *fnew = Jp + m, *qtf = fnew + m;
+    for (int32_t i = 0; i < n; ++i) {                        /* :999-1009 */
+        xl[i] = xl_in ? xl_in[i] : -DBL_MAX;
+        xu[i] = xu_in ? xu_in[i] : DBL_MAX;
+    }
+
+    cls_apply_limits(n, xl, xu, x);                          /* :1023-1031 */
+    fcn(ctx, n, x, m, fvec);
+    neval = 1;
+    fnorm = nlo_norm2(m, fvec);
+    xnorm = nlo_norm2(n, x);
+    if (!cls_is_finite(n, x) || !cls_is_finite(m, fvec)) {   /* silent return, :1029-1031 */
+        free(jac); free(qr); free(w);
+        return 0;
+    }
+
+    delta = delta0;                                          /* :1034 */
+    iter = 1;
+    for (;;) {                                               /* :1036-1160 */
+        nlo_fd_jacobian(fcn, jac_or_null, ctx, m, n, x, fvec, jac);
+        njac = njac + 1;
+        if (opt->print_status) print_status(iter, neval, njac, xnorm, fnorm);
+
+        memcpy(qr, jac, sizeof(double) * mn);                /* :1047 */
+        memcpy(qtf, fvec, sizeof(double) * (size_t)m);
+        nlo_qr_factor_rhs(m, n, qr, qtf);
+        nlo_coleman_li_scaling(n, x, xl, xu, s);             /* :1050 */
+        nlo_dogleg(m, n, delta, x, fvec, jac, qr, qtf, s, xl, xu, p, g, Jp, &prered, dwork);   /* :1053 */
+        xnorm = cls_scaled_norm(n, p, s, tmp);
+        gnorm = nlo_norm2(n, g);
+        for (int32_t i = 0; i < n; ++i) xnew[i] = x[i] + p[i];
+
+        fcn(ctx, n, xnew, m, fnew);                          /* :1060-1062 */
+        fnewnorm = nlo_norm2(m, fnew);
+        neval = neval + 1;
+
+        actred = 0.5 * (fnorm * fnorm - fnewnorm * fnewnorm);   /* :1065-1070 */
+        rho = (prered > 0.0 && actred >= 0.0) ? actred / prered : 0.0;
+
+        if (rho < 0.25) {                                    /* :1073-1077 (constant 0.25: kept) */
+            delta = dmax(0.25, 1.0e-12);
+        } else if (rho > 0.75 && fabs(xnorm - delta) < 1.0e-12 * delta) {
+            delta = dmin(2.0 * delta, delta_max);
+        }
+
+        if (rho > eta && fnewnorm <= fnorm) {                /* :1080-1086 */
+            memcpy(x, xnew, sizeof(double) * (size_t)n);
+            cls_apply_limits(n, xl, xu, x);
+            memcpy(fvec, fnew, sizeof(double) * (size_t)m);
+            fnorm = fnewnorm;
+            iter = iter + 1;
+        } else {                                             /* :1088-1123 */
+            dderiv = nlo_dot(n, g, p);
+            if (dderiv >= 0.0) {
+                delta = dmax(0.5 * delta, 1.0e-12);
+            } else {
+                stepscale = stepscale0;
+                for (k = 1; k <= ls_max_iter; ++k) {
+                    for (int32_t i = 0; i < n; ++i) xnew[i] = x[i] + stepscale * p[i];
+                    cls_apply_limits(n, xl, xu, xnew);
+                    fcn(ctx, n, xnew, m, fnew);
+                    neval = neval + 1;
+                    fnewnorm = nlo_norm2(m, fnew);
+                    if (fnewnorm <= fnorm + ls_cl * stepscale * dderiv) {
+                        memcpy(x, xnew, sizeof(double) * (size_t)n);
+                        memcpy(fvec, fnew, sizeof(double) * (size_t)m);
+                        fnorm = fnewnorm;
+                        iter = iter + 1;
+                        delta = dmax(stepscale * xnorm, 1.0e-12);
+                        break;
+                    }
+                    stepscale = stepscale * ls_beta;
+                }
+                if (k > ls_max_iter) delta = dmax(0.5 * delta, 1.0e-12);
+            }
+        }
+
+        if (!cls_is_finite(n, x) || !cls_is_finite(m, fvec)) break;   /* :1125-1127 */
+
+        if (xnorm <= xtol) { converged = 1; xcnvrg = 1; break; }      /* :1130-1149 */
+        if (fabs(actred) <= ftol && fabs(prered) <= ftol && 0.5 * rho <= 1.0) { converged = 1; fcnvrg = 1; break; }
+        if (gnorm <= gtol) { converged = 1; gcnvrg = 1; break; }
+        if (neval >= maxeval) break;
+    }
+
+    if (ib) {                                                /* :1163-1170 */
+        ib->iter_count = iter;
+        ib->fcn_count = neval;
+        ib->jacobian_count = njac;
+        ib->converge_on_fcn = fcnvrg;
+        ib->converge_on_chng = xcnvrg;
+        ib->converge_on_zero_diff = gcnvrg;
+    }
+    free(jac); free(qr); free(w);
+    return converged ? 0 : NLO_CONVERGENCE_ERROR;            /* :1173-1175 */
+}
+
+/* ---------------------------------------------------------------------------
  * Synthetic dense-quadratic family; not reference code.
  * ------------------------------------------------------------------------- */
 static void trace_push(nlo_trace *t, int32_t n, const double *x)
@@ -1227,6 +1510,15 @@ int nlo_dq_quasi_newton_solve(const nlo_options *opt, int32_t jdelta, const nlo_
 {
     nlo_dq_problem q = *p;
     int rc = nlo_quasi_newton_solve(opt, jdelta, nlo_dq_fcn, analytic ? nlo_dq_jac : NULL, &q, q.n, x, fvec, ib);
+    ((nlo_dq_problem *)p)->ncalls = q.ncalls;
+    return rc;
+}
+
+int nlo_dq_cls_solve(const nlo_options *opt, double delta0, double stepscale0, const double *xl, const double *xu,
+                     const nlo_dq_problem *p, double *x, double *fvec, nlo_iteration_behavior *ib)
+{
+    nlo_dq_problem q = *p;
+    int rc = nlo_cls_solve(opt, delta0, stepscale0, xl, xu, nlo_dq_fcn, NULL, &q, q.m, q.n, x, fvec, ib);
     ((nlo_dq_problem *)p)->ncalls = q.ncalls;
     return rc;
 }

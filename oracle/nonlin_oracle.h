@@ -152,6 +152,17 @@ int nlo_quasi_newton_solve(const nlo_options *opt, int32_t jdelta, nlo_vecfcn fc
                            nlo_jacfcn jac_or_null, void *ctx, int32_t n, double *x,
                            double *fvec, nlo_iteration_behavior *ib);
 
+/* constrained_least_squares_solver (src/nonlin_least_squares.f90:33-74, 793-1403). */
+void nlo_qr_factor_rhs(int32_t m, int32_t n, double *a, double *f);
+double nlo_alpha_box(int32_t n, const double *x, const double *p, const double *xl, const double *xu);
+void nlo_coleman_li_scaling(int32_t n, const double *x, const double *xl, const double *xu, double *s);
+void nlo_dogleg(int32_t m, int32_t n, double delta, const double *x, const double *f, const double *jac,
+                const double *r, const double *qtf, const double *s, const double *xl, const double *xu,
+                double *p, double *g, double *Jp, double *prered, double *work);
+int nlo_cls_solve(const nlo_options *opt, double delta0, double stepscale0, const double *xl,
+                  const double *xu, nlo_vecfcn fcn, nlo_jacfcn jac_or_null, void *ctx, int32_t m,
+                  int32_t n, double *x, double *fvec, nlo_iteration_behavior *ib);
+
 /* ---- Synthetic "dense-quadratic" residual family ----
  * u_i = sum_j A(i,j) x_j (j ascending, one multiply + one add per term, no FMA)
  * r_i = (u_i + gamma*u_i*u_i) - b_i ;  J(i,j) = (1 + 2*gamma*u_i) * A(i,j).   */
@@ -181,6 +192,8 @@ int nlo_dq_newton_solve(const nlo_options *opt, const nlo_dq_problem *p, int32_t
                         double *x, double *fvec, nlo_iteration_behavior *ib);
 int nlo_dq_quasi_newton_solve(const nlo_options *opt, int32_t jdelta, const nlo_dq_problem *p,
                               int32_t analytic, double *x, double *fvec, nlo_iteration_behavior *ib);
+int nlo_dq_cls_solve(const nlo_options *opt, double delta0, double stepscale0, const double *xl, const double *xu,
+                     const nlo_dq_problem *p, double *x, double *fvec, nlo_iteration_behavior *ib);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,11 @@ def lib():
                                                 C.POINTER(IterationBehavior)]
         L.nlo_quasi_newton_solve.argtypes = [C.POINTER(Options), C.c_int32, VECFCN, JACFCN, C.c_void_p, C.c_int32, dp, dp,
                                              C.POINTER(IterationBehavior)]
+        L.nlo_cls_solve.argtypes = [C.POINTER(Options), C.c_double, C.c_double, dp, dp, VECFCN, JACFCN, C.c_void_p,
+                                    C.c_int32, C.c_int32, dp, dp, C.POINTER(IterationBehavior)]
+        L.nlo_dq_cls_solve.argtypes = [C.POINTER(Options), C.c_double, C.c_double, dp, dp, C.POINTER(DqProblem), dp, dp,
+                                       C.POINTER(IterationBehavior)]
+        L.nlo_qr_factor_rhs.argtypes = [C.c_int32, C.c_int32, dp, dp]
         L.nlo_qr_factor_full.argtypes = [C.c_int32, dp, dp, dp]
         L.nlo_qr_rank1_update.argtypes = [C.c_int32, dp, dp, dp, dp]
         L.nlo_solve_upper.argtypes = [C.c_int32, dp, dp]
@@ -193,6 +198,36 @@ def quasi_newton_solve(fcn, n, x0, jac=None, opts=None, jdelta=5, record=None):
     cf, cj = _wrap_fcn(fcn, record), _wrap_jac(jac)
     rc = lib().nlo_quasi_newton_solve(C.byref(o), int(jdelta), cf, cj, None, n, _dp(x), _dp(fvec), C.byref(ib))
     return rc, x, fvec, ib.as_dict()
+
+
+def _bounds(v, n):
+    if v is None:
+        return None, None
+    a = np.ascontiguousarray(v, dtype=np.float64)
+    assert a.shape == (n,)
+    return a, _dp(a)
+
+
+def cls_solve(fcn, m, n, x0, jac=None, opts=None, lower=None, upper=None, delta=1.0, stepscale=1.0, record=None):
+    """constrained_least_squares_solver%solve.  Returns (rc, x, fvec, ib_dict)."""
+    x = np.array(x0, dtype=np.float64)
+    fvec = np.zeros(m)
+    ib = IterationBehavior()
+    o = opts or default_options()
+    cf, cj = _wrap_fcn(fcn, record), _wrap_jac(jac)
+    lo, plo = _bounds(lower, n)
+    hi, phi = _bounds(upper, n)
+    rc = lib().nlo_cls_solve(C.byref(o), float(delta), float(stepscale), plo, phi, cf, cj, None, m, n, _dp(x), _dp(fvec),
+                             C.byref(ib))
+    return rc, x, fvec, ib.as_dict()
+
+
+def qr_factor_rhs(a, f):
+    """Householder QR of a tall Fortran-order matrix with the reflectors applied to f.  Returns (r_full, qtf)."""
+    a = np.array(a, dtype=np.float64, order="F")
+    f = np.array(f, dtype=np.float64)
+    lib().nlo_qr_factor_rhs(a.shape[0], a.shape[1], _dp(a), _dp(f))
+    return a, f
 
 
 def qr_factor_full(a):
@@ -313,6 +348,20 @@ def dq_quasi_newton_solve(A, b, gamma, x0, analytic=True, opts=None, jdelta=5):
     o = opts or default_options()
     rc = lib().nlo_dq_quasi_newton_solve(C.byref(o), int(jdelta), C.byref(p), int(analytic), _dp(x), _dp(fvec),
                                          C.byref(ib))
+    return rc, x, fvec, ib.as_dict(), int(p.ncalls)
+
+
+def dq_cls_solve(A, b, gamma, x0, opts=None, lower=None, upper=None, delta=1.0, stepscale=1.0):
+    m, n = A.shape
+    p = _dq_problem(A, b, gamma)
+    x = np.array(x0, dtype=np.float64)
+    fvec = np.zeros(m)
+    ib = IterationBehavior()
+    o = opts or default_options()
+    lo, plo = _bounds(lower, n)
+    hi, phi = _bounds(upper, n)
+    rc = lib().nlo_dq_cls_solve(C.byref(o), float(delta), float(stepscale), plo, phi, C.byref(p), _dp(x), _dp(fvec),
+                                C.byref(ib))
     return rc, x, fvec, ib.as_dict(), int(p.ncalls)
 
 

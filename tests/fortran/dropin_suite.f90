@@ -191,6 +191,29 @@ program dropin_suite
         if (qn%get_jacobian_interval() /= 3) error stop 99
     end block
 
+    ! test_constrained_least_squares_1 (analytic Jacobian, infinite limits) and _bounds (FD Jacobian, box)
+    block
+        type(vecfcn_helper) :: o10, o11
+        type(constrained_least_squares_solver) :: cs, cs2
+        real(real64) :: big
+        big = huge(big)
+        fcn => fcn1
+        jac => jac1
+        call o10%set_fcn(fcn, 2, 2)
+        call o10%set_jacobian(jac)
+        call cs%set_upper_limits([big, big])
+        call cs%set_lower_limits([-big, -big])
+        x2 = 0.5d0
+        call cs%solve(o10, x2, f2, ib)
+        call report("cls_fcn1_an", ib, x2)
+        call o11%set_fcn(fcn, 2, 2)
+        call cs2%set_lower_limits([4.0d0, 2.0d0])
+        call cs2%set_upper_limits([5.6d0, 3.6d0])
+        x2 = 1.0d0
+        call cs2%solve(o11, x2, f2, ib)
+        call report("cls_fcn1_box", ib, x2)
+    end block
+
     ! test_jacobian_1: vecfcn_helper%jacobian (no fv)
     block
         type(vecfcn_helper) :: o6

@@ -92,6 +92,17 @@ def test_quasi_newton_problems(results, oracle):
     _cmp(results["qn_fcn1a_fd_j3"][0], rc, xo, ibo)
 
 
+def test_constrained_least_squares_problems(results, oracle):
+    """constrained_least_squares_solver through the Fortran shim (test_constrained_least_squares_1, _bounds)."""
+    big = float(np.finfo(np.float64).max)
+    rc, xo, fo, ibo = oracle.cls_solve(lambda x, f: P.fcn1(x, f, None), 2, 2, [0.5, 0.5], jac=lambda x, J: P.jac1(x, J, None),
+                                       lower=[-big, -big], upper=[big, big])
+    _cmp(results["cls_fcn1_an"][0], rc, xo, ibo)
+    rc, xo, fo, ibo = oracle.cls_solve(lambda x, f: P.fcn1(x, f, None), 2, 2, [1.0, 1.0], lower=[4.0, 2.0], upper=[5.6, 3.6])
+    _cmp(results["cls_fcn1_box"][0], rc, xo, ibo)
+    assert 4.0 <= xo[0] <= 5.6 and 2.0 <= xo[1] <= 3.6
+
+
 def test_fd_jacobian(results):
     J = results["jac_polar"][0]["x"].reshape(2, 2).T                  # printed column by column
     E = np.zeros((2, 2), order="F")

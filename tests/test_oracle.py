@@ -230,3 +230,51 @@ def test_quasinewton_square_dense_quadratic(oracle):
     assert rc == 0 and ib["converge_on_fcn"] == 1
     assert np.abs(f).max() < 1e-8
     assert 1 < ib["jacobian_count"] < ib["iter_count"]
+
+
+# ---------------------------------------------------------------------------
+# constrained_least_squares_solver: cls_solve, src/nonlin_least_squares.f90:938-1176
+# ---------------------------------------------------------------------------
+BIG = float(np.finfo(np.float64).max)
+
+
+def test_qr_factor_rhs_identities(oracle):
+    """Householder QR of a tall matrix with the reflectors applied to f: R^T R = A^T A, and the least-squares
+    solution R^-1 (Q^T f)(1:n) matches numpy's."""
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((40, 7))
+    f = rng.standard_normal(40)
+    r, qtf = oracle.qr_factor_rhs(A, f)
+    R = np.triu(r[:7, :])
+    assert np.array_equal(np.tril(r, -1), np.zeros_like(r))
+    assert np.abs(R.T @ R - A.T @ A).max() <= 1e-12
+    x = oracle.solve_upper(R, qtf[:7])
+    assert np.abs(x - np.linalg.lstsq(A, f, rcond=None)[0]).max() <= 1e-12
+    assert abs(np.linalg.norm(qtf) - np.linalg.norm(f)) <= 1e-12
+
+
+@pytest.mark.parametrize("ic", [(0.5, 0.5), (1.0, 1.0)])
+def test_constrained_least_squares_1_2_4(oracle, ic):
+    """tests/nonlin_test_solve.f90:975-1077, 1126-1184."""
+    rc, x, f, ib = oracle.cls_solve(lambda a, b: P.fcn1(a, b, None), 2, 2, ic, jac=lambda a, b: P.jac1(a, b, None),
+                                    lower=[-BIG, -BIG], upper=[BIG, BIG])
+    assert rc == 0 and abs(abs(x[0]) - 5.0) <= 1e-6 and abs(abs(x[1]) - 3.0) <= 1e-6
+    rc, x, f, ib = oracle.cls_solve(lambda a, b: P.fcn2(a, b, None), 2, 2, ic, opts=oracle.default_options(max_evals=5000))
+    assert rc == 0 and abs(x[0] - 5.0e3) <= 1e-6 and abs(x[1] - 10.0) <= 1e-6
+    for jac in (None, lambda a, b: P.jac1a(a, b, 2.0)):
+        rc, x, f, ib = oracle.cls_solve(lambda a, b: P.fcn1a(a, b, 2.0), 2, 2, ic, jac=jac)
+        assert rc == 0 and abs(abs(x[0]) - 5.0) <= 1e-6 and abs(abs(x[1]) - 3.0) <= 1e-6
+
+
+def test_constrained_least_squares_3_agrees_with_lm(oracle):
+    """:1080-1123: constrained and plain LM solutions of the README cubic fit within 1e-5."""
+    rc, xc, f, ib = oracle.cls_solve(lambda a, b: P.lsfcn1(a, b, None), 21, 4, [1.0] * 4)
+    rc2, x, f2, ib2 = oracle.lm_solve(lambda a, b: P.lsfcn1(a, b, None), 21, 4, [1.0] * 4)
+    assert rc == 0 and rc2 == 0 and np.abs(x - xc).max() <= 1e-5
+
+
+def test_constrained_least_squares_bounds(oracle):
+    """:1187-1228: start outside the box [4, 5.6] x [2, 3.6]; the result lies inside it."""
+    rc, x, f, ib = oracle.cls_solve(lambda a, b: P.fcn1(a, b, None), 2, 2, [1.0, 1.0], lower=[4.0, 2.0], upper=[5.6, 3.6])
+    assert rc == 0 and 4.0 <= x[0] <= 5.6 and 2.0 <= x[1] <= 3.6
+    assert abs(x[0] - 5.0) <= 1e-6 and abs(x[1] - 3.0) <= 1e-6
