@@ -235,6 +235,16 @@ int nlh_qr_rank1_update(nlh_handle *h, int32_t nprob, int32_t n, double *dQ, dou
                         const double *du, const double *dv);
 int nlh_solve_upper(nlh_handle *h, int32_t nprob, int32_t n, const double *dRt, double *dx);
 
+/* polynomial%fit / polynomial%fit_thru_zero (src/nonlin_polynomials.f90:146-238): least-squares polynomial of
+ * the given order through npts points; coef = c0 .. c_order (c0 = 0 for thru_zero).  Returns 4 where the
+ * reference stops with 4 (order >= npts or order < 1).  solve_least_squares (third-party linalg) is the
+ * Householder QR + back substitution of nlh_cls_solve.  The batch form takes device arrays
+ * dx, dy [nprob][npts], dcoef [nprob][order + 1]. */
+int nlh_poly_fit(nlh_handle *h, int32_t npts, int32_t order, int32_t thru_zero, const double *x,
+                 const double *y, double *coef);
+int nlh_poly_fit_batch(nlh_handle *h, int32_t nprob, int32_t npts, int32_t order, int32_t thru_zero,
+                       const double *dx, const double *dy, double *dcoef);
+
 /* ---- per-kernel timing (HIP events on the handle's stream) ------------------ */
 #define NLH_K_DQ_RESIDUAL   0
 #define NLH_K_DQ_PANEL      1

@@ -87,6 +87,8 @@ SYMBOLS = {
     "nlh_qr_factor_full": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_qr_rank1_update": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_solve_upper": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "nlh_poly_fit": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "nlh_poly_fit_batch": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_timing_enable": (None, [_H, C.c_int32]),
     "nlh_timing_reset": (None, [_H]),
     "nlh_timing_get": (C.c_int, [_H, C.c_int32, c_double_p, C.POINTER(C.c_int64)]),

@@ -432,3 +432,58 @@ class newton_solver(line_search_solver):
             ib._fill(cib)
         if rc:
             raise NonlinError(rc)
+
+
+class polynomial:
+    """src/nonlin_polynomials.f90:39-62 -- the fitting front end only (initialize, order, fit, fit_thru_zero,
+    evaluate, get, get_all, set); roots / arithmetic are outside the hot path."""
+
+    def __init__(self, order=None):
+        self._c = None
+        if order is not None:
+            self.initialize(order)
+
+    def initialize(self, order_or_coeffs):                    # :69-109
+        if np.ndim(order_or_coeffs) == 0:
+            if order_or_coeffs < 0:
+                raise NonlinError(2)
+            self._c = np.zeros(int(order_or_coeffs) + 1)
+        else:
+            self._c = np.array(order_or_coeffs, dtype=np.float64).ravel().copy()
+
+    def order(self):                                          # :112-143
+        return -1 if self._c is None else self._c.size - 1
+
+    def _fit(self, x, y, order, thru_zero):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.size != x.size:
+            raise NonlinError(3)                              # :159-162
+        if order >= x.size or order < 1:
+            raise NonlinError(4)                              # :163-166
+        if self.order() != order:
+            self.initialize(order)
+        h = default_handle()
+        rc = h.lib.nlh_poly_fit(h.ptr, x.size, int(order), int(thru_zero), _dp(x), _dp(y), _dp(self._c))
+        h.check(rc, "nlh_poly_fit")
+        if rc:
+            raise NonlinError(rc)
+
+    def fit(self, x, y, order): self._fit(x, y, order, False)                 # :146-190
+    def fit_thru_zero(self, x, y, order): self._fit(x, y, order, True)        # :193-238
+
+    def evaluate(self, x):                                    # :241-268, Horner from the top
+        x = np.asarray(x, dtype=np.float64)
+        order = self.order()
+        if order == -1:
+            return np.zeros_like(x)
+        if order == 0:
+            return np.full_like(x, self._c[0])
+        y = self._c[order] * x + self._c[order - 1]
+        for j in range(order - 2, -1, -1):
+            y = y * x + self._c[j]
+        return y
+
+    def get(self, i): return float(self._c[i - 1])            # 1-based like the reference
+    def get_all(self): return self._c.copy()
+    def set(self, i, v): self._c[i - 1] = float(v)

@@ -1005,6 +1005,7 @@ static int newton_core(nlh_handle *h, const nlh_options *o, int n, NewtonEval &e
 // every O(n^2)/O(n^3) operation in the kernels of nlh_kernels_broyden.h.
 // ===========================================================================
 static const int QN_MAX_N = 4096;      // k_qn_retri: 4 columns per thread at most
+static const int QN_MAX_ROWS = 18000;  // k_qn_house_dot keeps the reflector (rows doubles) in LDS
 
 // B (column-major) -> Q, R: Householder QR with Q formed (qr_factor(b, q = q, r = r), :289)
 // Householder steps on the row-major work array [A | E] (rows x ncA | rows x ncE); vbuf slot 0 must hold column 0 of A.
@@ -1106,7 +1107,7 @@ static int quasi_newton_core(nlh_handle *h, const nlh_options *o, int jdelta, in
             HIPCHK(h, hipMemcpyAsync(dfv, fvec, sizeof(double) * n, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, 1), dim3(64), 0, s, n, n, dB, dfv, dgrad, 1.0);
             hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, 1), dim3(64), 0, s, n, n, dQ, dfv, dstep, -1.0);
-            hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dRt, dstep);
+            hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dRt, dstep, (size_t)n * n, (size_t)n);
             HIPCHK(h, hipMemcpyAsync(dx.data(), dgrad, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipMemcpyAsync(df.data(), dstep, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipStreamSynchronize(s));
@@ -1296,7 +1297,7 @@ static int cls_core(nlh_handle *h, const nlh_options *o, double delta0, double s
         hipLaunchKernelGGL(k_qn_col0, dim3((m + 255) / 256, 1), dim3(256), 0, s, m, n, dW, vbuf);
         launch_house_steps(h, 1, m, n, 1, dW, dE, vbuf, wbuf, st);
         HIPCHK(h, hipMemcpyAsync(dstep, dE, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dW, dstep);
+        hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dW, dstep, (size_t)m * n, (size_t)n);
         hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, 1), dim3(64), 0, s, m, n, dJ, dfv, dgv, 1.0);
         HIPCHK(h, hipMemcpyAsync(u.data(), dstep, sizeof(double) * n, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(g.data(), dgv, sizeof(double) * n, hipMemcpyDeviceToHost, s));
@@ -1633,6 +1634,7 @@ int nlh_cls_solve(nlh_handle *h, const nlh_options *o, double delta0, double ste
     if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :988
     if (!o || n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
     if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;           // :989
+    if (m > QN_MAX_ROWS) return NLH_ARRAY_SIZE_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     const size_t mn = (size_t)m * n;
@@ -1679,6 +1681,7 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (!o || n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
     if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;
+    if (m > QN_MAX_ROWS) return NLH_ARRAY_SIZE_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     const size_t mn = (size_t)m * n;
@@ -1936,8 +1939,57 @@ int nlh_solve_upper(nlh_handle *h, int32_t nprob, int32_t n, const double *dRt, 
     if (n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(k_qn_solve_upper, dim3(nprob), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n,
-                       h->stream, n, dRt, dx);
+                       h->stream, n, dRt, dx, (size_t)n * n, (size_t)n);
     HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// polynomial%fit / fit_thru_zero (src/nonlin_polynomials.f90:146-238) for nprob independent data sets of npts
+// points each: Vandermonde panel, Householder QR with y as the extra column, back substitution.
+// dx, dy: [nprob][npts] device; dcoef: [nprob][order + 1] device (c0 first; c0 = 0 for thru_zero).
+int nlh_poly_fit_batch(nlh_handle *h, int32_t nprob, int32_t npts, int32_t order, int32_t thru_zero, const double *dx,
+                       const double *dy, double *dcoef)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (nprob < 1) return 0;
+    if (order >= npts || order < 1) return 4;                   // :163-166
+    if (npts > QN_MAX_ROWS) return NLH_ARRAY_SIZE_ERROR;        // the reflector is staged in LDS
+    HIPCHK(h, hipSetDevice(h->device));
+    const int ncols = thru_zero ? order : order + 1;
+    int rc;
+    if ((rc = ensure(h, h->W2, sizeof(double) * (size_t)nprob * npts * ncols))) return rc;
+    if ((rc = ensure(h, h->qnV, sizeof(double) * ((size_t)nprob * (3 * (size_t)npts + ncols + 8))))) return rc;
+    double *dA = (double *)h->W2.p, *dv = (double *)h->qnV.p;
+    double *rhs = dv, *vbuf = dv + (size_t)nprob * npts, *wbuf = vbuf + (size_t)nprob * 2 * npts,
+           *st = wbuf + (size_t)nprob * (ncols + 1);
+    hipStream_t s = h->stream;
+    hipLaunchKernelGGL(k_vandermonde, dim3((npts + 255) / 256, nprob), dim3(256), 0, s, npts, ncols, thru_zero, dx, dy, dA, rhs);
+    hipLaunchKernelGGL(k_qn_col0, dim3((npts + 255) / 256, nprob), dim3(256), 0, s, npts, ncols, dA, vbuf);
+    launch_house_steps(h, nprob, npts, ncols, 1, dA, rhs, vbuf, wbuf, st);
+    hipLaunchKernelGGL(k_qn_solve_upper, dim3(nprob), dim3(64), sizeof(double) * ncols, s, ncols, dA, rhs,
+                       (size_t)npts * ncols, (size_t)npts);
+    if (thru_zero) HIPCHK(h, hipMemsetAsync(dcoef, 0, sizeof(double) * (size_t)nprob * (order + 1), s));
+    HIPCHK(h, hipMemcpy2DAsync(dcoef + (thru_zero ? 1 : 0), sizeof(double) * (order + 1), rhs, sizeof(double) * npts,
+                               sizeof(double) * ncols, nprob, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// Host-array front end for one data set (what polynomial%fit marshals to).
+int nlh_poly_fit(nlh_handle *h, int32_t npts, int32_t order, int32_t thru_zero, const double *x, const double *y, double *coef)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (order >= npts || order < 1) return 4;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * ((size_t)2 * npts + order + 1)))) return rc;
+    double *dxv = (double *)h->xdev.p, *dyv = dxv + npts, *dc = dyv + npts;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(dxv, x, sizeof(double) * npts, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(dyv, y, sizeof(double) * npts, hipMemcpyHostToDevice, s));
+    if ((rc = nlh_poly_fit_batch(h, 1, npts, order, thru_zero, dxv, dyv, dc))) return rc;
+    HIPCHK(h, hipMemcpyAsync(coef, dc, sizeof(double) * (order + 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
     return 0;
 }
 

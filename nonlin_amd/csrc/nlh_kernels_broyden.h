@@ -378,12 +378,12 @@ k_qn_retri(int n, double *__restrict__ Rt, double *__restrict__ c, double *__res
 
 // x <- R^-1 x, column oriented (DTRSV 'U','N','N'); R row-major.  Dynamic LDS: n doubles.
 __global__ void __launch_bounds__(1024)
-k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall)
+k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall, size_t stride_r, size_t stride_x)
 {
     extern __shared__ double bs[];
     const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
-    const double *R = Rt + (size_t)p * n * n;
-    double *x = xall + (size_t)p * n;
+    const double *R = Rt + (size_t)p * stride_r;   // leading n x n block, row-major with leading dimension n
+    double *x = xall + (size_t)p * stride_x;
     for (int i = tid; i < n; i += BS) bs[i] = x[i];
     __syncthreads();
     for (int j = n - 1; j >= 0; --j) {
@@ -397,4 +397,23 @@ k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall
         __syncthreads();
     }
     for (int i = tid; i < n; i += BS) x[i] = bs[i];
+}
+
+// Vandermonde panel of polynomial%fit (src/nonlin_polynomials.f90:177-184, :222-225), row-major npts x ncols:
+// column c = column c-1 * x, one thread per point (the products chain along the row).  Also copies y to rhs.
+__global__ void __launch_bounds__(256)
+k_vandermonde(int npts, int ncols, int thru_zero, const double *__restrict__ x, const double *__restrict__ y,
+              double *__restrict__ A, double *__restrict__ rhs)
+{
+    const int p = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= npts) return;
+    const double xj = x[(size_t)p * npts + j];
+    double *row = A + ((size_t)p * npts + j) * ncols;
+    double a;
+    int c;
+    if (thru_zero) { a = xj; row[0] = a; c = 1; }
+    else { row[0] = 1.0; a = xj; if (ncols > 1) row[1] = a; c = 2; }
+    for (; c < ncols; ++c) { a = a * xj; row[c] = a; }
+    rhs[(size_t)p * npts + j] = y[(size_t)p * npts + j];
 }

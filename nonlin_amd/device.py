@@ -238,6 +238,18 @@ class DeviceSolver:
         self.h.check(self.lib.nlh_solve_upper(self.h.ptr, nprob, n, Rt.data_ptr(), x.data_ptr()), "nlh_solve_upper")
         return x
 
+    def poly_fit_batch(self, x, y, order, thru_zero=False):
+        """polynomial%fit for every row of x / y ([nprob, npts]).  Returns coefficients [nprob, order + 1]."""
+        nprob, npts = x.shape
+        _chk(x, (nprob, npts), "x"); _chk(y, (nprob, npts), "y")
+        coef = torch.empty((nprob, order + 1), dtype=torch.float64, device=x.device)
+        rc = self.lib.nlh_poly_fit_batch(self.h.ptr, nprob, npts, int(order), int(thru_zero), x.data_ptr(), y.data_ptr(),
+                                         coef.data_ptr())
+        self.h.check(rc, "nlh_poly_fit_batch")
+        if rc:
+            raise RuntimeError(f"nlh_poly_fit_batch returned {rc}")
+        return coef
+
     def lu_solve(self, LU, ipvt, b):
         nprob, n, _ = LU.shape
         self.h.check(self.lib.nlh_lu_solve(self.h.ptr, nprob, n, LU.data_ptr(), ipvt.data_ptr(), b.data_ptr()),

@@ -6,6 +6,7 @@ module nonlin
     use nonlin_linesearch
     use nonlin_solve
     use nonlin_least_squares
+    use nonlin_polynomials
     implicit none
     public
 end module

@@ -75,6 +75,14 @@ module nonlin_hip_c
             type(nlh_iteration_behavior), intent(out) :: ib
             integer(c_int) :: rc
         end function
+        function nlh_poly_fit(h, npts, order, thru_zero, x, y, coef) bind(C, name="nlh_poly_fit") result(rc)
+            import :: c_ptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: h
+            integer(c_int32_t), value :: npts, order, thru_zero
+            real(c_double), intent(in) :: x(*), y(*)
+            real(c_double), intent(out) :: coef(*)
+            integer(c_int) :: rc
+        end function
         function nlh_cls_solve(h, opts, delta0, stepscale0, xl, xu, m, n, fcn, jacfcn, ctx, x, fvec, ib) &
                 bind(C, name="nlh_cls_solve") result(rc)
             import :: c_ptr, c_funptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior

@@ -1409,6 +1409,60 @@ int nlo_cls_solve(const nlo_options *opt, double delta0, double stepscale0, cons
 }
 
 /* ---------------------------------------------------------------------------
+ * polynomial%fit / fit_thru_zero: src/nonlin_polynomials.f90:146-238.  Vandermonde panel exactly as
+ * the reference builds it (column j = column j-1 * x), then solve_least_squares (third-party linalg,
+ * DGELS for a full-rank tall system = Householder QR + Q^T y + back substitution), restated with
+ * nlo_qr_factor_rhs / nlo_solve_upper.  coef has order + 1 entries (coef[0] = 0 for thru_zero).
+ * y is not modified (the reference's y is intent(inout) scratch).
+ * ------------------------------------------------------------------------- */
+int nlo_poly_fit(int32_t npts, int32_t order, const double *x, const double *y, int32_t thru_zero, double *coef)
+{
+    if (order >= npts || order < 1) return 4;                /* :163-166 */
+    const int32_t ncols = thru_zero ? order : order + 1;
+    double *a = (double *)malloc(sizeof(double) * (size_t)npts * (size_t)ncols);
+    double *rhs = (double *)malloc(sizeof(double) * (size_t)npts);
+    for (int32_t j = 0; j < npts; ++j) {                     /* :177-184 / :222-225 */
+        if (thru_zero) {
+            A_(a, npts, j, 0) = x[j];
+        } else {
+            A_(a, npts, j, 0) = 1.0;
+            A_(a, npts, j, 1) = x[j];
+        }
+    }
+    for (int32_t c = (thru_zero ? 1 : 2); c < ncols; ++c)
+        for (int32_t j = 0; j < npts; ++j) A_(a, npts, j, c) = A_(a, npts, j, c - 1) * x[j];
+    memcpy(rhs, y, sizeof(double) * (size_t)npts);
+    nlo_qr_factor_rhs(npts, ncols, a, rhs);
+    /* back substitution on the leading ncols x ncols block (leading dimension npts) */
+    for (int32_t j = ncols - 1; j >= 0; --j) {
+        if (rhs[j] != 0.0) {
+            rhs[j] = rhs[j] / A_(a, npts, j, j);
+            const double t = rhs[j];
+            for (int32_t i = j - 1; i >= 0; --i) rhs[i] = rhs[i] - t * A_(a, npts, i, j);
+        }
+    }
+    if (thru_zero) {
+        coef[0] = 0.0;                                       /* :228 */
+        for (int32_t c = 0; c < ncols; ++c) coef[c + 1] = rhs[c];
+    } else {
+        for (int32_t c = 0; c < ncols; ++c) coef[c] = rhs[c];
+    }
+    free(a); free(rhs);
+    return 0;
+}
+
+/* polynomial%evaluate (real): src/nonlin_polynomials.f90:241-268 (Horner from the top). */
+double nlo_poly_eval(int32_t order, const double *c, double x)
+{
+    const int32_t n = order + 1;
+    if (order == -1) return 0.0;
+    if (order == 0) return c[0];
+    double y = c[n - 1] * x + c[order - 1];
+    for (int32_t j = n - 2; j >= 1; --j) y = y * x + c[j - 1];
+    return y;
+}
+
+/* ---------------------------------------------------------------------------
  * Synthetic dense-quadratic family; not reference code.
  * ------------------------------------------------------------------------- */
 static void trace_push(nlo_trace *t, int32_t n, const double *x)

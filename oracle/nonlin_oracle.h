@@ -163,6 +163,10 @@ int nlo_cls_solve(const nlo_options *opt, double delta0, double stepscale0, cons
                   const double *xu, nlo_vecfcn fcn, nlo_jacfcn jac_or_null, void *ctx, int32_t m,
                   int32_t n, double *x, double *fvec, nlo_iteration_behavior *ib);
 
+/* polynomial%fit / fit_thru_zero / evaluate (src/nonlin_polynomials.f90:146-268). */
+int nlo_poly_fit(int32_t npts, int32_t order, const double *x, const double *y, int32_t thru_zero, double *coef);
+double nlo_poly_eval(int32_t order, const double *c, double x);
+
 /* ---- Synthetic "dense-quadratic" residual family ----
  * u_i = sum_j A(i,j) x_j (j ascending, one multiply + one add per term, no FMA)
  * r_i = (u_i + gamma*u_i*u_i) - b_i ;  J(i,j) = (1 + 2*gamma*u_i) * A(i,j).   */

@@ -100,6 +100,9 @@ def lib():
         L.nlo_dq_cls_solve.argtypes = [C.POINTER(Options), C.c_double, C.c_double, dp, dp, C.POINTER(DqProblem), dp, dp,
                                        C.POINTER(IterationBehavior)]
         L.nlo_qr_factor_rhs.argtypes = [C.c_int32, C.c_int32, dp, dp]
+        L.nlo_poly_fit.argtypes = [C.c_int32, C.c_int32, dp, dp, C.c_int32, dp]
+        L.nlo_poly_eval.argtypes = [C.c_int32, dp, C.c_double]
+        L.nlo_poly_eval.restype = C.c_double
         L.nlo_qr_factor_full.argtypes = [C.c_int32, dp, dp, dp]
         L.nlo_qr_rank1_update.argtypes = [C.c_int32, dp, dp, dp, dp]
         L.nlo_solve_upper.argtypes = [C.c_int32, dp, dp]
@@ -220,6 +223,20 @@ def cls_solve(fcn, m, n, x0, jac=None, opts=None, lower=None, upper=None, delta=
     rc = lib().nlo_cls_solve(C.byref(o), float(delta), float(stepscale), plo, phi, cf, cj, None, m, n, _dp(x), _dp(fvec),
                              C.byref(ib))
     return rc, x, fvec, ib.as_dict()
+
+
+def poly_fit(x, y, order, thru_zero=False):
+    """polynomial%fit / fit_thru_zero.  Returns (rc, coefficients c0..c_order)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    coef = np.zeros(order + 1)
+    rc = lib().nlo_poly_fit(x.size, int(order), _dp(x), _dp(y), int(thru_zero), _dp(coef))
+    return rc, coef
+
+
+def poly_eval(coef, x):
+    coef = np.ascontiguousarray(coef, dtype=np.float64)
+    return np.array([lib().nlo_poly_eval(coef.size - 1, _dp(coef), float(v)) for v in np.atleast_1d(x)])
 
 
 def qr_factor_rhs(a, f):

@@ -214,6 +214,25 @@ program dropin_suite
         call report("cls_fcn1_box", ib, x2)
     end block
 
+    ! README Example 3: polynomial%fit on the Example 2 data
+    block
+        type(polynomial) :: pf
+        real(real64) :: xp(21), yp(21), yc(21)
+        integer :: i
+        xp = [(0.1d0 * (i - 1), i = 1, 21)]
+        xp = [0.0d0, 0.1d0, 0.2d0, 0.3d0, 0.4d0, 0.5d0, 0.6d0, 0.7d0, 0.8d0, 0.9d0, 1.0d0, 1.1d0, 1.2d0, 1.3d0, &
+            1.4d0, 1.5d0, 1.6d0, 1.7d0, 1.8d0, 1.9d0, 2.0d0]
+        yp = [1.216737514d0, 1.250032542d0, 1.305579195d0, 1.040182335d0, 1.751867738d0, 1.109716707d0, &
+            2.018141531d0, 1.992418729d0, 1.807916923d0, 2.078806005d0, 2.698801324d0, 2.644662712d0, &
+            3.412756702d0, 4.406137221d0, 4.567156645d0, 4.999550779d0, 5.652854194d0, 6.784320119d0, &
+            8.307936836d0, 8.395126494d0, 10.30252404d0]
+        yc = yp
+        call pf%fit(xp, yp, 3)
+        print '(A,I0,A,F12.10)', ("# poly c", i - 1, " = ", pf%get(i), i = 1, 4)
+        print '(A,F7.5)', "# poly Max Residual: ", maxval(abs(pf%evaluate(xp) - yc))
+        print '(A,4(1X,Z16.16))', "poly_readme 0 0 0 F F F", pf%get(1), pf%get(2), pf%get(3), pf%get(4)
+    end block
+
     ! test_jacobian_1: vecfcn_helper%jacobian (no fv)
     block
         type(vecfcn_helper) :: o6

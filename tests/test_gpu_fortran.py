@@ -103,6 +103,16 @@ def test_constrained_least_squares_problems(results, oracle):
     assert 4.0 <= xo[0] <= 5.6 and 2.0 <= xo[1] <= 3.6
 
 
+def test_polynomial_fit_readme_example_3(results, oracle):
+    """README.md:175-226 through the Fortran shim: printed coefficients and residual, coefficients bitwise."""
+    out = results["_stdout"]
+    for line in ("# poly c0 = 1.1866141861", "# poly c1 = 0.4466136311", "# poly c2 = -.1223204989",
+                 "# poly c3 = 1.0647628218", "# poly Max Residual: 0.50636"):
+        assert line in out, line
+    rc, co = oracle.poly_fit(P.XP, P.YP, 3)
+    assert np.array_equal(results["poly_readme"][0]["x"], co)
+
+
 def test_fd_jacobian(results):
     J = results["jac_polar"][0]["x"].reshape(2, 2).T                  # printed column by column
     E = np.zeros((2, 2), order="F")

@@ -278,3 +278,15 @@ def test_constrained_least_squares_bounds(oracle):
     rc, x, f, ib = oracle.cls_solve(lambda a, b: P.fcn1(a, b, None), 2, 2, [1.0, 1.0], lower=[4.0, 2.0], upper=[5.6, 3.6])
     assert rc == 0 and 4.0 <= x[0] <= 5.6 and 2.0 <= x[1] <= 3.6
     assert abs(x[0] - 5.0) <= 1e-6 and abs(x[1] - 3.0) <= 1e-6
+
+
+def test_poly_fit_readme_example_3(oracle):
+    """SURVEY 8(f) row f4.  README.md:175-226 prints c0..c3 and the max residual of the cubic fitted by
+    polynomial%fit to the Example 2 data: a golden vector for the Vandermonde + QR least-squares path."""
+    rc, c = oracle.poly_fit(P.XP, P.YP, 3)
+    assert rc == 0
+    assert ["%.10f" % v for v in c] == ["1.1866141861", "0.4466136311", "-0.1223204989", "1.0647628218"]
+    assert "%.5f" % np.abs(oracle.poly_eval(c, P.XP) - P.YP).max() == "0.50636"
+    rc, c0 = oracle.poly_fit(P.XP, P.YP, 3, thru_zero=True)
+    assert rc == 0 and c0[0] == 0.0
+    assert oracle.poly_fit(P.XP[:3], P.YP[:3], 3)[0] == 4
