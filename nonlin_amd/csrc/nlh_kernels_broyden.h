@@ -61,7 +61,13 @@ k_qn_house_dot(int rows, int ncA, int ncE, int j, const double *__restrict__ Aal
     const int p = blockIdx.y, tid = threadIdx.x;
     const double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
     const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
-    for (int i = j + 1 + tid; i < rows; i += QN_DOT_BS) vs[i] = vcur[i];
+    for (int i0 = j + 1 + tid; i0 < rows; i0 += 8 * QN_DOT_BS) {      // 8 loads in flight per thread
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * QN_DOT_BS; t[u] = (i < rows) ? vcur[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * QN_DOT_BS; if (i < rows) vs[i] = t[u]; }
+    }
     __syncthreads();
     if (tid == 0) {                                // one ordered sum; LDS reads batched 16 at a time
         double s = 0.0;
