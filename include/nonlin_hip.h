@@ -90,6 +90,9 @@ void nlh_default_options(nlh_options *opts);
 /* ---- user callbacks: vecfcn / jacobianfcn (src/nonlin_multi_eqn_mult_var.f90:14-38)
  * flattened to C.  The Fortran shim passes bind(C) trampolines; ctx carries the
  * vecfcn_helper and the optional class(*) args.  jac is column-major, ld = m. */
+/* fcnnvar / gradientfcn (src/nonlin_multi_var.f90:14-27) flattened to C. */
+typedef double (*nlh_fcnnvar)(void *ctx, int32_t n, const double *x);
+typedef void (*nlh_gradfcn)(void *ctx, int32_t n, const double *x, double *g);
 typedef void (*nlh_vecfcn)(void *ctx, int32_t n, const double *x, int32_t m, double *f);
 typedef void (*nlh_jacfcn)(void *ctx, int32_t n, const double *x, int32_t m, double *jac);
 
@@ -141,6 +144,16 @@ int nlh_cls_solve(nlh_handle *h, const nlh_options *opts, double delta0, double 
                   nlh_vecfcn fcn, nlh_jacfcn jacfcn, void *ctx,
                   double *x, double *fvec, nlh_iteration_behavior *ib);
 
+/* bfgs%solve -- bfgs_solve, src/nonlin_optimize.f90:557-770, with fcnnvar_helper%gradient
+ * (src/nonlin_multi_var.f90:182-246; gradfcn = NULL => forward differences) and ls_search_miso
+ * (src/nonlin_linesearch.f90:329-492).  opts->max_evals = get_max_fcn_evals() (500, :46),
+ * opts->gtol = get_tolerance() (1e-12, :47), opts->xtol = get_var_tolerance() (1e-12,
+ * src/nonlin_optimize.f90:47), use_line_search / ls_* as for newton.  fout may be NULL.
+ * ib->gradient_count is filled, ib->jacobian_count = 0. */
+int nlh_bfgs_solve(nlh_handle *h, const nlh_options *opts, int32_t n, nlh_fcnnvar fcn,
+                   nlh_gradfcn gradfcn, void *ctx, double *x, double *fout,
+                   nlh_iteration_behavior *ib);
+
 /* ===========================================================================
  * Device-model ("mode D") batched entry points: DEVICE pointers.
  * Residual family "dense-quadratic" (SURVEY.md 8(d)), evaluated on the GPU with
@@ -173,6 +186,13 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *opts, double delta0
                            const double *dA, const double *db, double gamma, double *dx,
                            double *dfvec, nlh_iteration_behavior *ib /* host, [nprob] */,
                            int32_t *status /* host, [nprob] */);
+
+/* bfgs on f(x) = 0.5 * sum_i r_i(x)^2 of the device model, forward-difference gradient on the device.
+ * hfout: [nprob] host (may be NULL). */
+int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *opts, int32_t nprob, int32_t m,
+                            int32_t n, const double *dA, const double *db, double gamma, double *dx,
+                            double *hfout, nlh_iteration_behavior *ib /* host, [nprob] */,
+                            int32_t *status /* host, [nprob] */);
 
 /* Synthetic problem generator of SURVEY.md 8(d) (bench/test inputs, not part of the
  * reference): counter-based splitmix64, U_k = mix(seed + (k+1)*0x9E3779B97F4A7C15),
@@ -234,6 +254,10 @@ int nlh_qr_factor_full(nlh_handle *h, int32_t nprob, int32_t n, const double *dB
 int nlh_qr_rank1_update(nlh_handle *h, int32_t nprob, int32_t n, double *dQ, double *dRt,
                         const double *du, const double *dv);
 int nlh_solve_upper(nlh_handle *h, int32_t nprob, int32_t n, const double *dRt, double *dx);
+/* cholesky_rank1_update (downdate = 0) / cholesky_rank1_downdate (1) stand-ins (call sites
+ * src/nonlin_optimize.f90:721-722): R1^T R1 = R^T R +- u u^T in place on the ROW-major upper factor dRt;
+ * du is consumed; *hinfo = 1 if the downdate would lose positive definiteness. */
+int nlh_chol_rank1(nlh_handle *h, int32_t n, int32_t downdate, double *dRt, double *du, int32_t *hinfo);
 
 /* polynomial%fit / polynomial%fit_thru_zero (src/nonlin_polynomials.f90:146-238): least-squares polynomial of
  * the given order through npts points; coef = c0 .. c_order (c0 = 0 for thru_zero).  Returns 4 where the

@@ -6,6 +6,7 @@ from .api import (  # noqa: F401
     NonlinError, iteration_behavior, vecfcn_helper, equation_solver, least_squares_solver,
     line_search, line_search_solver, newton_solver, quasi_newton_solver,
     constrained_equation_solver, constrained_least_squares_solver, polynomial,
+    fcnnvar_helper, equation_optimizer, line_search_optimizer, bfgs,
     NL_NO_ERROR, NL_INVALID_INPUT_ERROR, NL_ARRAY_SIZE_ERROR, NL_OUT_OF_MEMORY_ERROR,
     NL_INVALID_OPERATION_ERROR, NL_CONVERGENCE_ERROR, NL_DIVERGENT_BEHAVIOR_ERROR,
     NL_SPURIOUS_CONVERGENCE_ERROR, NL_TOLERANCE_TOO_SMALL_ERROR, NL_INDEX_OUT_OF_RANGE_ERROR,

@@ -14,6 +14,8 @@ c_int32_p = C.POINTER(C.c_int32)
 
 VECFCN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, c_double_p, C.c_int32, c_double_p)
 JACFCN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, c_double_p, C.c_int32, c_double_p)
+FCNNVAR = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int32, c_double_p)
+GRADFCN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, c_double_p, c_double_p)
 
 
 class IterationBehavior(C.Structure):
@@ -53,6 +55,8 @@ SYMBOLS = {
                                          c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
     "nlh_cls_solve": (C.c_int, [_H, C.POINTER(Options), C.c_double, C.c_double, c_double_p, c_double_p, C.c_int32, C.c_int32,
                                 VECFCN, JACFCN, C.c_void_p, c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
+    "nlh_bfgs_solve": (C.c_int, [_H, C.POINTER(Options), C.c_int32, FCNNVAR, GRADFCN, C.c_void_p, c_double_p, c_double_p,
+                                 C.POINTER(IterationBehavior)]),
     "nlh_dq_lm_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                         C.POINTER(IterationBehavior), c_int32_p]),
@@ -65,6 +69,8 @@ SYMBOLS = {
     "nlh_dq_cls_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_double, C.c_double, c_double_p, c_double_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                          C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_dq_bfgs_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_double, C.c_void_p, c_double_p, C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_dq_generate": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_double, C.c_double,
                                   C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_dq_residual": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
@@ -87,6 +93,7 @@ SYMBOLS = {
     "nlh_qr_factor_full": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_qr_rank1_update": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_solve_upper": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "nlh_chol_rank1": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_int32_p]),
     "nlh_poly_fit": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "nlh_poly_fit_batch": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_timing_enable": (None, [_H, C.c_int32]),

@@ -487,3 +487,125 @@ class polynomial:
     def get(self, i): return float(self._c[i - 1])            # 1-based like the reference
     def get_all(self): return self._c.copy()
     def set(self, i, v): self._c[i - 1] = float(v)
+
+
+class fcnnvar_helper:
+    """src/nonlin_multi_var.f90:29-43: holder of a scalar objective fcn(x, args) -> float and an optional
+    gradient routine grad(x, g, args)."""
+
+    def __init__(self):
+        self._fcn = None
+        self._grad = None
+        self._nvar = 0
+
+    def set_fcn(self, fcn, nvar):                             # :99-106
+        self._fcn = fcn
+        self._nvar = int(nvar)
+
+    def set_gradient_fcn(self, grad): self._grad = grad       # :116-120
+    def is_fcn_defined(self): return self._fcn is not None
+    def is_gradient_defined(self): return self._grad is not None
+    def get_variable_count(self): return self._nvar
+
+    def fcn(self, x, args=None):                              # :81-89
+        return float(self._fcn(x, args)) if self._fcn is not None else 0.0
+
+    def _c_fcn(self, args):
+        f = self._fcn
+
+        def _cb(ctx, n, xp):
+            return float(f(np.ctypeslib.as_array(xp, shape=(n,)), args))
+        return _lib.FCNNVAR(_cb)
+
+    def _c_grad(self, args):
+        if self._grad is None:
+            return C.cast(None, _lib.GRADFCN)
+        g = self._grad
+
+        def _cb(ctx, n, xp, gp):
+            g(np.ctypeslib.as_array(xp, shape=(n,)), np.ctypeslib.as_array(gp, shape=(n,)), args)
+        return _lib.GRADFCN(_cb)
+
+
+class equation_optimizer:
+    """src/nonlin_multi_var.f90:45-57."""
+
+    def __init__(self):
+        self._max_eval = 500                      # :46
+        self._tol = 1.0e-12                       # :47
+        self._print = False
+        self.handle = None
+
+    def get_max_fcn_evals(self): return self._max_eval
+    def set_max_fcn_evals(self, n): self._max_eval = int(n)
+    def get_tolerance(self): return self._tol
+    def set_tolerance(self, x): self._tol = float(x)
+    def get_print_status(self): return self._print
+    def set_print_status(self, x): self._print = bool(x)
+
+
+class line_search_optimizer(equation_optimizer):
+    """src/nonlin_optimize.f90:44-61."""
+
+    def __init__(self):
+        super().__init__()
+        self._line_search = None
+        self._use_line_search = True              # :46
+        self._xtol = 1.0e-12                      # :47
+
+    def get_line_search(self):
+        if self._line_search is None:
+            return None
+        ls = line_search()
+        ls.__dict__.update(self._line_search.__dict__)
+        return ls
+
+    def set_line_search(self, ls):
+        c = line_search()
+        c.__dict__.update(ls.__dict__)
+        self._line_search = c
+
+    def set_default_line_search(self): self._line_search = line_search()
+    def is_line_search_defined(self): return self._line_search is not None
+    def get_use_line_search(self): return self._use_line_search
+    def set_use_line_search(self, x): self._use_line_search = bool(x)
+    def get_var_tolerance(self): return self._xtol
+    def set_var_tolerance(self, x): self._xtol = float(x)
+
+
+class bfgs(line_search_optimizer):
+    """src/nonlin_optimize.f90:69-72."""
+
+    def solve(self, fcn, x, ib=None, args=None):
+        """bfgs_solve (:557-770).  x: initial estimate -> minimiser.  Returns fout."""
+        if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous):
+            raise ValueError("x must be a contiguous float64 numpy array (it is updated in place)")
+        if self.get_use_line_search() and not self.is_line_search_defined():
+            self.set_default_line_search()        # :604-608
+        if not fcn.is_fcn_defined():
+            raise NonlinError(NL_UNDEFINED_FUNCTION_ERROR)   # :614
+        n = fcn.get_variable_count()
+        if x.shape != (n,):
+            raise NonlinError(NL_INVALID_INPUT_ERROR)        # :615
+        o = _lib.default_options()
+        o.max_evals = self._max_eval
+        o.gtol = self._tol
+        o.xtol = self._xtol
+        o.print_status = 1 if self._print else 0
+        o.use_line_search = 1 if self._use_line_search else 0
+        if self._line_search is not None:
+            o.ls_max_evals = self._line_search._max_eval
+            o.ls_alpha = self._line_search._alpha
+            o.ls_factor = self._line_search._factor
+        h = self.handle or default_handle()
+        cib = _lib.IterationBehavior()
+        fout = C.c_double(0.0)
+        cf, cg = fcn._c_fcn(args), fcn._c_grad(args)
+        rc = h.lib.nlh_bfgs_solve(h.ptr, C.byref(o), n, cf, cg, None, _dp(x), C.cast(C.byref(fout), _lib.c_double_p),
+                                  C.byref(cib))
+        h.check(rc, "nlh_bfgs_solve")
+        if ib is not None:
+            ib._fill(cib)
+        if rc:
+            raise NonlinError(rc)                 # :765-767
+        return fout.value

@@ -25,6 +25,7 @@
 #include "nlh_kernels_lm.h"
 #include "nlh_kernels_lu.h"
 #include "nlh_kernels_broyden.h"
+#include "nlh_kernels_bfgs.h"
 #include "nlh_kernels_exact.h"
 
 // ---------------------------------------------------------------------------
@@ -49,7 +50,7 @@ struct nlh_handle {
     std::vector<DevBuf *> bufs;       // every workspace buffer, for destroy
     // named workspace buffers (grown on demand, reused across calls)
     DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2, R,
-           qnQ, qnR, qnV;
+           qnQ, qnR, qnV, bfB, bfR, bfV;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
 };
@@ -182,6 +183,11 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_dot, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_bf_solve_upper_t, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_bf_chol_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_bf_chol_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_bf_downdate_apply, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_matvec_cm, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_rot_q, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_hess_r, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_retri<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -1419,6 +1425,185 @@ static int cls_core(nlh_handle *h, const nlh_options *o, double delta0, double s
     return converged ? 0 : NLH_CONVERGENCE_ERROR;               // :1173-1175
 }
 
+
+// ===========================================================================
+// BFGS: bfgs_solve (src/nonlin_optimize.f90:557-770) as a host loop; the Hessian factor R (row-major) and
+// B = R^T R live on the device.  Host: ls_search_miso, the convergence tests and the O(n) vector algebra in the
+// reference's order.
+// ===========================================================================
+struct BfgsEval {
+    std::function<int(const double *x, double *f)> fcn;                 // objective at host x
+    std::function<int(double *x, double fv, double *g)> grad;           // gradient at host x (fv = f(x)) -> host g
+};
+
+// ls_search_miso, src/nonlin_linesearch.f90:329-492
+static int line_search_scalar(const nlh_options *o, BfgsEval &ev, int n, const double *xold, const double *grad,
+                              const double *dir, double *x, double fold, double *fx, int *fcn_count)
+{
+    const double tolx = 2.0 * DBL_EPSILON, alpha = o->ls_alpha, lambdamin = o->ls_factor;
+    const int maxeval = o->ls_max_evals;
+    int neval = 0, niter = 0, flag = 0, rc = 0;
+    double alam, alam1 = 0.0, alamin, f1 = 0.0, slope, test, tmplam = 0.0, f = 0.0;
+    *fcn_count = 0;
+    slope = h_dot(n, grad, dir);
+    if (slope >= 0.0) return NLH_DIVERGENT_BEHAVIOR_ERROR;
+    test = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double t = fabs(dir[i]) / fmax(fabs(xold[i]), 1.0);
+        if (t > test) test = t;
+    }
+    alamin = tolx / test;
+    alam = 1.0;
+    for (;;) {
+        for (int i = 0; i < n; ++i) x[i] = xold[i] + alam * dir[i];
+        if ((rc = ev.fcn(x, &f))) return rc;
+        neval += 1;
+        niter += 1;
+        if (alam < alamin) {
+            double sq = 0.0;
+            for (int i = 0; i < n; ++i) { const double d = x[i] - xold[i]; sq = sq + d * d; }
+            if (sqrt(sq) == 0.0) { rc = NLH_CONVERGENCE_ERROR; break; }
+            for (int i = 0; i < n; ++i) x[i] = xold[i];
+            break;
+        } else if (f <= fold + alpha * alam * slope) {
+            break;
+        } else {
+            tmplam = min_backtrack_search(niter, fold, f, f1, alam, alam1, slope);
+        }
+        alam1 = alam;
+        f1 = f;
+        alam = fmax(tmplam, lambdamin * alam);
+        if (neval >= maxeval) { flag = 1; break; }
+    }
+    *fx = f;
+    *fcn_count = neval;
+    if (rc) return rc;
+    return flag ? NLH_CONVERGENCE_ERROR : 0;
+}
+
+static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, double *x, double *fout,
+                     nlh_iteration_behavior *ib)
+{
+    int rc;
+    if (n > QN_MAX_N) return NLH_ARRAY_SIZE_ERROR;
+    const size_t nn = (size_t)n * n;
+    if ((rc = ensure(h, h->bfB, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->bfR, sizeof(double) * nn))) return rc;
+    if ((rc = ensure(h, h->bfV, sizeof(double) * ((size_t)6 * n + 8)))) return rc;
+    double *dB = (double *)h->bfB.p, *dR = (double *)h->bfR.p, *dv = (double *)h->bfV.p;
+    double *dvec = dv, *dout = dv + n, *du = dv + 2 * n, *dc = dv + 3 * n;
+    int *dinfo = (int *)(dv + 4 * n);
+    hipStream_t s = h->stream;
+    std::vector<double> g(n), dx(n), u(n), v(n), y(n), bdx(n), gold(n), xnew(n);
+    int xcnvrg = 0, gcnvrg = 0, neval = 0, ngrad = 0, flag = 0, iter = 0, hinfo = 0;
+    double fp, stpmax = 0.0, fret = 0.0, xtest = 0.0, gtest, temp, ydx;
+    const int bs1 = std::min(1024, ((n + 63) / 64) * 64);
+    rc = 0;
+
+    if ((rc = ev.fcn(x, &fp))) return rc;                       // :633-636
+    if ((rc = ev.grad(x, fp, g.data()))) return rc;
+    neval = 1;
+    ngrad = 1;
+    gtest = h_norm2(n, g.data());                               // :639-642
+    if (gtest < o->gtol) gcnvrg = 1;
+
+    if (!gcnvrg) {
+        for (;;) {                                              // :647-748
+            iter += 1;
+            if (iter == 1) {                                    // :653-656
+                for (int i = 0; i < n; ++i) dx[i] = -g[i];
+                stpmax = 100.0 * fmax(h_norm2(n, x), (double)n);
+            }
+            if (o->use_line_search) {                           // :659-669
+                const double mag = h_norm2(n, dx.data());       // limit_search_vector
+                if (mag != 0.0 && mag > stpmax) {
+                    const double sc = stpmax / mag;
+                    for (int i = 0; i < n; ++i) dx[i] = sc * dx[i];
+                }
+                int lcount = 0;
+                rc = line_search_scalar(o, ev, n, x, g.data(), dx.data(), xnew.data(), fp, &fret, &lcount);
+                neval += lcount;
+                if (rc) break;
+                fp = fret;
+            } else {
+                for (int i = 0; i < n; ++i) xnew[i] = x[i] + dx[i];
+                if ((rc = ev.fcn(xnew.data(), &fp))) break;
+                neval += 1;
+            }
+            for (int i = 0; i < n; ++i) {                       // :672-678
+                dx[i] = xnew[i] - x[i];
+                x[i] = xnew[i];
+                gold[i] = g[i];
+            }
+            if ((rc = ev.grad(x, fp, g.data()))) break;
+            ngrad += 1;
+
+            xtest = 0.0;                                        // :681-689
+            for (int i = 0; i < n; ++i) {
+                temp = fabs(dx[i]) / fmax(fabs(x[i]), 1.0);
+                xtest = fmax(temp, xtest);
+            }
+            if (xtest < o->xtol) { xcnvrg = 1; break; }
+            gtest = h_norm2(n, g.data());                       // :692-696
+            if (gtest < o->gtol) { gcnvrg = 1; break; }
+
+            for (int i = 0; i < n; ++i) y[i] = g[i] - gold[i];  // :699-700
+            ydx = h_dot(n, y.data(), dx.data());
+            if (iter == 1) {                                    // :703-706
+                temp = sqrt(h_dot(n, y.data(), y.data()) / ydx);
+                hipLaunchKernelGGL(k_bf_scaled_identity, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, n, temp, dR);
+            }
+            // B = R^T R (:709), bdx = B dx (:712)
+            hipLaunchKernelGGL(k_bf_rtr, dim3((n + 255) / 256, n), dim3(256), 0, s, n, dR, dB);
+            HIPCHK(h, hipMemcpyAsync(dvec, dx.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_matvec_cm, dim3((n + 255) / 256, 1), dim3(256), sizeof(double) * n, s, n, n, dB, dvec, dout);
+            HIPCHK(h, hipMemcpyAsync(bdx.data(), dout, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            if (ydx > 1.0e-10 && iter > 1) {                    // :715-724
+                const double s1 = sqrt(ydx), s2 = sqrt(h_dot(n, dx.data(), bdx.data()));
+                for (int i = 0; i < n; ++i) u[i] = y[i] / s1;
+                for (int i = 0; i < n; ++i) v[i] = bdx[i] / s2;
+                HIPCHK(h, hipMemcpyAsync(du, u.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+                if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_update<1>, dim3(1), dim3(bs1), sizeof(double) * 2 * n, s, n, dR, du);
+                else hipLaunchKernelGGL(k_bf_chol_update<4>, dim3(1), dim3(1024), sizeof(double) * 2 * n, s, n, dR, du);
+                HIPCHK(h, hipMemcpyAsync(du, v.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_bf_solve_upper_t, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dR, du);
+                hipLaunchKernelGGL(k_bf_downdate_rot, dim3(1), dim3(64), 0, s, n, du, dc, dinfo);
+                hipLaunchKernelGGL(k_bf_downdate_apply, dim3((n + 255) / 256), dim3(256), sizeof(double) * 2 * n, s, n, dR, dc, du, dinfo);
+            } else {
+                if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_factor<1>, dim3(1), dim3(bs1), 0, s, n, dB, dR, dinfo);
+                else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(1), dim3(1024), 0, s, n, dB, dR, dinfo);
+            }
+            // dx = -(R^T R)^-1 g (:727)
+            for (int i = 0; i < n; ++i) u[i] = -g[i];
+            HIPCHK(h, hipMemcpyAsync(dout, u.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_bf_solve_upper_t, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dR, dout);
+            hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dR, dout, (size_t)n * n, (size_t)n);
+            HIPCHK(h, hipMemcpyAsync(dx.data(), dout, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            if (hinfo) { rc = NLH_INVALID_OPERATION_ERROR; break; }     // linalg: matrix not positive definite
+
+            if (o->print_status) {                              // :730-737
+                printf("\n");
+                printf("Iteration: %d\n", iter);
+                printf("Function Evaluations: %d\n", neval);
+                printf("Function Value: %10.3E\n", fp);
+                printf("Change in Variable: %10.3E\n", xtest);
+                printf("Gradient: %10.3E\n", gtest);
+            }
+            if (neval >= o->max_evals) { flag = 1; break; }     // :740-743
+        }
+    }
+    if (ib) {                                                   // :751-759
+        ib->iter_count = iter; ib->fcn_count = neval; ib->jacobian_count = 0; ib->gradient_count = ngrad;
+        ib->converge_on_fcn = 0; ib->converge_on_chng = xcnvrg; ib->converge_on_zero_diff = gcnvrg;
+    }
+    if (fout) *fout = fp;                                       // :762
+    if (rc) return rc;
+    return flag ? NLH_CONVERGENCE_ERROR : 0;                    // :765-767
+}
+
 extern "C" {
 
 int nlh_newton_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_vecfcn fcn, nlh_jacfcn jacfcn,
@@ -1724,6 +1909,90 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
     return 0;
 }
 
+// bfgs%solve -- bfgs_solve, src/nonlin_optimize.f90:557-770; fcnnvar / gradientfcn callbacks flattened to C
+int nlh_bfgs_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_fcnnvar fcn, nlh_gradfcn gradfcn, void *ctx,
+                   double *x, double *fout, nlh_iteration_behavior *ib)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (ib) memset(ib, 0, sizeof *ib);
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :614
+    if (!o || n < 1) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    BfgsEval ev;
+    ev.fcn = [&](const double *xx, double *f) -> int { *f = fcn(ctx, n, xx); return 0; };
+    ev.grad = [&](double *xx, double fv, double *g) -> int {    // fnh_grad_fcn, src/nonlin_multi_var.f90:182-246
+        if (gradfcn) { gradfcn(ctx, n, xx, g); return 0; }
+        for (int j = 0; j < n; ++j) {
+            const double temp = xx[j];
+            double hh = NLH_SQRT_EPS * fabs(temp);
+            if (hh == 0.0) hh = NLH_SQRT_EPS;
+            xx[j] = temp + hh;
+            const double f1 = fcn(ctx, n, xx);
+            xx[j] = temp;
+            g[j] = (f1 - fv) / hh;
+        }
+        return 0;
+    };
+    int rc = bfgs_core(h, o, n, ev, x, fout, ib);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return NLH_ERR_HIP; }
+    return rc;
+}
+
+// Device model: minimise f(x) = 0.5 * sum_i r_i(x)^2 of the dense-quadratic residual with bfgs; the
+// forward-difference gradient (fnh_grad_fcn) is the residual panel kernel + k_bf_fd_gradient.
+int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n, const double *dA,
+                            const double *db, double gamma, double *dx, double *hfout, nlh_iteration_behavior *ib,
+                            int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!o || n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t mn = (size_t)m * n;
+    if ((rc = ensure(h, h->P, sizeof(double) * mn))) return rc;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * 2 * n))) return rc;
+    if ((rc = ensure(h, h->wa4, sizeof(double) * m))) return rc;
+    hipStream_t s = h->stream;
+    std::vector<double> x(n), f(m);
+    for (int p = 0; p < nprob; ++p) {
+        const double *A = dA + (size_t)p * mn, *b = db + (size_t)p * m;
+        double *dxp = dx + (size_t)p * n;
+        double *dxs = (double *)h->xdev.p, *dgs = dxs + n, *dfs = (double *)h->wa4.p;
+        HIPCHK(h, hipMemcpyAsync(x.data(), dxp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        BfgsEval ev;
+        ev.fcn = [&](const double *xx, double *fv) -> int {
+            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            launch_dq_residual(h, 1, m, n, A, b, gamma, dxs, dfs, nullptr, nullptr, -1);
+            HIPCHK(h, hipMemcpyAsync(f.data(), dfs, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            *fv = 0.5 * h_dot(m, f.data(), f.data());
+            return 0;
+        };
+        ev.grad = [&](double *xx, double fv, double *g) -> int {
+            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            launch_dq_panel(h, 1, m, n, A, b, gamma, dxs, (double *)h->P.p, nullptr, -1);
+            hipLaunchKernelGGL(k_bf_fd_gradient, dim3((n + 63) / 64), dim3(64), 0, s, m, n, (const double *)h->P.p, dxs, fv, dgs);
+            HIPCHK(h, hipMemcpyAsync(g, dgs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            return 0;
+        };
+        nlh_iteration_behavior lib;
+        memset(&lib, 0, sizeof lib);
+        double fo = 0.0;
+        rc = bfgs_core(h, o, n, ev, x.data(), &fo, &lib);
+        if (rc < 0) return rc;
+        if (ib) ib[p] = lib;
+        if (status) status[p] = rc;
+        if (hfout) hfout[p] = fo;
+        HIPCHK(h, hipMemcpyAsync(dxp, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 // ===========================================================================
 // Synthetic inputs + stage-level entry points
 // ===========================================================================
@@ -1940,6 +2209,36 @@ int nlh_solve_upper(nlh_handle *h, int32_t nprob, int32_t n, const double *dRt, 
     HIPCHK(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(k_qn_solve_upper, dim3(nprob), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n,
                        h->stream, n, dRt, dx, (size_t)n * n, (size_t)n);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// cholesky_rank1_update / cholesky_rank1_downdate stand-ins (call sites src/nonlin_optimize.f90:721-722): in place on the
+// row-major upper factor dRt (n x n); du is consumed.  *hinfo = 1 if the downdate would lose positive definiteness.
+int nlh_chol_rank1(nlh_handle *h, int32_t n, int32_t downdate, double *dRt, double *du, int32_t *hinfo)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (n < 1) return NLH_INVALID_INPUT_ERROR;
+    if (n > QN_MAX_N) return NLH_ARRAY_SIZE_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->bfV, sizeof(double) * ((size_t)6 * n + 8)))) return rc;
+    double *dc = (double *)h->bfV.p;
+    int *dinfo = (int *)(dc + n);
+    hipStream_t s = h->stream;
+    const int bs1 = std::min(1024, ((n + 63) / 64) * 64);
+    int info = 0;
+    if (!downdate) {
+        if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_update<1>, dim3(1), dim3(bs1), sizeof(double) * 2 * n, s, n, dRt, du);
+        else hipLaunchKernelGGL(k_bf_chol_update<4>, dim3(1), dim3(1024), sizeof(double) * 2 * n, s, n, dRt, du);
+    } else {
+        hipLaunchKernelGGL(k_bf_solve_upper_t, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dRt, du);
+        hipLaunchKernelGGL(k_bf_downdate_rot, dim3(1), dim3(64), 0, s, n, du, dc, dinfo);
+        hipLaunchKernelGGL(k_bf_downdate_apply, dim3((n + 255) / 256), dim3(256), sizeof(double) * 2 * n, s, n, dRt, dc, du, dinfo);
+        HIPCHK(h, hipMemcpyAsync(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (hinfo) *hinfo = info;
     HIPCHK(h, hipGetLastError());
     return 0;
 }

@@ -1,0 +1,197 @@
+// nlh_kernels_bfgs.h -- dense kernels of bfgs%solve (src/nonlin_optimize.f90:557-770) and the
+// finite-difference gradient of fcnnvar_helper (src/nonlin_multi_var.f90:182-246) for the device model.
+//
+// The reference takes B = R^T R, DSYMV, the rank-one Cholesky update / downdate, the Cholesky
+// factorisation and the triangular solves from the third-party linalg library (BLAS / LAPACK / qrupdate,
+// unpinned).  The CPU restatement defines them with ascending-index sums; the kernels perform the same
+// operations on every element, so R and every iterate are bit-identical to it.
+// R is kept ROW-major (Rt[j*n + c] = R(j,c), upper triangular): the update / downdate sweeps and the
+// forward solve touch one row of R across columns per step.
+#pragma once
+#include "nlh_common.h"
+#include "nlh_kernels_broyden.h"
+
+// B <- R^T R (tri_mtx_mult(.true., 1, r, 0, b), :709): thread per entry (i <= j), sum over k ascending;
+// both triangles of the column-major B are written.
+__global__ void __launch_bounds__(256)
+k_bf_rtr(int n, const double *__restrict__ Rt, double *__restrict__ B)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i > j || i >= n) return;
+    double t = 0.0;
+    for (int k = 0; k <= i; ++k) t = t + Rt[(size_t)k * n + i] * Rt[(size_t)k * n + j];
+    B[(size_t)j * n + i] = t;
+    B[(size_t)i * n + j] = t;
+}
+
+// x <- R^-T x (DTRSV 'U','T','N'), one workgroup: x_j loses R(i,j) x_i for i ascending, which is the dot form's
+// order of subtractions.  Dynamic LDS: n doubles.
+__global__ void __launch_bounds__(1024)
+k_bf_solve_upper_t(int n, const double *__restrict__ Rt, double *__restrict__ x)
+{
+    extern __shared__ double xs[];
+    const int tid = threadIdx.x, BS = blockDim.x;
+    for (int i = tid; i < n; i += BS) xs[i] = x[i];
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const double xi = xs[i] / Rt[(size_t)i * n + i];
+        __syncthreads();
+        for (int j = i + 1 + tid; j < n; j += BS) xs[j] = xs[j] - Rt[(size_t)i * n + j] * xi;
+        if (tid == 0) xs[i] = xi;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += BS) x[i] = xs[i];
+}
+
+// R1^T R1 = R^T R + u u^T (cholesky_rank1_update, qrupdate DCH1UP, :721).  One workgroup, thread per
+// column (NC columns per thread when n > blockDim): column c carries its u value through the rotations
+// 0 .. c-1 and then generates rotation c.  u is consumed.  Dynamic LDS: 2n doubles.
+template <int NC>
+__global__ void __launch_bounds__(1024)
+k_bf_chol_update(int n, double *__restrict__ Rt, const double *__restrict__ u)
+{
+    extern __shared__ double cs[];                 // c[n], s[n]
+    const int tid = threadIdx.x, BS = blockDim.x;
+    double ui[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) { const int c = tid + q * BS; ui[q] = (c < n) ? u[c] : 0.0; }
+    for (int j = 0; j < n; ++j) {
+        const int oq = j / BS, ot = j - oq * BS;
+        if (tid == ot) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (q == oq) {
+                    double cj, sj, rr;
+                    givens_dev(Rt[(size_t)j * n + j], ui[q], cj, sj, rr);
+                    cs[j] = cj; cs[n + j] = sj;
+                    Rt[(size_t)j * n + j] = rr;
+                }
+        }
+        __syncthreads();
+        const double cj = cs[j], sj = cs[n + j];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int c = tid + q * BS;
+            if (c > j && c < n) {
+                const double rjc = Rt[(size_t)j * n + c];
+                const double t = cj * rjc + sj * ui[q];
+                ui[q] = cj * ui[q] - sj * rjc;
+                Rt[(size_t)j * n + c] = t;
+            }
+        }
+    }
+}
+
+// Downdate, first half (qrupdate DCH1DN): given v = R^-T u (k_bf_solve_upper_t), rho = sqrt(1 - ||v||^2) with
+// NORM2 as the flang runtime evaluates it, then the rotations from the bottom.  info = 1: not positive definite.
+__global__ void k_bf_downdate_rot(int n, double *__restrict__ v, double *__restrict__ c, int *__restrict__ info)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double mx = 0.0, s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double a = fabs(v[i]);
+        if (mx == 0.0) mx = a;
+        else if (a > mx) { const double t = mx / a, tsq = t * t; s = s * tsq; s = s + tsq; mx = a; }
+        else if (a != 0.0) { const double t = a / mx; s = s + t * t; }
+    }
+    double rho = mx * sqrt(1.0 + s);
+    rho = 1.0 - rho * rho;
+    if (rho <= 0.0) { *info = 1; return; }
+    *info = 0;
+    rho = sqrt(rho);
+    for (int i = n - 1; i >= 0; --i) {
+        double ci, si, rr;
+        givens_dev(rho, v[i], ci, si, rr);
+        c[i] = ci; v[i] = si;
+        rho = rr;
+    }
+}
+
+// Downdate, second half: thread per column i, rows i .. 0.
+__global__ void __launch_bounds__(256)
+k_bf_downdate_apply(int n, double *__restrict__ Rt, const double *__restrict__ c, const double *__restrict__ s,
+                    const int *__restrict__ info)
+{
+    extern __shared__ double cs[];
+    if (*info) return;
+    for (int k = threadIdx.x; k < n; k += 256) { cs[k] = c[k]; cs[n + k] = s[k]; }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double ui = 0.0;
+    for (int j = i; j >= 0; --j) {
+        const double rji = Rt[(size_t)j * n + i];
+        const double t = cs[j] * ui + cs[n + j] * rji;
+        Rt[(size_t)j * n + i] = cs[j] * rji - cs[n + j] * ui;
+        ui = t;
+    }
+}
+
+// R <- chol(B), upper (cholesky_factor(b, .true.), DPOTF2 'U', :724), row-major result with zeros below the
+// diagonal.  One workgroup, thread per column (NC per thread).  info = 1-based index of a non-positive pivot.
+template <int NC>
+__global__ void __launch_bounds__(1024)
+k_bf_chol_factor(int n, const double *__restrict__ B, double *__restrict__ Rt, int *__restrict__ info)
+{
+    __shared__ double ajj_sh;
+    __shared__ int bad;
+    const int tid = threadIdx.x, BS = blockDim.x;
+    if (tid == 0) bad = 0;
+    for (size_t e = tid; e < (size_t)n * n; e += BS) {          // row-major copy of the symmetric B
+        const int r = (int)(e / n), c = (int)(e % n);
+        Rt[e] = (r <= c) ? B[(size_t)c * n + r] : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) {
+            double a = Rt[(size_t)j * n + j];
+            for (int k = 0; k < j; ++k) a = a - Rt[(size_t)k * n + j] * Rt[(size_t)k * n + j];
+            if (!(a > 0.0)) bad = j + 1;
+            else { a = sqrt(a); Rt[(size_t)j * n + j] = a; }
+            ajj_sh = a;
+        }
+        __syncthreads();
+        if (bad) break;
+        const double ajj = ajj_sh;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int c = tid + q * BS;
+            if (c > j && c < n) {
+                double t = Rt[(size_t)j * n + c];
+                for (int k = 0; k < j; ++k) t = t - Rt[(size_t)k * n + j] * Rt[(size_t)k * n + c];
+                Rt[(size_t)j * n + c] = t / ajj;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *info = bad;
+}
+
+// R <- temp * I (DLASET, :705)
+__global__ void __launch_bounds__(256)
+k_bf_scaled_identity(int n, double temp, double *__restrict__ Rt)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < (size_t)n * n) Rt[e] = (e / n == e % n) ? temp : 0.0;
+}
+
+// f_j = 0.5 * sum_i P(i,j)^2 for every column of the residual panel (objective of the device model at the
+// n perturbed points), sum over i ascending; then g_j = (f_j - f0) / h_j (:240).  Thread per column.
+__global__ void __launch_bounds__(64)
+k_bf_fd_gradient(int m, int n, const double *__restrict__ P, const double *__restrict__ x, double f0,
+                 double *__restrict__ g)
+{
+    __shared__ double tile[64 * 65];
+    const int t = threadIdx.x, k0 = blockIdx.x * 64;
+    double acc = 0.0;
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + t;
+        for (int kk = 0; kk < 64; ++kk)
+            tile[kk * 65 + t] = (i < m && k0 + kk < n) ? P[(size_t)(k0 + kk) * m + i] : 0.0;
+        __syncthreads();
+        const int lim = min(64, m - i0);
+        for (int ii = 0; ii < lim; ++ii) { const double r = tile[t * 65 + ii]; acc = acc + r * r; }
+        __syncthreads();
+    }
+    if (k0 + t < n) g[k0 + t] = (0.5 * acc - f0) / fd_step(x[k0 + t]);
+}

@@ -127,6 +127,22 @@ class DeviceSolver:
             raise RuntimeError(f"nlh_dq_cls_solve_batch returned {rc}")
         return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
 
+    def bfgs_solve_batch(self, A, b, gamma, x, opts=None):
+        """bfgs%solve on f(x) = 0.5 ||r(x)||^2 of every problem (FD gradient on the device).  x in place.
+        Returns (fout list, ib list, status list)."""
+        nprob, n, m = A.shape
+        _chk(A, (nprob, n, m), "A"); _chk(b, (nprob, m), "b"); _chk(x, (nprob, n), "x")
+        ib = (_lib.IterationBehavior * nprob)()
+        status = (C.c_int32 * nprob)()
+        fout = (C.c_double * nprob)()
+        o = opts or self.options(max_evals=500)
+        rc = self.lib.nlh_dq_bfgs_solve_batch(self.h.ptr, C.byref(o), nprob, m, n, A.data_ptr(), b.data_ptr(), float(gamma),
+                                              x.data_ptr(), fout, ib, status)
+        self.h.check(rc, "nlh_dq_bfgs_solve_batch")
+        if rc:
+            raise RuntimeError(f"nlh_dq_bfgs_solve_batch returned {rc}")
+        return [float(v) for v in fout], [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
+
     # -- stage-level kernels (parity tests, roofline) --------------------------
     def residual(self, A, b, gamma, x):
         nprob, n, m = A.shape
@@ -249,6 +265,15 @@ class DeviceSolver:
         if rc:
             raise RuntimeError(f"nlh_poly_fit_batch returned {rc}")
         return coef
+
+    def chol_rank1(self, Rt, u, downdate=False):
+        """In place on the row-major upper Cholesky factor Rt (n x n): R1^T R1 = R^T R +- u u^T.  Returns info."""
+        n = Rt.shape[0]
+        _chk(Rt, (n, n), "Rt"); _chk(u, (n,), "u")
+        info = C.c_int32(0)
+        self.h.check(self.lib.nlh_chol_rank1(self.h.ptr, n, int(downdate), Rt.data_ptr(), u.data_ptr(), C.byref(info)),
+                     "nlh_chol_rank1")
+        return int(info.value)
 
     def lu_solve(self, LU, ipvt, b):
         nprob, n, _ = LU.shape

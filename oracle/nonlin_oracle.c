@@ -1463,6 +1463,294 @@ double nlo_poly_eval(int32_t order, const double *c, double x)
 }
 
 /* ---------------------------------------------------------------------------
+ * fcnnvar_helper%gradient (src/nonlin_multi_var.f90:182-246) and bfgs%solve
+ * (src/nonlin_optimize.f90:557-770) with ls_search_miso (src/nonlin_linesearch.f90:329-492).
+ * Third-party pieces (linalg -> BLAS / qrupdate, unpinned), restated with ascending-index sums:
+ * tri_mtx_mult(.true., 1, r, 0, b) = B <- R^T R; DSYMV 'U'; cholesky_rank1_update = DCH1UP;
+ * cholesky_rank1_downdate = DCH1DN; cholesky_factor(b, upper) = DPOTF2 'U'; solve_cholesky = two DTRSV.
+ * ------------------------------------------------------------------------- */
+/* fnh_grad_fcn, :182-246.  fv_or_null: the function value at x, if known. */
+void nlo_fd_gradient(nlo_fcnnvar fcn, nlo_gradfcn grad_or_null, void *ctx, int32_t n, double *x,
+                     const double *fv_or_null, double *g)
+{
+    if (grad_or_null) { grad_or_null(ctx, n, x, g); return; }
+    const double f = fv_or_null ? *fv_or_null : fcn(ctx, n, x);
+    const double eps = sqrt(DBL_EPSILON);
+    for (int32_t j = 0; j < n; ++j) {
+        const double temp = x[j];
+        double h = eps * fabs(temp);
+        if (h == 0.0) h = eps;
+        x[j] = temp + h;
+        const double f1 = fcn(ctx, n, x);
+        x[j] = temp;
+        g[j] = (f1 - f) / h;
+    }
+}
+
+/* B <- R^T R for upper triangular R (tri_mtx_mult with trans = .true.); b is filled completely. */
+void nlo_rtr(int32_t n, const double *r, double *b)
+{
+    for (int32_t j = 0; j < n; ++j)
+        for (int32_t i = 0; i <= j; ++i) {
+            double t = 0.0;
+            for (int32_t k = 0; k <= i; ++k) t = t + A_(r, n, k, i) * A_(r, n, k, j);
+            A_(b, n, i, j) = t;
+            A_(b, n, j, i) = t;
+        }
+}
+
+/* y <- B x, B symmetric (DSYMV 'U' reads the upper triangle; written here as full row sums in ascending j
+ * over the symmetric matrix, which nlo_rtr fills on both sides). */
+void nlo_symv(int32_t n, const double *b, const double *x, double *y)
+{
+    for (int32_t i = 0; i < n; ++i) {
+        double t = 0.0;
+        for (int32_t j = 0; j < n; ++j) t = t + A_(b, n, i, j) * x[j];
+        y[i] = t;
+    }
+}
+
+/* R1^T R1 = R^T R + u u^T (qrupdate DCH1UP).  u is overwritten. */
+void nlo_chol_update(int32_t n, double *r, double *u)
+{
+    double *w = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int32_t i = 0; i < n; ++i) {
+        double ui = u[i];
+        for (int32_t j = 0; j < i; ++j) {
+            const double t = w[j] * A_(r, n, j, i) + u[j] * ui;
+            ui = w[j] * ui - u[j] * A_(r, n, j, i);
+            A_(r, n, j, i) = t;
+        }
+        double rr;
+        nlo_givens(A_(r, n, i, i), ui, &w[i], &u[i], &rr);
+        A_(r, n, i, i) = rr;
+    }
+    free(w);
+}
+
+/* R1^T R1 = R^T R - u u^T (qrupdate DCH1DN).  Returns 1 if the result would not be positive definite
+ * (r is then unchanged up to the triangular solve of u).  u is overwritten. */
+int nlo_chol_downdate(int32_t n, double *r, double *u)
+{
+    double *w = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    /* u <- R^-T u (DTRSV 'U','T','N'): forward substitution, dot form */
+    for (int32_t j = 0; j < n; ++j) {
+        double t = u[j];
+        for (int32_t i = 0; i < j; ++i) t = t - A_(r, n, i, j) * u[i];
+        u[j] = t / A_(r, n, j, j);
+    }
+    double rho = nlo_norm2(n, u);
+    rho = 1.0 - rho * rho;
+    if (rho <= 0.0) { free(w); return 1; }
+    rho = sqrt(rho);
+    for (int32_t i = n - 1; i >= 0; --i) {
+        const double ui = u[i];
+        double rr;
+        nlo_givens(rho, ui, &w[i], &u[i], &rr);
+        rho = rr;
+    }
+    for (int32_t i = n - 1; i >= 0; --i) {
+        double ui = 0.0;
+        for (int32_t j = i; j >= 0; --j) {
+            const double t = w[j] * ui + u[j] * A_(r, n, j, i);
+            A_(r, n, j, i) = w[j] * A_(r, n, j, i) - u[j] * ui;
+            ui = t;
+        }
+    }
+    free(w);
+    return 0;
+}
+
+/* Upper Cholesky factor of the symmetric positive definite b (DPOTF2 'U'), strict lower triangle zeroed.
+ * Returns the 1-based index of a non-positive pivot, 0 on success. */
+int nlo_chol_factor_upper(int32_t n, const double *b, double *r)
+{
+    memcpy(r, b, sizeof(double) * (size_t)n * (size_t)n);
+    for (int32_t j = 0; j < n; ++j) {
+        double ajj = A_(r, n, j, j);
+        for (int32_t k = 0; k < j; ++k) ajj = ajj - A_(r, n, k, j) * A_(r, n, k, j);
+        if (!(ajj > 0.0)) return j + 1;
+        ajj = sqrt(ajj);
+        A_(r, n, j, j) = ajj;
+        for (int32_t c = j + 1; c < n; ++c) {
+            double t = A_(r, n, j, c);
+            for (int32_t k = 0; k < j; ++k) t = t - A_(r, n, k, j) * A_(r, n, k, c);
+            A_(r, n, j, c) = t / ajj;
+        }
+    }
+    for (int32_t j = 0; j < n; ++j)
+        for (int32_t i = j + 1; i < n; ++i) A_(r, n, i, j) = 0.0;
+    return 0;
+}
+
+/* x <- (R^T R)^-1 x: R^T y = x (forward, dot form), then R x = y (nlo_solve_upper). */
+void nlo_solve_cholesky_upper(int32_t n, const double *r, double *x)
+{
+    for (int32_t j = 0; j < n; ++j) {
+        double t = x[j];
+        for (int32_t i = 0; i < j; ++i) t = t - A_(r, n, i, j) * x[i];
+        x[j] = t / A_(r, n, j, j);
+    }
+    nlo_solve_upper(n, r, x);
+}
+
+/* ls_search_miso, src/nonlin_linesearch.f90:329-492 (fold is always supplied by bfgs). */
+static int nlo_line_search_scalar(const nlo_options *opt, nlo_fcnnvar fcn, void *ctx, int32_t n, const double *xold,
+                                  const double *grad, const double *dir, double *x, double fold, double *fx,
+                                  int32_t *fcn_count)
+{
+    const double tolx = 2.0 * DBL_EPSILON, alpha = opt->ls_alpha, lambdamin = opt->ls_factor;
+    const int32_t maxeval = opt->ls_max_evals;
+    int32_t neval = 0, niter = 0, flag = 0;
+    double alam, alam1 = 0.0, alamin, f1 = 0.0, slope, test, tmplam = 0.0, f = 0.0;
+    int rc = 0;
+    *fcn_count = 0;
+    slope = nlo_dot(n, grad, dir);
+    if (slope >= 0.0) return NLO_DIVERGENT_BEHAVIOR_ERROR;
+    test = 0.0;
+    for (int32_t i = 0; i < n; ++i) {
+        const double t = fabs(dir[i]) / dmax(fabs(xold[i]), 1.0);
+        if (t > test) test = t;
+    }
+    alamin = tolx / test;
+    alam = 1.0;
+    for (;;) {
+        for (int32_t i = 0; i < n; ++i) x[i] = xold[i] + alam * dir[i];
+        f = fcn(ctx, n, x);
+        neval = neval + 1;
+        niter = niter + 1;
+        if (alam < alamin) {
+            double sq = 0.0;
+            for (int32_t i = 0; i < n; ++i) { const double d = x[i] - xold[i]; sq = sq + d * d; }
+            if (sqrt(sq) == 0.0) { rc = NLO_CONVERGENCE_ERROR; break; }
+            for (int32_t i = 0; i < n; ++i) x[i] = xold[i];
+            break;
+        } else if (f <= fold + alpha * alam * slope) {
+            break;
+        } else {
+            tmplam = nlo_min_backtrack_search(niter, fold, f, f1, alam, alam1, slope);
+        }
+        alam1 = alam;
+        f1 = f;
+        alam = dmax(tmplam, lambdamin * alam);
+        if (neval >= maxeval) { flag = 1; break; }
+    }
+    *fx = f;
+    *fcn_count = neval;
+    if (rc) return rc;
+    return flag ? NLO_CONVERGENCE_ERROR : 0;
+}
+
+/* bfgs_solve, src/nonlin_optimize.f90:557-770.  opt->max_evals = get_max_fcn_evals() (500), opt->gtol =
+ * get_tolerance() (1e-12), opt->xtol = get_var_tolerance() (1e-12); ib->gradient_count is filled. */
+int nlo_bfgs_solve(const nlo_options *opt, nlo_fcnnvar fcn, nlo_gradfcn grad_or_null, void *ctx, int32_t n,
+                   double *x, double *fout, nlo_iteration_behavior *ib)
+{
+    const double factor = 1.0e2, small = 1.0e-10;
+    int32_t xcnvrg = 0, gcnvrg = 0, neval = 0, ngrad = 0, flag = 0, iter = 0;
+    const int32_t maxeval = opt->max_evals;
+    const double gtol = opt->gtol, xtol = opt->xtol;
+    double fp, stpmax = 0.0, fret, xtest = 0.0, gtest, temp, ydx;
+    int rc = 0;
+
+    if (ib) memset(ib, 0, sizeof *ib);
+    if (!fcn) return NLO_UNDEFINED_FUNCTION_ERROR;           /* :614 */
+    const size_t nn = (size_t)n * (size_t)(n > 0 ? n : 1);
+    double *w = (double *)calloc((size_t)(8 * n + 1), sizeof(double));
+    double *g = w, *dx = g + n, *u = dx + n, *v = u + n, *y = v + n, *bdx = y + n, *gold = bdx + n, *xnew = gold + n;
+    double *b = (double *)calloc(nn, sizeof(double)), *r = (double *)calloc(nn, sizeof(double));
+
+    fp = fcn(ctx, n, x);                                     /* :633-636 */
+    nlo_fd_gradient(fcn, grad_or_null, ctx, n, x, &fp, g);
+    neval = 1;
+    ngrad = 1;
+    gtest = nlo_norm2(n, g);                                 /* :639-642 */
+    if (gtest < gtol) gcnvrg = 1;
+
+    if (!gcnvrg) {
+        for (;;) {                                           /* :647-748 */
+            iter = iter + 1;
+            if (iter == 1) {                                 /* :653-656 */
+                for (int32_t i = 0; i < n; ++i) dx[i] = -g[i];
+                stpmax = factor * dmax(nlo_norm2(n, x), (double)n);
+            }
+            if (opt->use_line_search) {                      /* :659-669 */
+                int32_t lcount = 0;
+                nlo_limit_search_vector(n, dx, stpmax);
+                rc = nlo_line_search_scalar(opt, fcn, ctx, n, x, g, dx, xnew, fp, &fret, &lcount);
+                neval = neval + lcount;
+                if (rc) break;
+                fp = fret;
+            } else {
+                for (int32_t i = 0; i < n; ++i) xnew[i] = x[i] + dx[i];
+                fp = fcn(ctx, n, xnew);
+                neval = neval + 1;
+            }
+            for (int32_t i = 0; i < n; ++i) {                /* :672-678 */
+                dx[i] = xnew[i] - x[i];
+                x[i] = xnew[i];
+                gold[i] = g[i];
+            }
+            nlo_fd_gradient(fcn, grad_or_null, ctx, n, x, &fp, g);
+            ngrad = ngrad + 1;
+
+            xtest = 0.0;                                     /* :681-689 */
+            for (int32_t i = 0; i < n; ++i) {
+                temp = fabs(dx[i]) / dmax(fabs(x[i]), 1.0);
+                xtest = dmax(temp, xtest);
+            }
+            if (xtest < xtol) { xcnvrg = 1; break; }
+            gtest = nlo_norm2(n, g);                         /* :692-696 */
+            if (gtest < gtol) { gcnvrg = 1; break; }
+
+            for (int32_t i = 0; i < n; ++i) y[i] = g[i] - gold[i];   /* :699-700 */
+            ydx = nlo_dot(n, y, dx);
+            if (iter == 1) {                                 /* :703-706: R = temp * I */
+                temp = sqrt(nlo_dot(n, y, y) / ydx);
+                for (size_t e = 0; e < nn; ++e) r[e] = 0.0;
+                for (int32_t i = 0; i < n; ++i) A_(r, n, i, i) = temp;
+            }
+            nlo_rtr(n, r, b);                                /* :709 */
+            nlo_symv(n, b, dx, bdx);                         /* :712 */
+            if (ydx > small && iter > 1) {                   /* :715-724 */
+                const double s1 = sqrt(ydx), s2 = sqrt(nlo_dot(n, dx, bdx));
+                for (int32_t i = 0; i < n; ++i) u[i] = y[i] / s1;
+                for (int32_t i = 0; i < n; ++i) v[i] = bdx[i] / s2;
+                nlo_chol_update(n, r, u);
+                if (nlo_chol_downdate(n, r, v)) { rc = NLO_INVALID_OPERATION_ERROR; break; }   /* linalg raises LA_MATRIX_FORMAT_ERROR */
+            } else {
+                if (nlo_chol_factor_upper(n, b, r)) { rc = NLO_INVALID_OPERATION_ERROR; break; }
+            }
+            for (int32_t i = 0; i < n; ++i) dx[i] = -g[i];   /* :727 dx = solve_cholesky(.true., r, -g) */
+            nlo_solve_cholesky_upper(n, r, dx);
+
+            if (opt->print_status) {                         /* :730-737 */
+                printf("\n");
+                printf("Iteration: %d\n", iter);
+                printf("Function Evaluations: %d\n", neval);
+                printf("Function Value: %10.3E\n", fp);
+                printf("Change in Variable: %10.3E\n", xtest);
+                printf("Gradient: %10.3E\n", gtest);
+            }
+            if (neval >= maxeval) { flag = 1; break; }       /* :740-743 */
+        }
+    }
+    if (ib) {                                                /* :751-759 */
+        ib->iter_count = iter;
+        ib->fcn_count = neval;
+        ib->jacobian_count = 0;
+        ib->gradient_count = ngrad;
+        ib->converge_on_fcn = 0;
+        ib->converge_on_chng = xcnvrg;
+        ib->converge_on_zero_diff = gcnvrg;
+    }
+    if (fout) *fout = fp;                                    /* :762 */
+    free(w); free(b); free(r);
+    if (rc) return rc;
+    return flag ? NLO_CONVERGENCE_ERROR : 0;                 /* :765-767 */
+}
+
+/* ---------------------------------------------------------------------------
  * Synthetic dense-quadratic family; not reference code.
  * ------------------------------------------------------------------------- */
 static void trace_push(nlo_trace *t, int32_t n, const double *x)
@@ -1573,6 +1861,26 @@ int nlo_dq_cls_solve(const nlo_options *opt, double delta0, double stepscale0, c
 {
     nlo_dq_problem q = *p;
     int rc = nlo_cls_solve(opt, delta0, stepscale0, xl, xu, nlo_dq_fcn, NULL, &q, q.m, q.n, x, fvec, ib);
+    ((nlo_dq_problem *)p)->ncalls = q.ncalls;
+    return rc;
+}
+
+/* Scalar objective of the device model for bfgs: f(x) = 0.5 * sum_i r_i(x)^2 (ascending sum). */
+static double dq_objective(void *ctx, int32_t n, const double *x)
+{
+    nlo_dq_problem *p = (nlo_dq_problem *)ctx;
+    double *r = (double *)malloc(sizeof(double) * (size_t)p->m);
+    nlo_dq_fcn(ctx, n, x, p->m, r);
+    const double f = 0.5 * nlo_dot(p->m, r, r);
+    free(r);
+    return f;
+}
+
+int nlo_dq_bfgs_solve(const nlo_options *opt, const nlo_dq_problem *p, double *x, double *fout,
+                      nlo_iteration_behavior *ib)
+{
+    nlo_dq_problem q = *p;
+    int rc = nlo_bfgs_solve(opt, dq_objective, NULL, &q, q.n, x, fout, ib);
     ((nlo_dq_problem *)p)->ncalls = q.ncalls;
     return rc;
 }

@@ -167,6 +167,20 @@ int nlo_cls_solve(const nlo_options *opt, double delta0, double stepscale0, cons
 int nlo_poly_fit(int32_t npts, int32_t order, const double *x, const double *y, int32_t thru_zero, double *coef);
 double nlo_poly_eval(int32_t order, const double *c, double x);
 
+/* fcnnvar_helper%gradient and bfgs%solve (src/nonlin_multi_var.f90:182-246, src/nonlin_optimize.f90:557-770). */
+typedef double (*nlo_fcnnvar)(void *ctx, int32_t n, const double *x);
+typedef void (*nlo_gradfcn)(void *ctx, int32_t n, const double *x, double *g);
+void nlo_fd_gradient(nlo_fcnnvar fcn, nlo_gradfcn grad_or_null, void *ctx, int32_t n, double *x,
+                     const double *fv_or_null, double *g);
+void nlo_rtr(int32_t n, const double *r, double *b);
+void nlo_symv(int32_t n, const double *b, const double *x, double *y);
+void nlo_chol_update(int32_t n, double *r, double *u);
+int nlo_chol_downdate(int32_t n, double *r, double *u);
+int nlo_chol_factor_upper(int32_t n, const double *b, double *r);
+void nlo_solve_cholesky_upper(int32_t n, const double *r, double *x);
+int nlo_bfgs_solve(const nlo_options *opt, nlo_fcnnvar fcn, nlo_gradfcn grad_or_null, void *ctx, int32_t n,
+                   double *x, double *fout, nlo_iteration_behavior *ib);
+
 /* ---- Synthetic "dense-quadratic" residual family ----
  * u_i = sum_j A(i,j) x_j (j ascending, one multiply + one add per term, no FMA)
  * r_i = (u_i + gamma*u_i*u_i) - b_i ;  J(i,j) = (1 + 2*gamma*u_i) * A(i,j).   */
@@ -198,6 +212,8 @@ int nlo_dq_quasi_newton_solve(const nlo_options *opt, int32_t jdelta, const nlo_
                               int32_t analytic, double *x, double *fvec, nlo_iteration_behavior *ib);
 int nlo_dq_cls_solve(const nlo_options *opt, double delta0, double stepscale0, const double *xl, const double *xu,
                      const nlo_dq_problem *p, double *x, double *fvec, nlo_iteration_behavior *ib);
+int nlo_dq_bfgs_solve(const nlo_options *opt, const nlo_dq_problem *p, double *x, double *fout,
+                      nlo_iteration_behavior *ib);
 
 #ifdef __cplusplus
 }

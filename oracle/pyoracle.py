@@ -12,6 +12,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
+FCNNVAR = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int32, C.POINTER(C.c_double))
+GRADFCN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double))
 VECFCN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double))
 JACFCN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double))
 
@@ -100,6 +102,16 @@ def lib():
         L.nlo_dq_cls_solve.argtypes = [C.POINTER(Options), C.c_double, C.c_double, dp, dp, C.POINTER(DqProblem), dp, dp,
                                        C.POINTER(IterationBehavior)]
         L.nlo_qr_factor_rhs.argtypes = [C.c_int32, C.c_int32, dp, dp]
+        L.nlo_bfgs_solve.argtypes = [C.POINTER(Options), FCNNVAR, GRADFCN, C.c_void_p, C.c_int32, dp, dp,
+                                     C.POINTER(IterationBehavior)]
+        L.nlo_dq_bfgs_solve.argtypes = [C.POINTER(Options), C.POINTER(DqProblem), dp, dp, C.POINTER(IterationBehavior)]
+        L.nlo_fd_gradient.argtypes = [FCNNVAR, GRADFCN, C.c_void_p, C.c_int32, dp, dp, dp]
+        L.nlo_rtr.argtypes = [C.c_int32, dp, dp]
+        L.nlo_symv.argtypes = [C.c_int32, dp, dp, dp]
+        L.nlo_chol_update.argtypes = [C.c_int32, dp, dp]
+        L.nlo_chol_downdate.argtypes = [C.c_int32, dp, dp]
+        L.nlo_chol_factor_upper.argtypes = [C.c_int32, dp, dp]
+        L.nlo_solve_cholesky_upper.argtypes = [C.c_int32, dp, dp]
         L.nlo_poly_fit.argtypes = [C.c_int32, C.c_int32, dp, dp, C.c_int32, dp]
         L.nlo_poly_eval.argtypes = [C.c_int32, dp, C.c_double]
         L.nlo_poly_eval.restype = C.c_double
@@ -223,6 +235,80 @@ def cls_solve(fcn, m, n, x0, jac=None, opts=None, lower=None, upper=None, delta=
     rc = lib().nlo_cls_solve(C.byref(o), float(delta), float(stepscale), plo, phi, cf, cj, None, m, n, _dp(x), _dp(fvec),
                              C.byref(ib))
     return rc, x, fvec, ib.as_dict()
+
+
+def _wrap_scalar(fcn):
+    def _f(ctx, n, xp):
+        return float(fcn(np.ctypeslib.as_array(xp, shape=(n,))))
+    return FCNNVAR(_f)
+
+
+def _wrap_grad(grad):
+    if grad is None:
+        return C.cast(None, GRADFCN)
+
+    def _g(ctx, n, xp, gp):
+        grad(np.ctypeslib.as_array(xp, shape=(n,)), np.ctypeslib.as_array(gp, shape=(n,)))
+    return GRADFCN(_g)
+
+
+def bfgs_solve(fcn, n, x0, grad=None, opts=None):
+    """bfgs%solve; fcn(x) -> float, grad(x, g) fills g.  opts: max_evals (500), gtol = get_tolerance (1e-12),
+    xtol = get_var_tolerance (1e-12).  Returns (rc, x, fout, ib_dict)."""
+    x = np.array(x0, dtype=np.float64)
+    fout = C.c_double(0.0)
+    ib = IterationBehavior()
+    o = opts or default_options(max_evals=500)
+    cf, cg = _wrap_scalar(fcn), _wrap_grad(grad)
+    rc = lib().nlo_bfgs_solve(C.byref(o), cf, cg, None, n, _dp(x), C.cast(C.byref(fout), C.POINTER(C.c_double)), C.byref(ib))
+    return rc, x, fout.value, ib.as_dict()
+
+
+def fd_gradient(fcn, x, fv=None):
+    x = np.array(x, dtype=np.float64)
+    g = np.zeros(x.size)
+    cf = _wrap_scalar(fcn)
+    pf = None
+    if fv is not None:
+        v = C.c_double(fv)
+        pf = C.cast(C.byref(v), C.POINTER(C.c_double))
+    lib().nlo_fd_gradient(cf, C.cast(None, GRADFCN), None, x.size, _dp(x), pf, _dp(g))
+    return g
+
+
+def rtr(r):
+    r = np.array(r, dtype=np.float64, order="F")
+    b = np.zeros_like(r, order="F")
+    lib().nlo_rtr(r.shape[0], _dp(r), _dp(b))
+    return b
+
+
+def chol_update(r, u):
+    r = np.array(r, dtype=np.float64, order="F")
+    u = np.array(u, dtype=np.float64)
+    lib().nlo_chol_update(r.shape[0], _dp(r), _dp(u))
+    return r
+
+
+def chol_downdate(r, u):
+    r = np.array(r, dtype=np.float64, order="F")
+    u = np.array(u, dtype=np.float64)
+    rc = lib().nlo_chol_downdate(r.shape[0], _dp(r), _dp(u))
+    return rc, r
+
+
+def chol_factor_upper(b):
+    b = np.array(b, dtype=np.float64, order="F")
+    r = np.zeros_like(b, order="F")
+    rc = lib().nlo_chol_factor_upper(b.shape[0], _dp(b), _dp(r))
+    return rc, r
+
+
+def solve_cholesky_upper(r, x):
+    r = np.array(r, dtype=np.float64, order="F")
+    x = np.array(x, dtype=np.float64)
+    lib().nlo_solve_cholesky_upper(r.shape[0], _dp(r), _dp(x))
+    return x
 
 
 def poly_fit(x, y, order, thru_zero=False):
@@ -380,6 +466,17 @@ def dq_cls_solve(A, b, gamma, x0, opts=None, lower=None, upper=None, delta=1.0, 
     rc = lib().nlo_dq_cls_solve(C.byref(o), float(delta), float(stepscale), plo, phi, C.byref(p), _dp(x), _dp(fvec),
                                 C.byref(ib))
     return rc, x, fvec, ib.as_dict(), int(p.ncalls)
+
+
+def dq_bfgs_solve(A, b, gamma, x0, opts=None):
+    """bfgs on 0.5 * ||r(x)||^2 of the dense-quadratic model, FD gradient.  Returns (rc, x, fout, ib, ncalls)."""
+    p = _dq_problem(A, b, gamma)
+    x = np.array(x0, dtype=np.float64)
+    fout = np.zeros(1)
+    ib = IterationBehavior()
+    o = opts or default_options(max_evals=500)
+    rc = lib().nlo_dq_bfgs_solve(C.byref(o), C.byref(p), _dp(x), _dp(fout), C.byref(ib))
+    return rc, x, float(fout[0]), ib.as_dict(), int(p.ncalls)
 
 
 def lmfactor(a):

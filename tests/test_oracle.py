@@ -290,3 +290,51 @@ def test_poly_fit_readme_example_3(oracle):
     rc, c0 = oracle.poly_fit(P.XP, P.YP, 3, thru_zero=True)
     assert rc == 0 and c0[0] == 0.0
     assert oracle.poly_fit(P.XP[:3], P.YP[:3], 3)[0] == 4
+
+
+# ---------------------------------------------------------------------------
+# bfgs + fcnnvar_helper%gradient: src/nonlin_optimize.f90:557-770, src/nonlin_multi_var.f90:182-246
+# ---------------------------------------------------------------------------
+def _rosen(x, a=1.0e2):
+    t = x[1] - x[0] * x[0]
+    return a * (t * t) + (x[0] - 1.0) * (x[0] - 1.0)
+
+
+def _beale(x):
+    a = 1.5 - x[0] + x[0] * x[1]
+    b = 2.25 - x[0] + x[0] * (x[1] * x[1])
+    c = 2.625 - x[0] + x[0] * (x[1] * x[1] * x[1])
+    return a * a + b * b + c * c
+
+
+def test_cholesky_update_downdate_identities(oracle):
+    rng = np.random.default_rng(5)
+    n = 12
+    M = rng.standard_normal((n, n))
+    B = M.T @ M + n * np.eye(n)
+    rc, R = oracle.chol_factor_upper(B)
+    assert rc == 0 and np.abs(R.T @ R - B).max() <= 1e-12 and np.array_equal(np.tril(R, -1), np.zeros((n, n)))
+    assert np.abs(oracle.rtr(R) - B).max() <= 1e-12
+    u = rng.standard_normal(n)
+    R1 = oracle.chol_update(R, u)
+    assert np.abs(R1.T @ R1 - (B + np.outer(u, u))).max() <= 1e-12
+    rc, R2 = oracle.chol_downdate(R1, u)
+    assert rc == 0 and np.abs(R2.T @ R2 - B).max() <= 1e-11
+    assert oracle.chol_downdate(R, 100.0 * np.ones(n))[0] == 1
+    x = rng.standard_normal(n)
+    assert np.abs(B @ oracle.solve_cholesky_upper(R, x) - x).max() <= 1e-12
+
+
+def test_bfgs_1_2_3(oracle):
+    """tests/nonlin_test_optimize.f90:184-300: Rosenbrock from 0, Beale from 1, Rosenbrock with args; tol 1e-5."""
+    rc, x, f, ib = oracle.bfgs_solve(_rosen, 2, [0.0, 0.0])
+    assert rc == 0 and np.abs(x - 1.0).max() <= 1e-5 and ib["gradient_count"] == ib["iter_count"] + 1
+    rc, x, f, ib = oracle.bfgs_solve(_beale, 2, [1.0, 1.0])
+    assert rc == 0 and abs(x[0] - 3.0) <= 1e-5 and abs(x[1] - 0.5) <= 1e-5
+    rc, x, f, ib = oracle.bfgs_solve(lambda v: _rosen(v, 1.0e2), 2, [0.0, 0.0])
+    assert rc == 0 and np.abs(x - 1.0).max() <= 1e-5
+
+
+def test_fd_gradient_matches_analytic(oracle):
+    g = oracle.fd_gradient(_rosen, [0.5, 0.5])
+    assert np.abs(g - np.array([-51.0, 50.0])).max() <= 1e-5
