@@ -7,6 +7,8 @@ module nonlin
     use nonlin_solve
     use nonlin_least_squares
     use nonlin_polynomials
+    use nonlin_multi_var
+    use nonlin_optimize
     implicit none
     public
 end module

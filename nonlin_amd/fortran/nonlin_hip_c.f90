@@ -75,6 +75,18 @@ module nonlin_hip_c
             type(nlh_iteration_behavior), intent(out) :: ib
             integer(c_int) :: rc
         end function
+        function nlh_bfgs_solve(h, opts, n, fcn, gradfcn, ctx, x, fout, ib) bind(C, name="nlh_bfgs_solve") result(rc)
+            import :: c_ptr, c_funptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h
+            type(nlh_options), intent(in) :: opts
+            integer(c_int32_t), value :: n
+            type(c_funptr), value :: fcn, gradfcn
+            type(c_ptr), value :: ctx
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fout
+            type(nlh_iteration_behavior), intent(out) :: ib
+            integer(c_int) :: rc
+        end function
         function nlh_poly_fit(h, npts, order, thru_zero, x, y, coef) bind(C, name="nlh_poly_fit") result(rc)
             import :: c_ptr, c_int, c_int32_t, c_double
             type(c_ptr), value :: h

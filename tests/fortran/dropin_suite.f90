@@ -72,6 +72,32 @@ contains
         f(1) = x(1) * cos(x(2))
         f(2) = x(1) * sin(x(2))
     end subroutine
+
+    function rosenbrock(x, args) result(f)
+        real(real64), intent(in), dimension(:) :: x
+        class(*), intent(inout), optional :: args
+        real(real64) :: f, a, t
+        a = 1.0d2
+        if (present(args)) then
+            select type (args)
+            type is (real(real64))
+                a = args
+            end select
+        end if
+        t = x(2) - x(1) * x(1)
+        f = a * (t * t) + (x(1) - 1.0d0) * (x(1) - 1.0d0)
+    end function
+
+    function beale(x, args) result(f)
+        real(real64), intent(in), dimension(:) :: x
+        class(*), intent(inout), optional :: args
+        real(real64) :: f, a, b, c
+        a = 1.5d0 - x(1) + x(1) * x(2)
+        b = 2.25d0 - x(1) + x(1) * (x(2) * x(2))
+        c = 2.625d0 - x(1) + x(1) * (x(2) * x(2) * x(2))
+        f = a * a + b * b + c * c
+    end function
+
 end module
 
 program dropin_suite
@@ -231,6 +257,33 @@ program dropin_suite
         print '(A,I0,A,F12.10)', ("# poly c", i - 1, " = ", pf%get(i), i = 1, 4)
         print '(A,F7.5)', "# poly Max Residual: ", maxval(abs(pf%evaluate(xp) - yc))
         print '(A,4(1X,Z16.16))', "poly_readme 0 0 0 F F F", pf%get(1), pf%get(2), pf%get(3), pf%get(4)
+    end block
+
+    ! test_bfgs_1 (Rosenbrock from 0), test_bfgs_2 (Beale from 1), test_bfgs_3 (Rosenbrock, a passed through args)
+    block
+        type(bfgs) :: bs
+        type(fcnnvar_helper) :: so
+        procedure(fcnnvar), pointer :: sf
+        real(real64) :: fo
+        sf => rosenbrock
+        call so%set_fcn(sf, 2)
+        x2 = 0.0d0
+        call bs%solve(so, x2, fo, ib)
+        print '(A,3(1X,I0),3(1X,L1),2(1X,Z16.16))', "bfgs_rosen", ib%iter_count, ib%fcn_count, ib%gradient_count, &
+            ib%converge_on_fcn, ib%converge_on_chng, ib%converge_on_zero_diff, x2(1), x2(2)
+        sf => beale
+        call so%set_fcn(sf, 2)
+        x2 = 1.0d0
+        call bs%solve(so, x2, fo, ib)
+        print '(A,3(1X,I0),3(1X,L1),2(1X,Z16.16))', "bfgs_beale", ib%iter_count, ib%fcn_count, ib%gradient_count, &
+            ib%converge_on_fcn, ib%converge_on_chng, ib%converge_on_zero_diff, x2(1), x2(2)
+        sf => rosenbrock
+        call so%set_fcn(sf, 2)
+        a = 1.0d2
+        x2 = 0.0d0
+        call bs%solve(so, x2, fo, ib, args = a)
+        print '(A,3(1X,I0),3(1X,L1),2(1X,Z16.16))', "bfgs_rosen_args", ib%iter_count, ib%fcn_count, ib%gradient_count, &
+            ib%converge_on_fcn, ib%converge_on_chng, ib%converge_on_zero_diff, x2(1), x2(2)
     end block
 
     ! test_jacobian_1: vecfcn_helper%jacobian (no fv)

@@ -113,6 +113,29 @@ def test_polynomial_fit_readme_example_3(results, oracle):
     assert np.array_equal(results["poly_readme"][0]["x"], co)
 
 
+def test_bfgs_problems(results, oracle):
+    """bfgs through the Fortran shim (test_bfgs_1 / 2 / 3): minimisers within 1e-5 and bit-identical to the CPU path.
+    The "counts" printed for bfgs are iter / fcn / gradient."""
+    def rosen(v, a=1.0e2):
+        t = v[1] - v[0] * v[0]
+        return a * (t * t) + (v[0] - 1.0) * (v[0] - 1.0)
+
+    def beale(v):
+        a = 1.5 - v[0] + v[0] * v[1]
+        b = 2.25 - v[0] + v[0] * (v[1] * v[1])
+        c = 2.625 - v[0] + v[0] * (v[1] * v[1] * v[1])
+        return a * a + b * b + c * c
+
+    for key, fcn, x0, ans in (("bfgs_rosen", rosen, [0.0, 0.0], [1.0, 1.0]), ("bfgs_beale", beale, [1.0, 1.0], [3.0, 0.5]),
+                              ("bfgs_rosen_args", rosen, [0.0, 0.0], [1.0, 1.0])):
+        rc, xo, fo, ibo = oracle.bfgs_solve(fcn, 2, x0)
+        r = results[key][0]
+        assert rc == 0
+        assert r["counts"] == (ibo["iter_count"], ibo["fcn_count"], ibo["gradient_count"]), (key, r, ibo)
+        assert np.array_equal(r["x"], xo), (key, r["x"], xo)
+        assert np.abs(xo - np.array(ans)).max() <= 1e-5
+
+
 def test_fd_jacobian(results):
     J = results["jac_polar"][0]["x"].reshape(2, 2).T                  # printed column by column
     E = np.zeros((2, 2), order="F")
