@@ -183,6 +183,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_dot, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_house_dot2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_solve_upper_t, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -1020,9 +1021,15 @@ static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int 
 {
     hipStream_t s = h->stream;
     const int steps = std::min(ncA, rows - 1), nc = ncA + ncE;
+    const bool wide = rows <= QN_DOT2_MAXROWS;          // workgroup-wide loads (reflector + two product tiles in LDS)
+    const size_t sh2 = sizeof(double) * ((size_t)rows + 2 * QN_DOT2_TR * QN_DOT2_CG);
     for (int j = 0; j < steps; ++j) {
-        hipLaunchKernelGGL(k_qn_house_dot, dim3((nc + QN_DOT_BS - 1) / QN_DOT_BS, nprob), dim3(QN_DOT_BS),
-                           sizeof(double) * rows, s, rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+        if (wide)
+            hipLaunchKernelGGL(k_qn_house_dot2, dim3((nc + QN_DOT2_CG - 1) / QN_DOT2_CG, nprob), dim3(256), sh2, s,
+                               rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+        else
+            hipLaunchKernelGGL(k_qn_house_dot, dim3((nc + QN_DOT_BS - 1) / QN_DOT_BS, nprob), dim3(QN_DOT_BS),
+                               sizeof(double) * rows, s, rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
         hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - j + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
                            rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
     }

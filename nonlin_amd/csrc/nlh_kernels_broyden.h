@@ -111,6 +111,103 @@ k_qn_house_dot(int rows, int ncA, int ncE, int j, const double *__restrict__ Aal
     wbuf[(size_t)p * (ncA + ncE) + k] = tau * w;
 }
 
+// The same first half with the loads spread over a whole workgroup: 16 columns per workgroup, 256 threads =
+// 16 columns x 16 row lanes.  A tile of 256 rows x 16 columns is fetched by all threads at once (each thread 16
+// independent loads of 128-byte row segments), the products v_i T(i,k) go to LDS, and one thread per column adds
+// them in row order -- the sum is still a single ordered chain per column (bit-identical to the kernel above), but
+// the memory latency is paid once per 256 rows instead of once per 32.  The loads of tile t+1 are in flight while
+// tile t is summed.  Reflector staged in LDS: rows <= QN_DOT2_MAXROWS.
+#define QN_DOT2_MAXROWS 8192
+#define QN_DOT2_CG 16
+#define QN_DOT2_TR 256
+__global__ void __launch_bounds__(256)
+k_qn_house_dot2(int rows, int ncA, int ncE, int j, const double *__restrict__ Aall, const double *__restrict__ Eall,
+                const double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st)
+{
+    extern __shared__ double sm2[];
+    double *vs = sm2;                                   // rows (index = row)
+    double *prod = sm2 + rows;                          // [2][QN_DOT2_TR][QN_DOT2_CG]
+    __shared__ double sq_sh;
+    const int p = blockIdx.y, tid = threadIdx.x;
+    const double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
+    const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
+    for (int i0 = j + 1 + tid; i0 < rows; i0 += 8 * 256) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; t[u] = (i < rows) ? vcur[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; if (i < rows) vs[i] = t[u]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        int i = j + 1;
+        for (; i + 16 <= rows; i += 16) {
+            double t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = vs[i + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = s + t[u] * t[u];
+        }
+        for (; i < rows; ++i) s = s + vs[i] * vs[i];
+        sq_sh = s;
+    }
+    __syncthreads();
+    const double sq = sq_sh;
+    if (sq == 0.0) {                                    // H = I (uniform)
+        if (blockIdx.x == 0 && tid == 0) { st[(size_t)p * 4] = 0.0; st[(size_t)p * 4 + 1] = 0.0; st[(size_t)p * 4 + 2] = 0.0; }
+        return;
+    }
+    const double alpha = A[(size_t)j * ncA + j];
+    const double beta = -copysign(sqrt(alpha * alpha + sq), alpha);
+    const double tau = (beta - alpha) / beta;
+    const double scal = 1.0 / (alpha - beta);
+    if (blockIdx.x == 0 && tid == 0) { st[(size_t)p * 4] = tau; st[(size_t)p * 4 + 1] = scal; st[(size_t)p * 4 + 2] = beta; }
+    for (int i = j + 1 + tid; i < rows; i += 256) vs[i] = vs[i] * scal;
+    __syncthreads();
+
+    const int c = tid & (QN_DOT2_CG - 1), r = tid >> 4;            // column within the group, row lane
+    const int k = blockIdx.x * QN_DOT2_CG + c;
+    const bool live = (k < ncA + ncE) && !(k < ncA && k <= j);
+    const double *T = (k < ncA) ? A + k : E + (k - ncA);
+    const size_t ld = (k < ncA) ? ncA : ncE;
+    double w = (live && r == 0) ? T[(size_t)j * ld] : 0.0;          // the summing thread of column c is (c, r = 0)
+    double tl[16];
+    const int ibeg = j + 1;
+#define QN_DOT2_LOAD(i0)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                       \
+        const int i = (i0) + r + 16 * u;                                                   \
+        tl[u] = (live && i < rows) ? T[(size_t)i * ld] : 0.0;                              \
+    }
+    QN_DOT2_LOAD(ibeg)
+    int buf = 0;
+    for (int i0 = ibeg; i0 < rows; i0 += QN_DOT2_TR) {
+        double *pb = prod + (size_t)buf * QN_DOT2_TR * QN_DOT2_CG;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = i0 + r + 16 * u;
+            if (i < rows) pb[(r + 16 * u) * QN_DOT2_CG + c] = vs[i] * tl[u];
+        }
+        __syncthreads();
+        if (i0 + QN_DOT2_TR < rows) { QN_DOT2_LOAD(i0 + QN_DOT2_TR) }
+        if (r == 0 && live) {
+            const int lim = min(QN_DOT2_TR, rows - i0);
+            int ii = 0;
+            for (; ii + 16 <= lim; ii += 16) {
+                double q[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) q[u] = pb[(ii + u) * QN_DOT2_CG + c];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w = w + q[u];
+            }
+            for (; ii < lim; ++ii) w = w + pb[ii * QN_DOT2_CG + c];
+        }
+        buf ^= 1;
+    }
+#undef QN_DOT2_LOAD
+    if (r == 0 && live) wbuf[(size_t)p * (ncA + ncE) + k] = tau * w;
+}
+
 // Second half: T(j,k) -= w_k, T(i,k) -= v_i w_k (elementwise, one thread per column and QN_RC rows),
 // column j becomes (beta, 0, ..., 0), and the updated column j+1 is copied to the other vbuf slot.
 #define QN_RC 16
