@@ -1054,7 +1054,7 @@ static void launch_qn_update(nlh_handle *h, int nprob, int n, double *dQ, double
 {
     hipStream_t s = h->stream;
     double *dw = dwcs, *dc = dwcs + (size_t)nprob * n, *dsn = dc + (size_t)nprob * n;
-    hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, nprob), dim3(64), 0, s, n, n, dQ, du, dw, 1.0);
+    hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, nprob), dim3(256), 0, s, n, n, dQ, du, dw, 1.0);
     hipLaunchKernelGGL(k_qn_fold, dim3(nprob), dim3(64), 0, s, n, dw, dc, dsn);
     const dim3 g1((n + 255) / 256, nprob);
     hipLaunchKernelGGL(k_qn_rot_q, g1, dim3(256), sizeof(double) * 2 * n, s, n, dQ, dc, dsn, 1);
@@ -1118,8 +1118,8 @@ static int quasi_newton_core(nlh_handle *h, const nlh_options *o, int jdelta, in
             }
             // grad = B^T f (:313), step = -R^-1 Q^T f (:322-328)
             HIPCHK(h, hipMemcpyAsync(dfv, fvec, sizeof(double) * n, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, 1), dim3(64), 0, s, n, n, dB, dfv, dgrad, 1.0);
-            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, 1), dim3(64), 0, s, n, n, dQ, dfv, dstep, -1.0);
+            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, 1), dim3(256), 0, s, n, n, dB, dfv, dgrad, 1.0);
+            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, 1), dim3(256), 0, s, n, n, dQ, dfv, dstep, -1.0);
             hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dRt, dstep, (size_t)n * n, (size_t)n);
             HIPCHK(h, hipMemcpyAsync(dx.data(), dgrad, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipMemcpyAsync(df.data(), dstep, sizeof(double) * n, hipMemcpyDeviceToHost, s));
@@ -1311,7 +1311,7 @@ static int cls_core(nlh_handle *h, const nlh_options *o, double delta0, double s
         launch_house_steps(h, 1, m, n, 1, dW, dE, vbuf, wbuf, st);
         HIPCHK(h, hipMemcpyAsync(dstep, dE, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dW, dstep, (size_t)m * n, (size_t)n);
-        hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 63) / 64, 1), dim3(64), 0, s, m, n, dJ, dfv, dgv, 1.0);
+        hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, 1), dim3(256), 0, s, m, n, dJ, dfv, dgv, 1.0);
         HIPCHK(h, hipMemcpyAsync(u.data(), dstep, sizeof(double) * n, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(g.data(), dgv, sizeof(double) * n, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));

@@ -322,29 +322,51 @@ k_qn_rank1(int n, double *__restrict__ B, const double *__restrict__ s, const do
 }
 
 // out_k = sign * sum_i M(i,k) f_i, M column-major m x n, sum over i ascending (grad = B^T f, -Q^T f, Q^T u, J^T f).
-// A 64-thread workgroup owns 64 columns; 64x64 tiles are read coalesced and re-read from LDS by column.
-__global__ void __launch_bounds__(64)
+// 16 columns per workgroup; a tile of 256 rows x 16 columns is fetched by all 256 threads (coalesced along the
+// rows), the products go to LDS and one thread per column adds them in row order; the loads of the next tile are
+// in flight during the sums.
+__global__ void __launch_bounds__(256)
 k_qn_colsdot(int m, int n, const double *__restrict__ M, const double *__restrict__ f, double *__restrict__ out,
              double sign)
 {
-    __shared__ double tile[64 * 65];
-    __shared__ double fs[64];
+    __shared__ double prod[2][16 * 257];
     const int p = blockIdx.y, t = threadIdx.x;
-    const int k0 = blockIdx.x * 64;
+    const int k0 = blockIdx.x * 16;
     const double *Mp = M + (size_t)p * m * n;
     const double *fp = f + (size_t)p * m;
     double acc = 0.0;
-    for (int i0 = 0; i0 < m; i0 += 64) {
-        const int i = i0 + t;
-        for (int kk = 0; kk < 64; ++kk)
-            tile[kk * 65 + t] = (i < m && k0 + kk < n) ? Mp[(size_t)(k0 + kk) * m + i] : 0.0;
-        fs[t] = (i < m) ? fp[i] : 0.0;
-        __syncthreads();
-        const int lim = min(64, m - i0);
-        for (int ii = 0; ii < lim; ++ii) acc = acc + tile[t * 65 + ii] * fs[ii];
-        __syncthreads();
+    double tl[16], fi = 0.0;
+#define CD_LOAD(i0)                                                                        \
+    {                                                                                      \
+        const int i = (i0) + t;                                                            \
+        fi = (i < m) ? fp[i] : 0.0;                                                        \
+        _Pragma("unroll") for (int u = 0; u < 16; ++u)                                     \
+            tl[u] = (i < m && k0 + u < n) ? Mp[(size_t)(k0 + u) * m + i] : 0.0;            \
     }
-    if (k0 + t < n) out[(size_t)p * n + k0 + t] = sign * acc;
+    CD_LOAD(0)
+    int buf = 0;
+    for (int i0 = 0; i0 < m; i0 += 256) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) prod[buf][u * 257 + t] = tl[u] * fi;
+        __syncthreads();
+        if (i0 + 256 < m) CD_LOAD(i0 + 256)
+        if (t < 16) {
+            const int lim = min(256, m - i0);
+            const double *pc = &prod[buf][t * 257];
+            int ii = 0;
+            for (; ii + 16 <= lim; ii += 16) {
+                double q[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) q[u] = pc[ii + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = acc + q[u];
+            }
+            for (; ii < lim; ++ii) acc = acc + pc[ii];
+        }
+        buf ^= 1;
+    }
+#undef CD_LOAD
+    if (t < 16 && k0 + t < n) out[(size_t)p * n + k0 + t] = sign * acc;
 }
 
 // DQRTV1: rotations folding w into w(0), generated from the bottom (one thread per problem).
