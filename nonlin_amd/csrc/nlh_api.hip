@@ -184,6 +184,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_dot, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_dot2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_house_fused, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_solve_upper_t, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -1019,8 +1020,21 @@ static const int QN_MAX_ROWS = 18000;  // k_qn_house_dot keeps the reflector (ro
 static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int ncE, double *dA, double *dE,
                                double *vbuf, double *wbuf, double *st)
 {
+    // vbuf: [nprob][2][rows]; wbuf: room for [nprob][2][ncA + ncE]; st: room for [nprob][2][4]
     hipStream_t s = h->stream;
     const int steps = std::min(ncA, rows - 1), nc = ncA + ncE;
+    if (steps < 1) return;
+    if (rows <= QN_FUSED_MAXROWS) {
+        // one pass per step: the update of step j-1 rides along with the sums of step j
+        const size_t sh3 = sizeof(double) * (2 * (size_t)rows + 2 * QN_DOT2_TR * QN_DOT2_CG);
+        for (int j = 0; j < steps; ++j)
+            hipLaunchKernelGGL(k_qn_house_fused, dim3((nc + QN_DOT2_CG - 1) / QN_DOT2_CG, nprob), dim3(256), sh3, s,
+                               rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+        const int jl = steps - 1, slot = jl & 1;
+        hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - jl + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
+                           rows, ncA, ncE, jl, dA, dE, vbuf, wbuf + (size_t)slot * nc, st + (size_t)slot * 4, 2 * nc, 8);
+        return;
+    }
     const bool wide = rows <= QN_DOT2_MAXROWS;          // workgroup-wide loads (reflector + two product tiles in LDS)
     const size_t sh2 = sizeof(double) * ((size_t)rows + 2 * QN_DOT2_TR * QN_DOT2_CG);
     for (int j = 0; j < steps; ++j) {
@@ -1031,15 +1045,15 @@ static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int 
             hipLaunchKernelGGL(k_qn_house_dot, dim3((nc + QN_DOT_BS - 1) / QN_DOT_BS, nprob), dim3(QN_DOT_BS),
                                sizeof(double) * rows, s, rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
         hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - j + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
-                           rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+                           rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, nc, 4);
     }
 }
 
 static void launch_qn_qr(nlh_handle *h, int nprob, int n, const double *dB, double *dQ, double *dRt, double *dvb)
 {
-    // dvb: per problem 2n (reflector column, two slots) + 2n (w) + 4 (tau, scal, beta)
+    // dvb: per problem 2n (reflector column, two slots) + 2 x 2n (w, two slots) + 2 x 4 (tau, scal, beta)
     hipStream_t s = h->stream;
-    double *vbuf = dvb, *wbuf = dvb + (size_t)nprob * 2 * n, *st = wbuf + (size_t)nprob * 2 * n;
+    double *vbuf = dvb, *wbuf = dvb + (size_t)nprob * 2 * n, *st = wbuf + (size_t)nprob * 4 * n;
     {
         dim3 grid((n + 31) / 32, (n + 31) / 32, nprob);
         hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, n, n, dB, dRt, (const LmState *)nullptr, -1);
@@ -1266,7 +1280,7 @@ static int cls_core(nlh_handle *h, const nlh_options *o, double delta0, double s
     if ((rc = ensure(h, h->qnV, sizeof(double) * ((size_t)6 * m + 6 * n + 16)))) return rc;
     double *dJ = (double *)h->J.p, *dW = (double *)h->W2.p, *dv = (double *)h->qnV.p;
     double *dE = dv, *dfv = dv + m, *dJv = dv + 2 * m, *vbuf = dv + 3 * m /* 2m */, *dgv = dv + 5 * m, *dvec = dgv + n,
-           *dstep = dvec + n, *wbuf = dstep + n /* n + 1 */, *st = wbuf + n + 2;
+           *dstep = dvec + n, *wbuf = dstep + n /* 2 (n + 1) */, *st = wbuf + 2 * (n + 1);
     hipStream_t s = h->stream;
     std::vector<double> xl(n), xu(n), sc(n), g(n), p(n), xnew(n), tmp(n), pgn(n), psd(n), u(n), v(n), Jg(m), Jp(m), fnew(m);
     int converged = 0, xcnvrg = 0, fcnvrg = 0, gcnvrg = 0, neval = 0, iter = 0, njac = 0;
@@ -2264,10 +2278,10 @@ int nlh_poly_fit_batch(nlh_handle *h, int32_t nprob, int32_t npts, int32_t order
     const int ncols = thru_zero ? order : order + 1;
     int rc;
     if ((rc = ensure(h, h->W2, sizeof(double) * (size_t)nprob * npts * ncols))) return rc;
-    if ((rc = ensure(h, h->qnV, sizeof(double) * ((size_t)nprob * (3 * (size_t)npts + ncols + 8))))) return rc;
+    if ((rc = ensure(h, h->qnV, sizeof(double) * ((size_t)nprob * (3 * (size_t)npts + 2 * ncols + 16))))) return rc;
     double *dA = (double *)h->W2.p, *dv = (double *)h->qnV.p;
     double *rhs = dv, *vbuf = dv + (size_t)nprob * npts, *wbuf = vbuf + (size_t)nprob * 2 * npts,
-           *st = wbuf + (size_t)nprob * (ncols + 1);
+           *st = wbuf + (size_t)nprob * 2 * (ncols + 1);
     hipStream_t s = h->stream;
     hipLaunchKernelGGL(k_vandermonde, dim3((npts + 255) / 256, nprob), dim3(256), 0, s, npts, ncols, thru_zero, dx, dy, dA, rhs);
     hipLaunchKernelGGL(k_qn_col0, dim3((npts + 255) / 256, nprob), dim3(256), 0, s, npts, ncols, dA, vbuf);

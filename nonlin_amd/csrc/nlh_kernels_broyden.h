@@ -208,18 +208,148 @@ k_qn_house_dot2(int rows, int ncA, int ncE, int j, const double *__restrict__ Aa
     if (r == 0 && live) wbuf[(size_t)p * (ncA + ncE) + k] = tau * w;
 }
 
+// Step j with the second half of step j-1 folded in: every element of the trailing matrix is read once, receives
+// the pending update T(i,k) -= v'_i w'_k of step j-1 (v', w', tau' from the slots of step j-1), is written back, and
+// its updated value goes straight into the ordered sums of step j.  The reflector of step j is rebuilt by every
+// workgroup from column j (the pending update applied on the fly); workgroup 0 publishes it for step j+1.
+// Same operations per element as k_qn_house_dot2 + k_qn_house_apply (bit-identical), one pass and one launch less
+// per step.  The last step's update is applied by k_qn_house_apply.  w and st are double-buffered by step parity
+// ([problem][slot]); LDS: two reflectors + two product tiles, rows <= QN_FUSED_MAXROWS.
+#define QN_FUSED_MAXROWS 4096
+__global__ void __launch_bounds__(256)
+k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
+                 double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st)
+{
+    extern __shared__ double sm3[];
+    double *vsp = sm3;                                  // previous reflector, scaled (rows >= j)
+    double *vs = sm3 + rows;                            // this step's reflector (rows >= j+1)
+    double *prod = sm3 + 2 * (size_t)rows;              // [2][QN_DOT2_TR][QN_DOT2_CG]
+    __shared__ double sq_sh, alpha_sh;
+    const int p = blockIdx.y, tid = threadIdx.x, nc = ncA + ncE, jp = j - 1;
+    double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
+    const double *vprev_g = vbuf + ((size_t)p * 2 + (jp & 1)) * rows;
+    double *vcur_g = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
+    const double *stp = st + ((size_t)p * 2 + (jp & 1)) * 4;
+    double *stc = st + ((size_t)p * 2 + (j & 1)) * 4;
+    const double *wprev = wbuf + ((size_t)p * 2 + (jp & 1)) * nc;
+    double *wcur = wbuf + ((size_t)p * 2 + (j & 1)) * nc;
+    const double tau_p = (j > 0) ? stp[0] : 0.0, scal_p = (j > 0) ? stp[1] : 0.0, beta_p = (j > 0) ? stp[2] : 0.0;
+    const bool pend = tau_p != 0.0;                     // step j-1 was a real reflector whose update is outstanding
+
+    if (pend)
+        for (int i = j + tid; i < rows; i += 256) vsp[i] = vprev_g[i] * scal_p;
+    __syncthreads();
+    {   // column j with the pending update applied: alpha (row j) and the unscaled reflector (rows > j)
+        const double wpj = pend ? wprev[j] : 0.0;
+        for (int i = j + tid; i < rows; i += 256) {
+            double t = A[(size_t)i * ncA + j];
+            if (pend) t = t - vsp[i] * wpj;
+            if (i == j) alpha_sh = t; else vs[i] = t;
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = j + 1 + tid; i < rows; i += 256) vcur_g[i] = vs[i];
+    if (tid == 0) {
+        double s = 0.0;
+        int i = j + 1;
+        for (; i + 16 <= rows; i += 16) {
+            double t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = vs[i + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = s + t[u] * t[u];
+        }
+        for (; i < rows; ++i) s = s + vs[i] * vs[i];
+        sq_sh = s;
+    }
+    __syncthreads();
+    const double sq = sq_sh, alpha = alpha_sh;
+    const bool refl = sq != 0.0;                        // H_j != I
+    double tau = 0.0, scal = 0.0, beta = 0.0;
+    if (refl) {
+        beta = -copysign(sqrt(alpha * alpha + sq), alpha);
+        tau = (beta - alpha) / beta;
+        scal = 1.0 / (alpha - beta);
+    }
+    if (blockIdx.x == 0 && tid == 0) { stc[0] = tau; stc[1] = scal; stc[2] = beta; }
+    if (!refl && !pend) return;                         // nothing to sum, nothing outstanding (uniform)
+    if (refl)
+        for (int i = j + 1 + tid; i < rows; i += 256) vs[i] = vs[i] * scal;
+    __syncthreads();
+
+    const int c = tid & (QN_DOT2_CG - 1), r = tid >> 4;
+    const int k = blockIdx.x * QN_DOT2_CG + c;
+    const bool inr = k < nc;
+    const bool upd = pend && inr && !(k < ncA && k < jp);            // columns the pending update touches (k == jp: beta', zeros)
+    const bool isjp = (k < ncA) && (k == jp);
+    const bool live = refl && inr && !(k < ncA && k <= j);           // columns that take part in step j's sums
+    double *T = (k < ncA) ? A + k : E + (k - ncA);
+    const size_t ld = (k < ncA) ? ncA : ncE;
+    const double wp = (upd && !isjp) ? wprev[k] : 0.0;
+    double w = 0.0;
+    if (r == 0 && inr) {
+        if (upd) {                                      // row j-1 of the pending update
+            double *e = T + (size_t)jp * ld;
+            *e = isjp ? beta_p : *e - wp;
+        }
+        double t = T[(size_t)j * ld];                   // row j
+        if (upd) { t = isjp ? 0.0 : t - vsp[j] * wp; T[(size_t)j * ld] = t; }
+        w = t;
+    }
+    double tl[16];
+    const int ibeg = j + 1;
+#define QN_F_LOAD(i0)                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                       \
+        const int i = (i0) + r + 16 * u;                                                   \
+        tl[u] = ((upd || live) && i < rows) ? T[(size_t)i * ld] : 0.0;                     \
+    }
+    QN_F_LOAD(ibeg)
+    int buf = 0;
+    for (int i0 = ibeg; i0 < rows; i0 += QN_DOT2_TR) {
+        double *pb = prod + (size_t)buf * QN_DOT2_TR * QN_DOT2_CG;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = i0 + r + 16 * u;
+            if (i < rows) {
+                double t = tl[u];
+                if (upd) { t = isjp ? 0.0 : t - vsp[i] * wp; T[(size_t)i * ld] = t; }
+                if (refl) pb[(r + 16 * u) * QN_DOT2_CG + c] = vs[i] * t;
+            }
+        }
+        __syncthreads();
+        if (i0 + QN_DOT2_TR < rows) { QN_F_LOAD(i0 + QN_DOT2_TR) }
+        if (r == 0 && live) {
+            const int lim = min(QN_DOT2_TR, rows - i0);
+            int ii = 0;
+            for (; ii + 16 <= lim; ii += 16) {
+                double q[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) q[u] = pb[(ii + u) * QN_DOT2_CG + c];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w = w + q[u];
+            }
+            for (; ii < lim; ++ii) w = w + pb[ii * QN_DOT2_CG + c];
+        }
+        buf ^= 1;
+    }
+#undef QN_F_LOAD
+    if (r == 0 && live) wcur[k] = tau * w;
+}
+
 // Second half: T(j,k) -= w_k, T(i,k) -= v_i w_k (elementwise, one thread per column and QN_RC rows),
 // column j becomes (beta, 0, ..., 0), and the updated column j+1 is copied to the other vbuf slot.
 #define QN_RC 16
 __global__ void __launch_bounds__(256)
 k_qn_house_apply(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
-                 double *__restrict__ vbuf, const double *__restrict__ wbuf, const double *__restrict__ st)
+                 double *__restrict__ vbuf, const double *__restrict__ wbuf, const double *__restrict__ st,
+                 int wps /* w doubles per problem */, int sps /* st doubles per problem */)
 {
     const int p = blockIdx.z;
     double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
     const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
     double *vnext = vbuf + ((size_t)p * 2 + ((j + 1) & 1)) * rows;
-    const double tau = st[(size_t)p * 4], scal = st[(size_t)p * 4 + 1], beta = st[(size_t)p * 4 + 2];
+    const double tau = st[(size_t)p * sps], scal = st[(size_t)p * sps + 1], beta = st[(size_t)p * sps + 2];
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int i0 = j + blockIdx.y * QN_RC, i1 = min(rows, i0 + QN_RC);
     if (k >= ncA + ncE || (k < ncA && k < j)) return;
@@ -235,7 +365,7 @@ k_qn_house_apply(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
         for (int i = i0; i < i1; ++i) T[(size_t)i * ld] = (i == j) ? beta : 0.0;
         return;
     }
-    const double w = wbuf[(size_t)p * (ncA + ncE) + k];
+    const double w = wbuf[(size_t)p * wps + k];
     double t[QN_RC];
 #pragma unroll
     for (int u = 0; u < QN_RC; ++u) t[u] = (i0 + u < i1) ? T[(size_t)(i0 + u) * ld] : 0.0;
