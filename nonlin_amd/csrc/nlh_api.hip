@@ -184,7 +184,8 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_dot, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_dot2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    hipFuncSetAttribute((const void *)k_qn_house_fused, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_house_fused<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_house_fused<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_solve_upper_t, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -1027,9 +1028,15 @@ static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int 
     if (rows <= QN_FUSED_MAXROWS) {
         // one pass per step: the update of step j-1 rides along with the sums of step j
         const size_t sh3 = sizeof(double) * (2 * (size_t)rows + 2 * QN_DOT2_TR * QN_DOT2_CG);
-        for (int j = 0; j < steps; ++j)
-            hipLaunchKernelGGL(k_qn_house_fused, dim3((nc + QN_DOT2_CG - 1) / QN_DOT2_CG, nprob), dim3(256), sh3, s,
-                               rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+        const bool skinny = (long)nc * nprob < 1536;     // few columns in total: 4 per workgroup so that the chip has work
+        for (int j = 0; j < steps; ++j) {
+            if (skinny)
+                hipLaunchKernelGGL(k_qn_house_fused<4>, dim3((nc + 3) / 4, nprob), dim3(256), sh3, s,
+                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+            else
+                hipLaunchKernelGGL(k_qn_house_fused<16>, dim3((nc + 15) / 16, nprob), dim3(256), sh3, s,
+                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+        }
         const int jl = steps - 1, slot = jl & 1;
         hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - jl + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
                            rows, ncA, ncE, jl, dA, dE, vbuf, wbuf + (size_t)slot * nc, st + (size_t)slot * 4, 2 * nc, 8);

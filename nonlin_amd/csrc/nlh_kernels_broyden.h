@@ -216,6 +216,9 @@ k_qn_house_dot2(int rows, int ncA, int ncE, int j, const double *__restrict__ Aa
 // per step.  The last step's update is applied by k_qn_house_apply.  w and st are double-buffered by step parity
 // ([problem][slot]); LDS: two reflectors + two product tiles, rows <= QN_FUSED_MAXROWS.
 #define QN_FUSED_MAXROWS 4096
+// CG = columns per workgroup (16: wide matrices; 4: tall-skinny ones, so that enough workgroups exist); a tile is
+// (4096 / CG) rows x CG columns.
+template <int CG>
 __global__ void __launch_bounds__(256)
 k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
                  double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st)
@@ -223,7 +226,8 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     extern __shared__ double sm3[];
     double *vsp = sm3;                                  // previous reflector, scaled (rows >= j)
     double *vs = sm3 + rows;                            // this step's reflector (rows >= j+1)
-    double *prod = sm3 + 2 * (size_t)rows;              // [2][QN_DOT2_TR][QN_DOT2_CG]
+    constexpr int RL = 256 / CG, TR = RL * 16;          // row lanes, rows per tile
+    double *prod = sm3 + 2 * (size_t)rows;              // [2][TR][CG]
     __shared__ double sq_sh, alpha_sh;
     const int p = blockIdx.y, tid = threadIdx.x, nc = ncA + ncE, jp = j - 1;
     double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
@@ -278,8 +282,8 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
         for (int i = j + 1 + tid; i < rows; i += 256) vs[i] = vs[i] * scal;
     __syncthreads();
 
-    const int c = tid & (QN_DOT2_CG - 1), r = tid >> 4;
-    const int k = blockIdx.x * QN_DOT2_CG + c;
+    const int c = tid % CG, r = tid / CG;
+    const int k = blockIdx.x * CG + c;
     const bool inr = k < nc;
     const bool upd = pend && inr && !(k < ncA && k < jp);            // columns the pending update touches (k == jp: beta', zeros)
     const bool isjp = (k < ncA) && (k == jp);
@@ -301,35 +305,35 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     const int ibeg = j + 1;
 #define QN_F_LOAD(i0)                                                                      \
     _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                       \
-        const int i = (i0) + r + 16 * u;                                                   \
+        const int i = (i0) + r + RL * u;                                                   \
         tl[u] = ((upd || live) && i < rows) ? T[(size_t)i * ld] : 0.0;                     \
     }
     QN_F_LOAD(ibeg)
     int buf = 0;
-    for (int i0 = ibeg; i0 < rows; i0 += QN_DOT2_TR) {
-        double *pb = prod + (size_t)buf * QN_DOT2_TR * QN_DOT2_CG;
+    for (int i0 = ibeg; i0 < rows; i0 += TR) {
+        double *pb = prod + (size_t)buf * TR * CG;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const int i = i0 + r + 16 * u;
+            const int i = i0 + r + RL * u;
             if (i < rows) {
                 double t = tl[u];
                 if (upd) { t = isjp ? 0.0 : t - vsp[i] * wp; T[(size_t)i * ld] = t; }
-                if (refl) pb[(r + 16 * u) * QN_DOT2_CG + c] = vs[i] * t;
+                if (refl) pb[(r + RL * u) * CG + c] = vs[i] * t;
             }
         }
         __syncthreads();
-        if (i0 + QN_DOT2_TR < rows) { QN_F_LOAD(i0 + QN_DOT2_TR) }
+        if (i0 + TR < rows) { QN_F_LOAD(i0 + TR) }
         if (r == 0 && live) {
-            const int lim = min(QN_DOT2_TR, rows - i0);
+            const int lim = min(TR, rows - i0);
             int ii = 0;
             for (; ii + 16 <= lim; ii += 16) {
                 double q[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) q[u] = pb[(ii + u) * QN_DOT2_CG + c];
+                for (int u = 0; u < 16; ++u) q[u] = pb[(ii + u) * CG + c];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) w = w + q[u];
             }
-            for (; ii < lim; ++ii) w = w + pb[ii * QN_DOT2_CG + c];
+            for (; ii < lim; ++ii) w = w + pb[ii * CG + c];
         }
         buf ^= 1;
     }
