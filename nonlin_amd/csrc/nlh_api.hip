@@ -1599,8 +1599,8 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
                 hipLaunchKernelGGL(k_bf_downdate_rot, dim3(1), dim3(64), 0, s, n, du, dc, dinfo);
                 hipLaunchKernelGGL(k_bf_downdate_apply, dim3((n + 255) / 256), dim3(256), sizeof(double) * 2 * n, s, n, dR, dc, du, dinfo);
             } else {
-                if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_factor<1>, dim3(1), dim3(bs1), 0, s, n, dB, dR, dinfo);
-                else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(1), dim3(1024), 0, s, n, dB, dR, dinfo);
+                if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_factor<1>, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dB, dR, dinfo);
+                else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(1), dim3(1024), sizeof(double) * n, s, n, dB, dR, dinfo);
             }
             // dx = -(R^T R)^-1 g (:727)
             for (int i = 0; i < n; ++i) u[i] = -g[i];

@@ -133,6 +133,7 @@ template <int NC>
 __global__ void __launch_bounds__(1024)
 k_bf_chol_factor(int n, const double *__restrict__ B, double *__restrict__ Rt, int *__restrict__ info)
 {
+    extern __shared__ double colj[];               // n: column j of R above the diagonal
     __shared__ double ajj_sh;
     __shared__ int bad;
     const int tid = threadIdx.x, BS = blockDim.x;
@@ -143,9 +144,19 @@ k_bf_chol_factor(int n, const double *__restrict__ B, double *__restrict__ Rt, i
     }
     __syncthreads();
     for (int j = 0; j < n; ++j) {
-        if (tid == 0) {
+        for (int k = tid; k < j; k += BS) colj[k] = Rt[(size_t)k * n + j];      // strided, all threads
+        __syncthreads();
+        if (tid == 0) {                             // ordered sum from LDS
             double a = Rt[(size_t)j * n + j];
-            for (int k = 0; k < j; ++k) a = a - Rt[(size_t)k * n + j] * Rt[(size_t)k * n + j];
+            int k = 0;
+            for (; k + 16 <= j; k += 16) {
+                double t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = colj[k + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a = a - t[u] * t[u];
+            }
+            for (; k < j; ++k) a = a - colj[k] * colj[k];
             if (!(a > 0.0)) bad = j + 1;
             else { a = sqrt(a); Rt[(size_t)j * n + j] = a; }
             ajj_sh = a;
@@ -158,7 +169,15 @@ k_bf_chol_factor(int n, const double *__restrict__ B, double *__restrict__ Rt, i
             const int c = tid + q * BS;
             if (c > j && c < n) {
                 double t = Rt[(size_t)j * n + c];
-                for (int k = 0; k < j; ++k) t = t - Rt[(size_t)k * n + j] * Rt[(size_t)k * n + c];
+                int k = 0;
+                for (; k + 16 <= j; k += 16) {      // 16 coalesced loads in flight per thread
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = Rt[(size_t)(k + u) * n + c];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t = t - colj[k + u] * v[u];
+                }
+                for (; k < j; ++k) t = t - colj[k] * Rt[(size_t)k * n + c];
                 Rt[(size_t)j * n + c] = t / ajj;
             }
         }
