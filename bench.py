@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("NLH_BENCH_BATCH", "256")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("NLH_BENCH_BATCH", "512")),
                     help="problems per GPU per step")
     ap.add_argument("--m", type=int, default=M)
     ap.add_argument("--n", type=int, default=N_VAR)

@@ -23,7 +23,7 @@ for grp in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE SQ; do
     [ -n "$f" ] && cp "$f" "$OUT/${TAG}_pmc_${grp}_counter_collection.csv"
 done
 f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" "$OUT/${TAG}_bench_b256_kernel_stats.csv"
+[ -n "$f" ] && cp "$f" "$OUT/${TAG}_bench_kernel_stats.csv"
 grep "^{\"metric\"" "$OUT/stats.log" > "$OUT/${TAG}_bench_under_rocprof.json"
 rm -rf "$OUT/stats" "$OUT/FETCH_SIZE" "$OUT/WRITE_SIZE" "$OUT/GRBM_GUI_ACTIVE" "$OUT/SQ"
 ls -la "$OUT"

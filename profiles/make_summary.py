@@ -13,7 +13,7 @@ gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads, so read bytes =
 The largest launch of a kernel is the one with every problem of the batch still active, so
 per-problem traffic = bytes of that launch / problems per launch.
 
-usage: python profiles/make_summary.py r01 [problems_per_launch m n]
+usage: python profiles/make_summary.py r01 [problems_per_launch m n]   (problems_per_launch = the bench batch, 512 by default)
 """
 import csv
 import json
