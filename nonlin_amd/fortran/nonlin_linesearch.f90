@@ -9,7 +9,7 @@ module nonlin_linesearch
     public :: limit_search_vector
 
     type line_search
-        integer(int32), private :: m_maxEval = 100
+        integer(int32), private :: max_evals_ = 100
         real(real64), private :: m_alpha = 1.0d-4
         real(real64), private :: m_factor = 0.1d0
     contains
@@ -25,13 +25,13 @@ contains
     pure function ls_get_max_eval(this) result(n)
         class(line_search), intent(in) :: this
         integer(int32) :: n
-        n = this%m_maxEval
+        n = this%max_evals_
     end function
 
     subroutine ls_set_max_eval(this, x)
         class(line_search), intent(inout) :: this
         integer(int32), intent(in) :: x
-        this%m_maxEval = x
+        this%max_evals_ = x
     end subroutine
 
     pure function ls_get_scale(this) result(x)

@@ -36,20 +36,20 @@ module nonlin_multi_eqn_mult_var
     end interface
 
     type vecfcn_helper
-        procedure(vecfcn), private, pointer, nopass :: m_fcn => null()
-        procedure(jacobianfcn), private, pointer, nopass :: m_jac => null()
-        integer(int32), private :: m_nfcn = 0
-        integer(int32), private :: m_nvar = 0
+        procedure(vecfcn), private, pointer, nopass :: fcn_ptr_ => null()
+        procedure(jacobianfcn), private, pointer, nopass :: jac_ptr_ => null()
+        integer(int32), private :: neqn_ = 0
+        integer(int32), private :: nvar_ = 0
     contains
-        procedure, public :: set_fcn => vfh_set_fcn
-        procedure, public :: set_jacobian => vfh_set_jac
-        procedure, public :: is_fcn_defined => vfh_is_fcn_defined
-        procedure, public :: is_jacobian_defined => vfh_is_jac_defined
-        procedure, public :: fcn => vfh_fcn
-        procedure, public :: jacobian => vfh_jac_fcn
-        procedure, public :: get_equation_count => vfh_get_nfcn
-        procedure, public :: get_variable_count => vfh_get_nvar
-        procedure, public :: call_jacobian => vfh_call_jac
+        procedure, public :: set_fcn => helper_bind_fcn
+        procedure, public :: set_jacobian => helper_bind_jac
+        procedure, public :: is_fcn_defined => helper_has_fcn
+        procedure, public :: is_jacobian_defined => helper_has_jac
+        procedure, public :: fcn => helper_eval
+        procedure, public :: jacobian => helper_jacobian
+        procedure, public :: get_equation_count => helper_neqn
+        procedure, public :: get_variable_count => helper_nvar
+        procedure, public :: call_jacobian => helper_user_jac
     end type
 
     !> What the C layer hands back to the trampolines through its void* ctx.
@@ -59,25 +59,25 @@ module nonlin_multi_eqn_mult_var
     end type
 
     type, abstract :: equation_solver
-        integer(int32), private :: m_maxEval = 100
-        real(real64), private :: m_fcnTol = 1.0d-8
-        real(real64), private :: m_xtol = 1.0d-12
-        real(real64), private :: m_gtol = 1.0d-12
-        logical, private :: m_printStatus = .false.
+        integer(int32), private :: max_evals_ = 100
+        real(real64), private :: ftol_ = 1.0d-8
+        real(real64), private :: xtol_ = 1.0d-12
+        real(real64), private :: gtol_ = 1.0d-12
+        logical, private :: verbose_ = .false.
         !> Extension: NLH_FACTOR_EXACT (default; reference operation order, bit-identical
         !> results), NLH_FACTOR_AUTO (J^T J + Cholesky) or NLH_FACTOR_QR.
         integer(int32), public :: factor_policy = NLH_FACTOR_EXACT
     contains
-        procedure, public :: get_max_fcn_evals => es_get_max_eval
-        procedure, public :: set_max_fcn_evals => es_set_max_eval
-        procedure, public :: get_fcn_tolerance => es_get_fcn_tol
-        procedure, public :: set_fcn_tolerance => es_set_fcn_tol
-        procedure, public :: get_var_tolerance => es_get_var_tol
-        procedure, public :: set_var_tolerance => es_set_var_tol
-        procedure, public :: get_gradient_tolerance => es_get_grad_tol
-        procedure, public :: set_gradient_tolerance => es_set_grad_tol
-        procedure, public :: get_print_status => es_get_print_status
-        procedure, public :: set_print_status => es_set_print_status
+        procedure, public :: get_max_fcn_evals => cfg_max_evals
+        procedure, public :: set_max_fcn_evals => cfg_put_max_evals
+        procedure, public :: get_fcn_tolerance => cfg_ftol
+        procedure, public :: set_fcn_tolerance => cfg_put_ftol
+        procedure, public :: get_var_tolerance => cfg_xtol
+        procedure, public :: set_var_tolerance => cfg_put_xtol
+        procedure, public :: get_gradient_tolerance => cfg_gtol
+        procedure, public :: set_gradient_tolerance => cfg_put_gtol
+        procedure, public :: get_print_status => cfg_verbose
+        procedure, public :: set_print_status => cfg_put_verbose
         procedure(nonlin_solver), deferred, public, pass :: solve
     end type
 
@@ -97,56 +97,56 @@ module nonlin_multi_eqn_mult_var
     end interface
 
 contains
-    subroutine vfh_set_fcn(this, fcn, nfcn, nvar)
+    subroutine helper_bind_fcn(this, fcn, nfcn, nvar)
         class(vecfcn_helper), intent(inout) :: this
         procedure(vecfcn), intent(in), pointer :: fcn
         integer(int32), intent(in) :: nfcn
         integer(int32), intent(in) :: nvar
-        this%m_fcn => fcn
-        this%m_nfcn = nfcn
-        this%m_nvar = nvar
+        this%fcn_ptr_ => fcn
+        this%neqn_ = nfcn
+        this%nvar_ = nvar
     end subroutine
 
-    subroutine vfh_set_jac(this, jac)
+    subroutine helper_bind_jac(this, jac)
         class(vecfcn_helper), intent(inout) :: this
         procedure(jacobianfcn), intent(in), pointer :: jac
-        this%m_jac => jac
+        this%jac_ptr_ => jac
     end subroutine
 
-    function vfh_is_fcn_defined(this) result(x)
+    function helper_has_fcn(this) result(x)
         class(vecfcn_helper), intent(in) :: this
         logical :: x
-        x = associated(this%m_fcn)
+        x = associated(this%fcn_ptr_)
     end function
 
-    function vfh_is_jac_defined(this) result(x)
+    function helper_has_jac(this) result(x)
         class(vecfcn_helper), intent(in) :: this
         logical :: x
-        x = associated(this%m_jac)
+        x = associated(this%jac_ptr_)
     end function
 
-    subroutine vfh_fcn(this, x, f, args)
+    subroutine helper_eval(this, x, f, args)
         class(vecfcn_helper), intent(in) :: this
         real(real64), intent(in), dimension(:) :: x
         real(real64), intent(out), dimension(:) :: f
         class(*), intent(inout), optional :: args
         if (this%is_fcn_defined()) then
-            call this%m_fcn(x, f, args)
+            call this%fcn_ptr_(x, f, args)
         end if
     end subroutine
 
     !> Invokes the user's analytic Jacobian routine (used by the C-side trampoline).
-    subroutine vfh_call_jac(this, x, jac, args)
+    subroutine helper_user_jac(this, x, jac, args)
         class(vecfcn_helper), intent(in) :: this
         real(real64), intent(in), dimension(:) :: x
         real(real64), intent(out), dimension(:,:) :: jac
         class(*), intent(inout), optional :: args
-        if (associated(this%m_jac)) call this%m_jac(x, jac, args)
+        if (associated(this%jac_ptr_)) call this%jac_ptr_(x, jac, args)
     end subroutine
 
-    !> vfh_jac_fcn (src/nonlin_multi_eqn_mult_var.f90:198-277): analytic dispatch, or n
+    !> helper_jacobian (src/nonlin_multi_eqn_mult_var.f90:198-277): analytic dispatch, or n
     !> perturbed evaluations on the host + the (f1 - f0)/h column write on the GPU.
-    subroutine vfh_jac_fcn(this, x, jac, fv, args)
+    subroutine helper_jacobian(this, x, jac, fv, args)
         class(vecfcn_helper), intent(in), target :: this
         real(real64), intent(inout), dimension(:) :: x
         real(real64), intent(out), dimension(:,:) :: jac
@@ -176,7 +176,7 @@ contains
         allocate(xc(n), jc(m, n))
         xc = x
         cjac = c_null_funptr
-        if (associated(this%m_jac)) cjac = c_funloc(nlh_jacfcn_trampoline)
+        if (associated(this%jac_ptr_)) cjac = c_funloc(nlh_jacfcn_trampoline)
         fvp = c_null_ptr
         if (present(fv)) then
             allocate(fvc(m))
@@ -190,76 +190,76 @@ contains
         jac = jc
     end subroutine
 
-    function vfh_get_nfcn(this) result(n)
+    function helper_neqn(this) result(n)
         class(vecfcn_helper), intent(in) :: this
         integer(int32) :: n
-        n = this%m_nfcn
+        n = this%neqn_
     end function
 
-    function vfh_get_nvar(this) result(n)
+    function helper_nvar(this) result(n)
         class(vecfcn_helper), intent(in) :: this
         integer(int32) :: n
-        n = this%m_nvar
+        n = this%nvar_
     end function
 
-    pure function es_get_max_eval(this) result(n)
+    pure function cfg_max_evals(this) result(n)
         class(equation_solver), intent(in) :: this
         integer(int32) :: n
-        n = this%m_maxEval
+        n = this%max_evals_
     end function
 
-    subroutine es_set_max_eval(this, n)
+    subroutine cfg_put_max_evals(this, n)
         class(equation_solver), intent(inout) :: this
         integer(int32), intent(in) :: n
-        this%m_maxEval = n
+        this%max_evals_ = n
     end subroutine
 
-    pure function es_get_fcn_tol(this) result(x)
+    pure function cfg_ftol(this) result(x)
         class(equation_solver), intent(in) :: this
         real(real64) :: x
-        x = this%m_fcnTol
+        x = this%ftol_
     end function
 
-    subroutine es_set_fcn_tol(this, x)
+    subroutine cfg_put_ftol(this, x)
         class(equation_solver), intent(inout) :: this
         real(real64), intent(in) :: x
-        this%m_fcnTol = x
+        this%ftol_ = x
     end subroutine
 
-    pure function es_get_var_tol(this) result(x)
+    pure function cfg_xtol(this) result(x)
         class(equation_solver), intent(in) :: this
         real(real64) :: x
-        x = this%m_xtol
+        x = this%xtol_
     end function
 
-    subroutine es_set_var_tol(this, x)
+    subroutine cfg_put_xtol(this, x)
         class(equation_solver), intent(inout) :: this
         real(real64), intent(in) :: x
-        this%m_xtol = x
+        this%xtol_ = x
     end subroutine
 
-    pure function es_get_grad_tol(this) result(x)
+    pure function cfg_gtol(this) result(x)
         class(equation_solver), intent(in) :: this
         real(real64) :: x
-        x = this%m_gtol
+        x = this%gtol_
     end function
 
-    subroutine es_set_grad_tol(this, x)
+    subroutine cfg_put_gtol(this, x)
         class(equation_solver), intent(inout) :: this
         real(real64), intent(in) :: x
-        this%m_gtol = x
+        this%gtol_ = x
     end subroutine
 
-    pure function es_get_print_status(this) result(x)
+    pure function cfg_verbose(this) result(x)
         class(equation_solver), intent(in) :: this
         logical :: x
-        x = this%m_printStatus
+        x = this%verbose_
     end function
 
-    subroutine es_set_print_status(this, x)
+    subroutine cfg_put_verbose(this, x)
         class(equation_solver), intent(inout) :: this
         logical, intent(in) :: x
-        this%m_printStatus = x
+        this%verbose_ = x
     end subroutine
 
     ! ---- trampolines: the C layer's nlh_vecfcn / nlh_jacfcn --------------------------------

@@ -34,18 +34,18 @@ module nonlin_multi_var
 
     type fcnnvar_helper
         private
-        procedure(fcnnvar), private, pointer, nopass :: m_fcn => null()
-        procedure(gradientfcn), private, pointer, nopass :: m_grad => null()
-        integer(int32), private :: m_nvar = 0
+        procedure(fcnnvar), private, pointer, nopass :: fcn_ptr_ => null()
+        procedure(gradientfcn), private, pointer, nopass :: grad_ptr_ => null()
+        integer(int32), private :: nvar_ = 0
     contains
-        procedure, public :: fcn => fnh_fcn
-        procedure, public :: is_fcn_defined => fnh_is_fcn_defined
-        procedure, public :: set_fcn => fnh_set_fcn
-        procedure, public :: get_variable_count => fnh_get_nvar
-        procedure, public :: set_gradient_fcn => fnh_set_grad
-        procedure, public :: is_gradient_defined => fnh_is_grad_defined
-        procedure, public :: gradient => fnh_grad_fcn
-        procedure, public :: call_gradient => fnh_call_grad
+        procedure, public :: fcn => obj_eval
+        procedure, public :: is_fcn_defined => obj_has_fcn
+        procedure, public :: set_fcn => obj_bind_fcn
+        procedure, public :: get_variable_count => obj_nvar
+        procedure, public :: set_gradient_fcn => obj_bind_grad
+        procedure, public :: is_gradient_defined => obj_has_grad
+        procedure, public :: gradient => obj_gradient
+        procedure, public :: call_gradient => obj_user_grad
     end type
 
     !> What the C layer hands back to the trampolines through its void* ctx.
@@ -55,16 +55,16 @@ module nonlin_multi_var
     end type
 
     type, abstract :: equation_optimizer
-        integer(int32), private :: m_maxEval = 500
-        real(real64), private :: m_tol = 1.0d-12
-        logical, private :: m_printStatus = .false.
+        integer(int32), private :: max_evals_ = 500
+        real(real64), private :: tol_ = 1.0d-12
+        logical, private :: verbose_ = .false.
     contains
-        procedure, public :: get_max_fcn_evals => oe_get_max_eval
-        procedure, public :: set_max_fcn_evals => oe_set_max_eval
-        procedure, public :: get_tolerance => oe_get_tol
-        procedure, public :: set_tolerance => oe_set_tol
-        procedure, public :: get_print_status => oe_get_print_status
-        procedure, public :: set_print_status => oe_set_print_status
+        procedure, public :: get_max_fcn_evals => opt_max_evals
+        procedure, public :: set_max_fcn_evals => opt_put_max_evals
+        procedure, public :: get_tolerance => opt_tol
+        procedure, public :: set_tolerance => opt_put_tol
+        procedure, public :: get_print_status => opt_verbose
+        procedure, public :: set_print_status => opt_put_verbose
         procedure(nonlin_optimize_fcn), deferred, public, pass :: solve
     end type
 
@@ -83,57 +83,57 @@ module nonlin_multi_var
         end subroutine
     end interface
 contains
-    function fnh_fcn(this, x, args) result(f)               ! :81-89
+    function obj_eval(this, x, args) result(f)               ! :81-89
         class(fcnnvar_helper), intent(in) :: this
         real(real64), intent(in), dimension(:) :: x
         class(*), intent(inout), optional :: args
         real(real64) :: f
         f = 0.0d0
-        if (associated(this%m_fcn)) f = this%m_fcn(x, args)
+        if (associated(this%fcn_ptr_)) f = this%fcn_ptr_(x, args)
     end function
 
-    function fnh_is_fcn_defined(this) result(x)
+    function obj_has_fcn(this) result(x)
         class(fcnnvar_helper), intent(in) :: this
         logical :: x
-        x = associated(this%m_fcn)
+        x = associated(this%fcn_ptr_)
     end function
 
-    subroutine fnh_set_fcn(this, fcn, nvar)                 ! :99-106
+    subroutine obj_bind_fcn(this, fcn, nvar)                 ! :99-106
         class(fcnnvar_helper), intent(inout) :: this
         procedure(fcnnvar), intent(in), pointer :: fcn
         integer(int32), intent(in) :: nvar
-        this%m_fcn => fcn
-        this%m_nvar = nvar
+        this%fcn_ptr_ => fcn
+        this%nvar_ = nvar
     end subroutine
 
-    function fnh_get_nvar(this) result(n)
+    function obj_nvar(this) result(n)
         class(fcnnvar_helper), intent(in) :: this
         integer(int32) :: n
-        n = this%m_nvar
+        n = this%nvar_
     end function
 
-    subroutine fnh_set_grad(this, fcn)
+    subroutine obj_bind_grad(this, fcn)
         class(fcnnvar_helper), intent(inout) :: this
         procedure(gradientfcn), pointer, intent(in) :: fcn
-        this%m_grad => fcn
+        this%grad_ptr_ => fcn
     end subroutine
 
-    function fnh_is_grad_defined(this) result(x)
+    function obj_has_grad(this) result(x)
         class(fcnnvar_helper), intent(in) :: this
         logical :: x
-        x = associated(this%m_grad)
+        x = associated(this%grad_ptr_)
     end function
 
-    subroutine fnh_call_grad(this, x, g, args)
+    subroutine obj_user_grad(this, x, g, args)
         class(fcnnvar_helper), intent(in) :: this
         real(real64), intent(in), dimension(:) :: x
         real(real64), intent(out), dimension(:) :: g
         class(*), intent(inout), optional :: args
-        call this%m_grad(x, g, args)
+        call this%grad_ptr_(x, g, args)
     end subroutine
 
-    ! fnh_grad_fcn, :182-246: n + 1 evaluations of a scalar; the work is the user's function, so it stays here.
-    subroutine fnh_grad_fcn(this, x, g, fv, args)
+    ! obj_gradient, :182-246: n + 1 evaluations of a scalar; the work is the user's function, so it stays here.
+    subroutine obj_gradient(this, x, g, fv, args)
         class(fcnnvar_helper), intent(in) :: this
         real(real64), intent(inout), dimension(:) :: x
         real(real64), intent(out), dimension(:) :: g
@@ -151,7 +151,7 @@ contains
         if (flag /= 0) error stop flag
         if (.not.this%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR
         if (this%is_gradient_defined()) then
-            call this%m_grad(x, g, args)
+            call this%grad_ptr_(x, g, args)
         else
             if (present(fv)) then
                 f = fv
@@ -171,35 +171,35 @@ contains
         end if
     end subroutine
 
-    pure function oe_get_max_eval(this) result(n)
+    pure function opt_max_evals(this) result(n)
         class(equation_optimizer), intent(in) :: this
         integer(int32) :: n
-        n = this%m_maxEval
+        n = this%max_evals_
     end function
-    subroutine oe_set_max_eval(this, n)
+    subroutine opt_put_max_evals(this, n)
         class(equation_optimizer), intent(inout) :: this
         integer(int32), intent(in) :: n
-        this%m_maxEval = n
+        this%max_evals_ = n
     end subroutine
-    pure function oe_get_tol(this) result(x)
+    pure function opt_tol(this) result(x)
         class(equation_optimizer), intent(in) :: this
         real(real64) :: x
-        x = this%m_tol
+        x = this%tol_
     end function
-    subroutine oe_set_tol(this, x)
+    subroutine opt_put_tol(this, x)
         class(equation_optimizer), intent(inout) :: this
         real(real64), intent(in) :: x
-        this%m_tol = x
+        this%tol_ = x
     end subroutine
-    pure function oe_get_print_status(this) result(x)
+    pure function opt_verbose(this) result(x)
         class(equation_optimizer), intent(in) :: this
         logical :: x
-        x = this%m_printStatus
+        x = this%verbose_
     end function
-    subroutine oe_set_print_status(this, x)
+    subroutine opt_put_verbose(this, x)
         class(equation_optimizer), intent(inout) :: this
         logical, intent(in) :: x
-        this%m_printStatus = x
+        this%verbose_ = x
     end subroutine
 
     function nlh_fcnnvar_trampoline(ctx, n, x) bind(C) result(f)

@@ -16,7 +16,7 @@ module nonlin_optimize
     type, abstract, extends(equation_optimizer) :: line_search_optimizer
         class(line_search), private, allocatable :: m_lineSearch
         logical, private :: m_useLineSearch = .true.
-        real(real64), private :: m_xtol = 1.0d-12
+        real(real64), private :: xtol_ = 1.0d-12
     contains
         procedure, public :: get_line_search => lso_get_line_search
         procedure, public :: set_line_search => lso_set_line_search
@@ -74,13 +74,13 @@ contains
     pure function lso_get_var_tol(this) result(x)
         class(line_search_optimizer), intent(in) :: this
         real(real64) :: x
-        x = this%m_xtol
+        x = this%xtol_
     end function
 
     subroutine lso_set_var_tol(this, x)
         class(line_search_optimizer), intent(inout) :: this
         real(real64), intent(in) :: x
-        this%m_xtol = x
+        this%xtol_ = x
     end subroutine
 
     subroutine bfgs_solve(this, fcn, x, fout, ib, args)     ! :557-770

@@ -7,17 +7,11 @@ module nonlin_types
     public :: value_pair
 
     type iteration_behavior
-        integer(int32) :: iter_count
-        integer(int32) :: fcn_count
-        integer(int32) :: jacobian_count
-        integer(int32) :: gradient_count
-        logical :: converge_on_fcn
-        logical :: converge_on_chng
-        logical :: converge_on_zero_diff
+        integer(int32) :: iter_count, fcn_count, jacobian_count, gradient_count   ! counters reported by every solve
+        logical :: converge_on_fcn, converge_on_chng, converge_on_zero_diff       ! which test stopped the iteration
     end type
 
     type value_pair
-        real(real64) :: x1
-        real(real64) :: x2
+        real(real64) :: x1, x2
     end type
 end module
