@@ -72,16 +72,29 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[a][c] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    const int arow = (wr * 32 + (lane & 15)) * GRAM_LD + (lane >> 4);
-    const int brow = (wc * 32 + (lane & 15)) * GRAM_LD + (lane >> 4);
-    // LDS byte addresses of this lane's first A / B operand (the low 32 bits of a generic LDS pointer)
-    const unsigned aaddr = (unsigned)(size_t)(tA + arow);
-    const unsigned baddr = (unsigned)(size_t)(tBp + brow);
+    // 16 x 16 MFMA tiles of this wave: A-side tile rows ai[0..1], B-side tile columns bi_[0..1] (in units of 16
+    // columns of the block), products acc[x][y] = tile (ai[x], bi_[y]).  Off the diagonal a wave owns a 2 x 2 patch.
+    // In a diagonal block only tiles on or below the diagonal are needed (k_gram_reduce mirrors elementwise), and they
+    // are dealt so that no wave has more than three: the block costs 3/4 of the MFMAs.
+    int ai0 = 2 * wr, ai1 = 2 * wr + 1, bt0 = 2 * wc, bt1 = 2 * wc + 1;
+    bool m00 = true, m01 = true, m10 = true, m11 = true;
+    if (diag) {
+        if (w == 0) { ai0 = 0; ai1 = 1; bt0 = 0; bt1 = 1; m01 = false; }                       // (0,0) (1,0) (1,1)
+        else if (w == 1) { ai0 = 2; ai1 = 2; bt0 = 0; bt1 = 1; m10 = false; m11 = false; }      // (2,0) (2,1)
+        else if (w == 2) { ai0 = 3; ai1 = 3; bt0 = 0; bt1 = 1; m10 = false; m11 = false; }      // (3,0) (3,1)
+        else { ai0 = 2; ai1 = 3; bt0 = 2; bt1 = 3; m01 = false; }                               // (2,2) (3,2) (3,3)
+    }
+    // LDS byte addresses of this lane's operands (the low 32 bits of a generic LDS pointer)
+    const int lrow = (lane & 15) * GRAM_LD + (lane >> 4);
+    const unsigned aaddr0 = (unsigned)(size_t)(tA + ai0 * 16 * GRAM_LD + lrow);
+    const unsigned aaddr1 = (unsigned)(size_t)(tA + ai1 * 16 * GRAM_LD + lrow);
+    const unsigned baddr0 = (unsigned)(size_t)(tBp + bt0 * 16 * GRAM_LD + lrow);
+    const unsigned baddr1 = (unsigned)(size_t)(tBp + bt1 * 16 * GRAM_LD + lrow);
 #define GRAM_LDS_READ4(x0, x1, y0, y1, OFF)                                                          \
-    asm volatile("ds_read_b64 %0, %4 offset:%6\n\tds_read_b64 %1, %4 offset:%7\n\t"                 \
-                 "ds_read_b64 %2, %5 offset:%6\n\tds_read_b64 %3, %5 offset:%7"                      \
+    asm volatile("ds_read_b64 %0, %4 offset:%8\n\tds_read_b64 %1, %5 offset:%8\n\t"                 \
+                 "ds_read_b64 %2, %6 offset:%8\n\tds_read_b64 %3, %7 offset:%8"                      \
                  : "=&v"(x0), "=&v"(x1), "=&v"(y0), "=&v"(y1)                                       \
-                 : "v"(aaddr), "v"(baddr), "n"(OFF), "n"((OFF) + 16 * GRAM_LD * 8)                  \
+                 : "v"(aaddr0), "v"(aaddr1), "v"(baddr0), "v"(baddr1), "n"(OFF)                     \
                  : "memory");
 #define GRAM_LDS_WAIT4(x0, x1, y0, y1)                                                               \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
@@ -137,10 +150,10 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
         for (int ks = 0; ks < GRAM_KT / 4; ++ks) {
             double na0 = 0.0, na1 = 0.0, nb0 = 0.0, nb1 = 0.0;
             if (ks + 1 < GRAM_KT / 4) GRAM_LDS_READ4(na0, na1, nb0, nb1, (ks + 1) * 32)
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            if (m00) acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            if (m01) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            if (m10) acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            if (m11) acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
             if (ks + 1 < GRAM_KT / 4) {
                 GRAM_LDS_WAIT4(na0, na1, nb0, nb1)
                 a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
@@ -165,16 +178,19 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
+            const bool on = (a == 0) ? (c == 0 ? m00 : m01) : (c == 0 ? m10 : m11);
+            if (!on) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gr = bi * GRAM_BT + wr * 32 + a * 16 + (lane >> 4) + 4 * r;   // A-side column of J
-                const int gc = bj * GRAM_BT + wc * 32 + c * 16 + (lane & 15);           // B-side column of J
+                const int gr = bi * GRAM_BT + (a == 0 ? ai0 : ai1) * 16 + (lane >> 4) + 4 * r;   // A-side column of J
+                const int gc = bj * GRAM_BT + (c == 0 ? bt0 : bt1) * 16 + (lane & 15);           // B-side column of J
                 if (gr < n && gc < n) Gp[(size_t)gc * n + gr] = acc[a][c][r];
             }
+        }
 }
 
-// Sum the K-split partials in split order and mirror the lower block triangle.
+// Sum the K-split partials in split order and mirror the lower triangle.
 __global__ void __launch_bounds__(256)
 k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__restrict__ G,
               const double *__restrict__ gpart, double *__restrict__ g,
@@ -191,7 +207,7 @@ k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__res
     }
     if (e >= nn) return;
     const int r = (int)(e % n), c = (int)(e / n);
-    const bool lower = (r / GRAM_BT) >= (c / GRAM_BT);
+    const bool lower = r >= c;                     // the slabs hold every entry with row >= column (16 x 16 tile granularity)
     const size_t src = lower ? ((size_t)c * n + r) : ((size_t)r * n + c);
     const double *gp = Gpart + (size_t)p * nsplit * nn + src;
     double s = 0.0;
