@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <thread>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -53,6 +55,7 @@ struct nlh_handle {
            qnQ, qnR, qnV, bfB, bfR, bfV;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    std::vector<nlh_handle *> workers;   // private handles (own stream + workspace) for concurrent host-loop solves
 };
 
 #define HIPCHK(h, call)                                                                 \
@@ -205,6 +208,8 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
 void nlh_destroy(nlh_handle *h)
 {
     if (!h) return;
+    for (auto *wk : h->workers) nlh_destroy(wk);
+    h->workers.clear();
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     timing_flush(h);
@@ -1039,7 +1044,7 @@ static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int 
         }
         const int jl = steps - 1, slot = jl & 1;
         hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - jl + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
-                           rows, ncA, ncE, jl, dA, dE, vbuf, wbuf + (size_t)slot * nc, st + (size_t)slot * 4, 2 * nc, 8);
+                           rows, ncA, ncE, jl, dA, dE, vbuf, wbuf + (size_t)slot * nc, st + (size_t)slot * 4, 2 * nc, 8, 1);
         return;
     }
     const bool wide = rows <= QN_DOT2_MAXROWS;          // workgroup-wide loads (reflector + two product tiles in LDS)
@@ -1052,7 +1057,7 @@ static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int 
             hipLaunchKernelGGL(k_qn_house_dot, dim3((nc + QN_DOT_BS - 1) / QN_DOT_BS, nprob), dim3(QN_DOT_BS),
                                sizeof(double) * rows, s, rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
         hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - j + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
-                           rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, nc, 4);
+                           rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, nc, 4, 0);
     }
 }
 
@@ -1632,6 +1637,52 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
     return flag ? NLH_CONVERGENCE_ERROR : 0;                    // :765-767
 }
 
+
+// Host-loop solvers (Newton, quasi-Newton, constrained least squares, bfgs) over a batch of independent problems:
+// the problems are dealt to a few host threads, each with a private handle (own HIP stream and workspace), so the
+// latency-bound kernels of different problems overlap on the device.  NLH_WORKERS sets the thread count (default 8).
+static int run_problems(nlh_handle *h, int nprob, const std::function<int(nlh_handle *, int)> &solve_one)
+{
+    int T = 8;
+    if (const char *e = getenv("NLH_WORKERS")) T = atoi(e);
+    T = std::max(1, std::min(T, nprob));
+    if (T == 1) {
+        for (int p = 0; p < nprob; ++p) {
+            const int rc = solve_one(h, p);
+            if (rc < 0) return rc;
+        }
+        return 0;
+    }
+    while ((int)h->workers.size() < T) {
+        nlh_handle *wk = new nlh_handle();
+        wk->device = h->device;
+        if (hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking) != hipSuccess) { delete wk; h->err = "hipStreamCreate"; return NLH_ERR_HIP; }
+        wk->own_stream = true;
+        h->workers.push_back(wk);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));                 // inputs written on the caller's stream are complete
+    std::atomic<int> next(0), err(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t)
+        pool.emplace_back([&, t]() {
+            nlh_handle *wk = h->workers[t];
+            if (hipSetDevice(wk->device) != hipSuccess) { err = NLH_ERR_HIP; return; }
+            for (;;) {
+                const int p = next.fetch_add(1);
+                if (p >= nprob || err.load() != 0) break;
+                const int rc = solve_one(wk, p);
+                if (rc < 0) { err = rc; break; }
+            }
+            hipStreamSynchronize(wk->stream);
+        });
+    for (auto &th : pool) th.join();
+    if (err.load() != 0) {
+        for (auto *wk : h->workers) if (!wk->err.empty()) { h->err = wk->err; break; }
+        return err.load();
+    }
+    return 0;
+}
+
 extern "C" {
 
 int nlh_newton_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_vecfcn fcn, nlh_jacfcn jacfcn,
@@ -1686,15 +1737,15 @@ int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (!o || n < 1) return NLH_INVALID_INPUT_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
-    int rc;
-    const size_t nn = (size_t)n * n;
-    if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
-    if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
-    if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
-    hipStream_t s = h->stream;
-    std::vector<double> x(n), f(n);
-    // Problems are independent and solved one after another (ns_solve is a host loop).
-    for (int p = 0; p < nprob; ++p) {
+    // one problem per call; run_problems deals the problems to worker threads with private handles
+    auto solve_one = [&](nlh_handle *h, int p) -> int {
+        int rc;
+        const size_t nn = (size_t)n * n;
+        if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
+        if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
+        if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
+        hipStream_t s = h->stream;
+        std::vector<double> x(n), f(n);
         const double *A = dA + (size_t)p * nn, *b = db + (size_t)p * n;
         double *dxp = dx + (size_t)p * n, *dfp = dfvec + (size_t)p * n;
         double *dxs = (double *)h->xdev.p, *dfs = (double *)h->wa4.p;
@@ -1730,7 +1781,10 @@ int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob
         HIPCHK(h, hipMemcpyAsync(dxp, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
         HIPCHK(h, hipMemcpyAsync(dfp, f.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
         HIPCHK(h, hipStreamSynchronize(s));
-    }
+        return 0;
+    };
+    const int rcb = run_problems(h, nprob, solve_one);
+    if (rcb) return rcb;
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -1789,14 +1843,15 @@ int nlh_dq_quasi_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (!o || n < 1) return NLH_INVALID_INPUT_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
-    int rc;
-    const size_t nn = (size_t)n * n;
-    if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
-    if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
-    if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
-    hipStream_t s = h->stream;
-    std::vector<double> x(n), f(n);
-    for (int p = 0; p < nprob; ++p) {                           // independent problems, one after another
+    // one problem per call; run_problems deals the problems to worker threads with private handles
+    auto solve_one = [&](nlh_handle *h, int p) -> int {
+        int rc;
+        const size_t nn = (size_t)n * n;
+        if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
+        if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
+        if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
+        hipStream_t s = h->stream;
+        std::vector<double> x(n), f(n);
         const double *A = dA + (size_t)p * nn, *b = db + (size_t)p * n;
         double *dxp = dx + (size_t)p * n, *dfp = dfvec + (size_t)p * n;
         double *dxs = (double *)h->xdev.p, *dfs = (double *)h->wa4.p;
@@ -1832,7 +1887,10 @@ int nlh_dq_quasi_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t
         HIPCHK(h, hipMemcpyAsync(dxp, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
         HIPCHK(h, hipMemcpyAsync(dfp, f.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
         HIPCHK(h, hipStreamSynchronize(s));
-    }
+        return 0;
+    };
+    const int rcb = run_problems(h, nprob, solve_one);
+    if (rcb) return rcb;
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -1896,14 +1954,15 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
     if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;
     if (m > QN_MAX_ROWS) return NLH_ARRAY_SIZE_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
-    int rc;
-    const size_t mn = (size_t)m * n;
-    if ((rc = ensure(h, h->P, sizeof(double) * mn))) return rc;
-    if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
-    if ((rc = ensure(h, h->wa4, sizeof(double) * m))) return rc;
-    hipStream_t s = h->stream;
-    std::vector<double> x(n), f(m);
-    for (int p = 0; p < nprob; ++p) {                           // independent problems, one after another
+    // one problem per call; run_problems deals the problems to worker threads with private handles
+    auto solve_one = [&](nlh_handle *h, int p) -> int {
+        int rc;
+        const size_t mn = (size_t)m * n;
+        if ((rc = ensure(h, h->P, sizeof(double) * mn))) return rc;
+        if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
+        if ((rc = ensure(h, h->wa4, sizeof(double) * m))) return rc;
+        hipStream_t s = h->stream;
+        std::vector<double> x(n), f(m);
         const double *A = dA + (size_t)p * mn, *b = db + (size_t)p * m;
         double *dxp = dx + (size_t)p * n, *dfp = dfvec + (size_t)p * m;
         double *dxs = (double *)h->xdev.p, *dfs = (double *)h->wa4.p;
@@ -1932,7 +1991,10 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
         HIPCHK(h, hipMemcpyAsync(dxp, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
         HIPCHK(h, hipMemcpyAsync(dfp, f.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
         HIPCHK(h, hipStreamSynchronize(s));
-    }
+        return 0;
+    };
+    const int rcb = run_problems(h, nprob, solve_one);
+    if (rcb) return rcb;
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -1976,14 +2038,15 @@ int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, 
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (!o || n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
-    int rc;
-    const size_t mn = (size_t)m * n;
-    if ((rc = ensure(h, h->P, sizeof(double) * mn))) return rc;
-    if ((rc = ensure(h, h->xdev, sizeof(double) * 2 * n))) return rc;
-    if ((rc = ensure(h, h->wa4, sizeof(double) * m))) return rc;
-    hipStream_t s = h->stream;
-    std::vector<double> x(n), f(m);
-    for (int p = 0; p < nprob; ++p) {
+    // one problem per call; run_problems deals the problems to worker threads with private handles
+    auto solve_one = [&](nlh_handle *h, int p) -> int {
+        int rc;
+        const size_t mn = (size_t)m * n;
+        if ((rc = ensure(h, h->P, sizeof(double) * mn))) return rc;
+        if ((rc = ensure(h, h->xdev, sizeof(double) * 2 * n))) return rc;
+        if ((rc = ensure(h, h->wa4, sizeof(double) * m))) return rc;
+        hipStream_t s = h->stream;
+        std::vector<double> x(n), f(m);
         const double *A = dA + (size_t)p * mn, *b = db + (size_t)p * m;
         double *dxp = dx + (size_t)p * n;
         double *dxs = (double *)h->xdev.p, *dgs = dxs + n, *dfs = (double *)h->wa4.p;
@@ -2016,7 +2079,10 @@ int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, 
         if (hfout) hfout[p] = fo;
         HIPCHK(h, hipMemcpyAsync(dxp, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
         HIPCHK(h, hipStreamSynchronize(s));
-    }
+        return 0;
+    };
+    const int rcb = run_problems(h, nprob, solve_one);
+    if (rcb) return rcb;
     HIPCHK(h, hipGetLastError());
     return 0;
 }

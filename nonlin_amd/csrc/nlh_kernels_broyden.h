@@ -237,8 +237,12 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     double *stc = st + ((size_t)p * 2 + (j & 1)) * 4;
     const double *wprev = wbuf + ((size_t)p * 2 + (jp & 1)) * nc;
     double *wcur = wbuf + ((size_t)p * 2 + (j & 1)) * nc;
-    const double tau_p = (j > 0) ? stp[0] : 0.0, scal_p = (j > 0) ? stp[1] : 0.0, beta_p = (j > 0) ? stp[2] : 0.0;
+    const double tau_p = (j > 0) ? stp[0] : 0.0, scal_p = (j > 0) ? stp[1] : 0.0;
     const bool pend = tau_p != 0.0;                     // step j-1 was a real reflector whose update is outstanding
+    // Column j-1 is finished here: (diagonal, zeros below).  Its rows >= j-1 were deliberately NOT written during
+    // step j-1 (every workgroup of that launch was still reading them to rebuild the reflector), so this is where
+    // they get their final values: beta of step j-1, or the plain diagonal value if that step was H = I.
+    const double dval_p = (j > 0) ? (pend ? stp[2] : stp[3]) : 0.0;
 
     if (pend)
         for (int i = j + tid; i < rows; i += 256) vsp[i] = vprev_g[i] * scal_p;
@@ -276,8 +280,9 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
         tau = (beta - alpha) / beta;
         scal = 1.0 / (alpha - beta);
     }
-    if (blockIdx.x == 0 && tid == 0) { stc[0] = tau; stc[1] = scal; stc[2] = beta; }
-    if (!refl && !pend) return;                         // nothing to sum, nothing outstanding (uniform)
+    if (blockIdx.x == 0 && tid == 0) { stc[0] = tau; stc[1] = scal; stc[2] = beta; stc[3] = alpha; }
+    const bool hasjp = (j > 0) && (jp / CG == (int)blockIdx.x);     // this workgroup finishes column j-1
+    if (!refl && !pend && !hasjp) return;               // nothing to sum, nothing outstanding (uniform)
     if (refl)
         for (int i = j + 1 + tid; i < rows; i += 256) vs[i] = vs[i] * scal;
     __syncthreads();
@@ -285,20 +290,21 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     const int c = tid % CG, r = tid / CG;
     const int k = blockIdx.x * CG + c;
     const bool inr = k < nc;
-    const bool upd = pend && inr && !(k < ncA && k < jp);            // columns the pending update touches (k == jp: beta', zeros)
-    const bool isjp = (k < ncA) && (k == jp);
+    const bool isjp = (j > 0) && (k < ncA) && (k == jp);
+    const bool isj = (k < ncA) && (k == j);             // never stored in this launch (other workgroups read it)
+    const bool upd = inr && (isjp || (pend && !(k < ncA && k < jp)));  // columns written back: the update, or the finish of j-1
     const bool live = refl && inr && !(k < ncA && k <= j);           // columns that take part in step j's sums
     double *T = (k < ncA) ? A + k : E + (k - ncA);
     const size_t ld = (k < ncA) ? ncA : ncE;
-    const double wp = (upd && !isjp) ? wprev[k] : 0.0;
+    const double wp = (upd && !isjp && pend) ? wprev[k] : 0.0;
     double w = 0.0;
     if (r == 0 && inr) {
-        if (upd) {                                      // row j-1 of the pending update
+        if (upd) {                                      // row j-1: the pending update, or the diagonal of column j-1
             double *e = T + (size_t)jp * ld;
-            *e = isjp ? beta_p : *e - wp;
+            *e = isjp ? dval_p : *e - wp;
         }
         double t = T[(size_t)j * ld];                   // row j
-        if (upd) { t = isjp ? 0.0 : t - vsp[j] * wp; T[(size_t)j * ld] = t; }
+        if (upd) { t = isjp ? 0.0 : t - vsp[j] * wp; if (!isj) T[(size_t)j * ld] = t; }
         w = t;
     }
     double tl[16];
@@ -317,7 +323,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
             const int i = i0 + r + RL * u;
             if (i < rows) {
                 double t = tl[u];
-                if (upd) { t = isjp ? 0.0 : t - vsp[i] * wp; T[(size_t)i * ld] = t; }
+                if (upd) { t = isjp ? 0.0 : t - vsp[i] * wp; if (!isj) T[(size_t)i * ld] = t; }
                 if (refl) pb[(r + RL * u) * CG + c] = vs[i] * t;
             }
         }
@@ -347,7 +353,8 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
 __global__ void __launch_bounds__(256)
 k_qn_house_apply(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
                  double *__restrict__ vbuf, const double *__restrict__ wbuf, const double *__restrict__ st,
-                 int wps /* w doubles per problem */, int sps /* st doubles per problem */)
+                 int wps /* w doubles per problem */, int sps /* st doubles per problem */,
+                 int fixcol /* 1 after k_qn_house_fused: column j was never stored during step j, finish it here */)
 {
     const int p = blockIdx.z;
     double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
@@ -363,6 +370,10 @@ k_qn_house_apply(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     if (tau == 0.0) {
         if (next_owner)
             for (int i = max(i0, j + 2); i < i1; ++i) vnext[i] = T[(size_t)i * ld];
+        if (fixcol && k == j && k < ncA) {                  // H = I: (diagonal value, zeros below)
+            const double alpha = st[(size_t)p * sps + 3];
+            for (int i = i0; i < i1; ++i) T[(size_t)i * ld] = (i == j) ? alpha : 0.0;
+        }
         return;
     }
     if (k == j) {

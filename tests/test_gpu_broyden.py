@@ -164,3 +164,21 @@ def test_dq_quasi_newton_batch_bitwise(ds, oracle, n, analytic, spread):
             assert ibs[p][k] == ibo[k], (k, ibs[p], ibo)
         assert np.array_equal(x[p].cpu().numpy(), xo)
         assert np.array_equal(fvec[p].cpu().numpy(), fo)
+
+
+def test_dq_quasi_newton_many_problems_concurrently(ds, oracle):
+    """The batch entry points deal problems to worker threads with private streams (NLH_WORKERS, default 8): every
+    problem must still come out bit-identical to the CPU path, whichever thread solved it and whatever ran beside it."""
+    nprob, n = 24, 48
+    A, b, xt, x0 = ds.generate(nprob, n, n, seed0=4321, sigma=0.0, spread=0.05, square_shift=True)
+    x = x0.clone()
+    fvec, ibs, status = ds.quasi_newton_solve_batch(A, b, 0.5, x, analytic=False, opts=ds.options(max_evals=500))
+    for p in range(nprob):
+        Ah = np.asfortranarray(A[p].cpu().numpy().T)
+        rc, xo, fo, ibo, _ = oracle.dq_quasi_newton_solve(Ah, b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(), analytic=False,
+                                                          opts=oracle.default_options(max_evals=500))
+        assert status[p] == rc
+        for k in COUNT_KEYS:
+            assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
+        assert np.array_equal(x[p].cpu().numpy(), xo), p
+        assert np.array_equal(fvec[p].cpu().numpy(), fo), p
