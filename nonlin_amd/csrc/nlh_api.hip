@@ -400,12 +400,15 @@ static int gram_splits(int nprob, int m, int n)
     return s;
 }
 
+// nact: how many of the nprob problems are expected to take part (the others return at once): the K-split is chosen for
+// that many, so that a round with a few stragglers still fills the chip.
 static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, const double *f,
-                       double *G, double *g, const LmState *st, int want)
+                       double *G, double *g, const LmState *st, int want, int nact = -1)
 {
     const int nb = (n + GRAM_BT - 1) / GRAM_BT;
     const int nblk = nb * (nb + 1) / 2;
-    const int ns = gram_splits(nprob, m, n);
+    int ns = gram_splits(nact > 0 ? std::min(nact, nprob) : nprob, m, n);
+    while (ns > 1 && (size_t)nprob * ns * n * n * sizeof(double) > ((size_t)4 << 30)) --ns;     // slab budget 4 GiB
     int rps = (m + ns - 1) / ns;
     rps = ((rps + GRAM_KT - 1) / GRAM_KT) * GRAM_KT;
     int rc = ensure(h, h->Gpart, sizeof(double) * ((size_t)nprob * ns * n * n + (size_t)nprob * ns * n));
@@ -495,7 +498,7 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
 // One pass over the factorisation + lmpar stages for every problem whose Jacobian is in
 // w.J (stage ST_HAVE_JAC or ST_NEED_QR) or whose factors are ready (inner-loop repeat).
 static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, int m, int n, LmWs &w,
-                              double *dx, const double *dfvec)
+                              double *dx, const double *dfvec, int nact = -1)
 {
     const int ft = factor_threads(n);
     const size_t shl = sizeof(double) * (size_t)(6 * n + 72);
@@ -516,7 +519,7 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
         }
         return 0;
     }
-    int rc = launch_gram(h, nprob, m, n, w.J, dfvec, w.G, w.g, w.st, ST_HAVE_JAC);
+    int rc = launch_gram(h, nprob, m, n, w.J, dfvec, w.G, w.g, w.st, ST_HAVE_JAC, nact);
     if (rc) return rc;
     constexpr int NB = 16;
     {   // fast path: blocked Cholesky in natural order, G -> R
@@ -631,6 +634,7 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         hipLaunchKernelGGL(k_lm_init, dim3(pb), dim3(256), 0, h->stream, nprob, w.nblk, w.part, w.st, first_stage);
 
     const int max_rounds = o->max_evals + 8;
+    int nact = nprob;                                           // problems still iterating (from the previous round)
     for (int round = 0; round < max_rounds; ++round) {
         // outer-loop head for problems that need a Jacobian (:221): n perturbed evaluations + FD
         if (o->fuse_fd) {
@@ -641,7 +645,7 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         }
         hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_NEED_JAC,
                            o->factor_policy != NLH_FACTOR_AUTO ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
-        if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec))) return rc;
+        if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec, nact))) return rc;
         // trial residual (:297-299)
         launch_dq_residual(h, nprob, m, n, dA, db, gamma, w.v.wa2, w.wa4, w.part, w.st, ST_TRIAL_READY);
         hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_TRIAL_READY,
@@ -651,6 +655,7 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         HIPCHK(h, hipMemcpyAsync(h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (*h_active == 0) break;
+        nact = *h_active;
     }
     HIPCHK(h, hipMemcpyAsync(h_state, w.st, sizeof(LmState) * (size_t)nprob, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
