@@ -185,6 +185,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_qr_exact, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lu_panel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_dot, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_dot2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_fused<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -442,9 +443,16 @@ static void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_
         return;
     }
     if (dinfo) hipMemsetAsync(dinfo, 0, sizeof(int32_t) * (size_t)nprob, h->stream);
-    for (int jb = 0; jb < n; jb += LU_NB) {
-        const int nb = (n - jb < LU_NB) ? (n - jb) : LU_NB;
-        hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
+    // panels of 16 columns factored in LDS while the panel fits (n - jb <= 1024 rows), 32-column panels in global memory before
+    for (int jb = 0; jb < n;) {
+        const bool lds = (n - jb) <= LU_PROWS;
+        const int pw = lds ? LU_PNB : LU_NB;
+        const int nb = (n - jb < pw) ? (n - jb) : pw;
+        if (lds)
+            hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(1024), sizeof(double) * (size_t)nb * (n - jb), h->stream,
+                               n, dA, dipvt, dinfo, jb, nb);
+        else
+            hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
         if (n - nb > 0)
             hipLaunchKernelGGL(k_lu_swap, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
                                (const int32_t *)dipvt, jb, nb);
@@ -453,6 +461,7 @@ static void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_
             hipLaunchKernelGGL(k_lu_trsm, dim3((nt + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA, jb, nb);
             hipLaunchKernelGGL(k_lu_gemm, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, h->stream, n, dA, jb, nb);
         }
+        jb += nb;
     }
 }
 

@@ -156,6 +156,79 @@ k_lu_panel(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int
     }
 }
 
+// The same panel factorisation with the panel resident in LDS (rows jb .. n-1 of nb <= LU_PNB columns): the column
+// steps are LDS round trips and barriers instead of global-memory round trips.  Identical operation sequence per
+// element (pivot search, in-panel interchange, reciprocal scaling, a(i,k) -= l(i) u(j,k) for j ascending), so the
+// factors stay bit-identical to the unblocked loop.  One workgroup per problem, thread per row of the panel;
+// rows = n - jb <= LU_PROWS.  Dynamic LDS: nb * rows doubles.
+#define LU_PNB 16
+#define LU_PROWS 1024
+__global__ void __launch_bounds__(1024)
+k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
+               int jb, int nb)
+{
+    extern __shared__ double pan[];                // pan[c * rows + r]: column jb + c, row jb + r
+    __shared__ double red[64];
+    int *redi = reinterpret_cast<int *>(red + 32);
+    const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    const int rows = n - jb;
+    double *a = Aall + (size_t)p * n * n;
+    int32_t *ipvt = ipvt_all + (size_t)p * n;
+    for (int r = tid; r < rows; r += BS) {         // all nb loads of a thread are in flight together
+        double t[LU_PNB];
+#pragma unroll
+        for (int c = 0; c < LU_PNB; ++c) t[c] = (c < nb) ? a[(size_t)(jb + c) * n + jb + r] : 0.0;
+#pragma unroll
+        for (int c = 0; c < LU_PNB; ++c) if (c < nb) pan[c * rows + r] = t[c];
+    }
+    __syncthreads();
+    for (int c = 0; c < nb; ++c) {                 // panel column c = matrix column j = jb + c, pivot row >= c
+        double *cj = pan + c * rows;
+        double bv = 0.0;
+        int bk = 0x7fffffff;
+        for (int r = c + tid; r < rows; r += BS) {
+            const double v = fabs(cj[r]);
+            if (bk == 0x7fffffff || v > bv) { bv = v; bk = r; }
+        }
+        const int piv = block_argmax_first(bv, bk, red, redi);     // row index within the panel
+        const double apj = cj[piv];
+        __syncthreads();
+        if (tid == 0) ipvt[jb + c] = jb + piv;
+        if (apj != 0.0) {
+            if (piv != c) {                        // interchange inside the panel; the rest of the matrix is deferred
+                for (int k = tid; k < nb; k += BS) {
+                    double *ck = pan + k * rows;
+                    const double t = ck[c]; ck[c] = ck[piv]; ck[piv] = t;
+                }
+                __syncthreads();
+            }
+            const double rcp = 1.0 / cj[c];        // row c is not touched below: no barrier needed before the scaling
+            for (int r = c + 1 + tid; r < rows; r += BS) {
+                const double lij = cj[r] * rcp;     // scale, then the rank-one update of the rest of the panel row
+                cj[r] = lij;
+                for (int k = c + 1; k < nb; ++k) {
+                    double *ck = pan + k * rows;
+                    ck[r] = ck[r] - lij * ck[c];
+                }
+            }
+        } else {
+            if (tid == 0 && info && info[p] == 0) info[p] = jb + c + 1;
+            for (int r = c + 1 + tid; r < rows; r += BS) {          // zero pivot: no scaling, the update still runs (l = column as is)
+                const double lij = cj[r];
+                for (int k = c + 1; k < nb; ++k) {
+                    double *ck = pan + k * rows;
+                    ck[r] = ck[r] - lij * ck[c];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int r = tid; r < rows; r += BS) {
+#pragma unroll
+        for (int c = 0; c < LU_PNB; ++c) if (c < nb) a[(size_t)(jb + c) * n + jb + r] = pan[c * rows + r];
+    }
+}
+
 // Deferred row interchanges of panel [jb, jb+nb) applied to every column outside the panel.
 __global__ void __launch_bounds__(256)
 k_lu_swap(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipvt_all, int jb, int nb)
