@@ -443,14 +443,13 @@ static void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_
         return;
     }
     if (dinfo) hipMemsetAsync(dinfo, 0, sizeof(int32_t) * (size_t)nprob, h->stream);
-    // panels of 16 columns factored in LDS while the panel fits (n - jb <= 1024 rows), 32-column panels in global memory before
+    // panels of 16 columns factored in registers (thread per row) while n - jb <= 1024 rows, 32-column panels in global memory before
     for (int jb = 0; jb < n;) {
         const bool lds = (n - jb) <= LU_PROWS;
         const int pw = lds ? LU_PNB : LU_NB;
         const int nb = (n - jb < pw) ? (n - jb) : pw;
         if (lds)
-            hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(1024), sizeof(double) * (size_t)nb * (n - jb), h->stream,
-                               n, dA, dipvt, dinfo, jb, nb);
+            hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
         else
             hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
         if (n - nb > 0)

@@ -156,76 +156,96 @@ k_lu_panel(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int
     }
 }
 
-// The same panel factorisation with the panel resident in LDS (rows jb .. n-1 of nb <= LU_PNB columns): the column
-// steps are LDS round trips and barriers instead of global-memory round trips.  Identical operation sequence per
-// element (pivot search, in-panel interchange, reciprocal scaling, a(i,k) -= l(i) u(j,k) for j ascending), so the
-// factors stay bit-identical to the unblocked loop.  One workgroup per problem, thread per row of the panel;
-// rows = n - jb <= LU_PROWS.  Dynamic LDS: nb * rows doubles.
+// The same panel factorisation with the panel held in registers: thread r owns row jb + r of the nb <= LU_PNB panel
+// columns (rows = n - jb <= LU_PROWS = blockDim).  A column step is: wave arg-max of |a(r, c)| and a 16-entry scan of
+// the per-wave results (first maximum), the pivot row and row c published through LDS, the two owners exchanging
+// rows, then every thread scales its multiplier and updates the rest of its row -- two barriers per column, no
+// global or LDS traffic for the panel body.  Identical operation sequence per element (pivot search, in-panel
+// interchange, reciprocal scaling, a(i,k) -= l(i) u(j,k) for j ascending): bit-identical to the unblocked loop.
 #define LU_PNB 16
 #define LU_PROWS 1024
 __global__ void __launch_bounds__(1024)
 k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
                int jb, int nb)
 {
-    extern __shared__ double pan[];                // pan[c * rows + r]: column jb + c, row jb + r
-    __shared__ double red[64];
-    int *redi = reinterpret_cast<int *>(red + 32);
-    const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    __shared__ double redv[2][16];
+    __shared__ int redi[2][16];
+    __shared__ double prow[2][LU_PNB], crow[2][LU_PNB];
+    const int p = blockIdx.x, r = threadIdx.x, lane = r & 63, wid = r >> 6, nw = (blockDim.x + 63) >> 6;
     const int rows = n - jb;
     double *a = Aall + (size_t)p * n * n;
     int32_t *ipvt = ipvt_all + (size_t)p * n;
-    for (int r = tid; r < rows; r += BS) {         // all nb loads of a thread are in flight together
-        double t[LU_PNB];
+    const bool mine = r < rows;
+    double row[LU_PNB];
 #pragma unroll
-        for (int c = 0; c < LU_PNB; ++c) t[c] = (c < nb) ? a[(size_t)(jb + c) * n + jb + r] : 0.0;
+    for (int k = 0; k < LU_PNB; ++k) row[k] = (mine && k < nb) ? a[(size_t)(jb + k) * n + jb + r] : 0.0;
 #pragma unroll
-        for (int c = 0; c < LU_PNB; ++c) if (c < nb) pan[c * rows + r] = t[c];
-    }
-    __syncthreads();
-    for (int c = 0; c < nb; ++c) {                 // panel column c = matrix column j = jb + c, pivot row >= c
-        double *cj = pan + c * rows;
-        double bv = 0.0;
-        int bk = 0x7fffffff;
-        for (int r = c + tid; r < rows; r += BS) {
-            const double v = fabs(cj[r]);
-            if (bk == 0x7fffffff || v > bv) { bv = v; bk = r; }
+    for (int c = 0; c < LU_PNB; ++c) {
+        if (c < nb) {                              // uniform
+            const int par = c & 1;
+            // first maximum of |a(r, c)| over r >= c
+            double v = (mine && r >= c) ? fabs(row[c]) : -1.0;
+            int idx = (mine && r >= c) ? r : 0x7fffffff;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_down(v, off, 64);
+                const int oi = __shfl_down(idx, off, 64);
+                const bool take = (oi != 0x7fffffff) && (idx == 0x7fffffff || ov > v || (ov == v && oi < idx));
+                if (take) { v = ov; idx = oi; }
+            }
+            if (lane == 0) { redv[par][wid] = v; redi[par][wid] = idx; }
+            __syncthreads();
+            double bv = redv[par][0];
+            int piv = redi[par][0];
+            for (int w = 1; w < nw; ++w) {
+                const double ov = redv[par][w];
+                const int oi = redi[par][w];
+                const bool take = (oi != 0x7fffffff) && (piv == 0x7fffffff || ov > bv || (ov == bv && oi < piv));
+                if (take) { bv = ov; piv = oi; }
+            }
+            // the pivot row and row c through LDS
+            if (r == piv) {
+#pragma unroll
+                for (int k = 0; k < LU_PNB; ++k) prow[par][k] = row[k];
+            }
+            if (r == c) {
+#pragma unroll
+                for (int k = 0; k < LU_PNB; ++k) crow[par][k] = row[k];
+            }
+            __syncthreads();
+            const double apj = prow[par][c];
+            if (r == 0) ipvt[jb + c] = jb + piv;
+            if (apj != 0.0) {
+                if (piv != c) {                    // interchange inside the panel; the rest of the matrix is deferred
+                    if (r == c) {
+#pragma unroll
+                        for (int k = 0; k < LU_PNB; ++k) row[k] = prow[par][k];
+                    } else if (r == piv) {
+#pragma unroll
+                        for (int k = 0; k < LU_PNB; ++k) row[k] = crow[par][k];
+                    }
+                }
+                if (mine && r > c) {
+                    const double rcp = 1.0 / apj;
+                    const double lij = row[c] * rcp;
+                    row[c] = lij;
+#pragma unroll
+                    for (int k = c + 1; k < LU_PNB; ++k) row[k] = row[k] - lij * prow[par][k];
+                }
+            } else {
+                if (r == 0 && info && info[p] == 0) info[p] = jb + c + 1;
+                if (mine && r > c) {               // zero pivot: no interchange, no scaling; the update still runs
+                    const double lij = row[c];
+#pragma unroll
+                    for (int k = c + 1; k < LU_PNB; ++k) row[k] = row[k] - lij * crow[par][k];
+                }
+            }
         }
-        const int piv = block_argmax_first(bv, bk, red, redi);     // row index within the panel
-        const double apj = cj[piv];
-        __syncthreads();
-        if (tid == 0) ipvt[jb + c] = jb + piv;
-        if (apj != 0.0) {
-            if (piv != c) {                        // interchange inside the panel; the rest of the matrix is deferred
-                for (int k = tid; k < nb; k += BS) {
-                    double *ck = pan + k * rows;
-                    const double t = ck[c]; ck[c] = ck[piv]; ck[piv] = t;
-                }
-                __syncthreads();
-            }
-            const double rcp = 1.0 / cj[c];        // row c is not touched below: no barrier needed before the scaling
-            for (int r = c + 1 + tid; r < rows; r += BS) {
-                const double lij = cj[r] * rcp;     // scale, then the rank-one update of the rest of the panel row
-                cj[r] = lij;
-                for (int k = c + 1; k < nb; ++k) {
-                    double *ck = pan + k * rows;
-                    ck[r] = ck[r] - lij * ck[c];
-                }
-            }
-        } else {
-            if (tid == 0 && info && info[p] == 0) info[p] = jb + c + 1;
-            for (int r = c + 1 + tid; r < rows; r += BS) {          // zero pivot: no scaling, the update still runs (l = column as is)
-                const double lij = cj[r];
-                for (int k = c + 1; k < nb; ++k) {
-                    double *ck = pan + k * rows;
-                    ck[r] = ck[r] - lij * ck[c];
-                }
-            }
-        }
-        __syncthreads();
     }
-    for (int r = tid; r < rows; r += BS) {
+    if (mine) {
 #pragma unroll
-        for (int c = 0; c < LU_PNB; ++c) if (c < nb) a[(size_t)(jb + c) * n + jb + r] = pan[c * rows + r];
+        for (int k = 0; k < LU_PNB; ++k)
+            if (k < nb) a[(size_t)(jb + k) * n + jb + r] = row[k];
     }
 }
 

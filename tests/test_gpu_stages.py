@@ -183,3 +183,22 @@ def test_lu_bit_exact(ds, oracle, n):
     assert np.array_equal(ipvt[0].cpu().numpy(), ipo)
     assert np.array_equal(Ad[0].cpu().numpy().T, lu)
     assert np.array_equal(bd[0].cpu().numpy(), xo)
+
+
+@pytest.mark.parametrize("n", [40, 130, 300])
+def test_lu_singular_and_tied_pivots(ds, oracle, n):
+    """A zero pivot column (info = its 1-based index, the update still runs) and exact ties in the pivot search
+    (the first maximum wins): the factors stay bit-identical to the CPU loop."""
+    import ctypes as C
+    rng = np.random.default_rng(n)
+    Ah = np.asfortranarray(rng.integers(-3, 4, size=(n, n)).astype(np.float64))     # many ties
+    Ah[:, 5] = 0.0                                                                    # structurally singular
+    lu = Ah.copy(order="F")
+    ipo = np.zeros(n, dtype=np.int32)
+    L = oracle.lib()
+    rc = L.nlo_lu_factor(n, lu.ctypes.data_as(C.POINTER(C.c_double)), n, ipo.ctypes.data_as(C.POINTER(C.c_int32)))
+    Ad = torch.tensor(np.ascontiguousarray(Ah.T), device="cuda").unsqueeze(0)
+    ipvt, info = ds.lu_factor(Ad)
+    assert int(info[0]) == rc and rc > 0
+    assert np.array_equal(ipvt[0].cpu().numpy(), ipo)
+    assert np.array_equal(Ad[0].cpu().numpy().T, lu, equal_nan=True)
