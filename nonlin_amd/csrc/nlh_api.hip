@@ -52,7 +52,7 @@ struct nlh_handle {
     std::vector<DevBuf *> bufs;       // every workspace buffer, for destroy
     // named workspace buffers (grown on demand, reused across calls)
     DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2, R,
-           qnQ, qnR, qnV, bfB, bfR, bfV;
+           qnQ, qnR, qnV, bfB, bfR, bfV, qxV;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     std::vector<nlh_handle *> workers;   // private handles (own stream + workspace) for concurrent host-loop solves
@@ -183,6 +183,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_lmpar<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qr_exact, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qr_exact_lazy<QX_B, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_panel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -477,7 +478,8 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
     int rc;
     const size_t mn = (size_t)nprob * m * n, pm = (size_t)nprob * m, pn = (size_t)nprob * n;
     if ((rc = ensure(h, h->J, sizeof(double) * mn))) return rc;
-    if (need_panel && (rc = ensure(h, h->P, sizeof(double) * mn))) return rc;
+    // + a residual column and read-ahead padding behind the last problem (exact QR, k_qr_exact_lazy)
+    if (need_panel && (rc = ensure(h, h->P, sizeof(double) * (mn + pm + (size_t)512 * (n + 1))))) return rc;
     if ((rc = ensure(h, h->wa4, sizeof(double) * pm))) return rc;
     if ((rc = ensure(h, h->scratch, sizeof(double) * pm))) return rc;
     if ((rc = ensure(h, h->G, sizeof(double) * (size_t)nprob * n * n))) return rc;
@@ -515,10 +517,24 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
         {
             Timed t(h, NLH_K_QR);
             dim3 grid((m + 31) / 32, (n + 31) / 32, nprob);
-            hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, w.st, (int)ST_NEED_QR);
-            size_t sh = sizeof(double) * (size_t)(2 * n + 64 + 3 * NLH_NCH + 8 + QX_VC);
-            hipLaunchKernelGGL(k_qr_exact, dim3(nprob), dim3(ft), sh, h->stream, m, n, w.P, dfvec, w.R, w.v,
-                               w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, 0);
+            const size_t lds_cap = 158 * 1024;
+            // deferred-update kernel (512 threads, 256 VGPRs each) up to n = 511; the plain one above that
+            const int qt = std::min(ft, 512);
+            const size_t sh8 = sizeof(double) * QlLds<QX_B, 512>::doubles(n, qt);
+            const bool lazy = m >= n && n + 1 <= qt && sh8 <= lds_cap;
+            if (lazy) {
+                // row stride n + 1 (residual as last column), reflector ring in h->qxV
+                int rc;
+                if ((rc = ensure(h, h->qxV, sizeof(double) * ((size_t)nprob * QX_B * m + 512)))) return rc;
+                hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, n + 1, w.st, (int)ST_NEED_QR);
+                hipLaunchKernelGGL((k_qr_exact_lazy<QX_B, 512>), dim3(nprob), dim3(qt), sh8, h->stream, m, n, w.P, dfvec,
+                                   w.R, w.v, w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, (double *)h->qxV.p);
+            } else {
+                hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, n, w.st, (int)ST_NEED_QR);
+                size_t sh = sizeof(double) * (size_t)(2 * n + 64 + 3 * NLH_NCH + 8 + QX_VC);
+                hipLaunchKernelGGL(k_qr_exact, dim3(nprob), dim3(ft), sh, h->stream, m, n, w.P, dfvec, w.R, w.v,
+                                   w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, 0);
+            }
         }
         {
             Timed t(h, NLH_K_LMPAR);
@@ -1081,7 +1097,7 @@ static void launch_qn_qr(nlh_handle *h, int nprob, int n, const double *dB, doub
     double *vbuf = dvb, *wbuf = dvb + (size_t)nprob * 2 * n, *st = wbuf + (size_t)nprob * 4 * n;
     {
         dim3 grid((n + 31) / 32, (n + 31) / 32, nprob);
-        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, n, n, dB, dRt, (const LmState *)nullptr, -1);
+        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, n, n, dB, dRt, n, (const LmState *)nullptr, -1);
     }
     hipLaunchKernelGGL(k_qn_qr_init, dim3(std::min(1024, (n * n + 255) / 256), nprob), dim3(256), 0, s, n, dRt, dQ, vbuf);
     launch_house_steps(h, nprob, n, n, n, dRt, dQ, vbuf, wbuf, st);
@@ -1344,7 +1360,7 @@ static int cls_core(nlh_handle *h, const nlh_options *o, double delta0, double s
         HIPCHK(h, hipMemcpyAsync(dE, dfv, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
         {
             dim3 grid((m + 31) / 32, (n + 31) / 32, 1);
-            hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, m, n, dJ, dW, (const LmState *)nullptr, -1);
+            hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, m, n, dJ, dW, n, (const LmState *)nullptr, -1);
         }
         hipLaunchKernelGGL(k_qn_col0, dim3((m + 255) / 256, 1), dim3(256), 0, s, m, n, dW, vbuf);
         launch_house_steps(h, 1, m, n, 1, dW, dE, vbuf, wbuf, st);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define NLH_WAVE 64
 
@@ -202,8 +203,29 @@ __device__ double norm2_flang_block(Get get, int len, double *scratch)
         }
         __syncthreads();
         if (tid == 0) {
+            // the recurrence itself is serial; read eight (c, d) pairs at a time so that the LDS latency
+            // is paid once per batch, and take the multiply out of the chain when no new maximum occurs
             double s = carry[1];
-            for (int i = 0; i < cl; ++i) {
+            int i = 0;
+            for (; i + 8 <= cl; i += 8) {
+                double c8[8], d8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { c8[u] = av[i + u]; d8[u] = dd[i + u]; }
+                bool plain = true;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) plain = plain && (c8[u] == 1.0);
+                if (plain) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = s + d8[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (c8[u] != 1.0) s = s * c8[u];
+                        s = s + d8[u];
+                    }
+                }
+            }
+            for (; i < cl; ++i) {
                 const double c = av[i];
                 if (c != 1.0) s = s * c;
                 s = s + dd[i];
@@ -213,6 +235,115 @@ __device__ double norm2_flang_block(Get get, int len, double *scratch)
         }
         __syncthreads();
     }
+    const double r = carry[0] * sqrt(1.0 + carry[1]);
+    __syncthreads();
+    return r;
+}
+
+// The same NORM2 with a wide chunk: cd holds 2*cap doubles (cap <= EMAX*blockDim), aux 40 + blockDim/2
+// doubles.  The running maximum before every element comes from a wave scan (shuffles) plus one LDS
+// exchange, i.e. three barriers per chunk instead of log2(chunk) of them.  The serial recurrence is
+// unchanged, but the one thread that runs it executes as few instructions as possible: every thread
+// flags whether its EMAX consecutive elements are free of a new maximum (all c == 1), and a flagged
+// run is a plain chain of adds over terms fetched one run ahead.  Bit-identical to norm2_flang_block.
+template <int EMAX, typename Get>
+__device__ double norm2_flang_block_wide(Get get, int len, double *cd, int cap, double *aux)
+{
+    static_assert(EMAX % 2 == 0, "runs are read as pairs");
+    const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
+    double *cs = cd, *dsv = cd + cap, *wmax = aux, *carry = aux + 32;
+    int *flags = reinterpret_cast<int *>(aux + 40);
+    __syncthreads();
+    if (tid == 0) { carry[0] = 0.0; carry[1] = 0.0; }
+    for (int base = 0; base < len; base += cap) {
+        const int cl = min(cap, len - base);
+        const int E = (cl + BS - 1) / BS, i0 = tid * E;              // E <= EMAX consecutive elements per thread
+        double a[EMAX], lm = 0.0;
+#pragma unroll
+        for (int u = 0; u < EMAX; ++u) {
+            a[u] = (u < E && i0 + u < cl) ? fabs(get(base + i0 + u)) : 0.0;
+            lm = fmax(lm, a[u]);
+        }
+        double sc = lm;                                              // inclusive prefix maximum over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(sc, off, 64);
+            if (lane >= off) sc = fmax(sc, o);
+        }
+        double ex = __shfl_up(sc, 1, 64);
+        if (lane == 0) ex = 0.0;
+        __syncthreads();                                             // carry of the previous chunk is final
+        if (lane == 63) wmax[wid] = sc;
+        __syncthreads();
+        const double mx_in = carry[0];
+        double prev = fmax(mx_in, ex);
+        for (int w = 0; w < wid; ++w) prev = fmax(prev, wmax[w]);
+        bool plain = (E == EMAX) && (i0 + EMAX <= cl);
+#pragma unroll
+        for (int u = 0; u < EMAX; ++u) {
+            if (u < E && i0 + u < cl) {
+                double c = 1.0, d = 0.0;
+                if (prev == 0.0) {
+                    // mx was zero: element becomes the maximum, s untouched
+                } else if (a[u] > prev) {
+                    const double t = prev / a[u], tsq = t * t;
+                    c = tsq; d = tsq;
+                } else if (a[u] != 0.0) {
+                    const double t = a[u] / prev;
+                    d = t * t;
+                }
+                plain = plain && (c == 1.0);
+                cs[i0 + u] = c;
+                dsv[i0 + u] = d;
+                prev = fmax(prev, a[u]);
+            }
+        }
+        flags[tid] = plain ? 1 : 0;
+        __syncthreads();
+        if (tid == 0) {
+            double s = carry[1];
+            const int nrun = (cl + E - 1) / E;                       // runs of E elements, one per contributing thread
+            auto general = [&](int i, int cnt) {
+                for (int u = 0; u < cnt; ++u) {
+                    const double c = cs[i + u];
+                    if (c != 1.0) s = s * c;
+                    s = s + dsv[i + u];
+                }
+            };
+            double da[EMAX], db[EMAX];
+            int fa = 0, fb = 0;
+            auto load = [&](double (&d)[EMAX], int &f, int r) {
+                f = flags[r];
+                const double2 *src = reinterpret_cast<const double2 *>(dsv + r * EMAX);   // plain runs have E == EMAX
+#pragma unroll
+                for (int u = 0; u < EMAX / 2; ++u) { const double2 v2 = src[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
+            };
+            auto chain = [&](const double (&d)[EMAX], int f, int r) {
+                if (f) {
+#pragma unroll
+                    for (int u = 0; u < EMAX; ++u) s = s + d[u];
+                } else {
+                    general(r * E, min(E, cl - r * E));
+                }
+            };
+            if (E == EMAX) {
+                load(da, fa, 0);
+                for (int r = 0; r < nrun; r += 2) {
+                    if (r + 1 < nrun) load(db, fb, r + 1);
+                    chain(da, fa, r);
+                    if (r + 2 < nrun) load(da, fa, r + 2);
+                    if (r + 1 < nrun) chain(db, fb, r + 1);
+                }
+            } else {
+                general(0, cl);
+            }
+            double mx = mx_in;
+            for (int w = 0; w < nw; ++w) mx = fmax(mx, wmax[w]);
+            carry[1] = s;
+            carry[0] = mx;
+        }
+    }
+    __syncthreads();
     const double r = carry[0] * sqrt(1.0 + carry[1]);
     __syncthreads();
     return r;

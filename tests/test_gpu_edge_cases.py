@@ -32,6 +32,28 @@ def test_lm_degenerate_and_square_shapes_exact_policy(ds, oracle, m, n):
         assert np.array_equal(x[p].cpu().numpy(), xo) and np.array_equal(fvec[p].cpu().numpy(), fo)
 
 
+@pytest.mark.parametrize("m,n", [(128, 12), (600, 70), (1500, 130)])
+def test_lm_rank_deficient_jacobian_exact_policy(ds, oracle, m, n):
+    """A zero column (lmfactor meets ajnorm == 0, :646) and a duplicated column (the downdated column norm collapses
+    and is recomputed, :656-661): bit-identical to the CPU path, whatever the status of the solve is."""
+    A, b, xt, x0 = ds.generate(3, m, n, seed0=77)
+    A[0, 3, :] = 0.0                                 # A is [nprob][n][m]: column 3 of problem 0
+    A[1, 5, :] = A[1, 2, :]
+    x0[1, 5] = x0[1, 2]                              # same variable value: the two Jacobian columns coincide too
+    A[2, 3, :] = 0.0
+    A[2, n - 1, :] = A[2, 0, :]
+    x0[2, n - 1] = x0[2, 0]
+    x = x0.clone()
+    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=200, factor_policy=2))
+    for p in range(3):
+        rc, xo, fo, ibo = _oracle_lm(oracle, A[p], b[p], x0[p], max_evals=200)[:4]
+        assert status[p] == rc
+        for k in COUNT_KEYS:
+            assert ibs[p][k] == ibo[k], (m, n, p, k, ibs[p], ibo)
+        assert np.array_equal(x[p].cpu().numpy(), xo, equal_nan=True)
+        assert np.array_equal(fvec[p].cpu().numpy(), fo, equal_nan=True)
+
+
 def test_empty_batch_is_a_no_op(ds):
     A = torch.empty((0, 4, 21), dtype=torch.float64, device=ds.device)
     b = torch.empty((0, 21), dtype=torch.float64, device=ds.device)
