@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--m", type=int, default=M)
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--cpu-sample", type=int, default=24, help="problems timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--exact-sample", type=int, default=64, help="problems for the exact-policy figure (0 = skip)")
+    ap.add_argument("--exact-sample", type=int, default=256, help="problems for the exact-policy figure (0 = skip)")
     ap.add_argument("--policy", type=int, default=0, help="0 auto (J^T J + Cholesky), 1 QR, 2 exact (reference order)")
     ap.add_argument("--fuse-fd", type=int, default=0,
                     help="1: form the Jacobian column in the panel kernel's epilogue (k_fd_jacobian is then not launched)")

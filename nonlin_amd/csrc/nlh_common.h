@@ -384,6 +384,32 @@ __device__ __forceinline__ double nrm2_block(Get get, int len, double *red, doub
     }
 }
 
+// Left-to-right sum of buf[0..len) (LDS, 16-byte aligned) by the calling thread: the reads of a batch are
+// issued together and one batch ahead, so only the adds themselves are serial.
+__device__ __forceinline__ double ordered_sum_lds(const double *buf, int len)
+{
+    double s = 0.0, a[8], b[8];
+    const double2 *src = reinterpret_cast<const double2 *>(buf);
+    const int nb = len >> 3;
+    auto load = [&](double (&d)[8], int g) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const double2 v2 = src[g * 4 + u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
+    };
+    if (nb > 0) load(a, 0);
+    for (int g = 0; g < nb; g += 2) {
+        if (g + 1 < nb) load(b, g + 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = s + a[u];
+        if (g + 2 < nb) load(a, g + 2);
+        if (g + 1 < nb) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = s + b[u];
+        }
+    }
+    for (int i = nb << 3; i < len; ++i) s = s + buf[i];
+    return s;
+}
+
 // Sum of term(0..len-1): left-to-right by one thread when EXACT, tree otherwise.  Broadcast.
 template <bool EXACT, typename Term>
 __device__ __forceinline__ double sum_block(Term term, int len, double *red)

@@ -27,7 +27,8 @@
 template <bool EXACT>
 __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, const double *diagv,
                             const double *qtb, double *x, double *sdiag, double *wa, double *red,
-                            double *Wrows, double *qtbp, double *rot /* LDS, n + 8 doubles */)
+                            double *Wrows, double *qtbp, double *rot /* LDS, n + 8 doubles */,
+                            double *sbuf /* LDS, n doubles, EXACT only */)
 {
     const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
     for (int j = 0; j < n; ++j) {                              // :710-714
@@ -39,80 +40,78 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
     for (int j = tid; j < n; j += BS) Wrows[(size_t)j * n + j] = diagv[ipvt[j]];   // sdiag(j) = diag(l) (:723)
     __syncthreads();
 
+    // State the sweep hands from one time step to the next lives in LDS, so that forming a rotation needs no
+    // global access: sdiag[k] carries the current diagonal of column k (its value after (k,k) is the sdiag of
+    // :763, and the diagonal of r in memory is never touched, which is the restore of :764), rot[j] the entry
+    // W_j[k] of working row j that the next rotation of elimination j eliminates.
+    for (int j = tid; j < n; j += BS) { sdiag[j] = x[j]; rot[j] = diagv[ipvt[j]]; }
+    __syncthreads();
     for (int t = 0; t <= 2 * (n - 1); ++t) {                   // :717-765 as a wavefront
         const int jlo = t - (n - 1) > 0 ? t - (n - 1) : 0, jhi = t >> 1;
         const int nrot = jhi - jlo + 1;
-        // phase A: one thread per rotation forms (cs, sn) and the scalar updates (:733-748)
-        for (int q = tid; q < nrot; q += BS) {
-            const int j = jlo + q, k = t - j;
-            double *Wj = Wrows + (size_t)j * n;
-            double *colk = r + (size_t)k * ldr;
-            const bool act = diagv[ipvt[j]] != 0.0;            // :721
-            const double sk = Wj[k];
-            double cs = 1.0, sn = 0.0;
-            if (act && sk != 0.0) {                            // :732
-                const double rkk = colk[k];
-                if (fabs(rkk) < fabs(sk)) {                    // :733-741
-                    const double ctan = rkk / sk;
-                    sn = 0.5 / sqrt(0.25 + 0.25 * (ctan * ctan));
-                    cs = sn * ctan;
-                } else {
-                    const double tn = sk / rkk;
-                    cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
-                    sn = cs * tn;
-                }
-                const double wk = wa[k], qj = qtbp[j];
-                colk[k] = cs * rkk + sn * sk;                  // :745
-                wa[k] = cs * wk + sn * qj;                     // :746-748
-                qtbp[j] = -sn * wk + cs * qj;
-                rot[2 * q] = cs;
-                rot[2 * q + 1] = sn;
-            } else {
-                rot[2 * q] = 2.0;                              // marker: rotation skipped (:732 cycle)
-                rot[2 * q + 1] = 0.0;
-            }
-            if (k == j) {                                      // :763-764 (column j is final after (j,j))
-                sdiag[j] = colk[j];
-                colk[j] = x[j];
-            }
-        }
-        __syncthreads();
-        // phase B: apply the rotations to the rest of column k and working row j (:753-757);
-        // a wave takes RG rotations at a time so their loads are in flight together
+        // A wave takes RG rotations at a time: their first loads are issued, lane u forms rotation u
+        // (:733-748) while they are in flight, and all lanes then apply the rotations to the rest of
+        // column k and working row j (:753-757).  One barrier per time step.
         constexpr int RG = 4;
         for (int q0 = wid * RG; q0 < nrot; q0 += nw * RG) {
-            double cs[RG], sn[RG];
             int kk[RG];
             double *cp[RG], *wp[RG];
-            int imax = 0;
+            double rv[RG], sv[RG];
 #pragma unroll
             for (int u = 0; u < RG; ++u) {
-                const int q = q0 + u;
-                const bool ok = q < nrot && rot[2 * (q < nrot ? q : 0)] != 2.0;
-                const int j = jlo + (q < nrot ? q : 0), k = t - j;
-                cs[u] = ok ? rot[2 * q] : 1.0;
-                sn[u] = ok ? rot[2 * q + 1] : 0.0;
-                kk[u] = ok ? k : n;                             // n => no elements
+                const int q = q0 + u < nrot ? q0 + u : q0;
+                const int j = jlo + q, k = t - j;
+                kk[u] = k;
                 cp[u] = r + (size_t)k * ldr;
                 wp[u] = Wrows + (size_t)j * n;
-                if (ok && n - k - 1 > imax) imax = n - k - 1;
+                const int i = k + 1 + lane;
+                const bool in = (q0 + u < nrot) && i < n;
+                rv[u] = in ? cp[u][i] : 0.0;
+                sv[u] = in ? wp[u][i] : 0.0;
             }
-            for (int e = lane; e < imax; e += 64) {
-                double rv[RG], sv[RG];
-#pragma unroll
-                for (int u = 0; u < RG; ++u) {
-                    const int i = kk[u] + 1 + e;
-                    const bool in = i < n;
-                    rv[u] = in ? cp[u][i] : 0.0;
-                    sv[u] = in ? wp[u][i] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < RG; ++u) {
-                    const int i = kk[u] + 1 + e;
-                    if (i < n) {
-                        cp[u][i] = cs[u] * rv[u] + sn[u] * sv[u];
-                        wp[u][i] = -sn[u] * rv[u] + cs[u] * sv[u];
+            double mycs = 1.0, mysn = 0.0;
+            int myok = 0;
+            if (lane < RG && q0 + lane < nrot) {
+                const int j = jlo + q0 + lane, k = t - j;
+                const bool act = diagv[ipvt[j]] != 0.0;            // :721
+                const double sk = rot[j];
+                if (act && sk != 0.0) {                            // :732
+                    const double rkk = sdiag[k];
+                    if (fabs(rkk) < fabs(sk)) {                    // :733-741
+                        const double ctan = rkk / sk;
+                        mysn = 0.5 / sqrt(0.25 + 0.25 * (ctan * ctan));
+                        mycs = mysn * ctan;
+                    } else {
+                        const double tn = sk / rkk;
+                        mycs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
+                        mysn = mycs * tn;
                     }
+                    const double wk = wa[k], qj = qtbp[j];
+                    sdiag[k] = mycs * rkk + mysn * sk;             // :745
+                    wa[k] = mycs * wk + mysn * qj;                 // :746-748
+                    qtbp[j] = -mysn * wk + mycs * qj;
+                    myok = 1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RG; ++u) {
+                const double cs = __shfl(mycs, u, 64), sn = __shfl(mysn, u, 64);
+                const int ok = __shfl(myok, u, 64);
+                if (q0 + u >= nrot) continue;                      // uniform
+                const int k = kk[u], j = t - k;
+                if (!ok) {                                         // rotation skipped (:732 cycle): row and column untouched
+                    if (lane == 0 && k + 1 < n) rot[j] = sv[u];
+                    continue;
+                }
+                double rcur = rv[u], scur = sv[u];
+                for (int i = k + 1 + lane; i < n; i += 64) {
+                    const bool more = i + 64 < n;
+                    const double rnx = more ? cp[u][i + 64] : 0.0, snx = more ? wp[u][i + 64] : 0.0;
+                    const double wnew = -sn * rcur + cs * scur;
+                    cp[u][i] = cs * rcur + sn * scur;
+                    wp[u][i] = wnew;
+                    if (i == k + 1) rot[j] = wnew;
+                    rcur = rnx; scur = snx;
                 }
             }
         }
@@ -130,10 +129,19 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
     for (int k = 1; k <= ns; ++k) {
         const int j = ns - k;
         const double *colj = r + (size_t)j * ldr;
-        const double sm = sum_block<EXACT>([&](int i) { return colj[j + 1 + i] * wa[j + 1 + i]; }, ns - j - 1, red);
-        __syncthreads();
-        if (tid == 0) wa[j] = (wa[j] - sm) / sdiag[j];
-        __syncthreads();
+        if (EXACT && n <= 3 * NLH_NCH) {
+            // products in parallel, then their ascending sum by one thread (the reference's dot product, :779)
+            const int len = ns - j - 1;
+            for (int i = tid; i < len; i += BS) sbuf[i] = colj[j + 1 + i] * wa[j + 1 + i];
+            __syncthreads();
+            if (tid == 0) wa[j] = (wa[j] - ordered_sum_lds(sbuf, len)) / sdiag[j];
+            __syncthreads();
+        } else {
+            const double sm = sum_block<EXACT>([&](int i) { return colj[j + 1 + i] * wa[j + 1 + i]; }, ns - j - 1, red);
+            __syncthreads();
+            if (tid == 0) wa[j] = (wa[j] - sm) / sdiag[j];
+            __syncthreads();
+        }
     }
     for (int j = tid; j < n; j += BS) x[ipvt[j]] = wa[j];       // :787-790
     __syncthreads();
@@ -190,12 +198,31 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
         __syncthreads();
         for (int j = tid; j < n; j += BS) { const int l = ipvt[j]; wa1[j] = diag[l] * (wa2n[l] / dxnorm); }
         __syncthreads();
-        for (int j = 0; j < n; ++j) {
-            const double *colj = r + (size_t)j * ldr;
-            const double sm = sum_block<EXACT>([&](int i) { return colj[i] * wa1[i]; }, j, red);
+        if (EXACT && n <= 3 * NLH_NCH) {
+            // forward substitution with one accumulator per row: row j adds r(i,j) * wa1(i) as soon as wa1(i) is
+            // final, i.e. in ascending i -- the order of the reference's inner loop (:495-499) -- for all rows at once
+            for (int j = tid; j < n; j += BS) scratch[j] = 0.0;
             __syncthreads();
-            if (tid == 0) wa1[j] = (wa1[j] - sm) / colj[j];
+            if (tid == 0) wa1[0] = (wa1[0] - 0.0) / r[0];
             __syncthreads();
+            for (int i = 0; i + 1 < n; ++i) {
+                const double wi = wa1[i];
+                for (int j = i + 1 + tid; j < n; j += BS) {
+                    const double *colj = r + (size_t)j * ldr;
+                    const double acc = scratch[j] + colj[i] * wi;
+                    scratch[j] = acc;
+                    if (j == i + 1) wa1[j] = (wa1[j] - acc) / colj[j];
+                }
+                __syncthreads();
+            }
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const double *colj = r + (size_t)j * ldr;
+                const double sm = sum_block<EXACT>([&](int i) { return colj[i] * wa1[i]; }, j, red);
+                __syncthreads();
+                if (tid == 0) wa1[j] = (wa1[j] - sm) / colj[j];
+                __syncthreads();
+            }
         }
         temp = nrm2_block<EXACT>([&](int j) { return wa1[j]; }, n, red, scratch);
         parl = ((fp / delta) / temp) / temp;
@@ -223,7 +250,7 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
         __syncthreads();
         for (int i = tid; i < n; i += BS) wa1[i] = temp * diag[i];
         __syncthreads();
-        lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red, Wrows, z, rot);
+        lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red, Wrows, z, rot, scratch);
         for (int i = tid; i < n; i += BS) wa2n[i] = diag[i] * x[i];
         __syncthreads();
         if (EXACT) {                                           // :531 deviation A: norm over all m entries
