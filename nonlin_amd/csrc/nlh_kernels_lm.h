@@ -169,13 +169,29 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
     nsing = -(int)block_reduce_max((double)(-nsing), red);
     for (int j = tid; j < n; j += BS) wa1[j] = (j < nsing) ? qtb[j] : 0.0;
     __syncthreads();
-    for (int k = 1; k <= nsing; ++k) {
-        const int j = nsing - k;
-        const double temp = wa1[j] / r[(size_t)j * ldr + j];
-        const double *colj = r + (size_t)j * ldr;
-        for (int i = tid; i < j; i += BS) wa1[i] = wa1[i] - colj[i] * temp;
-        if (tid == 0) z[j] = temp;
-        __syncthreads();
+    {
+        // column j-1 (first element per thread and the diagonal) is fetched while column j is applied, so that a
+        // step costs a barrier instead of a dependent global load
+        double pre = 0.0, dpre = 1.0;
+        if (nsing > 0) {
+            const int j0 = nsing - 1;
+            pre = (tid < j0) ? r[(size_t)j0 * ldr + tid] : 0.0;
+            dpre = r[(size_t)j0 * ldr + j0];
+        }
+        for (int k = 1; k <= nsing; ++k) {
+            const int j = nsing - k;
+            const double cur = pre, dcur = dpre;
+            if (j > 0) {
+                pre = (tid < j - 1) ? r[(size_t)(j - 1) * ldr + tid] : 0.0;
+                dpre = r[(size_t)(j - 1) * ldr + j - 1];
+            }
+            const double temp = wa1[j] / dcur;
+            const double *colj = r + (size_t)j * ldr;
+            if (tid < j) wa1[tid] = wa1[tid] - cur * temp;
+            for (int i = tid + BS; i < j; i += BS) wa1[i] = wa1[i] - colj[i] * temp;
+            if (tid == 0) z[j] = temp;
+            __syncthreads();
+        }
     }
     for (int j = tid; j < n; j += BS) {
         const double v = (j < nsing) ? z[j] : 0.0;
@@ -463,9 +479,19 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
     const double pnorm = nrm2_block<EXACT>([&](int j) { return wa1[j]; }, n, red, scratch);
     __syncthreads();
     // :307-312  wa3 = R (P^T p), row i accumulates columns j ascending
+    for (int j = tid; j < n; j += BS) wa1[j] = xs[ipvt[j]];    // P^T p (wa1 is free after pnorm)
+    __syncthreads();
     for (int i = tid; i < n; i += BS) {
         double acc = 0.0;
-        for (int j = i; j < n; ++j) acc = acc + R[(size_t)j * n + i] * xs[ipvt[j]];
+        int j = i;
+        for (; j + 8 <= n; j += 8) {                           // eight loads in flight, adds in column order
+            double rv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rv[u] = R[(size_t)(j + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + rv[u] * wa1[j + u];
+        }
+        for (; j < n; ++j) acc = acc + R[(size_t)j * n + i] * wa1[j];
         z[i] = acc;
     }
     __syncthreads();
