@@ -72,24 +72,43 @@ k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ 
             if (q != j) { const double t = bs[j]; bs[j] = bs[q]; bs[q] = t; }
         }
     __syncthreads();
-    for (int j = 0; j < n; ++j) {                 // L y = P b (unit diagonal)
-        const double bj = bs[j];
-        if (bj != 0.0) {
-            const double *cj = a + (size_t)j * n;
-            for (int i = j + 1 + tid; i < n; i += BS) bs[i] = bs[i] - bj * cj[i];
-        }
-        __syncthreads();
-    }
-    for (int j = n - 1; j >= 0; --j) {            // U x = y
-        const double bjr = bs[j];
-        if (bjr != 0.0) {
-            const double *cj = a + (size_t)j * n;
-            const double bj = bjr / cj[j];
+    // Each thread owns row tid (+ BS, ...).  Its entry of the next column is fetched before the barrier of the
+    // current step, so a step costs a barrier and an LDS update rather than a global load issued after it.
+    {
+        double pre = (tid > 0 && tid < n) ? a[tid] : 0.0;          // column 0
+        for (int j = 0; j < n; ++j) {                              // L y = P b (unit diagonal)
+            const double cur = pre;
+            if (j + 1 < n) pre = (tid > j + 1 && tid < n) ? a[(size_t)(j + 1) * n + tid] : 0.0;
+            const double bj = bs[j];
+            if (bj != 0.0) {
+                const double *cj = a + (size_t)j * n;
+                if (tid > j && tid < n) bs[tid] = bs[tid] - bj * cur;
+                for (int i = tid + BS; i < n; i += BS)
+                    if (i > j) bs[i] = bs[i] - bj * cj[i];
+            }
             __syncthreads();
-            for (int i = tid; i < j; i += BS) bs[i] = bs[i] - bj * cj[i];
-            if (tid == 0) bs[j] = bj;
         }
-        __syncthreads();
+    }
+    {
+        const int jl = n - 1;
+        double pre = (tid < jl) ? a[(size_t)jl * n + tid] : 0.0, dpre = a[(size_t)jl * n + jl];
+        for (int j = n - 1; j >= 0; --j) {                         // U x = y
+            const double cur = pre, dcur = dpre;
+            if (j > 0) {
+                pre = (tid < j - 1) ? a[(size_t)(j - 1) * n + tid] : 0.0;
+                dpre = a[(size_t)(j - 1) * n + j - 1];
+            }
+            const double bjr = bs[j];
+            if (bjr != 0.0) {
+                const double *cj = a + (size_t)j * n;
+                const double bj = bjr / dcur;
+                __syncthreads();
+                if (tid < j) bs[tid] = bs[tid] - bj * cur;
+                for (int i = tid + BS; i < j; i += BS) bs[i] = bs[i] - bj * cj[i];
+                if (tid == 0) bs[j] = bj;
+            }
+            __syncthreads();
+        }
     }
     for (int i = tid; i < n; i += BS) b[i] = bs[i];
 }
