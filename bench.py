@@ -74,6 +74,82 @@ def cpu_baseline(sample, m, n):
     return out
 
 
+
+def other_paths(ds):
+    """The remaining rows of SURVEY section 8 (a16-a24 Newton, f1 quasi-Newton, f2 bounded least squares, f3 BFGS,
+    f4 polynomial fit), one problem each (4096 fits for the polynomial), second (warm) run timed on the GPU;
+    the CPU oracle runs the same problem on one host core and the solutions are compared bit for bit."""
+    import numpy as np
+    import torch
+    from oracle import pyoracle as O
+
+    def timed(f):
+        f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = f()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    def cpu(f):
+        t0 = time.perf_counter()
+        r = f()
+        return r, time.perf_counter() - t0
+
+    rows = []
+    n = 1024
+    xg = [None]
+    for name, gsolve, csolve, gen in (
+            ("newton_solver (LU), analytic Jacobian, n=1024", ds.newton_solve_batch, O.dq_newton_solve, {}),
+            ("quasi_newton_solver (Broyden, QR + rank-1 update), analytic Jacobian, n=1024", ds.quasi_newton_solve_batch,
+             O.dq_quasi_newton_solve, dict(spread=0.03))):
+        A, b, xt, x0 = ds.generate(1, n, n, seed0=12345, sigma=0.0, square_shift=True, **gen)
+        Ah, bh, xh = np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), x0[0].cpu().numpy()
+
+        def run_square():
+            xg[0] = x0.clone()
+            return gsolve(A, b, 0.5, xg[0], analytic=True, opts=ds.options(max_evals=500))
+        (_, ibs, st), tg = timed(run_square)
+        ro, tc = cpu(lambda: csolve(Ah, bh, 0.5, xh, opts=O.default_options(max_evals=500)))
+        rows.append({"path": name, "gpu_ms": 1e3 * tg, "cpu_oracle_ms": 1e3 * tc, "iterations": ibs[0]["iter_count"],
+                     "bitwise_equal": bool(np.array_equal(ro[1], xg[0][0].cpu().numpy()))})
+    m, n = 4096, 256
+    A, b, xt, x0 = ds.generate(1, m, n, seed0=12345)
+    Ah, bh, xh = np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), x0[0].cpu().numpy()
+    lo, up = np.full(n, -2.0), np.full(n, 2.0)
+
+    def run_cls():
+        xg[0] = x0.clone()
+        return ds.cls_solve_batch(A, b, 0.5, xg[0], opts=ds.options(max_evals=500), lower=lo, upper=up)
+    (_, ibs, st), tg = timed(run_cls)
+    ro, tc = cpu(lambda: O.dq_cls_solve(Ah, bh, 0.5, xh, opts=O.default_options(max_evals=500), lower=lo, upper=up))
+    rows.append({"path": "constrained_least_squares_solver (bounded dog-leg), FD Jacobian, 4096x256", "gpu_ms": 1e3 * tg,
+                 "cpu_oracle_ms": 1e3 * tc, "iterations": ibs[0]["iter_count"],
+                 "bitwise_equal": bool(np.array_equal(ro[1], xg[0][0].cpu().numpy()))})
+    m, n = 2048, 256
+    A, b, xt, x0 = ds.generate(1, m, n, seed0=77, spread=0.1)
+    Ah, bh, xh = np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), x0[0].cpu().numpy()
+    ob = dict(max_evals=400, gtol=1e-8, xtol=1e-12)
+
+    def run_bfgs():
+        xg[0] = x0.clone()
+        return ds.bfgs_solve_batch(A, b, 0.5, xg[0], opts=ds.options(**ob))
+    (_, ibs, st), tg = timed(run_bfgs)
+    ro, tc = cpu(lambda: O.dq_bfgs_solve(Ah, bh, 0.5, xh, opts=O.default_options(**ob)))
+    rows.append({"path": "bfgs (FD gradient, Cholesky rank-1 updates), 2048x256", "gpu_ms": 1e3 * tg, "cpu_oracle_ms": 1e3 * tc,
+                 "iterations": ibs[0]["iter_count"], "bitwise_equal": bool(np.array_equal(ro[1], xg[0][0].cpu().numpy()))})
+    nfit, npts, order = 4096, 4096, 7
+    g = torch.Generator(device=ds.device).manual_seed(1)
+    px = torch.rand((nfit, npts), dtype=torch.float64, device=ds.device, generator=g) * 2 - 1
+    py = torch.cos(3 * px) + 0.01 * torch.randn((nfit, npts), dtype=torch.float64, device=ds.device, generator=g)
+    c, tg = timed(lambda: ds.poly_fit_batch(px, py, order))
+    xs, ys = px[:16].cpu().numpy(), py[:16].cpu().numpy()
+    co, tc = cpu(lambda: [O.poly_fit(xs[q], ys[q], order)[1] for q in range(16)])
+    rows.append({"path": "polynomial%fit, 4096 fits x 4096 points, order 7", "gpu_ms": 1e3 * tg,
+                 "cpu_oracle_ms": 1e3 * tc * nfit / 16, "cpu_sample": "16 fits, scaled to 4096",
+                 "bitwise_equal": bool(all(np.array_equal(c[q].cpu().numpy(), co[q]) for q in range(16)))})
+    return rows
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +161,9 @@ def main():
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--cpu-sample", type=int, default=24, help="problems timed on the CPU oracle (0 = skip)")
     ap.add_argument("--exact-sample", type=int, default=256, help="problems for the exact-policy figure (0 = skip)")
+    ap.add_argument("--other-paths", type=int, default=1,
+                    help="1 = also time the Newton / quasi-Newton / bounded LSQ / BFGS / polynomial rows (SURVEY 8 a16-a24, f1-f4) "
+                         "on the GPU and on the CPU oracle and check the results bit for bit")
     ap.add_argument("--policy", type=int, default=0, help="0 auto (J^T J + Cholesky), 1 QR, 2 exact (reference order)")
     ap.add_argument("--fuse-fd", type=int, default=0,
                     help="1: form the Jacobian column in the panel kernel's epilogue (k_fd_jacobian is then not launched)")
@@ -275,6 +354,8 @@ def main():
             te = time.perf_counter() - te
             out["exact_policy"] = {"value": sum(i["jacobian_count"] for i in ibe) / te, "unit": "LM iterations/s",
                                    "problems": Be, "note": "NLH_FACTOR_EXACT: bit-identical to the CPU path"}
+        if world == 1 and args.other_paths:
+            out["other_paths"] = other_paths(ds)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -9,8 +9,8 @@ TAG=${1:-r01}
 cd "${GRAFT_REPO_ROOT:-.}" && export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --exact-sample 0"
-ONE="python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --exact-sample 0"
+BENCH="python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --exact-sample 0 --other-paths 0"
+ONE="python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --exact-sample 0 --other-paths 0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$TAG" -- $BENCH > "$OUT/stats.log" 2>&1
 for grp in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
     timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/$grp" -o "$TAG" -- $ONE > "$OUT/$grp.log" 2>&1

@@ -34,6 +34,8 @@ def test_bench_single_process():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert d["exact_policy"]["value"] > 0
+    rows = d["other_paths"]                                   # Newton, quasi-Newton, bounded LSQ, BFGS, polynomial
+    assert len(rows) == 5 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
 
 
 def test_bench_under_torchrun_one_rank():
@@ -41,7 +43,7 @@ def test_bench_under_torchrun_one_rank():
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
                           "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "16", "--cpu-sample", "0",
-                          "--exact-sample", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                          "--exact-sample", "0", "--other-paths", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     _check(line, 1)
