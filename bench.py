@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--cpu-sample", type=int, default=24, help="problems timed on the CPU oracle (0 = skip)")
     ap.add_argument("--exact-sample", type=int, default=256, help="problems for the exact-policy figure (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="0 = skip the single_problem and fused_fd legs (profiles/capture.sh: every launch rocprofv3 sees "
+                         "then belongs to a warm-up or timed step, so its per-kernel averages are the ones printed here)")
     ap.add_argument("--other-paths", type=int, default=1,
                     help="1 = also time the Newton / quasi-Newton / bounded LSQ / BFGS / polynomial rows (SURVEY 8 a16-a24, f1-f4) "
                          "on the GPU and on the CPU oracle and check the results bit for bit")
@@ -310,7 +313,7 @@ def main():
             {"kernel": "k_dq_residual", "bound": "hbm", "achieved": resid_bytes / max(rms * 1e-3, 1e-30) / 1e9,
              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": resid_bytes / max(rms * 1e-3, 1e-30) / 1e9 / HBM_PEAK_GBS},
         ]
-        if world == 1:
+        if world == 1 and args.extras:
             # latency of BASELINE config 2 taken literally: ONE 4096 x 256 problem (seed 12345), warm handle
             x1 = x0[:1].clone()
             ds.lm_solve_batch(A[:1], b[:1], gamma, x1, opts)
@@ -322,7 +325,7 @@ def main():
             t1 = time.perf_counter() - t1
             out["single_problem"] = {"ms": 1e3 * t1, "lm_iterations": ib1[0]["jacobian_count"],
                                      "lm_iterations_per_s": ib1[0]["jacobian_count"] / t1}
-        if world == 1 and not args.fuse_fd:
+        if world == 1 and args.extras and not args.fuse_fd:
             # same batch with the FD column write fused into the panel kernel (bit-identical results, one kernel
             # and one 8mn-byte round trip less per Jacobian); the headline keeps the stand-alone FD kernel
             of = ds.options(max_evals=max_evals, factor_policy=args.policy, fuse_fd=1)
