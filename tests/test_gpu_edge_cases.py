@@ -54,6 +54,23 @@ def test_lm_rank_deficient_jacobian_exact_policy(ds, oracle, m, n):
         assert np.array_equal(fvec[p].cpu().numpy(), fo, equal_nan=True)
 
 
+@pytest.mark.parametrize("m,n", [(70, 63), (64, 64), (131, 65), (200, 95), (99, 96), (300, 127), (260, 128), (259, 129),
+                                 (258, 255), (515, 257), (520, 511), (513, 512)])
+def test_lm_exact_policy_at_kernel_boundaries(ds, oracle, m, n):
+    """Sizes on either side of every switch inside the exact-policy QR (64 / 128 / 256 / 512 column slots, the
+    256- and 512-thread launches, the n = 512 hand-over to the plain kernel) with m barely above n, so that the
+    last tiles are short or absent: bit-identical to the CPU path."""
+    A, b, xt, x0 = ds.generate(2, m, n, seed0=1000 + n, square_shift=(m == n))
+    x = x0.clone()
+    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=60 * (n + 1), factor_policy=2))
+    for p in range(2):
+        rc, xo, fo, ibo = _oracle_lm(oracle, A[p], b[p], x0[p], max_evals=60 * (n + 1))[:4]
+        assert status[p] == rc
+        for k in COUNT_KEYS:
+            assert ibs[p][k] == ibo[k], (m, n, p, k, ibs[p], ibo)
+        assert np.array_equal(x[p].cpu().numpy(), xo) and np.array_equal(fvec[p].cpu().numpy(), fo)
+
+
 def test_empty_batch_is_a_no_op(ds):
     A = torch.empty((0, 4, 21), dtype=torch.float64, device=ds.device)
     b = torch.empty((0, 21), dtype=torch.float64, device=ds.device)
