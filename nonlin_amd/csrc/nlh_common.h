@@ -371,6 +371,47 @@ __device__ __forceinline__ double norm2_flang_serial(Get get, int len)
     return mx * sqrt(1.0 + s);
 }
 
+// norm2_flang_serial over p[0], p[stride], ...: sixteen loads in flight, the next sixteen issued before the
+// recurrence consumes the current ones (a column walk would otherwise pay one memory latency per element).
+__device__ __forceinline__ double norm2_flang_serial_strided(const double *p, size_t stride, int len)
+{
+    double mx = 0.0, s = 0.0;
+    auto step = [&](double v) {
+        const double a = fabs(v);
+        if (mx == 0.0) {
+            mx = a;
+        } else if (a > mx) {
+            const double t = mx / a, tsq = t * t;
+            s = s * tsq;
+            s = s + tsq;
+            mx = a;
+        } else if (a != 0.0) {
+            const double t = a / mx;
+            s = s + t * t;
+        }
+    };
+    double xa[16], xb[16];
+    const int nb = len >> 4;
+    auto load = [&](double (&x)[16], int g) {
+        const double *q = p + (size_t)g * 16 * stride;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = q[(size_t)u * stride];
+    };
+    if (nb > 0) load(xa, 0);
+    for (int g = 0; g < nb; g += 2) {
+        if (g + 1 < nb) load(xb, g + 1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) step(xa[u]);
+        if (g + 2 < nb) load(xa, g + 2);
+        if (g + 1 < nb) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) step(xb[u]);
+        }
+    }
+    for (int i = nb << 4; i < len; ++i) step(p[(size_t)i * stride]);
+    return mx * sqrt(1.0 + s);
+}
+
 // Norm of get(0..len-1): reference order when EXACT, tree sum of squares otherwise.
 template <bool EXACT, typename Get>
 __device__ __forceinline__ double nrm2_block(Get get, int len, double *red, double *scratch)

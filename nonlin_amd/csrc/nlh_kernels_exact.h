@@ -95,7 +95,7 @@ k_qr_exact(int m, int n, double *__restrict__ Jt_all, const double *__restrict__
 
     // initial column norms (:611-616): one thread per column, reference-order NORM2
     for (int k = tid; k < n; k += BS) {
-        const double nr = norm2_flang_serial([&](int i) { return a[(size_t)i * n + k]; }, m);
+        const double nr = norm2_flang_serial_strided(a + k, n, m);
         acnorm[k] = nr; rdiag[k] = nr; wa[k] = nr; ipvt[k] = k;
     }
     __syncthreads();
@@ -295,14 +295,14 @@ k_qr_exact_lazy(int m, int n, double *__restrict__ At_all, const double *__restr
     const double *f = fall + (size_t)p * m;
     for (int i = tid; i < m; i += BS) a[(size_t)i * ld + n] = f[i];          // wa4 = fvec (:241)
     for (int k = tid; k < n; k += BS) {                                       // :611-616
-        const double nr = norm2_flang_serial([&](int i) { return a[(size_t)i * ld + k]; }, m);
+        const double nr = norm2_flang_serial_strided(a + k, ld, m);
         acnorm[k] = nr; rdiag[k] = nr; wa[k] = nr; ipvt[k] = k;
     }
     __syncthreads();
 
     int s0 = 0, np = 0;                             // pending reflectors live in slots (s0 + q) & (B-1), q < np
 #ifdef QX_PROFILE
-    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, tl0 = wall_clock64();
+    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, tl0 = wall_clock64(), tstart = tl0;
     unsigned long long tc2[3] = {0, 0, 0}, tl2 = 0;
 #define QX_TICK(x) { unsigned long long t_ = wall_clock64(); tc[x] += t_ - tl0; tl0 = t_; tl2 = t_; }
 #define QX_TICK2(x) { unsigned long long t_ = wall_clock64(); tc2[x] += t_ - tl2; tl2 = t_; }
@@ -585,6 +585,7 @@ k_qr_exact_lazy(int m, int n, double *__restrict__ At_all, const double *__restr
 
 #ifdef QX_PROFILE
     if (p == 0 && tid == 0)
+        printf("qx total in loop %llu; ", wall_clock64() - tstart);
         printf("qx cycles(100MHz): pivot+form %llu norm %llu scale %llu pass %llu post %llu misc %llu | elementwise+sum %llu barrier %llu - %llu\n", tc[0], tc[1], tc[2],
                tc[3], tc[4], tc[5], tc2[0], tc2[1], tc2[2]);
 #endif
