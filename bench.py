@@ -342,6 +342,42 @@ def main():
                 nj += sum(i["jacobian_count"] for i in ibf)
             out["fused_fd"] = {"value": nj / tf, "unit": "LM iterations/s", "identical_x": bool(torch.equal(xf, x)),
                                "note": "opts.fuse_fd = 1: Jacobian column formed in the panel kernel's epilogue"}
+        if world == 1 and args.extras:
+            # several batches in flight: one handle (workspace + HIP stream) per host thread, so that the
+            # latency-bound stages of one batch (Cholesky, lmpar, straggler rounds, the per-round status read-back)
+            # overlap the streaming kernels of another.  Same inputs, same results; per-kernel times are not
+            # meaningful in this mode, which is why the headline and its roofline are measured one batch at a time.
+            import threading
+            nfl, ksteps = 4, 12
+            streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+            solvers = []
+            for st_ in streams:
+                with torch.cuda.stream(st_):
+                    solvers.append(DeviceSolver(local_rank))
+            for label, of in (("pipelined", opts), ("pipelined_fused_fd", ds.options(max_evals=max_evals, factor_policy=args.policy,
+                                                                                  fuse_fd=1))):
+                xs_ = [x0.clone() for _ in range(nfl)]
+                counts = [0] * nfl
+
+                def work(i, nsteps):
+                    with torch.cuda.stream(streams[i]):
+                        for _ in range(nsteps):
+                            xs_[i].copy_(x0)
+                            _, ibw, _ = solvers[i].lm_solve_batch(A, b, gamma, xs_[i], of)
+                            counts[i] += sum(q["jacobian_count"] for q in ibw)
+                for timed_pass in (False, True):
+                    for i in range(nfl):
+                        counts[i] = 0
+                    torch.cuda.synchronize()
+                    tp0 = time.perf_counter()
+                    th = [threading.Thread(target=work, args=(i, ksteps // nfl if timed_pass else 1)) for i in range(nfl)]
+                    [t_.start() for t_ in th]
+                    [t_.join() for t_ in th]
+                    torch.cuda.synchronize()
+                    tp = time.perf_counter() - tp0
+                out[label] = {"value": sum(counts) / tp, "unit": "LM iterations/s", "batches_in_flight": nfl, "steps": ksteps,
+                              "ms_per_step": 1e3 * tp / ksteps, "identical_x": bool(all(torch.equal(xq, x) for xq in xs_))}
+            del solvers
         if world == 1 and args.policy == 0 and args.exact_sample > 0:
             # the same workload under the exact factor policy (reference operation order: x, fvec and all
             # counts bit-identical to the CPU path, tests/test_gpu_solvers.py), one untimed + one timed pass

@@ -34,6 +34,7 @@ def test_bench_single_process():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert d["exact_policy"]["value"] > 0
+    assert d["pipelined"]["identical_x"] and d["pipelined"]["value"] > 0 and d["pipelined_fused_fd"]["identical_x"]
     rows = d["other_paths"]                                   # Newton, quasi-Newton, bounded LSQ, BFGS, polynomial
     assert len(rows) == 5 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
 
