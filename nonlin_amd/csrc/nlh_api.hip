@@ -177,6 +177,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     h->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
     // allow the single-workgroup kernels their full dynamic LDS (n-vectors live there)
     const int lds_max = 160 * 1024 - 2048;
+    hipFuncSetAttribute((const void *)k_gram_tri, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_nopiv<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -420,9 +421,17 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
     {
         Timed t(h, NLH_K_GRAM);
         const long items = (long)ns * nprob;
-        const long groups = (items + 7) / 8;
-        hipLaunchKernelGGL(k_gram_mfma, dim3((unsigned)(groups * 8 * nblk)), dim3(256), 0, h->stream, m, n, rps, J, Gp,
-                           g ? f : (const double *)nullptr, gp, st, want, nblk, ns, nprob);
+        const long active = (long)ns * (nact > 0 ? std::min(nact, nprob) : nprob);
+        if (n > 224 && n <= GRAM_TN && active >= 256) {
+            // enough items to give every CU a workgroup: whole lower triangle per workgroup, J staged once
+            const size_t sh = sizeof(double) * (size_t)(GRAM_TN * GRAM_LD + GRAM_KT + 1024);
+            hipLaunchKernelGGL(k_gram_tri, dim3((unsigned)items), dim3(512), sh, h->stream, m, n, rps, J, Gp,
+                               g ? f : (const double *)nullptr, gp, st, want, ns);
+        } else {
+            const long groups = (items + 7) / 8;
+            hipLaunchKernelGGL(k_gram_mfma, dim3((unsigned)(groups * 8 * nblk)), dim3(256), 0, h->stream, m, n, rps, J, Gp,
+                               g ? f : (const double *)nullptr, gp, st, want, nblk, ns, nprob);
+        }
     }
     {
         Timed t(h, NLH_K_GRAM_REDUCE);

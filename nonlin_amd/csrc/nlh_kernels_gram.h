@@ -190,6 +190,132 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 224 < n <= 256: one 512-thread workgroup per (problem, K-split) item forms the WHOLE lower triangle.
+// k_gram_mfma gives every 64x64 block of G its own workgroup, so the rows of J are staged ~4 times per item (PMC:
+// 26.8 MB fetched per 4096x256 problem against 8.4 MB of J) and a barrier pair covers only 32 MFMAs per wave.
+// Here the 32-row tile of all 256 columns is staged once (69.6 KB of LDS) and the 136 MFMA tiles of the lower
+// triangle are dealt 17 to a wave: wave W takes tile rows 15-W and W (16-W and W+1 tiles, whose column operands
+// coincide), i.e. 2 + 16-W operand reads for 17 MFMAs per k-step and 136 MFMAs per wave between barriers.
+// Same accumulation order as k_gram_mfma (rows ascending inside a split, splits summed by k_gram_reduce), same
+// output slabs: bitwise the same G and g.
+#define GRAM_TN 256
+template <int W>
+__device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, int kend, int m, int n,
+                                              const double *Jp, const double *fp, double *Gp, double *gout, double *gscr)
+{
+    constexpr int NL = 16 - W, NS = W + 1, RL = 15 - W, RS = W;      // long / short tile row of this wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int lr = tid % GRAM_KT, lc0 = tid / GRAM_KT;                // loader: row lr, columns lc0 + 16*cc
+    constexpr int LSTEP = 512 / GRAM_KT, NLD = GRAM_TN / LSTEP;
+    v4d accL[NL], accS[NS];
+#pragma unroll
+    for (int c = 0; c < NL; ++c) accL[c] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < NS; ++c) accS[c] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int lrow = (lane & 15) * GRAM_LD + (lane >> 4);
+    const unsigned baddr = (unsigned)(size_t)(tA + lrow);
+    const unsigned aaddrL = (unsigned)(size_t)(tA + RL * 16 * GRAM_LD + lrow);
+    const unsigned aaddrS = (unsigned)(size_t)(tA + RS * 16 * GRAM_LD + lrow);
+    double ra[NLD];
+    auto load_tile = [&](int k0) {
+        const int row = k0 + lr;
+        const bool rok = row < kend;
+#pragma unroll
+        for (int cc = 0; cc < NLD; ++cc) {
+            const int col = lc0 + LSTEP * cc;
+            ra[cc] = (rok && col < n) ? Jp[(size_t)col * m + row] : 0.0;
+        }
+    };
+    // g = J^T f: column tid & 255, two quarters of the tile per thread (the same four partial sums per column as
+    // k_gram_mfma keeps in four threads)
+    const int gc = tid & 255, gh = tid >> 8;
+    double gq0 = 0.0, gq1 = 0.0;
+    if (kbeg < kend) load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GRAM_KT) {
+#pragma unroll
+        for (int cc = 0; cc < NLD; ++cc) tA[(lc0 + LSTEP * cc) * GRAM_LD + lr] = ra[cc];
+        if (fp && tid < GRAM_KT) fs[tid] = (k0 + tid < kend) ? fp[k0 + tid] : 0.0;
+        __syncthreads();
+        if (k0 + GRAM_KT < kend) load_tile(k0 + GRAM_KT);
+        if (fp) {
+            const double *col = tA + gc * GRAM_LD + gh * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gq0 = gq0 + col[i] * fs[gh * 16 + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gq1 = gq1 + col[8 + i] * fs[gh * 16 + 8 + i];
+        }
+#pragma unroll
+        for (int ks = 0; ks < GRAM_KT / 4; ++ks) {
+            double aL, aS, b[NL];
+            asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4"
+                         : "=&v"(aL), "=&v"(aS) : "v"(aaddrL), "v"(aaddrS), "n"(ks * 32) : "memory");
+#pragma unroll
+            for (int c = 0; c < NL; ++c)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(b[c]) : "v"(baddr), "n"(c * 16 * GRAM_LD * 8 + ks * 32) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aL), "+v"(aS));
+#pragma unroll
+            for (int c = 0; c < NL; ++c) asm volatile("" : "+v"(b[c]));
+#pragma unroll
+            for (int c = 0; c < NL; ++c) {
+                accL[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL, b[c], accL[c], 0, 0, 0);
+                if (c < NS) accS[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS, b[c], accS[c], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (fp) {
+        gscr[tid] = gq0;
+        gscr[512 + tid] = gq1;
+        __syncthreads();
+        if (tid < 256 && tid < n)
+            gout[tid] = ((gscr[tid] + gscr[512 + tid]) + gscr[256 + tid]) + gscr[768 + tid];
+    }
+    // f64 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
+#pragma unroll
+    for (int c = 0; c < NL; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = RL * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
+            if (gr < n && gcol < n) Gp[(size_t)gcol * n + gr] = accL[c][r];
+        }
+#pragma unroll
+    for (int c = 0; c < NS; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = RS * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
+            if (gr < n && gcol < n) Gp[(size_t)gcol * n + gr] = accS[c][r];
+        }
+}
+
+__global__ void __launch_bounds__(512)
+k_gram_tri(int m, int n, int rows_per_split, const double *__restrict__ J, double *__restrict__ Gpart,
+           const double *__restrict__ f, double *__restrict__ gpart, const LmState *__restrict__ st, int want_stage,
+           int nsplit)
+{
+    extern __shared__ double gsm[];
+    double *tA = gsm;                                   // GRAM_TN * GRAM_LD
+    double *fs = tA + GRAM_TN * GRAM_LD;                // GRAM_KT
+    double *gscr = fs + GRAM_KT;                        // 1024
+    const int item = blockIdx.x, p = item / nsplit, split = item % nsplit;
+    if (st && st[p].stage != want_stage) return;
+    const int kbeg = split * rows_per_split, kend = min(m, kbeg + rows_per_split);
+    const double *Jp = J + (size_t)p * m * n;
+    const double *fp = f ? f + (size_t)p * m : nullptr;
+    double *Gp = Gpart + ((size_t)p * nsplit + split) * (size_t)n * n;
+    double *gout = gpart + ((size_t)p * nsplit + split) * n;
+    switch (threadIdx.x >> 6) {
+    case 0: gram_tri_wave<0>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
+    case 1: gram_tri_wave<1>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
+    case 2: gram_tri_wave<2>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
+    case 3: gram_tri_wave<3>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
+    case 4: gram_tri_wave<4>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
+    case 5: gram_tri_wave<5>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
+    case 6: gram_tri_wave<6>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
+    default: gram_tri_wave<7>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
+    }
+}
+
 // Sum the K-split partials in split order and mirror the lower triangle.
 __global__ void __launch_bounds__(256)
 k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__restrict__ G,
