@@ -559,7 +559,10 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
         Timed t(h, NLH_K_CHOL);
         size_t sh = sizeof(double) * ((size_t)NB * n + NB * NB + n + NB + 64);
         if (sh <= 150 * 1024) {
-            hipLaunchKernelGGL(k_chol_nopiv<NB>, dim3(nprob), dim3(ft), sh, h->stream, n, w.G, w.g, w.R, w.v, dx, w.st,
+            // more problems than CUs: 512-thread workgroups, two of which fit a CU (128 VGPRs each), so that the
+            // latency-bound phases of one factorisation overlap the MFMA phase of the other
+            const int ct = (ft == 1024 && (nact < 0 ? nprob : nact) > 256) ? 512 : ft;
+            hipLaunchKernelGGL(k_chol_nopiv<NB>, dim3(nprob), dim3(ct), sh, h->stream, n, w.G, w.g, w.R, w.v, dx, w.st,
                                o->factor, o->gtol, o->ne_pivot_tol);
         } else {    // panel does not fit LDS: go straight to the pivoted (unblocked) factorisation
             size_t sh2 = sizeof(double) * (size_t)(3 * n + 64);
@@ -569,7 +572,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
     }
     {
         Timed t(h, NLH_K_LMPAR);
-        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.R, w.v, dx, w.wa4, w.P,
+        const int lt = (ft == 1024 && n <= 512 && (nact < 0 ? nprob : nact) > 256) ? 512 : ft;   // two workgroups per CU, as for the Cholesky
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(lt), shl, h->stream, m, n, w.R, w.v, dx, w.wa4, w.P,
                            w.J, w.W2, w.st, (int)ST_NE_READY);
     }
     {   // problems whose lmpar iteration needs lmfactor's pivot order (or with a weak pivot)

@@ -412,6 +412,22 @@ def test_lm_c4_batch_property_and_spot_parity(ds, oracle):
         assert _rel(x[p].cpu().numpy(), xo) <= RTOL_X_FD_NOISE
 
 
+def test_lm_batch_larger_than_the_chip(ds, oracle):
+    """More problems than CUs (320 > 256): the Cholesky and lmpar stages then run as 512-thread workgroups, two to a
+    CU, and 4096 x 256 problems take the whole-triangle Gram kernel.  Every problem converges; spot parity with the
+    oracle at the FD-noise bound, for a small shape and for the headline shape."""
+    for (nprob, m, n, spots) in ((320, 512, 128, (0, 160, 319)), (288, 4096, 256, (287,))):
+        A, b, xt, x0 = ds.generate(nprob, m, n, seed0=4242)
+        x = x0.clone()
+        fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500))
+        assert all(s == 0 for s in status)
+        for p in spots:
+            rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5,
+                                                       x0[p].cpu().numpy(), opts=oracle.default_options(max_evals=500))
+            assert rc == 0 and _counts_match(ibs[p], ibo, strict=False)
+            assert _rel(x[p].cpu().numpy(), xo) <= RTOL_X_FD_NOISE
+
+
 @pytest.mark.parametrize("m,n", [(1024, 300), (700, 513)])
 def test_lm_wide_problems_both_policies(ds, oracle, m, n):
     """n > 256 (several Gram blocks per row, multi-panel blocked Cholesky, n + 1 > 256 column threads):
