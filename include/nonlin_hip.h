@@ -283,6 +283,8 @@ int nlh_poly_fit_batch(nlh_handle *h, int32_t nprob, int32_t npts, int32_t order
 #define NLH_K_LU           10
 #define NLH_K_DQ_JACOBIAN  11
 #define NLH_K_COUNT        12
+/* on: 0 = off, 1 = every kernel group, otherwise a mask with bit (k + 1) set for each group NLH_K_<k> to time
+   (two HIP event records per timed launch on the handle's stream). */
 void nlh_timing_enable(nlh_handle *h, int32_t on);
 void nlh_timing_reset(nlh_handle *h);
 /* Synchronises the stream, then returns total milliseconds and launch count. */

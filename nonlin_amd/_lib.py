@@ -161,8 +161,15 @@ class Handle:
             raise RuntimeError(f"{what}: library error {rc}: {self.lib.nlh_last_error(self._h).decode()}")
         return rc
 
-    def timing_enable(self, on=True):
-        self.lib.nlh_timing_enable(self._h, 1 if on else 0)
+    def timing_enable(self, on=True, kernels=None):
+        """on: every kernel group; kernels=[names]: only those groups (two event records per timed launch)."""
+        if kernels:
+            mask = 0
+            for k in kernels:
+                mask |= 1 << (KERNEL_IDS[k] + 1)
+            self.lib.nlh_timing_enable(self._h, mask)
+        else:
+            self.lib.nlh_timing_enable(self._h, 1 if on else 0)
 
     def timing_reset(self):
         self.lib.nlh_timing_reset(self._h)

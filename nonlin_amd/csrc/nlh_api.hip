@@ -43,7 +43,7 @@ struct nlh_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    bool timing = false;
+    uint32_t timing = 0;              // bit k: kernel group k is bracketed by HIP events
     struct Pair { hipEvent_t a, b; int kid; };
     std::vector<Pair> pending;
     std::vector<hipEvent_t> pool;
@@ -120,7 +120,7 @@ static hipEvent_t ev_get(nlh_handle *h)
 
 struct Timed {
     nlh_handle *h; int kid; hipEvent_t a{}, b{}; bool on;
-    Timed(nlh_handle *h_, int kid_) : h(h_), kid(kid_), on(h_->timing)
+    Timed(nlh_handle *h_, int kid_) : h(h_), kid(kid_), on((h_->timing >> kid_) & 1u)
     {
         if (on) { a = ev_get(h); b = ev_get(h); hipEventRecord(a, h->stream); }
     }
@@ -225,7 +225,13 @@ void nlh_destroy(nlh_handle *h)
 
 const char *nlh_last_error(const nlh_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
-void nlh_timing_enable(nlh_handle *h, int32_t on) { if (h) h->timing = on != 0; }
+void nlh_timing_enable(nlh_handle *h, int32_t on)
+{
+    if (!h) return;
+    // 0 = off, 1 = every kernel group, otherwise bit (k + 1) selects group NLH_K_<k> (timing costs two event records
+    // per launch, so a caller that needs one kernel's durations can leave the others unbracketed)
+    h->timing = on == 0 ? 0u : on == 1 ? 0xffffffffu : ((uint32_t)on >> 1);
+}
 void nlh_timing_reset(nlh_handle *h)
 {
     if (!h) return;
@@ -414,7 +420,12 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
     while (ns > 1 && (size_t)nprob * ns * n * n * sizeof(double) > ((size_t)4 << 30)) --ns;     // slab budget 4 GiB
     int rps = (m + ns - 1) / ns;
     rps = ((rps + GRAM_KT - 1) / GRAM_KT) * GRAM_KT;
-    int rc = ensure(h, h->Gpart, sizeof(double) * ((size_t)nprob * ns * n * n + (size_t)nprob * ns * n));
+    // The slab is sized once for the deepest split any round of this batch can ask for (a straggler round uses more
+    // splits than the first one): growing it in the middle of a solve is a device-wide free + malloc.
+    int nscap = gram_splits(1, m, n);
+    while (nscap > 1 && (size_t)nprob * nscap * n * n * sizeof(double) > ((size_t)4 << 30)) --nscap;
+    if (nscap < ns) nscap = ns;
+    int rc = ensure(h, h->Gpart, sizeof(double) * ((size_t)nprob * nscap * n * n + (size_t)nprob * nscap * n));
     if (rc) return rc;
     double *Gp = (double *)h->Gpart.p;
     double *gp = Gp + (size_t)nprob * ns * n * n;
