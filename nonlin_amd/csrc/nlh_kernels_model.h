@@ -119,16 +119,28 @@ k_dq_panel(int m, int n, const double *__restrict__ A, const double *__restrict_
         }
     }
     {
+        // the loads of the next PF columns are in flight while the JT * PF adds of the current ones run
         int k = j0 + JT;
-        for (; k + PF <= n; k += PF) {
-            double av[PF];
+        double av[PF], aw[PF];
+        if (k + PF <= n) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) av[u] = a[(size_t)(k + u) * m];
+        }
+        for (; k + PF <= n; k += PF) {
+            const bool more = k + 2 * PF <= n;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) aw[u] = a[(size_t)(k + PF + u) * m];
+            }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const double pr = av[u] * xs[k + u];
 #pragma unroll
                 for (int jj = 0; jj < JT; ++jj) acc[jj] = acc[jj] + pr;
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) av[u] = aw[u];
             }
         }
         for (; k < n; ++k) {
