@@ -157,8 +157,9 @@ k_dq_panel(int m, int n, const double *__restrict__ A, const double *__restrict_
         if (jj < jt) {
             const double u = acc[jj];
             const double r = (u + (gamma * u) * u) - bi;
-            if (FUSE) Pp[(size_t)(j0 + jj) * m] = (r - f0i) / fd_step(xs[j0 + jj]);
-            else Pp[(size_t)(j0 + jj) * m] = r;
+            // written once, read once by the next kernel: non-temporal, so that it does not displace A (re-read n/JT times)
+            if (FUSE) __builtin_nontemporal_store((r - f0i) / fd_step(xs[j0 + jj]), Pp + (size_t)(j0 + jj) * m);
+            else __builtin_nontemporal_store(r, Pp + (size_t)(j0 + jj) * m);
         }
     }
 }
