@@ -361,7 +361,11 @@ static void launch_dq_residual(nlh_handle *h, int nprob, int m, int n, const dou
     Timed t(h, NLH_K_DQ_RESIDUAL);
     dim3 grid((m + RB - 1) / RB, nprob);
     size_t sh = sizeof(double) * (size_t)(n + 32);
-    hipLaunchKernelGGL(k_dq_residual<RB>, grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, f, part, st, want);
+    const bool vec2 = (m % 2 == 0) && ((((uintptr_t)A | (uintptr_t)b | (uintptr_t)f) & 15) == 0);
+    if (vec2)       // two rows per thread, 16-byte accesses; a block covers the same RB rows
+        hipLaunchKernelGGL(k_dq_residual2<RB / 2>, grid, dim3(RB / 2), sh, h->stream, m, n, A, b, gamma, x, f, part, st, want);
+    else
+        hipLaunchKernelGGL(k_dq_residual<RB>, grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, f, part, st, want);
 }
 
 static void launch_dq_panel(nlh_handle *h, int nprob, int m, int n, const double *A, const double *b,
