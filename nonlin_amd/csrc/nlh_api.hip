@@ -440,8 +440,11 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
         if (n > 224 && n <= GRAM_TN && active >= 256) {
             // enough items to give every CU a workgroup: whole lower triangle per workgroup, J staged once
             const size_t sh = sizeof(double) * (size_t)(GRAM_TN * GRAM_LD + GRAM_KT + 1024);
+            const bool direct = ns == 1;
             hipLaunchKernelGGL(k_gram_tri, dim3((unsigned)items), dim3(512), sh, h->stream, m, n, rps, J, Gp,
-                               g ? f : (const double *)nullptr, gp, st, want, ns);
+                               g ? f : (const double *)nullptr, gp, st, want, ns, direct ? G : (double *)nullptr,
+                               direct ? g : (double *)nullptr);
+            if (direct) return 0;          // one split: G and g are final, nothing to reduce
         } else {
             const long groups = (items + 7) / 8;
             hipLaunchKernelGGL(k_gram_mfma, dim3((unsigned)(groups * 8 * nblk)), dim3(256), 0, h->stream, m, n, rps, J, Gp,

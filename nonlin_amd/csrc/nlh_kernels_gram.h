@@ -202,7 +202,7 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
 #define GRAM_TN 256
 template <int W>
 __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, int kend, int m, int n,
-                                              const double *Jp, const double *fp, double *Gp, double *gout, double *gscr)
+                                              const double *Jp, const double *fp, double *Gp, double *gout, double *gscr, bool direct)
 {
     constexpr int NL = 16 - W, NS = W + 1, RL = 15 - W, RS = W;      // long / short tile row of this wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -277,22 +277,30 @@ __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gr = RL * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
-            if (gr < n && gcol < n) Gp[(size_t)gcol * n + gr] = accL[c][r];
+            if (gr < n && gcol < n) {
+                if (!direct) Gp[(size_t)gcol * n + gr] = accL[c][r];
+                else if (gr >= gcol) { Gp[(size_t)gcol * n + gr] = accL[c][r]; Gp[(size_t)gr * n + gcol] = accL[c][r]; }
+            }
         }
 #pragma unroll
     for (int c = 0; c < NS; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gr = RS * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
-            if (gr < n && gcol < n) Gp[(size_t)gcol * n + gr] = accS[c][r];
+            if (gr < n && gcol < n) {
+                if (!direct) Gp[(size_t)gcol * n + gr] = accS[c][r];
+                else if (gr >= gcol) { Gp[(size_t)gcol * n + gr] = accS[c][r]; Gp[(size_t)gr * n + gcol] = accS[c][r]; }
+            }
         }
 }
 
 __global__ void __launch_bounds__(512)
 k_gram_tri(int m, int n, int rows_per_split, const double *__restrict__ J, double *__restrict__ Gpart,
            const double *__restrict__ f, double *__restrict__ gpart, const LmState *__restrict__ st, int want_stage,
-           int nsplit)
+           int nsplit, double *__restrict__ Gdirect, double *__restrict__ gdirect)
 {
+    // Gdirect != null (only with nsplit == 1): there is nothing to sum, so G (lower triangle mirrored, exactly what
+    // k_gram_reduce would produce) and g are written in place and the reduce launch is skipped.
     extern __shared__ double gsm[];
     double *tA = gsm;                                   // GRAM_TN * GRAM_LD
     double *fs = tA + GRAM_TN * GRAM_LD;                // GRAM_KT
@@ -302,17 +310,18 @@ k_gram_tri(int m, int n, int rows_per_split, const double *__restrict__ J, doubl
     const int kbeg = split * rows_per_split, kend = min(m, kbeg + rows_per_split);
     const double *Jp = J + (size_t)p * m * n;
     const double *fp = f ? f + (size_t)p * m : nullptr;
-    double *Gp = Gpart + ((size_t)p * nsplit + split) * (size_t)n * n;
-    double *gout = gpart + ((size_t)p * nsplit + split) * n;
+    const bool direct = Gdirect != nullptr;
+    double *Gp = direct ? Gdirect + (size_t)p * n * n : Gpart + ((size_t)p * nsplit + split) * (size_t)n * n;
+    double *gout = direct ? (gdirect ? gdirect + (size_t)p * n : nullptr) : gpart + ((size_t)p * nsplit + split) * n;
     switch (threadIdx.x >> 6) {
-    case 0: gram_tri_wave<0>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
-    case 1: gram_tri_wave<1>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
-    case 2: gram_tri_wave<2>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
-    case 3: gram_tri_wave<3>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
-    case 4: gram_tri_wave<4>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
-    case 5: gram_tri_wave<5>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
-    case 6: gram_tri_wave<6>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
-    default: gram_tri_wave<7>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr); break;
+    case 0: gram_tri_wave<0>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+    case 1: gram_tri_wave<1>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+    case 2: gram_tri_wave<2>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+    case 3: gram_tri_wave<3>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+    case 4: gram_tri_wave<4>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+    case 5: gram_tri_wave<5>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+    case 6: gram_tri_wave<6>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+    default: gram_tri_wave<7>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
     }
 }
 
