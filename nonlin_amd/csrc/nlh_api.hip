@@ -555,7 +555,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
                 if ((rc = ensure(h, h->qxV, sizeof(double) * ((size_t)nprob * QX_B * m + 512)))) return rc;
                 hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, n + 1, w.st, (int)ST_NEED_QR);
                 hipLaunchKernelGGL((k_qr_exact_lazy<QX_B, 512>), dim3(nprob), dim3(qt), sh8, h->stream, m, n, w.P, dfvec,
-                                   w.R, w.v, w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, (double *)h->qxV.p);
+                                   w.R, w.v, w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, (double *)h->qxV.p,
+                                   (size_t)nprob * m * (n + 1) * sizeof(double) > ((size_t)1 << 30) ? 1 : 0);
             } else {
                 hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, n, w.st, (int)ST_NEED_QR);
                 size_t sh = sizeof(double) * (size_t)(2 * n + 64 + 3 * NLH_NCH + 8 + QX_VC);

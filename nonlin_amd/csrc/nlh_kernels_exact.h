@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(MAXT)
 k_qr_exact_lazy(int m, int n, double *__restrict__ At_all, const double *__restrict__ fall,
                 double *__restrict__ Rall, LmVecs v, double *__restrict__ wa4all,
                 double *__restrict__ scratch_all, const double *__restrict__ xall,
-                LmState *__restrict__ st, double factor, double gtol, double *__restrict__ Vall)
+                LmState *__restrict__ st, double factor, double gtol, double *__restrict__ Vall, int stream_nt)
 {
     extern __shared__ double smem[];
     const int p = blockIdx.x;
@@ -385,8 +385,9 @@ k_qr_exact_lazy(int m, int n, double *__restrict__ At_all, const double *__restr
             double sm = 0.0;
 
             // The tile loop is instantiated for every pending count and column split: straight-line update chains.
-            auto run = [&](auto npc, auto lcc) {
+            auto run = [&](auto npc, auto lcc, auto ntc) {
                 constexpr int NP = decltype(npc)::value;
+                constexpr bool NTL = decltype(ntc)::value;                     // stream the working matrix past the caches
                 constexpr int LC = decltype(lcc)::value, CPT = 1 << LC, RPR = QL_RPT >> LC;
                 constexpr bool FL = (NP == B - 1);
                 int kc[CPT];                                                   // my columns (idle slots shadow column j+1)
@@ -409,7 +410,10 @@ k_qr_exact_lazy(int m, int n, double *__restrict__ At_all, const double *__restr
 #pragma unroll
                     for (int r = 0; r < RPR; ++r)
 #pragma unroll
-                        for (int c = 0; c < CPT; ++c) buf[r * CPT + c] = fp[(size_t)r * ld + kc[c]];
+                        for (int c = 0; c < CPT; ++c) {
+                            if constexpr (NTL) buf[r * CPT + c] = __builtin_nontemporal_load(fp + (size_t)r * ld + kc[c]);
+                            else buf[r * CPT + c] = fp[(size_t)r * ld + kc[c]];
+                        }
                     vv = *fv;
                     fp += tstride; fv += TR;
                 };
@@ -474,7 +478,10 @@ k_qr_exact_lazy(int m, int n, double *__restrict__ At_all, const double *__restr
                         for (int r = 0; r < RPR; ++r) {
                             if (!GD || wv * RPR + r < rem) {
 #pragma unroll
-                                for (int c = 0; c < CPT; ++c) wp[(size_t)r * ld + kc[c]] = e[r * CPT + c];
+                                for (int c = 0; c < CPT; ++c) {
+                                    if constexpr (NTL) __builtin_nontemporal_store(e[r * CPT + c], wp + (size_t)r * ld + kc[c]);
+                                    else wp[(size_t)r * ld + kc[c]] = e[r * CPT + c];
+                                }
                             }
                         }
                     }
@@ -514,23 +521,30 @@ k_qr_exact_lazy(int m, int n, double *__restrict__ At_all, const double *__restr
                 __syncthreads();
                 QX_TICK(3)
             };
-            auto with_np = [&](auto lcc) {
+            auto with_np = [&](auto lcc, auto ntc) {
                 switch (np) {
-                case 0: run(std::integral_constant<int, 0>{}, lcc); break;
-                case 1: run(std::integral_constant<int, 1>{}, lcc); break;
-                case 2: run(std::integral_constant<int, 2>{}, lcc); break;
-                case 3: if constexpr (B > 3) run(std::integral_constant<int, (B > 3 ? 3 : 0)>{}, lcc); break;
-                case 4: if constexpr (B > 4) run(std::integral_constant<int, (B > 4 ? 4 : 0)>{}, lcc); break;
-                case 5: if constexpr (B > 5) run(std::integral_constant<int, (B > 5 ? 5 : 0)>{}, lcc); break;
-                case 6: if constexpr (B > 6) run(std::integral_constant<int, (B > 6 ? 6 : 0)>{}, lcc); break;
-                default: if constexpr (B > 7) run(std::integral_constant<int, (B > 7 ? 7 : 0)>{}, lcc); break;
+                case 0: run(std::integral_constant<int, 0>{}, lcc, ntc); break;
+                case 1: run(std::integral_constant<int, 1>{}, lcc, ntc); break;
+                case 2: run(std::integral_constant<int, 2>{}, lcc, ntc); break;
+                case 3: if constexpr (B > 3) run(std::integral_constant<int, (B > 3 ? 3 : 0)>{}, lcc, ntc); break;
+                case 4: if constexpr (B > 4) run(std::integral_constant<int, (B > 4 ? 4 : 0)>{}, lcc, ntc); break;
+                case 5: if constexpr (B > 5) run(std::integral_constant<int, (B > 5 ? 5 : 0)>{}, lcc, ntc); break;
+                case 6: if constexpr (B > 6) run(std::integral_constant<int, (B > 6 ? 6 : 0)>{}, lcc, ntc); break;
+                default: if constexpr (B > 7) run(std::integral_constant<int, (B > 7 ? 7 : 0)>{}, lcc, ntc); break;
                 }
             };
-            switch (lcpt) {
-            case 0: with_np(std::integral_constant<int, 0>{}); break;
-            case 1: with_np(std::integral_constant<int, 1>{}); break;
-            case 2: with_np(std::integral_constant<int, 2>{}); break;
-            default: with_np(std::integral_constant<int, 3>{}); break;
+            // Working matrices that exceed the Infinity Cache are read and rewritten with non-temporal accesses in the
+            // 256-slot steps, which leaves L2 to the reflectors: -6 % with 256 problems of 4096 x 256 in flight, but
+            // +5 % with 64 (whose matrices the cache does hold), hence the switch.
+            if (stream_nt && lcpt == 2) {
+                with_np(std::integral_constant<int, 2>{}, std::true_type{});
+            } else {
+                switch (lcpt) {
+                case 0: with_np(std::integral_constant<int, 0>{}, std::false_type{}); break;
+                case 1: with_np(std::integral_constant<int, 1>{}, std::false_type{}); break;
+                case 2: with_np(std::integral_constant<int, 2>{}, std::false_type{}); break;
+                default: with_np(std::integral_constant<int, 3>{}, std::false_type{}); break;
+                }
             }
             if (summer) {
                 const int k = j + 1 + tid;
