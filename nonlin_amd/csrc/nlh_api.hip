@@ -177,7 +177,8 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     h->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
     // allow the single-workgroup kernels their full dynamic LDS (n-vectors live there)
     const int lds_max = 160 * 1024 - 2048;
-    hipFuncSetAttribute((const void *)k_gram_tri, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_gram_tri<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_gram_tri<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_nopiv<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -437,13 +438,21 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
         Timed t(h, NLH_K_GRAM);
         const long items = (long)ns * nprob;
         const long active = (long)ns * (nact > 0 ? std::min(nact, nprob) : nprob);
-        if (n > 224 && n <= GRAM_TN && active >= 256) {
+        const bool tri16 = n > 224 && n <= 256 && active >= 256;
+        const bool tri8 = n > 96 && n <= 128 && active >= 512;
+        if (tri16 || tri8) {
             // enough items to give every CU a workgroup: whole lower triangle per workgroup, J staged once
-            const size_t sh = sizeof(double) * (size_t)(GRAM_TN * GRAM_LD + GRAM_KT + 1024);
+            const int nt = tri16 ? 16 : 8;
+            const size_t sh = sizeof(double) * (size_t)(16 * nt * GRAM_LD + GRAM_KT + 64 * nt);
             const bool direct = ns == 1;
-            hipLaunchKernelGGL(k_gram_tri, dim3((unsigned)items), dim3(512), sh, h->stream, m, n, rps, J, Gp,
-                               g ? f : (const double *)nullptr, gp, st, want, ns, direct ? G : (double *)nullptr,
-                               direct ? g : (double *)nullptr);
+            if (tri16)
+                hipLaunchKernelGGL(k_gram_tri<16>, dim3((unsigned)items), dim3(512), sh, h->stream, m, n, rps, J, Gp,
+                                   g ? f : (const double *)nullptr, gp, st, want, ns, direct ? G : (double *)nullptr,
+                                   direct ? g : (double *)nullptr);
+            else
+                hipLaunchKernelGGL(k_gram_tri<8>, dim3((unsigned)items), dim3(256), sh, h->stream, m, n, rps, J, Gp,
+                                   g ? f : (const double *)nullptr, gp, st, want, ns, direct ? G : (double *)nullptr,
+                                   direct ? g : (double *)nullptr);
             if (direct) return 0;          // one split: G and g are final, nothing to reduce
         } else {
             const long groups = (items + 7) / 8;

@@ -200,14 +200,16 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
 // Same accumulation order as k_gram_mfma (rows ascending inside a split, splits summed by k_gram_reduce), same
 // output slabs: bitwise the same G and g.
 #define GRAM_TN 256
-template <int W>
+// NT = tile rows of the triangle: 16 (n <= 256, 8 waves) or 8 (n <= 128, 4 waves, same scheme at half the size).
+template <int W, int NT>
 __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, int kend, int m, int n,
                                               const double *Jp, const double *fp, double *Gp, double *gout, double *gscr, bool direct)
 {
-    constexpr int NL = 16 - W, NS = W + 1, RL = 15 - W, RS = W;      // long / short tile row of this wave
+    constexpr int NL = NT - W, NS = W + 1, RL = NT - 1 - W, RS = W;  // long / short tile row of this wave
+    constexpr int NTH = 32 * NT, TN = 16 * NT, HALF = NTH / 2;       // threads, columns, columns again
     const int tid = threadIdx.x, lane = tid & 63;
     const int lr = tid % GRAM_KT, lc0 = tid / GRAM_KT;                // loader: row lr, columns lc0 + 16*cc
-    constexpr int LSTEP = 512 / GRAM_KT, NLD = GRAM_TN / LSTEP;
+    constexpr int LSTEP = NTH / GRAM_KT, NLD = TN / LSTEP;
     v4d accL[NL], accS[NS];
 #pragma unroll
     for (int c = 0; c < NL; ++c) accL[c] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -229,7 +231,7 @@ __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, 
     };
     // g = J^T f: column tid & 255, two quarters of the tile per thread (the same four partial sums per column as
     // k_gram_mfma keeps in four threads)
-    const int gc = tid & 255, gh = tid >> 8;
+    const int gc = tid & (HALF - 1), gh = tid / HALF;
     double gq0 = 0.0, gq1 = 0.0;
     if (kbeg < kend) load_tile(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += GRAM_KT) {
@@ -266,10 +268,10 @@ __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, 
     }
     if (fp) {
         gscr[tid] = gq0;
-        gscr[512 + tid] = gq1;
+        gscr[NTH + tid] = gq1;
         __syncthreads();
-        if (tid < 256 && tid < n)
-            gout[tid] = ((gscr[tid] + gscr[512 + tid]) + gscr[256 + tid]) + gscr[768 + tid];
+        if (tid < HALF && tid < n)
+            gout[tid] = ((gscr[tid] + gscr[NTH + tid]) + gscr[HALF + tid]) + gscr[NTH + HALF + tid];
     }
     // f64 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
 #pragma unroll
@@ -294,7 +296,8 @@ __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, 
         }
 }
 
-__global__ void __launch_bounds__(512)
+template <int NT>
+__global__ void __launch_bounds__(32 * NT)
 k_gram_tri(int m, int n, int rows_per_split, const double *__restrict__ J, double *__restrict__ Gpart,
            const double *__restrict__ f, double *__restrict__ gpart, const LmState *__restrict__ st, int want_stage,
            int nsplit, double *__restrict__ Gdirect, double *__restrict__ gdirect)
@@ -302,9 +305,9 @@ k_gram_tri(int m, int n, int rows_per_split, const double *__restrict__ J, doubl
     // Gdirect != null (only with nsplit == 1): there is nothing to sum, so G (lower triangle mirrored, exactly what
     // k_gram_reduce would produce) and g are written in place and the reduce launch is skipped.
     extern __shared__ double gsm[];
-    double *tA = gsm;                                   // GRAM_TN * GRAM_LD
-    double *fs = tA + GRAM_TN * GRAM_LD;                // GRAM_KT
-    double *gscr = fs + GRAM_KT;                        // 1024
+    double *tA = gsm;                                   // 16 NT * GRAM_LD
+    double *fs = tA + 16 * NT * GRAM_LD;                // GRAM_KT
+    double *gscr = fs + GRAM_KT;                        // 64 NT
     const int item = blockIdx.x, p = item / nsplit, split = item % nsplit;
     if (st && st[p].stage != want_stage) return;
     const int kbeg = split * rows_per_split, kend = min(m, kbeg + rows_per_split);
@@ -313,15 +316,25 @@ k_gram_tri(int m, int n, int rows_per_split, const double *__restrict__ J, doubl
     const bool direct = Gdirect != nullptr;
     double *Gp = direct ? Gdirect + (size_t)p * n * n : Gpart + ((size_t)p * nsplit + split) * (size_t)n * n;
     double *gout = direct ? (gdirect ? gdirect + (size_t)p * n : nullptr) : gpart + ((size_t)p * nsplit + split) * n;
-    switch (threadIdx.x >> 6) {
-    case 0: gram_tri_wave<0>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
-    case 1: gram_tri_wave<1>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
-    case 2: gram_tri_wave<2>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
-    case 3: gram_tri_wave<3>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
-    case 4: gram_tri_wave<4>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
-    case 5: gram_tri_wave<5>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
-    case 6: gram_tri_wave<6>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
-    default: gram_tri_wave<7>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+    const int wv = threadIdx.x >> 6;
+    if constexpr (NT == 16) {
+        switch (wv) {
+        case 0: gram_tri_wave<0, 16>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        case 1: gram_tri_wave<1, 16>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        case 2: gram_tri_wave<2, 16>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        case 3: gram_tri_wave<3, 16>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        case 4: gram_tri_wave<4, 16>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        case 5: gram_tri_wave<5, 16>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        case 6: gram_tri_wave<6, 16>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        default: gram_tri_wave<7, 16>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        }
+    } else {
+        switch (wv) {
+        case 0: gram_tri_wave<0, 8>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        case 1: gram_tri_wave<1, 8>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        case 2: gram_tri_wave<2, 8>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        default: gram_tri_wave<3, 8>(tA, fs, kbeg, kend, m, n, Jp, fp, Gp, gout, gscr, direct); break;
+        }
     }
 }
 
