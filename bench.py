@@ -221,6 +221,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
+    gc.collect()
+    gc.disable()        # a generation-2 collection of the harness (one dict per problem and step) costs tens of ms
     sync()
     t0 = time.perf_counter()
     njac = 0
@@ -235,6 +238,7 @@ def main():
         last_ibs = ibs
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     cnt = torch.tensor([float(njac), float(naccept), float(bad)], dtype=torch.float64, device=dev)
