@@ -1004,12 +1004,11 @@ static int newton_core(nlh_handle *h, const nlh_options *o, int n, NewtonEval &e
             iter += 1;
             if ((rc = ev.jac(x, fvec, dJ))) break;              // :561-562
             njac += 1;
-            // grad(i) = dot(jac(:,i), fvec)  (:565-567), wave per column on the device
+            // grad(i) = dot(jac(:,i), fvec)  (:565-567), rows ascending as in the reference
             HIPCHK(h, hipMemcpyAsync(dfvec, fvec, sizeof(double) * n, hipMemcpyHostToDevice, s));
             {
                 Timed t(h, NLH_K_JTF);
-                hipLaunchKernelGGL(k_jtf, dim3((n + 3) / 4, 1), dim3(256), 0, s, n, n, dJ, dfvec, dgrad,
-                                   (const LmState *)nullptr, -1);
+                hipLaunchKernelGGL(k_jtf_exact, dim3((n + 255) / 256), dim3(256), 0, s, n, n, dJ, dfvec, dgrad);
             }
             // LU of a copy (:570) and solve for -fvec (:577)
             HIPCHK(h, hipMemcpyAsync(dLU, dJ, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));

@@ -387,3 +387,25 @@ k_jtf(int m, int n, const double *__restrict__ J, const double *__restrict__ f,
     double s = wave_reduce_sum((s0 + s1) + (s2 + s3));
     if (lane == 0) g[(size_t)p * n + j] = s;
 }
+
+// grad(i) = dot(jac(:,i), fvec) in the reference's order (src/nonlin_solve.f90:565-567): one thread per column,
+// rows ascending, separate multiply and add.  The Newton line search feeds dot(grad, dir) into the backtracking
+// formula, so a reordered sum changes the accepted step in its last bits.
+__global__ void __launch_bounds__(256)
+k_jtf_exact(int m, int n, const double *__restrict__ J, const double *__restrict__ f, double *__restrict__ g)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double *col = J + (size_t)j * m;
+    double s = 0.0;
+    int i = 0;
+    for (; i + 8 <= m; i += 8) {
+        double c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = col[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = s + c[u] * f[i + u];
+    }
+    for (; i < m; ++i) s = s + col[i] * f[i];
+    g[j] = s;
+}

@@ -393,6 +393,29 @@ def test_dq_newton_c3_full_size(ds, oracle):
     assert np.abs(fo).max() < 1e-8
 
 
+@pytest.mark.parametrize("n,seed,analytic,spread", [(64, 2506, True, 0.3), (200, 73602, True, 0.3), (200, 26774, False, 0.3),
+                                                    (200, 19210, False, 0.1), (33, 22757, True, 0.3), (129, 63083, False, 0.3)])
+def test_newton_backtracking_steps_bitwise(ds, oracle, n, seed, analytic, spread):
+    """Starts far enough from the root that the line search backtracks (fcn_count > iter_count + 1): the step length
+    then comes out of min_backtrack_search, which takes slope = dot(grad, dir) as an input, so grad = J^T f has to be
+    summed in the reference's order too.  (Found by a randomised sweep: with a tree-reduced gradient these six cases
+    differed from the CPU path in the last bits of x.)"""
+    A, b, xt, x0 = ds.generate(2, n, n, seed0=seed, sigma=0.0, spread=spread, square_shift=True)
+    x = x0.clone()
+    fvec, ibs, status = ds.newton_solve_batch(A, b, 0.5, x, analytic=analytic, opts=ds.options(max_evals=300))
+    backtracked = False
+    for p in range(2):
+        rc, xo, fo, ibo = oracle.dq_newton_solve(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5,
+                                                  x0[p].cpu().numpy(), analytic=analytic,
+                                                  opts=oracle.default_options(max_evals=300))[:4]
+        assert status[p] == rc
+        for k in COUNT_KEYS:
+            assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
+        assert np.array_equal(x[p].cpu().numpy(), xo) and np.array_equal(fvec[p].cpu().numpy(), fo)
+        backtracked = backtracked or ibo["fcn_count"] > ibo["iter_count"] + 1
+    assert backtracked
+
+
 def test_lm_c4_batch_property_and_spot_parity(ds, oracle):
     """BASELINE config 4 shape (2048 x 128 problems, 256 of them here): every problem converges, counts
     are in the recorded range, and a spot check of three problems against the oracle holds the FD-noise bound."""
