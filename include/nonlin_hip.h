@@ -78,14 +78,22 @@ typedef struct nlh_options {
     int32_t ls_max_evals;     /* 100   */
     double  ls_alpha;         /* 1e-4  */
     double  ls_factor;        /* 0.1   */
-    int32_t factor_policy;    /* NLH_FACTOR_AUTO */
+    int32_t factor_policy;    /* NLH_FACTOR_EXACT */
     double  ne_pivot_tol;     /* 1e-4: Cholesky pivot / column-norm^2 below this => QR */
-    int32_t fuse_fd;          /* 0.  Device-model solves only: 1 = the kernel that evaluates the n perturbed
+    int32_t fuse_fd;          /* 1.  Device-model solves only: 1 = the kernel that evaluates the n perturbed
                                  residuals also forms jac(:,j) = (f_j - f0)/h_j (:274) in its epilogue and the
                                  residual panel is never written; same operations per element, same bits */
+    int32_t sub_batches;      /* 0.  Batched device-model LM solves: number of sub-batches kept in flight on private
+                                 streams (0 = automatic: nprob / 128, at most 3; 1 = one lock-step batch).  Results do not
+                                 depend on it */
 } nlh_options;
 
 void nlh_default_options(nlh_options *opts);
+
+/* print_status (src/nonlin_helper.f90:17-33) as text: the block the solvers print between outer iterations when
+ * print_status is set -- a blank line, "Iteration: <I0>", "Function Evaluations: <I0>", "Jacobian Evaluations: <I0>"
+ * (only when > 0), "Change in Variable: <E10.3>", "Residual: <E10.3>".  snprintf semantics: returns the length needed. */
+int nlh_format_status(int32_t iter, int32_t nfeval, int32_t njaceval, double xnorm, double fnorm, char *buf, int32_t len);
 
 /* ---- user callbacks: vecfcn / jacobianfcn (src/nonlin_multi_eqn_mult_var.f90:14-38)
  * flattened to C.  The Fortran shim passes bind(C) trampolines; ctx carries the
@@ -282,7 +290,9 @@ int nlh_poly_fit_batch(nlh_handle *h, int32_t nprob, int32_t npts, int32_t order
 #define NLH_K_UPDATE        9
 #define NLH_K_LU           10
 #define NLH_K_DQ_JACOBIAN  11
-#define NLH_K_COUNT        12
+#define NLH_K_QRX_PASS     12   /* exact lmfactor: trailing pass of a Householder step (nlh_qrx.hip) */
+#define NLH_K_QRX_PIVOT    13   /* exact lmfactor: pivot + reflector of a step */
+#define NLH_K_COUNT        14
 /* on: 0 = off, 1 = every kernel group, otherwise a mask with bit (k + 1) set for each group NLH_K_<k> to time
    (two HIP event records per timed launch on the handle's stream). */
 void nlh_timing_enable(nlh_handle *h, int32_t on);

@@ -34,13 +34,15 @@ class Options(C.Structure):
                 ("gtol", C.c_double), ("print_status", C.c_int32), ("factor", C.c_double),
                 ("use_line_search", C.c_int32), ("ls_max_evals", C.c_int32),
                 ("ls_alpha", C.c_double), ("ls_factor", C.c_double),
-                ("factor_policy", C.c_int32), ("ne_pivot_tol", C.c_double), ("fuse_fd", C.c_int32)]
+                ("factor_policy", C.c_int32), ("ne_pivot_tol", C.c_double), ("fuse_fd", C.c_int32),
+                ("sub_batches", C.c_int32)]
 
 
 # every symbol include/nonlin_hip.h declares: name -> (restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = {
     "nlh_default_options": (None, [C.POINTER(Options)]),
+    "nlh_format_status": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_char_p, C.c_int32]),
     "nlh_create": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p]),
     "nlh_destroy": (None, [_H]),
     "nlh_device_count": (C.c_int, []),
@@ -104,7 +106,7 @@ SYMBOLS = {
 
 KERNEL_IDS = {
     "dq_residual": 0, "dq_panel": 1, "fd_jacobian": 2, "gram": 3, "gram_reduce": 4, "jtf": 5,
-    "chol": 6, "lmpar": 7, "qr": 8, "update": 9, "lu": 10, "dq_jacobian": 11,
+    "chol": 6, "lmpar": 7, "qr": 8, "update": 9, "lu": 10, "dq_jacobian": 11, "qrx_pass": 12, "qrx_pivot": 13,
 }
 
 _lib = None

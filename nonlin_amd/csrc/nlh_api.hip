@@ -29,6 +29,7 @@
 #include "nlh_kernels_broyden.h"
 #include "nlh_kernels_bfgs.h"
 #include "nlh_kernels_exact.h"
+#include "nlh_qrx.h"
 
 // ---------------------------------------------------------------------------
 // handle
@@ -55,6 +56,7 @@ struct nlh_handle {
            qnQ, qnR, qnV, bfB, bfR, bfV, qxV;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    bool qrx_open_on = false; hipEvent_t qrx_a{}, qrx_b{}; int qrx_kid = 0;   // open bracket of a nlh_qrx.hip launch
     std::vector<nlh_handle *> workers;   // private handles (own stream + workspace) for concurrent host-loop solves
 };
 
@@ -94,7 +96,8 @@ static int ensure_pinned(nlh_handle *h, size_t bytes)
 
 static const char *k_names[NLH_K_COUNT] = {
     "k_dq_residual", "k_dq_panel", "k_fd_jacobian", "k_gram_mfma", "k_gram_reduce", "k_jtf",
-    "k_chol_factor", "k_lmpar", "k_qr_factor", "k_lm_update", "k_lu_factor", "k_dq_jacobian"};
+    "k_chol_factor", "k_lmpar", "k_qr_factor", "k_lm_update", "k_lu_factor", "k_dq_jacobian", "k_qrx_pass",
+    "k_qrx_pivot"};
 
 static void timing_flush(nlh_handle *h)
 {
@@ -134,6 +137,24 @@ struct Timed {
     }
 };
 
+// Brackets for the launches of nlh_qrx.hip (another translation unit): which = 0 pivot kernel, 1 trailing pass, 2 rest.
+static void qrx_time_begin(nlh_handle *h, int which)
+{
+    const int kid = which == 1 ? NLH_K_QRX_PASS : which == 0 ? NLH_K_QRX_PIVOT : NLH_K_QR;
+    h->qrx_open_on = (h->timing >> kid) & 1u;
+    if (h->qrx_open_on) { h->qrx_a = ev_get(h); h->qrx_b = ev_get(h); hipEventRecord(h->qrx_a, h->stream); }
+    h->qrx_kid = kid;
+}
+static void qrx_time_end(nlh_handle *h, int)
+{
+    if (!h->qrx_open_on) return;
+    hipEventRecord(h->qrx_b, h->stream);
+    h->pending.push_back({h->qrx_a, h->qrx_b, h->qrx_kid});
+    if (h->pending.size() > 8192) timing_flush(h);
+}
+
+static int ensure_workers(nlh_handle *h, int T);
+
 __global__ void k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const double *diag_all,
                                    const double *qtf_all, const double *delta_all, const double *tailsq_all,
                                    double *par_all, double *x_all, double *sdiag_all, double *Wall);
@@ -152,9 +173,10 @@ void nlh_default_options(nlh_options *o)
     o->ls_max_evals = 100;       // src/nonlin_linesearch.f90:35
     o->ls_alpha = 1.0e-4;        // :38
     o->ls_factor = 0.1;          // :46
-    o->factor_policy = NLH_FACTOR_AUTO;
+    o->factor_policy = NLH_FACTOR_EXACT;   // the parity-carrying policy; AUTO / QR are explicit opt-ins
     o->ne_pivot_tol = 1.0e-4;
-    o->fuse_fd = 0;
+    o->fuse_fd = 1;
+    o->sub_batches = 0;
 }
 
 int nlh_device_count(void)
@@ -402,46 +424,34 @@ static void launch_fd(nlh_handle *h, int nprob, int m, int n, const double *P, c
     }
 }
 
-static int gram_splits(int nprob, int m, int n)
+// K-splits of the Gram contraction.  The split count and the kernel are functions of the problem SHAPE only, never of how
+// many problems share the launch: G = sum over splits (in split order) of a row-ascending accumulation, so a problem's
+// bits do not depend on its batch, the round it is active in, the sub-batch or the rank it was dealt to.
+static int gram_splits(int m)
 {
-    const int nb = (n + GRAM_BT - 1) / GRAM_BT;
-    const int nblk = nb * (nb + 1) / 2;
-    long base = (long)nprob * nblk;
-    int s = (int)((2048 + base - 1) / base);          // aim for >= 2048 workgroups
-    int smax = (m + 511) / 512;                       // keep >= 512 rows per split
-    if (s > smax) s = smax;
-    if (s < 1) s = 1;
-    return s;
+    const int s = (m + 1023) / 1024;                  // 1024 rows per split
+    return s < 1 ? 1 : s;
 }
 
-// nact: how many of the nprob problems are expected to take part (the others return at once): the K-split is chosen for
-// that many, so that a round with a few stragglers still fills the chip.
 static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, const double *f,
-                       double *G, double *g, const LmState *st, int want, int nact = -1)
+                       double *G, double *g, const LmState *st, int want)
 {
     const int nb = (n + GRAM_BT - 1) / GRAM_BT;
     const int nblk = nb * (nb + 1) / 2;
-    int ns = gram_splits(nact > 0 ? std::min(nact, nprob) : nprob, m, n);
-    while (ns > 1 && (size_t)nprob * ns * n * n * sizeof(double) > ((size_t)4 << 30)) --ns;     // slab budget 4 GiB
+    const int ns = gram_splits(m);
     int rps = (m + ns - 1) / ns;
     rps = ((rps + GRAM_KT - 1) / GRAM_KT) * GRAM_KT;
-    // The slab is sized once for the deepest split any round of this batch can ask for (a straggler round uses more
-    // splits than the first one): growing it in the middle of a solve is a device-wide free + malloc.
-    int nscap = gram_splits(1, m, n);
-    while (nscap > 1 && (size_t)nprob * nscap * n * n * sizeof(double) > ((size_t)4 << 30)) --nscap;
-    if (nscap < ns) nscap = ns;
-    int rc = ensure(h, h->Gpart, sizeof(double) * ((size_t)nprob * nscap * n * n + (size_t)nprob * nscap * n));
+    int rc = ensure(h, h->Gpart, sizeof(double) * ((size_t)nprob * ns * n * n + (size_t)nprob * ns * n));
     if (rc) return rc;
     double *Gp = (double *)h->Gpart.p;
     double *gp = Gp + (size_t)nprob * ns * n * n;
     {
         Timed t(h, NLH_K_GRAM);
         const long items = (long)ns * nprob;
-        const long active = (long)ns * (nact > 0 ? std::min(nact, nprob) : nprob);
-        const bool tri16 = n > 224 && n <= 256 && active >= 256;
-        const bool tri8 = n > 96 && n <= 128 && active >= 512;
+        const bool tri16 = n > 224 && n <= 256;
+        const bool tri8 = n > 96 && n <= 128;
         if (tri16 || tri8) {
-            // enough items to give every CU a workgroup: whole lower triangle per workgroup, J staged once
+            // whole lower triangle per workgroup, J staged once
             const int nt = tri16 ? 16 : 8;
             const size_t sh = sizeof(double) * (size_t)(16 * nt * GRAM_LD + GRAM_KT + 64 * nt);
             const bool direct = ns == 1;
@@ -515,7 +525,8 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
     const size_t mn = (size_t)nprob * m * n, pm = (size_t)nprob * m, pn = (size_t)nprob * n;
     if ((rc = ensure(h, h->J, sizeof(double) * mn))) return rc;
     // + a residual column and read-ahead padding behind the last problem (exact QR, k_qr_exact_lazy)
-    if (need_panel && (rc = ensure(h, h->P, sizeof(double) * (mn + pm + (size_t)512 * (n + 1))))) return rc;
+    if (need_panel && (rc = ensure(h, h->P, sizeof(double) * std::max(mn + pm + (size_t)512 * (n + 1),
+                                                                      qrx_matrix_doubles(nprob, m, n))))) return rc;
     if ((rc = ensure(h, h->wa4, sizeof(double) * pm))) return rc;
     if ((rc = ensure(h, h->scratch, sizeof(double) * pm))) return rc;
     if ((rc = ensure(h, h->G, sizeof(double) * (size_t)nprob * n * n))) return rc;
@@ -558,7 +569,16 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
             const int qt = std::min(ft, 512);
             const size_t sh8 = sizeof(double) * QlLds<QX_B, 512>::doubles(n, qt);
             const bool lazy = m >= n && n + 1 <= qt && sh8 <= lds_cap;
-            if (lazy) {
+            static const bool use_qrx = !(getenv("NLH_QRX") && atoi(getenv("NLH_QRX")) == 0);
+            if (use_qrx && m >= n) {
+                // streaming form: the batch advances through the Householder steps in lock step (nlh_qrx.hip)
+                int rc;
+                if ((rc = ensure(h, h->qxV, qrx_workspace_bytes(nprob, m, n)))) return rc;
+                QrxTimer tm{h, [](void *c, int which) { qrx_time_begin((nlh_handle *)c, which); },
+                            [](void *c, int which) { qrx_time_end((nlh_handle *)c, which); }};
+                qrx_factor(h->stream, nprob, m, n, w.J, w.P, dfvec, w.R, w.v, w.wa4, w.scratch, dx, w.st, o->factor,
+                           o->gtol, h->qxV.p, &tm);
+            } else if (lazy) {
                 // row stride n + 1 (residual as last column), reflector ring in h->qxV
                 int rc;
                 if ((rc = ensure(h, h->qxV, sizeof(double) * ((size_t)nprob * QX_B * m + 512)))) return rc;
@@ -580,7 +600,7 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
         }
         return 0;
     }
-    int rc = launch_gram(h, nprob, m, n, w.J, dfvec, w.G, w.g, w.st, ST_HAVE_JAC, nact);
+    int rc = launch_gram(h, nprob, m, n, w.J, dfvec, w.G, w.g, w.st, ST_HAVE_JAC);
     if (rc) return rc;
     constexpr int NB = 16;
     {   // fast path: blocked Cholesky in natural order, G -> R
@@ -651,12 +671,44 @@ static void fill_ib(const LmState &s, nlh_iteration_behavior *ib)
     ib->converge_on_zero_diff = s.gcnvrg;
 }
 
+// Fortran edit descriptor E10.3 (src/nonlin_helper.f90:32): three significant digits as 0.dddE+ee, right-justified in
+// ten columns; a three-digit exponent drops the letter (0.123+100), as the standard prescribes.
+static void format_e10_3(double v, char out[16])
+{
+    char body[16];
+    if (std::isnan(v)) { snprintf(out, 16, "%10s", "NaN"); return; }
+    if (std::isinf(v)) { snprintf(out, 16, "%10s", v < 0 ? "-Inf" : "Inf"); return; }
+    char sci[32];
+    snprintf(sci, sizeof sci, "%.2e", fabs(v));                 // d.dde+XX, correctly rounded to 3 digits
+    int ex = atoi(sci + 5);
+    if (v != 0.0) ex += 1;                                      // d.dd x 10^X = 0.ddd x 10^(X+1)
+    const char sign = std::signbit(v) && v != 0.0 ? '-' : ' ';
+    if (abs(ex) < 100) snprintf(body, sizeof body, "%c0.%c%c%cE%c%02d", sign, sci[0], sci[2], sci[3], ex < 0 ? '-' : '+', abs(ex));
+    else snprintf(body, sizeof body, "%c0.%c%c%c%c%03d", sign, sci[0], sci[2], sci[3], ex < 0 ? '-' : '+', abs(ex));
+    snprintf(out, 16, "%10s", body);
+}
+
+// print_status, src/nonlin_helper.f90:17-33: `print *, ""` (a blank), then A,I0 / A,E10.3 lines.
 static void print_status(int iter, int nfeval, int njaceval, double xnorm, double fnorm)
 {
-    // src/nonlin_helper.f90:17-33
+    char a[16], b[16];
+    format_e10_3(xnorm, a);
+    format_e10_3(fnorm, b);
     printf(" \nIteration: %d\nFunction Evaluations: %d\n", iter, nfeval);
     if (njaceval > 0) printf("Jacobian Evaluations: %d\n", njaceval);
-    printf("Change in Variable: %10.3E\nResidual: %10.3E\n", xnorm, fnorm);
+    printf("Change in Variable: %s\nResidual: %s\n", a, b);
+    fflush(stdout);
+}
+
+extern "C" int nlh_format_status(int32_t iter, int32_t nfeval, int32_t njaceval, double xnorm, double fnorm, char *buf,
+                                 int32_t len)
+{
+    char a[16], b[16], jl[48] = "";
+    format_e10_3(xnorm, a);
+    format_e10_3(fnorm, b);
+    if (njaceval > 0) snprintf(jl, sizeof jl, "Jacobian Evaluations: %d\n", njaceval);
+    return snprintf(buf, len > 0 ? (size_t)len : 0, " \nIteration: %d\nFunction Evaluations: %d\n%sChange in Variable: %s\nResidual: %s\n",
+                    iter, nfeval, jl, a, b);
 }
 
 static int check_opts_lm(const nlh_options *o, int m, int n)
@@ -673,14 +725,11 @@ extern "C" {
 // ===========================================================================
 // Device-model LM, batched: lss_solve as a lock-step state machine.
 // ===========================================================================
-int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n,
+static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n,
                           const double *dA, const double *db, double gamma, double *dx, double *dfvec,
                           nlh_iteration_behavior *ib, int32_t *status)
 {
-    if (!h) return NLH_ERR_BAD_HANDLE;
-    if (nprob <= 0) return 0;
-    int rc = check_opts_lm(o, m, n);
-    if (rc) return rc;
+    int rc;
     HIPCHK(h, hipSetDevice(h->device));
     LmWs w;
     if ((rc = lm_workspace(h, nprob, m, n, w, true))) return rc;
@@ -728,6 +777,61 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     for (int p = 0; p < nprob; ++p) {
         if (ib) fill_ib(h_state[p], &ib[p]);
         if (status) status[p] = (h_state[p].flag != 0 || h_state[p].stage != ST_DONE) ? NLH_CONVERGENCE_ERROR : 0;  // :388-390
+    }
+    return 0;
+}
+
+// Several sub-batches in flight.  A batch is a lock-step state machine whose rounds contain latency-bound stages (pivot /
+// NORM2 chains of the exact lmfactor, Cholesky, lmpar's iteration for the few problems that need it, straggler rounds,
+// the status read-back): with the batch dealt to S host threads, each driving its own stream and workspace, those stages
+// of one sub-batch run under the streaming kernels of the others.  Problems are independent and a problem's arithmetic
+// does not depend on its neighbours, so x, fvec and all counts are the same bits for any S.
+static int lm_sub_batches(const nlh_options *o, int nprob, int m, int n)
+{
+    int S = o->sub_batches;
+    if (const char *e = getenv("NLH_SUB_BATCHES")) S = atoi(e);
+    if (S <= 0) {                                   // auto: >= 128 problems per sub-batch, at most 3 in flight (measured
+        S = nprob / 128;                            // on 512 x 4096x256 exact: 1 / 2 / 3 / 4 -> 1032 / 959 / 928 / 1036 ms)
+        if (S > 3) S = 3;
+    }
+    if (S > nprob) S = nprob;
+    return S < 1 ? 1 : S;
+}
+
+int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n,
+                          const double *dA, const double *db, double gamma, double *dx, double *dfvec,
+                          nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (nprob <= 0) return 0;
+    int rc = check_opts_lm(o, m, n);
+    if (rc) return rc;
+    const int S = lm_sub_batches(o, nprob, m, n);
+    if (S == 1) return lm_solve_range(h, o, nprob, m, n, dA, db, gamma, dx, dfvec, ib, status);
+    if ((rc = ensure_workers(h, S))) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));                 // inputs written on the caller's stream are complete
+    std::vector<int> rcs(S, 0);
+    std::vector<std::thread> pool;
+    const size_t mn = (size_t)m * n;
+    for (int t = 0; t < S; ++t) {
+        const int p0 = (int)((long)nprob * t / S), p1 = (int)((long)nprob * (t + 1) / S);
+        pool.emplace_back([&, t, p0, p1]() {
+            nlh_handle *wk = h->workers[t];
+            wk->timing = h->timing;
+            rcs[t] = lm_solve_range(wk, o, p1 - p0, m, n, dA + (size_t)p0 * mn, db + (size_t)p0 * m, gamma,
+                                    dx + (size_t)p0 * n, dfvec + (size_t)p0 * m, ib ? ib + p0 : nullptr,
+                                    status ? status + p0 : nullptr);
+        });
+    }
+    for (auto &th : pool) th.join();
+    for (int t = 0; t < S; ++t) {
+        nlh_handle *wk = h->workers[t];
+        if (h->timing) {                                        // fold the workers' kernel timers into the caller's
+            timing_flush(wk);
+            for (int k = 0; k < NLH_K_COUNT; ++k) { h->ms[k] += wk->ms[k]; h->launches[k] += wk->launches[k]; wk->ms[k] = 0; wk->launches[k] = 0; }
+        }
+        if (rcs[t]) { h->err = wk->err; return rcs[t]; }
     }
     return 0;
 }
@@ -1687,12 +1791,12 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
             if (hinfo) { rc = NLH_INVALID_OPERATION_ERROR; break; }     // linalg: matrix not positive definite
 
             if (o->print_status) {                              // :730-737
-                printf("\n");
+                printf(" \n");
                 printf("Iteration: %d\n", iter);
                 printf("Function Evaluations: %d\n", neval);
-                printf("Function Value: %10.3E\n", fp);
-                printf("Change in Variable: %10.3E\n", xtest);
-                printf("Gradient: %10.3E\n", gtest);
+                char e1[16], e2[16], e3[16];
+                format_e10_3(fp, e1); format_e10_3(xtest, e2); format_e10_3(gtest, e3);
+                printf("Function Value: %s\nChange in Variable: %s\nGradient: %s\n", e1, e2, e3);
             }
             if (neval >= o->max_evals) { flag = 1; break; }     // :740-743
         }
@@ -1710,6 +1814,19 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
 // Host-loop solvers (Newton, quasi-Newton, constrained least squares, bfgs) over a batch of independent problems:
 // the problems are dealt to a few host threads, each with a private handle (own HIP stream and workspace), so the
 // latency-bound kernels of different problems overlap on the device.  NLH_WORKERS sets the thread count (default 8).
+// Private handles (own non-blocking stream + workspace) for work the caller's handle deals out to host threads.
+static int ensure_workers(nlh_handle *h, int T)
+{
+    while ((int)h->workers.size() < T) {
+        nlh_handle *wk = new nlh_handle();
+        wk->device = h->device;
+        if (hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking) != hipSuccess) { delete wk; h->err = "hipStreamCreate"; return NLH_ERR_HIP; }
+        wk->own_stream = true;
+        h->workers.push_back(wk);
+    }
+    return 0;
+}
+
 static int run_problems(nlh_handle *h, int nprob, const std::function<int(nlh_handle *, int)> &solve_one)
 {
     int T = 8;
@@ -1718,17 +1835,11 @@ static int run_problems(nlh_handle *h, int nprob, const std::function<int(nlh_ha
     if (T == 1) {
         for (int p = 0; p < nprob; ++p) {
             const int rc = solve_one(h, p);
-            if (rc < 0) return rc;
+            if (rc != 0) return rc;
         }
         return 0;
     }
-    while ((int)h->workers.size() < T) {
-        nlh_handle *wk = new nlh_handle();
-        wk->device = h->device;
-        if (hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking) != hipSuccess) { delete wk; h->err = "hipStreamCreate"; return NLH_ERR_HIP; }
-        wk->own_stream = true;
-        h->workers.push_back(wk);
-    }
+    { const int rcw = ensure_workers(h, T); if (rcw) return rcw; }
     HIPCHK(h, hipStreamSynchronize(h->stream));                 // inputs written on the caller's stream are complete
     std::atomic<int> next(0), err(0);
     std::vector<std::thread> pool;
@@ -1740,7 +1851,7 @@ static int run_problems(nlh_handle *h, int nprob, const std::function<int(nlh_ha
                 const int p = next.fetch_add(1);
                 if (p >= nprob || err.load() != 0) break;
                 const int rc = solve_one(wk, p);
-                if (rc < 0) { err = rc; break; }
+                if (rc != 0) { err = rc; break; }
             }
             hipStreamSynchronize(wk->stream);
         });

@@ -20,6 +20,7 @@ module nonlin_hip_c
         integer(c_int32_t) :: factor_policy
         real(c_double) :: ne_pivot_tol
         integer(c_int32_t) :: fuse_fd
+        integer(c_int32_t) :: sub_batches
     end type
 
     integer(c_int32_t), parameter :: NLH_FACTOR_AUTO = 0, NLH_FACTOR_QR = 1, NLH_FACTOR_EXACT = 2
