@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- LM iterations/s on batched 4096 x 256 fp64 LM problems with the finite-difference
-Jacobian (BASELINE.json metric; workload = configs[1] instantiated per SURVEY.md 8(d), batched
-as north_star's "batched 4096x256 LM problems at 1 GPU").
+"""bench.py -- LM iterations/s on batched m x n fp64 LM problems with the finite-difference Jacobian
+(BASELINE.json metric; default workload = configs[1] instantiated per SURVEY.md 8(d), batched as
+north_star's "batched 4096x256 LM problems at 1 GPU").
 
-A "step" is one pass of the hot path over one batch: every problem of the batch is solved from
-its start point by least_squares_solver (nlh_dq_lm_solve_batch): FD Jacobian (n perturbed
-evaluations + column write) -> J^T J / J^T f (fp64 MFMA) -> pivoted Cholesky -> lmpar -> trial
-evaluation -> trust-region update, until every problem has converged.  Inputs are generated on
-the device before the timed region and stay resident in HBM.
+A "step" is one pass of the hot path over one batch: every problem of the batch is solved from its start
+point by least_squares_solver (nlh_dq_lm_solve_batch) under the factor policy that carries parity with the
+reference -- NLH_FACTOR_EXACT: FD Jacobian (n perturbed evaluations, column formed in the same kernel) ->
+lmfactor + Q^T f in the reference's operation order (nlh_qrx.hip) -> lmpar -> trial evaluation ->
+trust-region update, until every problem has converged.  x, fvec and all counts are bit-identical to the CPU
+path (checked against the oracle on a sample of the same problems, `parity` in the JSON line).  Inputs are
+generated on the device before the timed region and stay resident in HBM.
 
-value = sum of jacobian_count (= LM outer iterations) over all problems, steps and ranks,
-divided by the max-over-ranks wall time of the K timed steps.  N > 1: one process per GPU
-(torchrun), independent problems sharded block-cyclically, weak scaling (fixed batch per GPU),
-no data-path collective; RCCL is used for the config broadcast and the result gather.
+value = sum of jacobian_count (= LM outer iterations) over all problems, steps and ranks, divided by the
+max-over-ranks wall time of the K timed steps.
+
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run as a
+child process, before anything touches a GPU); under an external torchrun it reads RANK / WORLD_SIZE from the
+environment.  Independent problems are dealt block-cyclically (problem k -> rank k mod N), no data-path collective;
+RCCL carries the config broadcast and the result gather.
+  --scaling weak   (default): --batch problems per GPU
+  --scaling strong          : --total-problems problems in all (north_star: 8192 x 2048x128, 1024 x 2048x128)
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +37,20 @@ sys.path.insert(0, ROOT)
 M, N_VAR = 4096, 256
 GAMMA, SIGMA, SPREAD = 0.5, 1e-3, 0.3
 SEED0 = 12345
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
+POLICY_NAMES = {0: "auto (J^T J MFMA + Cholesky, QR fallback)", 1: "householder-qr (tree reductions)",
+                2: "exact (lmfactor / lmpar in the reference's operation order)"}
 
 
 def fd_bytes(m, n):
     # read one m x n panel + f0 (m) + x,h (2n), write J (m x n)
     return 8.0 * (2.0 * m * n + m + 2.0 * n)
+
+
+def qr_pass_bytes(m, n):
+    """Algorithmic bytes of the trailing passes of ONE exact factorisation: every element of the
+    trailing matrix (columns j+1..n plus the residual column, rows j..m-1) is read once per Householder step."""
+    return 8.0 * sum((m - j) * (n - j) for j in range(n))
 
 
 def _cpu_solve_one(arg):
@@ -42,37 +59,39 @@ def _cpu_solve_one(arg):
     A, b, xt, x0 = O.dq_generate(SEED0 + k, m, n, gamma=GAMMA, sigma=SIGMA, spread=SPREAD)
     t0 = time.perf_counter()
     rc, x, f, ib, nc, _ = O.dq_lm_solve(A, b, GAMMA, x0, opts=O.default_options(max_evals=500))
-    return ib["jacobian_count"], time.perf_counter() - t0
+    return ib["jacobian_count"], time.perf_counter() - t0, x, ib, rc
 
 
-def cpu_baseline(sample, m, n):
+def cpu_baseline(sample, m, n, all_cores=True):
     """Oracle (C restatement of the reference path) on the host: one core (the reference is single-threaded),
     then the same problems farmed over every host core (the CPU analogue of sharding).  Must run before the
-    GPU is initialised: the all-cores leg forks workers."""
+    GPU is initialised: the all-cores leg forks workers.  Also returns the oracle's solutions (parity check)."""
     njac = 0
     t = 0.0
+    sols = []
     for k in range(sample):
-        nj, dt = _cpu_solve_one((k, m, n))
+        nj, dt, x, ib, rc = _cpu_solve_one((k, m, n))
         njac += nj
         t += dt
+        sols.append((x, ib, rc))
     out = {"value": njac / t, "unit": "LM iterations/s", "cores": 1, "kind": "port",
            "sample": f"{sample} problems {m}x{n} (seeds {SEED0}..{SEED0 + sample - 1}), single thread, "
                      f"oracle/nonlin_oracle.c -O2 -ffp-contract=off, {t:.1f} s"}
-    try:
-        import multiprocessing as mp
-        cores = len(os.sched_getaffinity(0))
-        nprob = max(cores, sample)
-        t0 = time.perf_counter()
-        with mp.get_context("fork").Pool(cores) as pool:
-            res = pool.map(_cpu_solve_one, [(k, m, n) for k in range(nprob)], chunksize=1)
-        wall = time.perf_counter() - t0
-        out["all_cores"] = {"value": sum(r[0] for r in res) / wall, "unit": "LM iterations/s", "cores": cores,
-                            "sample": f"{nprob} problems over {cores} worker processes, {wall:.1f} s wall "
-                                      f"(includes problem generation)"}
-    except Exception as e:                                   # the single-core figure is the contract
-        out["all_cores"] = {"error": repr(e)}
-    return out
-
+    if all_cores:
+        try:
+            import multiprocessing as mp
+            cores = len(os.sched_getaffinity(0))
+            nprob = max(cores, sample)
+            t0 = time.perf_counter()
+            with mp.get_context("fork").Pool(cores) as pool:
+                res = pool.map(_cpu_solve_one, [(k, m, n) for k in range(nprob)], chunksize=1)
+            wall = time.perf_counter() - t0
+            out["all_cores"] = {"value": sum(r[0] for r in res) / wall, "unit": "LM iterations/s", "cores": cores,
+                                "sample": f"{nprob} problems over {cores} worker processes, {wall:.1f} s wall "
+                                          f"(includes problem generation)"}
+        except Exception as e:                                   # the single-core figure is the contract
+            out["all_cores"] = {"error": repr(e)}
+    return out, sols
 
 
 def other_paths(ds):
@@ -150,70 +169,126 @@ def other_paths(ds):
                  "bitwise_equal": bool(all(np.array_equal(c[q].cpu().numpy(), co[q]) for q in range(16)))})
     return rows
 
+
+def fd_mode_h_roofline(ds, m=65536, n=512, reps=5):
+    """The stand-alone FD column kernel (what the host-callback path runs: J(:,j) = (P(:,j) - f0)/h_j over a panel of
+    perturbed residuals) at BASELINE config 5's size, HIP events on the launch stream."""
+    import torch
+    P = torch.rand((1, n, m), dtype=torch.float64, device=ds.device)
+    f0 = torch.rand((1, m), dtype=torch.float64, device=ds.device)
+    x = torch.rand((1, n), dtype=torch.float64, device=ds.device) + 0.5
+    J = torch.empty_like(P)
+    ds.fd_jacobian_panel(P, f0, x, out=J)
+    ds.h.timing_enable(kernels=["fd_jacobian"])
+    ds.h.timing_reset()
+    for _ in range(reps):
+        ds.fd_jacobian_panel(P, f0, x, out=J)
+    ms, cnt = ds.h.timing("fd_jacobian")
+    ds.h.timing_enable(False)
+    gbs = fd_bytes(m, n) * cnt / max(ms * 1e-3, 1e-30) / 1e9
+    return {"kernel": "k_fd_jacobian (host-callback path, nlh_fd_jacobian_panel)", "bound": "hbm", "achieved": gbs,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "m": m, "n": n, "launches": int(cnt),
+            "avg_launch_ms": ms / max(cnt, 1), "bytes_per_launch": fd_bytes(m, n)}
+
+
+def spawn_ranks(ngpus):
+    """`bench.py --gpus N` without an external launcher: start the N ranks as children of a fresh
+    torch.distributed.run process.  Nothing in this process has touched a GPU yet, and it only waits."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    argv = [{"--m": "--mrows", "--n": "--ncols"}.get(a, a) for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("NLH_BENCH_BATCH", "512")),
-                    help="problems per GPU per step")
-    ap.add_argument("--m", type=int, default=M)
-    ap.add_argument("--n", type=int, default=N_VAR)
-    ap.add_argument("--cpu-sample", type=int, default=24, help="problems timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--exact-sample", type=int, default=256, help="problems for the exact-policy figure (0 = skip)")
+                    help="problems per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--total-problems", type=int, default=8192, help="problems in all (strong scaling)")
+    # --mrows / --ncols: the spellings that survive torch.distributed.run's own option parser (it rejects --m / --n as
+    # ambiguous abbreviations of its options even behind the script name)
+    ap.add_argument("--m", "--mrows", dest="m", type=int, default=M)
+    ap.add_argument("--n", "--ncols", dest="n", type=int, default=N_VAR)
+    ap.add_argument("--cpu-sample", type=int, default=32,
+                    help="problems solved by the CPU oracle: the cpu_baseline timing and the parity sample (0 = skip)")
     ap.add_argument("--extras", type=int, default=1,
-                    help="0 = skip the single_problem and fused_fd legs (profiles/capture.sh: every launch rocprofv3 sees "
-                         "then belongs to a warm-up or timed step, so its per-kernel averages are the ones printed here)")
+                    help="0 = only the timed steps (profiles/capture.sh: every launch rocprofv3 sees then belongs to a "
+                         "warm-up or timed step, so its per-kernel averages are the ones printed here)")
     ap.add_argument("--other-paths", type=int, default=1,
-                    help="1 = also time the Newton / quasi-Newton / bounded LSQ / BFGS / polynomial rows (SURVEY 8 a16-a24, f1-f4) "
-                         "on the GPU and on the CPU oracle and check the results bit for bit")
-    ap.add_argument("--policy", type=int, default=0, help="0 auto (J^T J + Cholesky), 1 QR, 2 exact (reference order)")
-    ap.add_argument("--fuse-fd", type=int, default=0,
-                    help="1: form the Jacobian column in the panel kernel's epilogue (k_fd_jacobian is then not launched)")
+                    help="1 = also time the Newton / quasi-Newton / bounded LSQ / BFGS / polynomial rows (SURVEY 8 a16-a24, "
+                         "f1-f4) on the GPU and on the CPU oracle and check the results bit for bit")
+    ap.add_argument("--policy", type=int, default=2,
+                    help="factor policy of the timed steps: 2 exact (reference operation order, the parity-carrying one), "
+                         "0 auto (J^T J + Cholesky), 1 QR with tree reductions")
+    ap.add_argument("--sub-batches", type=int, default=1,
+                    help="sub-batches in flight during the timed steps (1: per-kernel durations are those of one lock-step "
+                         "batch; the library default -- several in flight -- is reported as `default_options`)")
     args = ap.parse_args()
 
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    cpu = cpu_baseline(args.cpu_sample, args.m, args.n) if (world_env == 1 and args.cpu_sample > 0) else None
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python bench.py --gpus N starts them itself)")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    m, n = args.m, args.n
+
+    cpu, sols = (None, [])
+    if world == 1 and args.cpu_sample > 0:
+        cpu, sols = cpu_baseline(args.cpu_sample, m, n, all_cores=bool(args.extras))
 
     import torch
     import torch.distributed as dist
     from nonlin_amd.device import DeviceSolver
     from nonlin_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    m, n, B = args.m, args.n, args.batch
 
     ds = DeviceSolver(local_rank)
-    # options / seed come from rank 0 (broadcast over RCCL when N > 1)
-    cfg = sharding.broadcast_config([500, SEED0, GAMMA, SIGMA, SPREAD], dev)
+    # options / seed come from rank 0 (broadcast over RCCL when N > 1); problem k of the job goes to rank k mod N
+    nprob_total = args.total_problems if args.scaling == "strong" else args.batch * world
+    cfg = sharding.broadcast_config([500, SEED0, GAMMA, SIGMA, SPREAD, nprob_total], dev)
     max_evals, seed0 = int(cfg[0]), int(cfg[1])
-    gamma, sigma, spread = cfg[2], cfg[3], cfg[4]
-    nprob_total = B * world
-    # block-cyclic: local problem i is global problem rank + i*world, seed = seed0 + global index
-    A, b, xt, x0 = ds.generate(B, m, n, seed0=seed0 + rank, gamma=gamma, sigma=sigma, spread=spread,
-                               seed_stride=world)
-    opts = ds.options(max_evals=max_evals, factor_policy=args.policy, fuse_fd=args.fuse_fd)
+    gamma, sigma, spread, nprob_total = cfg[2], cfg[3], cfg[4], int(cfg[5])
+    B = sharding.shard_count(nprob_total, rank, world)
+    # local problem i is global problem rank + i*world, seed = seed0 + global index
+    A, b, xt, x0 = ds.generate(B, m, n, seed0=seed0 + rank, gamma=gamma, sigma=sigma, spread=spread, seed_stride=world)
+    opts = ds.options(max_evals=max_evals, factor_policy=args.policy, sub_batches=args.sub_batches)
     x = x0.clone()
+    fv = [None]
 
     def step():
         x.copy_(x0)
         fvec, ibs, status = ds.lm_solve_batch(A, b, gamma, x, opts)
+        fv[0] = fvec
         return ibs, status
 
     for _ in range(args.warmup):
         step()
-    # Timed region: only the roofline kernel is bracketed by HIP events (two event records per launch on the launch
-    # stream cost ~3 % of a step when every one of the ~100 launches is bracketed); the per-kernel breakdown comes from
-    # a second, untimed pass over the same steps below.
-    ds.h.timing_enable(kernels=["fd_jacobian"])
+    # Timed region: only the roofline kernel is bracketed by HIP events (on the launch stream); the per-kernel breakdown
+    # comes from a second, untimed pass over the same steps below.
+    roof_kernel = "qrx_pass" if args.policy == 2 else "fd_jacobian"
+    if args.policy != 2:
+        opts.fuse_fd = 0                       # the stand-alone FD column kernel is the HBM-bound one of these policies
+    ds.h.timing_enable(kernels=[roof_kernel])
+    ds.h.timing_samples(roof_kernel, select_only=True)       # keep this group's per-launch durations
     ds.h.timing_reset()
 
     def sync():
@@ -248,35 +323,48 @@ def main():
     elapsed = float(tt[0])
     njac_all, naccept_all, bad_all = (float(v) for v in cnt.tolist())
 
-    # gather per-problem results (iteration counts + an x checksum) on every rank: the "gather" end
+    # gather per-problem results (counts + an x checksum) in global problem order on every rank: the "gather" end
     rows = torch.tensor([[ib["iter_count"], ib["fcn_count"], ib["jacobian_count"]] for ib in last_ibs],
-                        dtype=torch.float64, device=dev)
+                        dtype=torch.float64, device=dev).reshape(B, 3)
     rows = torch.cat([rows, x.sum(dim=1, keepdim=True)], dim=1)
     allrows = sharding.gather_results(rows, nprob_total, rank, world)
 
-    fd_ms, fd_launches = ds.h.timing("fd_jacobian")
-    ds.h.timing_enable(True)                       # breakdown pass: same steps, every kernel group timed, not part of `value`
-    ds.h.timing_reset()
-    for _ in range(args.steps):
-        step()
-    kernel_ms = {k: ds.h.timing(k)[0] for k in
-                 ("dq_residual", "dq_panel", "fd_jacobian", "gram", "gram_reduce", "jtf", "chol", "lmpar", "qr", "update")}
+    roof_ms, roof_launches = ds.h.timing(roof_kernel)
+    roof_samples = ds.h.timing_samples(roof_kernel) if args.sub_batches == 1 else []
+    kernel_ms = None
+    if args.extras:
+        ds.h.timing_enable(True)                   # breakdown pass: same steps, every kernel group timed, not part of `value`
+        ds.h.timing_reset()
+        for _ in range(args.steps):
+            step()
+        kernel_ms = {k: ds.h.timing(k)[0] for k in
+                     ("dq_residual", "dq_panel", "fd_jacobian", "gram", "gram_reduce", "chol", "lmpar", "qr", "qrx_pass",
+                      "qrx_pivot", "update")}
     ds.h.timing_enable(False)
 
     if rank == 0:
-        achieved = fd_bytes(m, n) * (njac / max(fd_ms * 1e-3, 1e-30)) / 1e9      # this rank's launches
-        # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950
-        # corrections applied), committed under profiles/; scaled to the average launch of this run.
-        traffic = None
+        if args.policy == 2:
+            unit_bytes, units = qr_pass_bytes(m, n), "problem-factorisations"
+            kname = "k_qrx_pass (trailing pass of a Householder step, exact lmfactor)"
+        else:
+            unit_bytes, units = fd_bytes(m, n), "problem-Jacobians"
+            kname = "k_fd_jacobian"
+        achieved = unit_bytes * (njac / max(roof_ms * 1e-3, 1e-30)) / 1e9      # this rank's launches
+        # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections
+        # applied) committed under profiles/: bytes moved per algorithmic byte, scaled to this run's average launch.
+        traffic, traffic_src = None, None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            if (prof["m"], prof["n"]) == (m, n):
-                per_problem = prof["kernels"]["k_fd_jacobian<256, 8, true>"]["hbm_bytes_per_problem"]
-                traffic = per_problem * njac / max(fd_launches, 1)
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            if (prof["m"], prof["n"], prof.get("policy")) == (m, n, args.policy):
+                ratio = prof["roofline_kernel"]["hbm_bytes_per_algorithmic_byte"]
+                traffic = ratio * unit_bytes * njac / max(roof_launches, 1)
+                traffic_src = ("profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                               f"command at commit {prof.get('commit', '?')}): measured bytes per algorithmic byte x this "
+                               "run's algorithmic bytes per average launch")
         except Exception:
             traffic = None
         out = {
-            "metric": "LM iterations/sec on m=4096,n=256 fp64; FD-Jacobian GB/s vs HBM peak",
+            "metric": f"LM iterations/sec on m={m},n={n} fp64; FD-Jacobian GB/s vs HBM peak",
             "value": njac_all / elapsed,
             "unit": "LM iterations/s",
             "n_gpus": world,
@@ -284,126 +372,116 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"batched LM {m}x{n} fp64, FD Jacobian, dense-quadratic residual family "
                             f"(SURVEY 8(d): gamma={gamma}, sigma={sigma}, spread={spread}, seeds {seed0}+k), "
-                            f"{B} problems per GPU per step",
-                "problems_per_gpu": B, "m": m, "n": n, "max_fcn_evals": max_evals,
-                "factor_policy": {0: "auto (J^T J MFMA + pivoted Cholesky, QR fallback)", 1: "householder-qr",
-                                  2: "exact (reference operation order)"}[args.policy],
+                            + (f"{args.batch} problems per GPU per step" if args.scaling == "weak"
+                               else f"{nprob_total} problems per step in all"),
+                "problems_total": nprob_total, "problems_rank0": B, "m": m, "n": n, "max_fcn_evals": max_evals,
+                "factor_policy": POLICY_NAMES[args.policy],
+                "sub_batches_in_flight": args.sub_batches,
                 "parallelism": f"independent problems, block-cyclic over {world} rank(s)",
                 "accepted_steps_per_s": naccept_all / elapsed,
                 "non_converged": int(bad_all),
                 "iters_first_problem": [int(v) for v in allrows[0, :3].tolist()],
             },
             "roofline": {
-                "kernel": "k_fd_jacobian", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), bytes per average launch",
-                "algorithmic_bytes_per_launch": fd_bytes(m, n) * njac / max(fd_launches, 1),
-                "bytes_per_unit": fd_bytes(m, n), "units": "problem-Jacobians", "launches": int(fd_launches),
-                "avg_launch_ms": fd_ms / max(fd_launches, 1),
+                "kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": unit_bytes * njac / max(roof_launches, 1),
+                "bytes_per_unit": unit_bytes, "units": units, "launches": int(roof_launches),
+                "avg_launch_ms": roof_ms / max(roof_launches, 1),
             },
-            "kernel_ms_per_step": {k: v / args.steps for k, v in kernel_ms.items()},
         }
-        # the other kernels of an outer iteration against the bound that applies to each
-        nfev = sum(ib["fcn_count"] for ib in last_ibs) * args.steps
-        gram_flops = (m * n * (n + 1) + 2 * m * n) * njac             # symmetric half + J^T f
-        panel_adds = m * (n * (n + 1) // 2) * njac                    # dependent adds of n perturbed row sums
-        resid_bytes = 8 * (m * n + 2 * m + n) * nfev
-        gms, pms, rms = kernel_ms["gram"], kernel_ms["dq_panel"], kernel_ms["dq_residual"]
-        out["kernel_rooflines"] = [
-            {"kernel": "k_gram_tri / k_gram_mfma", "bound": "mfma", "achieved": gram_flops / max(gms * 1e-3, 1e-30) / 1e12,
-             "peak": 78.6, "unit": "TFLOP/s", "frac": gram_flops / max(gms * 1e-3, 1e-30) / 1e12 / 78.6},
-            {"kernel": "k_dq_panel", "bound": "valu-f64-add", "achieved": panel_adds / max(pms * 1e-3, 1e-30) / 1e12,
-             "peak": 39.3, "unit": "Tadd/s", "frac": panel_adds / max(pms * 1e-3, 1e-30) / 1e12 / 39.3},
-            {"kernel": "k_dq_residual", "bound": "hbm", "achieved": resid_bytes / max(rms * 1e-3, 1e-30) / 1e9,
-             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": resid_bytes / max(rms * 1e-3, 1e-30) / 1e9 / HBM_PEAK_GBS},
-        ]
+        if args.policy == 2 and roof_samples and len(roof_samples) % (n * args.steps) == 0:
+            # A step is a sequence of lock-step rounds of n launches each; in the first round of a step every problem of
+            # the batch is active (later rounds serve ever fewer problems and are bound by the serial row recurrences of
+            # the few that remain, not by HBM): the same kernel on full launches only.
+            per_step = len(roof_samples) // args.steps
+            full_ms = sum(sum(roof_samples[s * per_step: s * per_step + n]) for s in range(args.steps))
+            full = unit_bytes * B * args.steps / max(full_ms * 1e-3, 1e-30) / 1e9
+            out["roofline"]["full_launches"] = {
+                "achieved": full, "frac": full / HBM_PEAK_GBS, "launches": n * args.steps,
+                "avg_launch_ms": full_ms / (n * args.steps), "rounds_per_step": per_step // n,
+                "note": "first round of each step: all problems of the batch active in every launch"}
+        if sols:
+            # parity of the timed path with the CPU oracle on the first problems of the batch (same seeds)
+            import numpy as np
+            ns = min(len(sols), B)
+            xg = x[:ns].cpu().numpy()
+            eq = sum(1 for k in range(ns) if np.array_equal(xg[k], sols[k][0]))
+            keys = ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn", "converge_on_chng", "converge_on_zero_diff")
+            ceq = sum(1 for k in range(ns) if all(last_ibs[k][q] == sols[k][1][q] for q in keys))
+            rel = max(float(np.abs(xg[k] - sols[k][0]).max() / np.abs(sols[k][0]).max()) for k in range(ns))
+            out["parity"] = {"checked_against": "oracle/nonlin_oracle.c (CPU restatement of the reference path)",
+                             "problems": ns, "x_bitwise_equal": eq, "counts_and_flags_equal": ceq,
+                             "max_rel_dev_x": rel}
+        if kernel_ms is not None:
+            out["kernel_ms_per_step"] = {k: v / args.steps for k, v in kernel_ms.items()}
+            # the other kernels of an outer iteration against the bound that applies to each
+            nfev = sum(ib["fcn_count"] for ib in last_ibs) * args.steps
+            panel_adds = m * (n * (n + 1) // 2) * njac                    # dependent adds of n perturbed row sums
+            resid_bytes = 8 * (m * n + 2 * m + n) * nfev
+            pms, rms = kernel_ms["dq_panel"], kernel_ms["dq_residual"]
+            kr = [
+                {"kernel": "k_dq_panel (n perturbed evaluations + FD column in the epilogue)", "bound": "valu-f64-add",
+                 "achieved": panel_adds / max(pms * 1e-3, 1e-30) / 1e12, "peak": 39.3, "unit": "Tadd/s",
+                 "frac": panel_adds / max(pms * 1e-3, 1e-30) / 1e12 / 39.3,
+                 "hbm_GBs": 8.0 * (2 * m * n + 2 * m + 2 * n) * njac / max(pms * 1e-3, 1e-30) / 1e9},
+                {"kernel": "k_dq_residual", "bound": "hbm", "achieved": resid_bytes / max(rms * 1e-3, 1e-30) / 1e9,
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": resid_bytes / max(rms * 1e-3, 1e-30) / 1e9 / HBM_PEAK_GBS},
+            ]
+            if kernel_ms["gram"] > 0:
+                gram_flops = (m * n * (n + 1) + 2 * m * n) * njac         # symmetric half + J^T f
+                kr.insert(0, {"kernel": "k_gram_tri / k_gram_mfma", "bound": "mfma",
+                              "achieved": gram_flops / max(kernel_ms["gram"] * 1e-3, 1e-30) / 1e12, "peak": 78.6,
+                              "unit": "TFLOP/s", "frac": gram_flops / max(kernel_ms["gram"] * 1e-3, 1e-30) / 1e12 / 78.6})
+            out["kernel_rooflines"] = kr
         if world == 1 and args.extras:
-            # latency of BASELINE config 2 taken literally: ONE 4096 x 256 problem (seed 12345), warm handle
-            x1 = x0[:1].clone()
-            ds.lm_solve_batch(A[:1], b[:1], gamma, x1, opts)
-            x1.copy_(x0[:1])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            _, ib1, _ = ds.lm_solve_batch(A[:1], b[:1], gamma, x1, opts)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter() - t1
-            out["single_problem"] = {"ms": 1e3 * t1, "lm_iterations": ib1[0]["jacobian_count"],
-                                     "lm_iterations_per_s": ib1[0]["jacobian_count"] / t1}
-        if world == 1 and args.extras and not args.fuse_fd:
-            # same batch with the FD column write fused into the panel kernel (bit-identical results, one kernel
-            # and one 8mn-byte round trip less per Jacobian); the headline keeps the stand-alone FD kernel
-            of = ds.options(max_evals=max_evals, factor_policy=args.policy, fuse_fd=1)
-            xf = x0.clone()
-            ds.lm_solve_batch(A, b, gamma, xf, of)
-            tf, nj = 0.0, 0
-            for _ in range(args.steps):
-                xf.copy_(x0)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                _, ibf, _ = ds.lm_solve_batch(A, b, gamma, xf, of)
-                torch.cuda.synchronize()
-                tf += time.perf_counter() - t1
-                nj += sum(i["jacobian_count"] for i in ibf)
-            out["fused_fd"] = {"value": nj / tf, "unit": "LM iterations/s", "identical_x": bool(torch.equal(xf, x)),
-                               "note": "opts.fuse_fd = 1: Jacobian column formed in the panel kernel's epilogue"}
-        if world == 1 and args.extras:
-            # several batches in flight: one handle (workspace + HIP stream) per host thread, so that the
-            # latency-bound stages of one batch (Cholesky, lmpar, straggler rounds, the per-round status read-back)
-            # overlap the streaming kernels of another.  Same inputs, same results; per-kernel times are not
-            # meaningful in this mode, which is why the headline and its roofline are measured one batch at a time.
-            import threading
-            nfl, ksteps = 4, 12
-            streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
-            solvers = []
-            for st_ in streams:
-                with torch.cuda.stream(st_):
-                    solvers.append(DeviceSolver(local_rank))
-            for label, of in (("pipelined", opts), ("pipelined_fused_fd", ds.options(max_evals=max_evals, factor_policy=args.policy,
-                                                                                  fuse_fd=1))):
-                xs_ = [x0.clone() for _ in range(nfl)]
-                counts = [0] * nfl
+            def run_policy(o, nrep=1, xs=None, sel=slice(None)):
+                xq = x0[sel].clone() if xs is None else xs
+                ds.lm_solve_batch(A[sel], b[sel], gamma, xq, o)         # warm
+                tq, nj, ibq = 0.0, 0, None
+                for _ in range(nrep):
+                    xq.copy_(x0[sel])
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    _, ibq, _ = ds.lm_solve_batch(A[sel], b[sel], gamma, xq, o)
+                    torch.cuda.synchronize()
+                    tq += time.perf_counter() - t1
+                    nj += sum(i["jacobian_count"] for i in ibq)
+                return nj / tq, xq, ibq, tq / nrep
 
-                def work(i, nsteps):
-                    with torch.cuda.stream(streams[i]):
-                        for _ in range(nsteps):
-                            xs_[i].copy_(x0)
-                            _, ibw, _ = solvers[i].lm_solve_batch(A, b, gamma, xs_[i], of)
-                            counts[i] += sum(q["jacobian_count"] for q in ibw)
-                for timed_pass in (False, True):
-                    for i in range(nfl):
-                        counts[i] = 0
-                    torch.cuda.synchronize()
-                    tp0 = time.perf_counter()
-                    th = [threading.Thread(target=work, args=(i, ksteps // nfl if timed_pass else 1)) for i in range(nfl)]
-                    [t_.start() for t_ in th]
-                    [t_.join() for t_ in th]
-                    torch.cuda.synchronize()
-                    tp = time.perf_counter() - tp0
-                out[label] = {"value": sum(counts) / tp, "unit": "LM iterations/s", "batches_in_flight": nfl, "steps": ksteps,
-                              "ms_per_step": 1e3 * tp / ksteps, "identical_x": bool(all(torch.equal(xq, x) for xq in xs_))}
-            del solvers
-        if world == 1 and args.policy == 0 and args.exact_sample > 0:
-            # the same workload under the exact factor policy (reference operation order: x, fvec and all
-            # counts bit-identical to the CPU path, tests/test_gpu_solvers.py), one untimed + one timed pass
-            Be = min(B, args.exact_sample)
-            oe = ds.options(max_evals=max_evals, factor_policy=2)
-            xe = x0[:Be].clone()
-            ds.lm_solve_batch(A[:Be], b[:Be], gamma, xe, oe)
-            xe.copy_(x0[:Be])
-            torch.cuda.synchronize()
-            te = time.perf_counter()
-            _, ibe, _ = ds.lm_solve_batch(A[:Be], b[:Be], gamma, xe, oe)
-            torch.cuda.synchronize()
-            te = time.perf_counter() - te
-            out["exact_policy"] = {"value": sum(i["jacobian_count"] for i in ibe) / te, "unit": "LM iterations/s",
-                                   "problems": Be, "note": "NLH_FACTOR_EXACT: bit-identical to the CPU path"}
+            # the library's default options (several sub-batches in flight): same bits, the product's own throughput
+            v, xd, _, _ = run_policy(ds.options(max_evals=max_evals), nrep=min(args.steps, 3))
+            out["default_options"] = {"value": v, "unit": "LM iterations/s", "identical_x": bool(torch.equal(xd, x)),
+                                      "note": "nlh_default_options (exact policy, sub_batches = auto: latency-bound stages of one "
+                                              "sub-batch run under the streaming kernels of another)"}
+            # latency of BASELINE config 2 taken literally: ONE problem (seed 12345), warm handle
+            v1, _, ib1, t1 = run_policy(ds.options(max_evals=max_evals), nrep=1, sel=slice(0, 1))
+            out["single_problem"] = {"ms": 1e3 * t1, "lm_iterations": ib1[0]["jacobian_count"], "lm_iterations_per_s": v1,
+                                     "factor_policy": POLICY_NAMES[2]}
+            # the fast non-parity policy: J^T J on the fp64 MFMA + Cholesky; deviation from the CPU path measured here
+            va, xa, iba, _ = run_policy(ds.options(max_evals=max_evals, factor_policy=0), nrep=min(args.steps, 5))
+            auto = {"value": va, "unit": "LM iterations/s", "factor_policy": POLICY_NAMES[0],
+                    "note": "opt-in policy: a different factorisation (normal equations), not bit-identical; "
+                            "its deviation from the CPU oracle on the first problems of the batch:"}
+            if sols:
+                import numpy as np
+                ns = min(len(sols), B)
+                xg = xa[:ns].cpu().numpy()
+                dev_ = [float(np.abs(xg[k] - sols[k][0]).max() / np.abs(sols[k][0]).max()) for k in range(ns)]
+                mism = sum(1 for k in range(ns) if any(iba[k][q] != sols[k][1][q] for q in ("iter_count", "fcn_count", "jacobian_count")))
+                auto.update({"problems_compared": ns, "max_rel_dev_x": max(dev_), "median_rel_dev_x": sorted(dev_)[ns // 2],
+                             "count_mismatch_rate": mism / ns})
+            out["auto_policy"] = auto
+            v1a, _, ib1a, t1a = run_policy(ds.options(max_evals=max_evals, factor_policy=0), nrep=1, sel=slice(0, 1))
+            out["auto_policy"]["single_problem_ms"] = 1e3 * t1a
+            out["fd_jacobian_mode_h"] = fd_mode_h_roofline(ds)
         if world == 1 and args.other_paths:
             out["other_paths"] = other_paths(ds)
         if cpu is not None:

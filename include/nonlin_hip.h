@@ -299,6 +299,9 @@ void nlh_timing_enable(nlh_handle *h, int32_t on);
 void nlh_timing_reset(nlh_handle *h);
 /* Synchronises the stream, then returns total milliseconds and launch count. */
 int  nlh_timing_get(nlh_handle *h, int32_t kernel_id, double *total_ms, int64_t *launches);
+/* Per-launch durations (ms, launch order) of ONE kernel group since the last nlh_timing_reset.  The first call with a
+ * new kernel_id selects that group and returns 0; later calls copy up to cap samples and return how many there are. */
+int64_t nlh_timing_samples(nlh_handle *h, int32_t kernel_id, float *out_ms, int64_t cap);
 const char *nlh_kernel_name(int32_t kernel_id);
 
 #ifdef __cplusplus

@@ -101,6 +101,7 @@ SYMBOLS = {
     "nlh_timing_enable": (None, [_H, C.c_int32]),
     "nlh_timing_reset": (None, [_H]),
     "nlh_timing_get": (C.c_int, [_H, C.c_int32, c_double_p, C.POINTER(C.c_int64)]),
+    "nlh_timing_samples": (C.c_int64, [_H, C.c_int32, C.POINTER(C.c_float), C.c_int64]),
     "nlh_kernel_name": (C.c_char_p, [C.c_int32]),
 }
 
@@ -182,6 +183,17 @@ class Handle:
         cnt = C.c_int64(0)
         self.lib.nlh_timing_get(self._h, KERNEL_IDS[kernel], C.byref(ms), C.byref(cnt))
         return ms.value, cnt.value
+
+    def timing_samples(self, kernel, select_only=False):
+        """Per-launch durations (ms, launch order) of one kernel group since the last timing_reset.  The group must have
+        been selected before the launches (select_only=True) and be enabled in timing_enable."""
+        kid = KERNEL_IDS[kernel]
+        n = self.lib.nlh_timing_samples(self._h, kid, None, 0)
+        if select_only or n <= 0:
+            return []
+        buf = (C.c_float * n)()
+        n = self.lib.nlh_timing_samples(self._h, kid, buf, n)
+        return [float(buf[i]) for i in range(n)]
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

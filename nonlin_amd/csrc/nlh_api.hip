@@ -50,6 +50,8 @@ struct nlh_handle {
     std::vector<hipEvent_t> pool;
     double ms[NLH_K_COUNT] = {0};
     int64_t launches[NLH_K_COUNT] = {0};
+    int sample_kid = -1;              // kernel group whose per-launch durations are kept (nlh_timing_samples)
+    std::vector<float> samples;
     std::vector<DevBuf *> bufs;       // every workspace buffer, for destroy
     // named workspace buffers (grown on demand, reused across calls)
     DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2, R,
@@ -107,6 +109,7 @@ static void timing_flush(nlh_handle *h)
         float t = 0.f;
         if (hipEventElapsedTime(&t, pr.a, pr.b) == hipSuccess) h->ms[pr.kid] += (double)t;
         h->launches[pr.kid] += 1;
+        if (pr.kid == h->sample_kid) h->samples.push_back(t);
         h->pool.push_back(pr.a);
         h->pool.push_back(pr.b);
     }
@@ -132,7 +135,7 @@ struct Timed {
         if (on) {
             hipEventRecord(b, h->stream);
             h->pending.push_back({a, b, kid});
-            if (h->pending.size() > 8192) timing_flush(h);
+            if (h->pending.size() > 65536) timing_flush(h);
         }
     }
 };
@@ -150,7 +153,7 @@ static void qrx_time_end(nlh_handle *h, int)
     if (!h->qrx_open_on) return;
     hipEventRecord(h->qrx_b, h->stream);
     h->pending.push_back({h->qrx_a, h->qrx_b, h->qrx_kid});
-    if (h->pending.size() > 8192) timing_flush(h);
+    if (h->pending.size() > 65536) timing_flush(h);
 }
 
 static int ensure_workers(nlh_handle *h, int T);
@@ -260,6 +263,21 @@ void nlh_timing_reset(nlh_handle *h)
     if (!h) return;
     timing_flush(h);
     for (int k = 0; k < NLH_K_COUNT; ++k) { h->ms[k] = 0; h->launches[k] = 0; }
+    h->samples.clear();
+}
+int64_t nlh_timing_samples(nlh_handle *h, int32_t kid, float *out_ms, int64_t cap)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (kid != h->sample_kid) {                 // select the group; samples accumulate from the next reset on
+        timing_flush(h);
+        h->sample_kid = kid;
+        h->samples.clear();
+        return 0;
+    }
+    timing_flush(h);
+    const int64_t cnt = (int64_t)h->samples.size();
+    for (int64_t i = 0; i < cnt && i < cap; ++i) out_ms[i] = h->samples[(size_t)i];
+    return cnt;
 }
 int nlh_timing_get(nlh_handle *h, int32_t kid, double *total_ms, int64_t *launches)
 {

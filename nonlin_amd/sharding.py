@@ -45,3 +45,18 @@ def gather_results(local, nprob, rank, world):
         if idx:
             full[torch.tensor(idx, device=local.device)] = out[r * per: r * per + len(idx)]
     return full
+
+
+def solve_sharded(nprob, rank, world, device, config, solve_local):
+    """One sharded batch from end to end: broadcast `config` (a flat list of numbers, rank 0's values win), deal the
+    problems block-cyclically, let `solve_local(config, global_indices)` solve this rank's share and return one float64
+    row per problem ([nlocal, width], shard order), gather the rows in global problem order on every rank.
+
+    bench.py's N > 1 path is these three calls around its timed loop; the CPU tests drive the same function over gloo
+    with a stub `solve_local`, the GPU tests with the real batched solver.  Returns (config, rows [nprob, width])."""
+    cfg = broadcast_config(config, device)
+    idx = shard_indices(nprob, rank, world)
+    local = solve_local(cfg, idx)
+    if local.dim() != 2 or local.shape[0] != len(idx):
+        raise ValueError(f"solve_local returned {tuple(local.shape)} for {len(idx)} problems")
+    return cfg, gather_results(local, nprob, rank, world)

@@ -1,0 +1,87 @@
+"""BASELINE.json configs 4 and 5 at their stated sizes, under the parity-carrying exact policy (the library default).
+
+The oracle needs ~0.25 s per 2048 x 128 problem and minutes for one 65536 x 512 problem on a host core, so at full size
+the comparison with it is a sample (config 4) or opt-in (config 5, NLH_SLOW_TESTS=1); everything else is held through
+properties that do not depend on the size: every problem converges, sharding does not change a bit of any problem,
+the exact and the normal-equations policies agree at the forward-difference noise level, R^T R = P^T J^T J P."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn", "converge_on_chng", "converge_on_zero_diff")
+RTOL_X_FD_NOISE = 2e-6      # tests/test_gpu_solvers.py explains the bound
+
+
+def test_c4_1024_problems_exact_policy_and_sharding_invariance(ds, oracle):
+    """Config 4: 1024 independent 2048 x 128 problems, seeds 12345 + k.  (a) all converge; (b) a sample of 12 problems is
+    bit-identical to the CPU oracle (x, fvec, counts, flags); (c) dealing the problems block-cyclically to 2, 4 or 8 ranks
+    (here: solving each rank's share as its own batch on this GPU, which is all a rank does -- there is no data-path
+    collective) reproduces every problem of the unsharded batch bit for bit."""
+    nprob, m, n = 1024, 2048, 128
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=12345)
+    x = x0.clone()
+    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500))
+    assert all(s == 0 for s in status)
+    assert all(3 <= ib["jacobian_count"] <= 8 for ib in ibs)
+    for p in list(range(0, nprob, 93)):                          # 12 problems spread over the batch
+        rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5,
+                                                   x0[p].cpu().numpy(), opts=oracle.default_options(max_evals=500))
+        assert rc == 0 and all(ibs[p][k] == ibo[k] for k in KEYS), (p, ibs[p], ibo)
+        assert np.array_equal(x[p].cpu().numpy(), xo) and np.array_equal(fvec[p].cpu().numpy(), fo), p
+    for world in (2, 4, 8):
+        rank = world - 1                                          # one rank's share is enough per world size
+        Ar, br, _, x0r = ds.generate(len(range(rank, nprob, world)), m, n, seed0=12345 + rank, seed_stride=world)
+        assert torch.equal(Ar, A[rank::world]) and torch.equal(x0r, x0[rank::world])    # the rank generates ITS problems
+        xr = x0r.clone()
+        fr, ibr, str_ = ds.lm_solve_batch(Ar, br, 0.5, xr, ds.options(max_evals=500))
+        assert torch.equal(xr, x[rank::world]) and torch.equal(fr, fvec[rank::world])
+        assert ibr == ibs[rank::world] and str_ == status[rank::world]
+
+
+def test_c5_tall_skinny_65536x512_full_solve(ds, oracle):
+    """Config 5: one 65536 x 512 problem, seed 12345.  Exact policy: converges; the normal-equations policy (MFMA J^T J
+    contraction) reaches the same point at the forward-difference noise level with the same counts; the Gram matrix of
+    the FD Jacobian agrees with an fp64 reference product.  NLH_SLOW_TESTS=1 adds the bit-for-bit comparison with the
+    oracle (minutes of host time)."""
+    m, n = 65536, 512
+    A, b, xt, x0 = ds.generate(1, m, n, seed0=12345)
+    xe = x0.clone()
+    fe, ibe, ste = ds.lm_solve_batch(A, b, 0.5, xe, ds.options(max_evals=500))
+    assert ste == [0] and ibe[0]["converge_on_fcn"] == 1 and 3 <= ibe[0]["jacobian_count"] <= 8
+    xa = x0.clone()
+    fa, iba, sta = ds.lm_solve_batch(A, b, 0.5, xa, ds.options(max_evals=500, factor_policy=0))
+    assert sta == [0] and all(abs(iba[0][k] - ibe[0][k]) <= 1 for k in KEYS[:3])
+    rel = float((xa - xe).abs().max() / xe.abs().max())
+    assert rel <= RTOL_X_FD_NOISE, rel
+    # residual norm at the solution ~ sigma * sqrt(m / 3): the noise floor of the generator
+    fn = float(fe.norm())
+    assert 0.3 * 1e-3 * np.sqrt(m / 3.0) < fn < 3 * 1e-3 * np.sqrt(m / 3.0)
+    # MFMA contraction property: G = J^T J of the FD Jacobian at x0 against torch's fp64 product, 1e-12 of |G|_max
+    f0 = ds.residual(A, b, 0.5, x0)
+    J = ds.fd_jacobian_panel(ds.fd_panel(A, b, 0.5, x0), f0, x0)
+    G, g = ds.gram(J, f0)
+    Gref = torch.matmul(J[0], J[0].T)
+    assert float((G[0] - Gref).abs().max() / Gref.abs().max()) < 1e-12
+    assert float((g[0] - torch.mv(J[0], f0[0])).abs().max() / g[0].abs().max()) < 1e-11
+    if os.environ.get("NLH_SLOW_TESTS"):
+        rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), 0.5,
+                                                   x0[0].cpu().numpy(), opts=oracle.default_options(max_evals=500))
+        assert rc == 0 and all(ibe[0][k] == ibo[k] for k in KEYS), (ibe[0], ibo)
+        assert np.array_equal(xe[0].cpu().numpy(), xo) and np.array_equal(fe[0].cpu().numpy(), fo)
+
+
+def test_c5_shape_scaled_down_bitwise(ds, oracle):
+    """The same 128:1 aspect ratio and n = 512 column count at a size the oracle finishes in seconds (n > 256 takes more
+    than four 64-column windows per row of the working matrix)."""
+    m, n = 4096, 512
+    A, b, xt, x0 = ds.generate(1, m, n, seed0=777)
+    x = x0.clone()
+    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500))
+    rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), 0.5,
+                                               x0[0].cpu().numpy(), opts=oracle.default_options(max_evals=500))
+    assert status[0] == rc == 0 and all(ibs[0][k] == ibo[k] for k in KEYS)
+    assert np.array_equal(x[0].cpu().numpy(), xo) and np.array_equal(fvec[0].cpu().numpy(), fo)

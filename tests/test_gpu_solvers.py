@@ -38,6 +38,8 @@ def _check_batch(ds, oracle, nprob, m, n, seed0, gen_kw, opt_kw, rtol=RTOL_X, bi
     gamma = gen_kw.get("gamma", 0.5)
     A, b, xt, x0 = ds.generate(nprob, m, n, seed0=seed0, **gen_kw)
     x = x0.clone()
+    if "factor_policy" not in opt_kw:          # the library default is the exact policy; these cases are about the
+        opt_kw = dict(opt_kw, factor_policy=0)  # normal-equations one (NLH_FACTOR_AUTO), an explicit opt-in
     fvec, ibs, status = ds.lm_solve_batch(A, b, gamma, x, ds.options(**opt_kw))
     worst = 0.0
     for p in range(nprob):
@@ -66,7 +68,7 @@ def test_lm_batch_c2_single_problem(ds, oracle):
     """BASELINE config 2: one 4096 x 256 problem, seed 12345 (reference: 5 / 5 / 4)."""
     A, b, xt, x0 = ds.generate(1, 4096, 256, seed0=12345)
     x = x0.clone()
-    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500))
+    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500, factor_policy=0))
     rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), 0.5,
                                                x0[0].cpu().numpy(), opts=oracle.default_options(max_evals=500))
     assert (ibo["iter_count"], ibo["fcn_count"], ibo["jacobian_count"]) == (5, 5, 4)     # recorded reference counts
@@ -136,12 +138,13 @@ def test_lm_linearity_property_full_size(ds):
     """Size-independent property at BASELINE size 4096 x 256: with gamma = 0 the model is linear,
     so LM must land on the least-squares solution: J^T r = 0 to rounding."""
     A, b, xt, x0 = ds.generate(2, 4096, 256, seed0=99, gamma=0.0, sigma=1e-3)
-    x = x0.clone()
-    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.0, x, ds.options(max_evals=100))
-    assert status == [0, 0]
-    grad = torch.matmul(A, fvec.unsqueeze(-1)).squeeze(-1)      # A^T r per problem
-    # the FD Jacobian carries ~2 sqrt(eps) relative noise, so J_fd^T r = 0 leaves A^T r at that level
-    assert float(grad.abs().max()) <= 1e-5 * float(fvec.norm(dim=1).max())
+    for policy in (2, 0):
+        x = x0.clone()
+        fvec, ibs, status = ds.lm_solve_batch(A, b, 0.0, x, ds.options(max_evals=100, factor_policy=policy))
+        assert status == [0, 0]
+        grad = torch.matmul(A, fvec.unsqueeze(-1)).squeeze(-1)      # A^T r per problem
+        # the FD Jacobian carries ~2 sqrt(eps) relative noise, so J_fd^T r = 0 leaves A^T r at that level
+        assert float(grad.abs().max()) <= 1e-5 * float(fvec.norm(dim=1).max())
 
 
 # ---------------------------------------------------------------------------
@@ -422,7 +425,7 @@ def test_lm_c4_batch_property_and_spot_parity(ds, oracle):
     nprob, m, n = 256, 2048, 128
     A, b, xt, x0 = ds.generate(nprob, m, n, seed0=12345)
     x = x0.clone()
-    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500))
+    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500, factor_policy=0))
     assert all(s == 0 for s in status)
     assert all(3 <= ib["jacobian_count"] <= 8 for ib in ibs)
     # residual norm at the solution ~ sigma * sqrt(m/3): the noise floor of the generator
@@ -442,7 +445,7 @@ def test_lm_batch_larger_than_the_chip(ds, oracle):
     for (nprob, m, n, spots) in ((320, 512, 128, (0, 160, 319)), (288, 4096, 256, (287,))):
         A, b, xt, x0 = ds.generate(nprob, m, n, seed0=4242)
         x = x0.clone()
-        fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500))
+        fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500, factor_policy=0))
         assert all(s == 0 for s in status)
         for p in spots:
             rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5,
