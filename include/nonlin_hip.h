@@ -202,6 +202,26 @@ int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *opts, int32_t npro
                             double *hfout, nlh_iteration_behavior *ib /* host, [nprob] */,
                             int32_t *status /* host, [nprob] */);
 
+/* ---- device residual models behind HOST arrays (no reference counterpart: the extension of vecfcn_helper that lets
+ * `solver%solve` reach the batched device path -- nonlin_amd/fortran: vecfcn_helper%set_device_model, device_model_batch,
+ * least_squares_solver%solve_batch).  A model owns device copies of nprob problems of the dense-quadratic family
+ * r = (u + gamma u u) - b, u = A x: A [nprob][n][m] (each problem column-major m x n), b [nprob][m].
+ * x [nprob][n] in/out and fvec [nprob][m] out are host arrays; status[p] = 0 or the NL_* code the reference would stop
+ * with for problem p (no process abort). ---- */
+typedef struct nlh_dq_model nlh_dq_model;
+int  nlh_dq_model_create(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *A, const double *b,
+                         double gamma, nlh_dq_model **model);
+void nlh_dq_model_destroy(nlh_dq_model *model);
+void nlh_dq_model_shape(const nlh_dq_model *model, int32_t *nprob, int32_t *m, int32_t *n);
+/* vecfcn (src/nonlin_multi_eqn_mult_var.f90:14-25) of the model, every problem */
+int  nlh_dq_model_eval(nlh_handle *h, const nlh_dq_model *model, const double *x, double *f);
+/* lss_solve (src/nonlin_least_squares.f90:118-391) / ns_solve (src/nonlin_solve.f90:452-638) on every problem */
+int  nlh_dq_model_lm_solve(nlh_handle *h, const nlh_options *opts, const nlh_dq_model *model, double *x, double *fvec,
+                           nlh_iteration_behavior *ib, int32_t *status);
+int  nlh_dq_model_newton_solve(nlh_handle *h, const nlh_options *opts, const nlh_dq_model *model, int32_t analytic,
+                               double *x, double *fvec, nlh_iteration_behavior *ib, int32_t *status);
+
+
 /* Synthetic problem generator of SURVEY.md 8(d) (bench/test inputs, not part of the
  * reference): counter-based splitmix64, U_k = mix(seed + (k+1)*0x9E3779B97F4A7C15),
  * draw order A (column-major), x_true, noise, x0; problem p uses seed0 + p*seed_stride.

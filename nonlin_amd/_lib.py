@@ -98,6 +98,14 @@ SYMBOLS = {
     "nlh_chol_rank1": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_int32_p]),
     "nlh_poly_fit": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "nlh_poly_fit_batch": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlh_dq_model_create": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_double, C.POINTER(C.c_void_p)]),
+    "nlh_dq_model_destroy": (None, [C.c_void_p]),
+    "nlh_dq_model_shape": (None, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p]),
+    "nlh_dq_model_eval": (C.c_int, [_H, C.c_void_p, c_double_p, c_double_p]),
+    "nlh_dq_model_lm_solve": (C.c_int, [_H, C.POINTER(Options), C.c_void_p, c_double_p, c_double_p,
+                                        C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_dq_model_newton_solve": (C.c_int, [_H, C.POINTER(Options), C.c_void_p, C.c_int32, c_double_p, c_double_p,
+                                            C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_timing_enable": (None, [_H, C.c_int32]),
     "nlh_timing_reset": (None, [_H]),
     "nlh_timing_get": (C.c_int, [_H, C.c_int32, c_double_p, C.POINTER(C.c_int64)]),

@@ -2306,6 +2306,120 @@ int nlh_dq_generate(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, uint64_t
     return 0;
 }
 
+// ===========================================================================
+// Device residual models behind host arrays: what a Fortran / C caller without device pointers uses to reach the
+// batched device path (the extension of vecfcn_helper SURVEY.md section 7 asks for: set_device_model).
+// A model owns device copies of the data of nprob dense-quadratic problems (SURVEY 8(d) family:
+// r = (u + gamma u u) - b, u = A x); the solves stage x / fvec through the handle's buffers.
+// ===========================================================================
+struct nlh_dq_model {
+    int32_t nprob, m, n, device;
+    double gamma;
+    double *dA, *db, *dx, *df;
+};
+
+int nlh_dq_model_create(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *A, const double *b,
+                        double gamma, nlh_dq_model **out)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!out || !A || !b || nprob < 1 || m < 1 || n < 1) return NLH_INVALID_INPUT_ERROR;
+    *out = nullptr;
+    HIPCHK(h, hipSetDevice(h->device));
+    nlh_dq_model *md = new nlh_dq_model();
+    md->nprob = nprob; md->m = m; md->n = n; md->gamma = gamma; md->device = h->device;
+    const size_t mn = (size_t)nprob * m * n, pm = (size_t)nprob * m, pn = (size_t)nprob * n;
+    double *base = nullptr;
+    if (hipMalloc(&base, sizeof(double) * (mn + 2 * pm + pn)) != hipSuccess) {
+        delete md;
+        h->err = "hipMalloc (device model)";
+        return NLH_OUT_OF_MEMORY_ERROR;
+    }
+    md->dA = base; md->db = base + mn; md->df = md->db + pm; md->dx = md->df + pm;
+    hipError_t e1 = hipMemcpyAsync(md->dA, A, sizeof(double) * mn, hipMemcpyHostToDevice, h->stream);
+    hipError_t e2 = hipMemcpyAsync(md->db, b, sizeof(double) * pm, hipMemcpyHostToDevice, h->stream);
+    hipError_t e3 = hipStreamSynchronize(h->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        hipFree(base);
+        delete md;
+        h->err = "hipMemcpy (device model)";
+        return NLH_ERR_HIP;
+    }
+    *out = md;
+    return 0;
+}
+
+void nlh_dq_model_destroy(nlh_dq_model *md)
+{
+    if (!md) return;
+    hipSetDevice(md->device);
+    hipFree(md->dA);
+    delete md;
+}
+
+void nlh_dq_model_shape(const nlh_dq_model *md, int32_t *nprob, int32_t *m, int32_t *n)
+{
+    if (nprob) *nprob = md ? md->nprob : 0;
+    if (m) *m = md ? md->m : 0;
+    if (n) *n = md ? md->n : 0;
+}
+
+// vecfcn of the model: f = F(x) for every problem, host arrays x [nprob][n], f [nprob][m].
+int nlh_dq_model_eval(nlh_handle *h, const nlh_dq_model *md, const double *x, double *f)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!md || !x || !f) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t pm = (size_t)md->nprob * md->m, pn = (size_t)md->nprob * md->n;
+    HIPCHK(h, hipMemcpyAsync(md->dx, x, sizeof(double) * pn, hipMemcpyHostToDevice, h->stream));
+    launch_dq_residual(h, md->nprob, md->m, md->n, md->dA, md->db, md->gamma, md->dx, md->df, nullptr, nullptr, -1);
+    HIPCHK(h, hipMemcpyAsync(f, md->df, sizeof(double) * pm, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int model_stage_in(nlh_handle *h, const nlh_dq_model *md, const double *x)
+{
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(md->dx, x, sizeof(double) * (size_t)md->nprob * md->n, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+static int model_stage_out(nlh_handle *h, const nlh_dq_model *md, double *x, double *fvec)
+{
+    HIPCHK(h, hipMemcpyAsync(x, md->dx, sizeof(double) * (size_t)md->nprob * md->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(fvec, md->df, sizeof(double) * (size_t)md->nprob * md->m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// least_squares_solver%solve on every problem of the model (nlh_dq_lm_solve_batch behind host arrays).
+int nlh_dq_model_lm_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_model *md, double *x, double *fvec,
+                          nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!md || !x || !fvec) return NLH_INVALID_INPUT_ERROR;
+    int rc = model_stage_in(h, md, x);
+    if (rc) return rc;
+    rc = nlh_dq_lm_solve_batch(h, o, md->nprob, md->m, md->n, md->dA, md->db, md->gamma, md->dx, md->df, ib, status);
+    if (rc) return rc;
+    return model_stage_out(h, md, x, fvec);
+}
+
+// newton_solver%solve on every (square) problem of the model; analytic != 0: the model's own Jacobian
+// J(i,j) = (1 + 2 gamma u_i) A(i,j) plays the role of a jacobianfcn, otherwise forward differences.
+int nlh_dq_model_newton_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_model *md, int32_t analytic, double *x,
+                              double *fvec, nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!md || !x || !fvec) return NLH_INVALID_INPUT_ERROR;
+    if (md->m != md->n) return NLH_INVALID_INPUT_ERROR;         // src/nonlin_solve.f90:519
+    int rc = model_stage_in(h, md, x);
+    if (rc) return rc;
+    rc = nlh_dq_newton_solve_batch(h, o, md->nprob, md->n, md->dA, md->db, md->gamma, analytic, md->dx, md->df, ib, status);
+    if (rc) return rc;
+    return model_stage_out(h, md, x, fvec);
+}
+
 int nlh_dq_residual(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dA, const double *db,
                     double gamma, const double *dx, double *df)
 {

@@ -81,7 +81,8 @@ struct QrxWs {
     double *rdiag;     // [nprob][n]
     double *wa;        // [nprob][n]
     QrxStep *step;     // [nprob]
-    int32_t *src;      // [nprob][n + 1]
+    int32_t *src;      // [nprob][n + 1]: physical column holding slot k
+    int32_t *slotof;   // [nprob][ld]: slot held by a physical column, -1 = consumed / never used
 };
 
 static size_t qrx_carve(void *base, int nprob, int m, int n, QrxWs *w)
@@ -94,10 +95,12 @@ static size_t qrx_carve(void *base, int nprob, int m, int n, QrxWs *w)
     const size_t owa = take(sizeof(double) * (size_t)nprob * n);
     const size_t ost = take(sizeof(QrxStep) * (size_t)nprob);
     const size_t osr = take(sizeof(int32_t) * (size_t)nprob * (n + 1));
+    const size_t oso = take(sizeof(int32_t) * (size_t)nprob * qrx_ld(n));
     if (w) {
         char *b = (char *)base;
         w->V = (double *)(b + oV); w->tp = (double *)(b + otp); w->rdiag = (double *)(b + ord);
         w->wa = (double *)(b + owa); w->step = (QrxStep *)(b + ost); w->src = (int32_t *)(b + osr);
+        w->slotof = (int32_t *)(b + oso);
     }
     return off;
 }
@@ -146,13 +149,14 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
         v.ipvt[(size_t)p * n + k] = k;
     }
     for (int k = tid; k <= n; k += BS) w.src[(size_t)p * (n + 1) + k] = coff + k;    // physical column of slot k
+    for (int c = tid; c < ld; c += BS) w.slotof[(size_t)p * ld + c] = c >= coff ? c - coff : -1;
 }
 
 // Step j, part 1: pivot (:622-637), the pivot column with its pending updates -> reflector (:642-646).
 // The new reflector goes to slot np of the current bank, or to slot 0 of the other bank when this step's pass
 // flushes (np == QRX_C - 1).
 __global__ void __launch_bounds__(256)
-k_qrx_pivot(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, int np, int flush, const double *__restrict__ T, QrxWs w,
+k_qrx_pivot(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
 {
     __shared__ double cd[2 * QRX_NE * 256];
@@ -176,6 +180,7 @@ k_qrx_pivot(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, int np
     }
     const int kmax = block_argmax_first(bv, bk, red, redi);
     const int srck = src[kmax];
+    int32_t *slotof = w.slotof + (size_t)p * ld;
     double tk[QRX_C];
 #pragma unroll
     for (int q = 0; q < QRX_C; ++q) tk[q] = (q < np) ? tpc[(size_t)q * ldp + kmax] : 0.0;
@@ -185,7 +190,17 @@ k_qrx_pivot(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, int np
             rdiag[kmax] = rdiag[j];
             wa[kmax] = wa[j];
             const int32_t t = ipvt[j]; ipvt[j] = ipvt[kmax]; ipvt[kmax] = t;
-            src[kmax] = src[j];
+            if (j == 0) {
+                // first step only: a physical interchange (slot 0's column is copied over the consumed pivot column in the
+                // gather below), so that the live columns are coff + 1 .. from the start -- with n + 1 = 1 (mod 64) a
+                // live column at coff + 0 would cost every pass of the first cycle a whole extra 64-column window
+                slotof[src[0]] = -1;
+                slotof[srck] = kmax;
+            } else {
+                src[kmax] = src[j];                              // slot kmax now lives where slot j's data is
+                slotof[src[j]] = kmax;
+                slotof[srck] = -1;                               // the pivot column is consumed
+            }
         }
         if (tid < np) tpc[(size_t)tid * ldp + kmax] = tpc[(size_t)tid * ldp + j];
         for (int i = tid; i < j; i += BS) {                      // rows of R already final
@@ -193,19 +208,24 @@ k_qrx_pivot(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, int np
             R[(size_t)j * n + i] = R[(size_t)kmax * n + i];
             R[(size_t)kmax * n + i] = t;
         }
+    } else if (tid == 0) {
+        slotof[srck] = -1;                                       // the pivot column is consumed
     }
+    const bool move0 = (j == 0 && kmax != 0);                   // see above: slot 0's column takes the pivot column's place
+    const int src0 = coff;                                       // physical column of slot 0 at step 0
     // The pivot column with its pending updates applied, oldest first.  Four rows per thread are loaded together (the
     // column walk costs a 64-byte sector per element, the pending reflector entries are coalesced) before any is stored.
     const double *__restrict__ Vc = w.V + ((size_t)p * 2 + cur) * QRX_C * vst;          // slot q at Vc + q * vst
     double *__restrict__ Vn = flush ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
                                     : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
-    const double *__restrict__ col = T + (size_t)p * tst + srck;
+    double *col = T + (size_t)p * tst + srck;
     for (int i0 = j + tid; i0 < m; i0 += 4 * BS) {
-        double e[4], vq[4][QRX_C - 1];
+        double e[4], vq[4][QRX_C - 1], mv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = min(i0 + u * BS, m - 1);
             e[u] = col[(size_t)row * ld];
+            mv[u] = move0 ? col[(size_t)row * ld + (src0 - srck)] : 0.0;
 #pragma unroll
             for (int q = 0; q < QRX_C - 1; ++q) vq[u][q] = (q < np) ? Vc[(size_t)q * vst + row] : 0.0;
         }
@@ -214,7 +234,10 @@ k_qrx_pivot(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, int np
 #pragma unroll
             for (int q = 0; q < QRX_C - 1; ++q)
                 if (q < np) e[u] = e[u] - tk[q] * vq[u][q];
-            if (i0 + u * BS < m) Vn[i0 + u * BS] = e[u];
+            if (i0 + u * BS < m) {
+                Vn[i0 + u * BS] = e[u];
+                if (move0) col[(size_t)(i0 + u * BS) * ld] = mv[u];
+            }
         }
     }
     __syncthreads();
@@ -248,8 +271,9 @@ k_qrx_pivot(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, int np
 // tile ahead (coalesced 64-byte rows -> broadcast ds_reads); with CPT = 4 a row's nine LDS values serve 256 elements.
 template <int NP, bool FLUSH, int CPT>
 __global__ void __launch_bounds__(64)
-k_qrx_pass(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *__restrict__ T, const double *__restrict__ Vall,
-           double *__restrict__ tpall, int32_t *__restrict__ srcall, double *__restrict__ rdall,
+k_qrx_pass(int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
+           double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
+           int32_t *__restrict__ srcall, int32_t *__restrict__ slotall, double *__restrict__ rdall,
            double *__restrict__ waall, const QrxStep *__restrict__ stepall, double *__restrict__ Rall,
            double *__restrict__ qtfall, const LmState *__restrict__ st)
 {
@@ -258,30 +282,40 @@ k_qrx_pass(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cu
     constexpr int LP = QRX_C;              // LDS row: the pending entries and the new one (NP + 1 <= QRX_C doubles)
     constexpr int NPI = NP < QRX_C ? NP : 0;
     __shared__ double vt[2][TR * LP];
-    const int p = blockIdx.y;
+    // Workgroup -> (problem, window): consecutive workgroup ids go to consecutive XCDs, so the windows of one problem
+    // are given ids that agree modulo 8: they share an L2 (reflector tiles, multipliers, the row segment two windows
+    // both touch are fetched from the fabric once).
+    const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
+    const int p = grp * 8 + (r_ & 7), win = r_ >> 3;
+    if (p >= nprob) return;
     if (st && st[p].stage != ST_NEED_QR) return;
     const int lane = threadIdx.x, ldp = n + 1;
-    const int wtop = ld - 64 * CPT * (int)blockIdx.x;                   // end (exclusive) of this wave's topmost window
+    const int wtop = ld - 64 * CPT * win;                               // end (exclusive) of this wave's topmost window
     const QrxStep step = stepall[p];
     const bool refl = step.ajnorm != 0.0;
     const double ajj = step.ajj;
     int32_t *srcp = srcall + (size_t)p * ldp;
+    int32_t *slotp = slotall + (size_t)p * ld;
     double *tpc = tpall + ((size_t)p * 2 + cur) * QRX_C * ldp;
     const double *vc = Vall + ((size_t)p * 2 + cur) * QRX_C * vst + j;          // slot q, row j + r at vc[q * vst + r]
     const double *vo = Vall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst + j;   // slot 0 of the other bank
-    double *Tj = T + (size_t)p * tst + (size_t)j * ld;               // row j
+    double *Tj = T + (size_t)p * tst + (size_t)j * ld;                  // row j
     const int nrows = m - j;
 
-    // A load address is a wave-uniform row base plus a per-lane 32-bit column offset (scalar base + vector offset).
-    unsigned kc[CPT], sc[CPT];
+    // A lane owns a PHYSICAL column; which slot of the permuted matrix that column currently holds comes from the
+    // inverse map (the interchange never moves data).  Since the last flush the live columns are coff + lo .. ld - 1
+    // (lo = the step after that flush, 0 before the first one) minus the consumed ones, at most QRX_C - 1 of them,
+    // whose lanes idle: every load is the lane's own column, i.e. one aligned 512-byte span per wave and row.
+    unsigned kc[CPT], pc[CPT];
     bool act[CPT];
     double tq[CPT][NP > 0 ? NP : 1], s[CPT], rowj[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        const int k = wtop - 64 * (c + 1) + lane - coff;                // slot of physical column wtop - 64(c+1) + lane
+        const int col = wtop - 64 * (c + 1) + lane;
+        const int k = (col >= coff + lo) ? slotp[col] : -1;
         act[c] = k > j;
-        kc[c] = act[c] ? k : n;                                         // idle lanes shadow the residual column
-        sc[c] = (unsigned)srcp[kc[c]];
+        pc[c] = (unsigned)col;
+        kc[c] = act[c] ? (unsigned)k : (unsigned)n;                     // idle lanes: any valid slot for the table reads
 #pragma unroll
         for (int q = 0; q < NP; ++q) tq[c][q] = tpc[(size_t)q * ldp + kc[c]];
         s[c] = 0.0;
@@ -297,7 +331,7 @@ k_qrx_pass(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cu
 #pragma unroll
         for (int q = 0; q < NP; ++q) v0[q] = vc[(size_t)q * vst];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) rowj[c] = pending(Tj[sc[c]], c, v0);
+        for (int c = 0; c < CPT; ++c) rowj[c] = pending(Tj[pc[c]], c, v0);
     }
 
     // reflector tile t: lane l fetches the entries of row t*TR + l (one coalesced 512-byte read per slot); the staged
@@ -321,7 +355,10 @@ k_qrx_pass(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cu
         __builtin_amdgcn_make_buffer_rsrc(Tj, 0, (int)((size_t)nrows * ld * sizeof(double)), 0x00020000);
     unsigned so[CPT], ko[CPT];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) { so[c] = sc[c] * 8u; ko[c] = (kc[c] + (unsigned)coff) * 8u; }
+    for (int c = 0; c < CPT; ++c) {
+        so[c] = act[c] ? pc[c] * 8u : 0x80000000u;      // idle lanes: past the descriptor's range, nothing is fetched
+        ko[c] = (kc[c] + (unsigned)coff) * 8u;
+    }
     const unsigned ldb = (unsigned)ld * 8u;
     double a0[U][CPT], a1[U][CPT];
     auto load = [&](double (&buf)[U][CPT], int r0) {
@@ -429,7 +466,11 @@ k_qrx_pass(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cu
         const int k = (int)kc[c];
         const double temp = refl ? s[c] / ajj : 0.0;                    // :654 (residual: see nlh_kernels_exact.h)
         tpn[k] = temp;
-        if (FLUSH) srcp[k] = coff + k;
+        if (FLUSH) {                                                    // the column now sits at its slot's own position
+            srcp[k] = coff + k;
+            slotp[coff + k] = k;
+            if ((int)pc[c] != coff + k) slotp[pc[c]] = -1;
+        }
         const double rjk = refl ? rowj[c] - temp * ajj : rowj[c];       // :655 at i = j: row j is final
         if (k == n) { qtfall[(size_t)p * n + j] = rjk; continue; }
         Rall[(size_t)p * n * n + (size_t)k * n + j] = rjk;
@@ -440,7 +481,7 @@ k_qrx_pass(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cu
             rk = rk * sqrt(fmax(0.0, 1.0 - t2 * t2));
             const double q = rk / wa[k];
             if (!(5.0e-2 * (q * q) > NLH_EPS)) {
-                const double *colp = Tj + sc[c];
+                const double *colp = Tj + pc[c];
                 const double *dstp = Tj + coff + kc[c];
                 rk = norm2_flang_serial([&](int i2) {
                     const int row = 1 + i2;
@@ -508,27 +549,28 @@ k_qrx_finish(int m, int n, int ld, int coff, size_t tst, size_t vst, int cur, in
 }
 
 template <int NP, bool FLUSH>
-static void launch_pass(hipStream_t stream, int nprob, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
+static void launch_pass(hipStream_t stream, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
                         double *R, double *qtf, const LmState *st)
 {
     // One column per lane (CPT = 1): measured against two and four columns per lane (fewer waves, the LDS row shared by
     // more elements) on 512 x 4096x256, 1024 x 2048x128 and a single problem, more waves won every time.
     constexpr int CPT = 1;
-    const dim3 grid((n - j + 64 * CPT - 1) / (64 * CPT), nprob);
-    hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH, CPT>), grid, dim3(64), 0, stream, m, n, ld, coff, tst, vst, j, cur, T,
-                       (const double *)w.V, w.tp, w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+    const int nwin = (n + 1 - lo + 64 * CPT - 1) / (64 * CPT);         // live physical columns coff + lo .. coff + n
+    const dim3 grid((unsigned)(((nprob + 7) / 8) * 8 * nwin));
+    hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH, CPT>), grid, dim3(64), 0, stream, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                       T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
 }
 
 // np = 0 .. QRX_C - 2: plain pass with np pending updates; np = QRX_C - 1: the flushing pass.
 template <int NP>
-static void dispatch_pass(int np, hipStream_t stream, int nprob, int m, int n, int ld, int coff, size_t tst, size_t vst,
+static void dispatch_pass(int np, hipStream_t stream, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst,
                           int j, int cur, double *T, const QrxWs &w, double *R, double *qtf, const LmState *st)
 {
     if constexpr (NP == QRX_C - 1) {
-        launch_pass<NP, true>(stream, nprob, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
+        launch_pass<NP, true>(stream, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
     } else {
-        if (np == NP) launch_pass<NP, false>(stream, nprob, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
-        else dispatch_pass<NP + 1>(np, stream, nprob, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
+        if (np == NP) launch_pass<NP, false>(stream, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
+        else dispatch_pass<NP + 1>(np, stream, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
     }
 }
 
@@ -547,17 +589,17 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
                        (const LmState *)st);
     hipLaunchKernelGGL(k_qrx_init, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
     te(2);
-    int cur = 0, np = 0;
+    int cur = 0, np = 0, lo = 1;             // lo: first slot position that can still hold live data (step 0 moves physically)
     for (int j = 0; j < n; ++j) {
         const bool flush = (np == QRX_C - 1);
         tb(0);
-        hipLaunchKernelGGL(k_qrx_pivot, dim3(nprob), dim3(256), 0, stream, m, n, ld, tst, vst, j, cur, np, flush ? 1 : 0,
-                           (const double *)T, w, R, v, (const LmState *)st);
+        hipLaunchKernelGGL(k_qrx_pivot, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
+                           T, w, R, v, (const LmState *)st);
         te(0);
         tb(1);
-        dispatch_pass<0>(np, stream, nprob, m, n, ld, coff, tst, vst, j, cur, T, w, R, v.qtf, st);
+        dispatch_pass<0>(np, stream, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, v.qtf, st);
         te(1);
-        if (flush) { cur ^= 1; np = 1; } else { np += 1; }
+        if (flush) { cur ^= 1; np = 1; lo = j + 1; } else { np += 1; }
     }
     tb(2);
     hipLaunchKernelGGL(k_qrx_finish, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, cur, np, (const double *)T, w, R, v,

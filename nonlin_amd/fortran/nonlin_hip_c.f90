@@ -124,6 +124,49 @@ module nonlin_hip_c
             type(nlh_iteration_behavior), intent(out) :: ib
             integer(c_int) :: rc
         end function
+        ! ---- device residual models behind host arrays (include/nonlin_hip.h: nlh_dq_model_*) ----
+        function nlh_dq_model_create(h, nprob, m, n, a, b, gamma, model) bind(C, name="nlh_dq_model_create") result(rc)
+            import :: c_ptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: h
+            integer(c_int32_t), value :: nprob, m, n
+            real(c_double), intent(in) :: a(*), b(*)
+            real(c_double), value :: gamma
+            type(c_ptr), intent(out) :: model
+            integer(c_int) :: rc
+        end function
+        subroutine nlh_dq_model_destroy(model) bind(C, name="nlh_dq_model_destroy")
+            import :: c_ptr
+            type(c_ptr), value :: model
+        end subroutine
+        function nlh_dq_model_eval(h, model, x, f) bind(C, name="nlh_dq_model_eval") result(rc)
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: h, model
+            real(c_double), intent(in) :: x(*)
+            real(c_double), intent(out) :: f(*)
+            integer(c_int) :: rc
+        end function
+        function nlh_dq_model_lm_solve(h, opts, model, x, fvec, ib, status) bind(C, name="nlh_dq_model_lm_solve") result(rc)
+            import :: c_ptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h, model
+            type(nlh_options), intent(in) :: opts
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fvec(*)
+            type(nlh_iteration_behavior), intent(out) :: ib(*)
+            integer(c_int32_t), intent(out) :: status(*)
+            integer(c_int) :: rc
+        end function
+        function nlh_dq_model_newton_solve(h, opts, model, analytic, x, fvec, ib, status) &
+                bind(C, name="nlh_dq_model_newton_solve") result(rc)
+            import :: c_ptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h, model
+            type(nlh_options), intent(in) :: opts
+            integer(c_int32_t), value :: analytic
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fvec(*)
+            type(nlh_iteration_behavior), intent(out) :: ib(*)
+            integer(c_int32_t), intent(out) :: status(*)
+            integer(c_int) :: rc
+        end function
     end interface
 
     type(c_ptr), save, private :: default_handle = c_null_ptr

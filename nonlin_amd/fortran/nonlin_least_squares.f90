@@ -21,6 +21,7 @@ module nonlin_least_squares
         procedure, public :: get_step_scaling_factor => lss_get_factor
         procedure, public :: set_step_scaling_factor => lss_set_factor
         procedure, public :: solve => lss_solve
+        procedure, public :: solve_batch => lss_solve_batch
     end type
 
     type, abstract, extends(least_squares_solver) :: constrained_equation_solver
@@ -75,10 +76,12 @@ contains
         integer(int32) :: neqn, nvar, flag
         integer(c_int) :: rc
         type(nlh_options) :: opts
-        type(nlh_iteration_behavior) :: cib
+        type(nlh_iteration_behavior) :: cib, cibs(1)
         type(nlh_callback_ctx), target :: ctx
         type(c_funptr) :: cjac
         real(c_double), allocatable :: xc(:), fc(:)
+        type(device_model_batch) :: dm
+        integer(c_int32_t) :: st(1)
 
         neqn = fcn%get_equation_count()
         nvar = fcn%get_variable_count()
@@ -111,8 +114,17 @@ contains
         if (fcn%is_jacobian_defined()) cjac = c_funloc(nlh_jacfcn_trampoline)
         allocate(xc(nvar), fc(neqn))    ! contiguous copies: the dummies may be strided sections
         xc = x
-        rc = nlh_lm_solve(nlh_default_handle(), opts, neqn, nvar, c_funloc(nlh_vecfcn_trampoline), cjac, &
-            c_loc(ctx), xc, fc, cib)
+        if (fcn%is_device_model_defined()) then
+            ! set_device_model: the whole iteration runs on the GPU (FD Jacobian, factorisation, lmpar, trial
+            ! evaluations), no host callback; st is the code the reference would stop with
+            dm = fcn%device_model()
+            rc = nlh_dq_model_lm_solve(nlh_default_handle(), opts, dm%c_handle(), xc, fc, cibs, st)
+            cib = cibs(1)
+            if (rc == 0) rc = st(1)
+        else
+            rc = nlh_lm_solve(nlh_default_handle(), opts, neqn, nvar, c_funloc(nlh_vecfcn_trampoline), cjac, &
+                c_loc(ctx), xc, fc, cib)
+        end if
         x = xc
         fvec = fc
         if (present(ib)) then           ! :378-385
@@ -125,6 +137,66 @@ contains
             ib%converge_on_zero_diff = cib%converge_on_zero_diff /= 0
         end if
         if (rc /= 0) error stop rc      ! :388-390 (NL_CONVERGENCE_ERROR) or a library failure
+    end subroutine
+
+    !> Extension: least_squares_solver%solve (lss_solve, :118-391) for every problem of a device model batch in
+    !> one call.  x(n, nprob) start points in / solutions out, fvec(m, nprob) residuals at the solutions,
+    !> ib(nprob) the counters and flags of each solve, status(nprob) = 0 or the code the reference would
+    !> `error stop` with for that problem (no process abort: the other problems are unaffected).
+    subroutine lss_solve_batch(this, model, x, fvec, ib, status)
+        class(least_squares_solver), intent(inout) :: this
+        class(device_model_batch), intent(in) :: model
+        real(real64), intent(inout), dimension(:,:) :: x
+        real(real64), intent(out), dimension(:,:) :: fvec
+        type(iteration_behavior), intent(out), dimension(:), optional :: ib
+        integer(int32), intent(out), dimension(:), optional :: status
+
+        integer(int32) :: neqn, nvar, nprob, k
+        integer(c_int) :: rc
+        type(nlh_options) :: opts
+        type(nlh_iteration_behavior), allocatable :: cib(:)
+        integer(c_int32_t), allocatable :: st(:)
+        real(c_double), allocatable :: xc(:,:), fc(:,:)
+
+        if (.not.model%is_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR
+        neqn = model%get_equation_count()
+        nvar = model%get_variable_count()
+        nprob = model%get_problem_count()
+        if (nvar > neqn) error stop NL_UNDERDEFINED_PROBLEM_ERROR
+        if (size(x, 1) /= nvar .or. size(x, 2) /= nprob) error stop 3
+        if (size(fvec, 1) /= neqn .or. size(fvec, 2) /= nprob) error stop 4
+        if (present(ib)) then
+            if (size(ib) /= nprob) error stop 5
+        end if
+        if (present(status)) then
+            if (size(status) /= nprob) error stop 6
+        end if
+        call nlh_default_options(opts)
+        opts%max_evals = this%get_max_fcn_evals()
+        opts%ftol = this%get_fcn_tolerance()
+        opts%xtol = this%get_var_tolerance()
+        opts%gtol = this%get_gradient_tolerance()
+        opts%print_status = 0
+        opts%factor = this%m_factor
+        opts%factor_policy = this%factor_policy
+        allocate(cib(nprob), st(nprob), fc(neqn, nprob))
+        xc = x
+        rc = nlh_dq_model_lm_solve(nlh_default_handle(), opts, model%c_handle(), xc, fc, cib, st)
+        if (rc /= 0) error stop rc      ! a library failure, not a per-problem outcome
+        x = xc
+        fvec = fc
+        if (present(status)) status = st
+        if (present(ib)) then
+            do k = 1, nprob
+                ib(k)%iter_count = cib(k)%iter_count
+                ib(k)%fcn_count = cib(k)%fcn_count
+                ib(k)%jacobian_count = cib(k)%jacobian_count
+                ib(k)%gradient_count = cib(k)%gradient_count
+                ib(k)%converge_on_fcn = cib(k)%converge_on_fcn /= 0
+                ib(k)%converge_on_chng = cib(k)%converge_on_chng /= 0
+                ib(k)%converge_on_zero_diff = cib(k)%converge_on_zero_diff /= 0
+            end do
+        end if
     end subroutine
 
     pure function ces_get_upper_bounds(this) result(rst)    ! :796-808

@@ -16,6 +16,8 @@ module nonlin_multi_eqn_mult_var
     public :: equation_solver
     public :: nonlin_solver
     public :: nlh_callback_ctx
+    public :: device_model_batch
+    public :: NLH_MODEL_DENSE_QUADRATIC
     public :: nlh_vecfcn_trampoline
     public :: nlh_jacfcn_trampoline
 
@@ -35,12 +37,42 @@ module nonlin_multi_eqn_mult_var
         end subroutine
     end interface
 
+    !> Registered device residual families (SURVEY.md 8(d)): 1 = dense quadratic,
+    !> r_i = (u_i + gamma u_i u_i) - b_i with u = A x accumulated in ascending column order.
+    integer(int32), parameter :: NLH_MODEL_DENSE_QUADRATIC = 1
+
+    !> Extension (no counterpart in the reference): the data of nprob independent problems of a registered
+    !> residual family, resident on the GPU.  What least_squares_solver%solve_batch / newton_solver%solve_batch
+    !> solve in one call, and what vecfcn_helper%set_device_model wraps for a single problem.
+    type device_model_batch
+        type(c_ptr), private :: model_ = c_null_ptr
+        integer(int32), private :: nprob_ = 0
+        integer(int32), private :: neqn_ = 0
+        integer(int32), private :: nvar_ = 0
+        logical, private :: analytic_ = .false.
+    contains
+        procedure, public :: create => dmb_create
+        procedure, public :: destroy => dmb_destroy
+        procedure, public :: is_defined => dmb_defined
+        procedure, public :: get_problem_count => dmb_nprob
+        procedure, public :: get_equation_count => dmb_neqn
+        procedure, public :: get_variable_count => dmb_nvar
+        procedure, public :: uses_analytic_jacobian => dmb_analytic
+        procedure, public :: evaluate => dmb_eval
+        procedure, public :: c_handle => dmb_handle
+    end type
+
     type vecfcn_helper
         procedure(vecfcn), private, pointer, nopass :: fcn_ptr_ => null()
         procedure(jacobianfcn), private, pointer, nopass :: jac_ptr_ => null()
         integer(int32), private :: neqn_ = 0
         integer(int32), private :: nvar_ = 0
+        type(device_model_batch), private :: model_      ! set_device_model: one problem on the device
     contains
+        procedure, public :: set_device_model => helper_bind_model
+        procedure, public :: clear_device_model => helper_drop_model
+        procedure, public :: is_device_model_defined => helper_has_model
+        procedure, public :: device_model => helper_model
         procedure, public :: set_fcn => helper_bind_fcn
         procedure, public :: set_jacobian => helper_bind_jac
         procedure, public :: is_fcn_defined => helper_has_fcn
@@ -116,8 +148,129 @@ contains
     function helper_has_fcn(this) result(x)
         class(vecfcn_helper), intent(in) :: this
         logical :: x
-        x = associated(this%fcn_ptr_)
+        x = associated(this%fcn_ptr_) .or. this%model_%is_defined()
     end function
+
+    !> Extension: instead of a host procedure, the residual is a registered device model (kind =
+    !> NLH_MODEL_DENSE_QUADRATIC: a(m,n), b(m), gamma).  solver%solve then runs the whole iteration on the GPU
+    !> (no host callbacks); analytic = .true. makes newton_solver use the model's own Jacobian, as set_jacobian would.
+    subroutine helper_bind_model(this, kind, a, b, gamma, analytic)
+        class(vecfcn_helper), intent(inout) :: this
+        integer(int32), intent(in) :: kind
+        real(real64), intent(in), dimension(:,:) :: a
+        real(real64), intent(in), dimension(:) :: b
+        real(real64), intent(in) :: gamma
+        logical, intent(in), optional :: analytic
+        real(real64), allocatable :: a3(:,:,:), b2(:,:)
+        allocate(a3(size(a, 1), size(a, 2), 1), b2(size(b), 1))
+        a3(:,:,1) = a
+        b2(:,1) = b
+        call this%model_%create(kind, a3, b2, gamma, analytic)
+        this%neqn_ = size(a, 1)
+        this%nvar_ = size(a, 2)
+    end subroutine
+
+    subroutine helper_drop_model(this)
+        class(vecfcn_helper), intent(inout) :: this
+        call this%model_%destroy()
+    end subroutine
+
+    function helper_has_model(this) result(x)
+        class(vecfcn_helper), intent(in) :: this
+        logical :: x
+        x = this%model_%is_defined() .and. .not.associated(this%fcn_ptr_)
+    end function
+
+    function helper_model(this) result(md)
+        class(vecfcn_helper), intent(in) :: this
+        type(device_model_batch) :: md
+        md = this%model_
+    end function
+
+    ! ---- device_model_batch -------------------------------------------------------------------
+    subroutine dmb_create(this, kind, a, b, gamma, analytic)
+        class(device_model_batch), intent(inout) :: this
+        integer(int32), intent(in) :: kind
+        real(real64), intent(in), dimension(:,:,:) :: a      ! (m, n, nprob)
+        real(real64), intent(in), dimension(:,:) :: b        ! (m, nprob)
+        real(real64), intent(in) :: gamma
+        logical, intent(in), optional :: analytic
+        integer(c_int) :: rc
+        real(c_double), allocatable :: ac(:,:,:), bc(:,:)
+        if (kind /= NLH_MODEL_DENSE_QUADRATIC) error stop NL_INVALID_INPUT_ERROR
+        if (size(b, 1) /= size(a, 1) .or. size(b, 2) /= size(a, 3)) error stop NL_ARRAY_SIZE_ERROR
+        call this%destroy()
+        ac = a                                               ! contiguous copies: the dummies may be sections
+        bc = b
+        rc = nlh_dq_model_create(nlh_default_handle(), int(size(a, 3), c_int32_t), int(size(a, 1), c_int32_t), &
+            int(size(a, 2), c_int32_t), ac, bc, gamma, this%model_)
+        if (rc /= 0) error stop rc
+        this%neqn_ = size(a, 1)
+        this%nvar_ = size(a, 2)
+        this%nprob_ = size(a, 3)
+        this%analytic_ = .false.
+        if (present(analytic)) this%analytic_ = analytic
+    end subroutine
+
+    subroutine dmb_destroy(this)
+        class(device_model_batch), intent(inout) :: this
+        if (c_associated(this%model_)) call nlh_dq_model_destroy(this%model_)
+        this%model_ = c_null_ptr
+        this%nprob_ = 0; this%neqn_ = 0; this%nvar_ = 0
+    end subroutine
+
+    pure function dmb_defined(this) result(x)
+        class(device_model_batch), intent(in) :: this
+        logical :: x
+        x = c_associated(this%model_)
+    end function
+
+    pure function dmb_nprob(this) result(n)
+        class(device_model_batch), intent(in) :: this
+        integer(int32) :: n
+        n = this%nprob_
+    end function
+
+    pure function dmb_neqn(this) result(n)
+        class(device_model_batch), intent(in) :: this
+        integer(int32) :: n
+        n = this%neqn_
+    end function
+
+    pure function dmb_nvar(this) result(n)
+        class(device_model_batch), intent(in) :: this
+        integer(int32) :: n
+        n = this%nvar_
+    end function
+
+    pure function dmb_analytic(this) result(x)
+        class(device_model_batch), intent(in) :: this
+        logical :: x
+        x = this%analytic_
+    end function
+
+    function dmb_handle(this) result(h)
+        class(device_model_batch), intent(in) :: this
+        type(c_ptr) :: h
+        h = this%model_
+    end function
+
+    !> vecfcn of every problem: f(:,k) = F_k(x(:,k)).
+    subroutine dmb_eval(this, x, f)
+        class(device_model_batch), intent(in) :: this
+        real(real64), intent(in), dimension(:,:) :: x        ! (n, nprob)
+        real(real64), intent(out), dimension(:,:) :: f       ! (m, nprob)
+        integer(c_int) :: rc
+        real(c_double), allocatable :: xc(:,:), fc(:,:)
+        if (.not.this%is_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR
+        if (size(x, 1) /= this%nvar_ .or. size(x, 2) /= this%nprob_) error stop NL_ARRAY_SIZE_ERROR
+        if (size(f, 1) /= this%neqn_ .or. size(f, 2) /= this%nprob_) error stop NL_ARRAY_SIZE_ERROR
+        xc = x
+        allocate(fc(this%neqn_, this%nprob_))
+        rc = nlh_dq_model_eval(nlh_default_handle(), this%model_, xc, fc)
+        if (rc /= 0) error stop rc
+        f = fc
+    end subroutine
 
     function helper_has_jac(this) result(x)
         class(vecfcn_helper), intent(in) :: this
@@ -130,8 +283,14 @@ contains
         real(real64), intent(in), dimension(:) :: x
         real(real64), intent(out), dimension(:) :: f
         class(*), intent(inout), optional :: args
-        if (this%is_fcn_defined()) then
+        real(real64), allocatable :: x2(:,:), f2(:,:)
+        if (associated(this%fcn_ptr_)) then
             call this%fcn_ptr_(x, f, args)
+        else if (this%model_%is_defined()) then                 ! device model: one evaluation on the GPU
+            allocate(x2(size(x), 1), f2(size(f), 1))
+            x2(:,1) = x
+            call this%model_%evaluate(x2, f2)
+            f = f2(:,1)
         end if
     end subroutine
 

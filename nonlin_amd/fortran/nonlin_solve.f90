@@ -30,6 +30,7 @@ module nonlin_solve
     type, extends(line_search_solver) :: newton_solver
     contains
         procedure, public :: solve => ns_solve
+        procedure, public :: solve_batch => ns_solve_batch
     end type
 
     type, extends(line_search_solver) :: quasi_newton_solver
@@ -89,11 +90,13 @@ contains
         integer(int32) :: neqn, nvar, flag
         integer(c_int) :: rc
         type(nlh_options) :: opts
-        type(nlh_iteration_behavior) :: cib
+        type(nlh_iteration_behavior) :: cib, cibs(1)
         type(nlh_callback_ctx), target :: ctx
         type(c_funptr) :: cjac
         real(c_double), allocatable :: xc(:), fc(:)
         class(line_search), allocatable :: ls
+        type(device_model_batch) :: dm
+        integer(c_int32_t) :: st(1)
 
         neqn = fcn%get_equation_count()
         nvar = fcn%get_variable_count()
@@ -132,8 +135,18 @@ contains
         if (fcn%is_jacobian_defined()) cjac = c_funloc(nlh_jacfcn_trampoline)
         allocate(xc(nvar), fc(neqn))
         xc = x
-        rc = nlh_newton_solve(nlh_default_handle(), opts, nvar, c_funloc(nlh_vecfcn_trampoline), cjac, &
-            c_loc(ctx), xc, fc, cib)
+        if (fcn%is_device_model_defined()) then
+            ! set_device_model: residuals, Jacobian (the model's own when it was bound with analytic = .true.,
+            ! forward differences otherwise) and the LU solve on the GPU, no host callback
+            dm = fcn%device_model()
+            rc = nlh_dq_model_newton_solve(nlh_default_handle(), opts, dm%c_handle(), &
+                merge(1_c_int32_t, 0_c_int32_t, dm%uses_analytic_jacobian()), xc, fc, cibs, st)
+            cib = cibs(1)
+            if (rc == 0) rc = st(1)
+        else
+            rc = nlh_newton_solve(nlh_default_handle(), opts, nvar, c_funloc(nlh_vecfcn_trampoline), cjac, &
+                c_loc(ctx), xc, fc, cib)
+        end if
         x = xc
         fvec = fc
         if (present(ib)) then           ! :624-632
@@ -146,6 +159,65 @@ contains
             ib%converge_on_zero_diff = cib%converge_on_zero_diff /= 0
         end if
         if (rc /= 0) error stop rc      ! :635-637, :604-608, line-search stops
+    end subroutine
+
+    !> Extension: newton_solver%solve (ns_solve, :452-638) for every (square) problem of a device model batch.
+    !> Arguments as least_squares_solver%solve_batch.
+    subroutine ns_solve_batch(this, model, x, fvec, ib, status)
+        class(newton_solver), intent(inout) :: this
+        class(device_model_batch), intent(in) :: model
+        real(real64), intent(inout), dimension(:,:) :: x
+        real(real64), intent(out), dimension(:,:) :: fvec
+        type(iteration_behavior), intent(out), dimension(:), optional :: ib
+        integer(int32), intent(out), dimension(:), optional :: status
+
+        integer(int32) :: n, nprob, k
+        integer(c_int) :: rc
+        type(nlh_options) :: opts
+        type(nlh_iteration_behavior), allocatable :: cib(:)
+        integer(c_int32_t), allocatable :: st(:)
+        real(c_double), allocatable :: xc(:,:), fc(:,:)
+        class(line_search), allocatable :: ls
+
+        if (.not.model%is_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR
+        n = model%get_variable_count()
+        nprob = model%get_problem_count()
+        if (model%get_equation_count() /= n) error stop NL_INVALID_INPUT_ERROR
+        if (size(x, 1) /= n .or. size(x, 2) /= nprob) error stop 3
+        if (size(fvec, 1) /= n .or. size(fvec, 2) /= nprob) error stop 4
+        call nlh_default_options(opts)
+        if (this%get_use_line_search()) then
+            if (.not.this%is_line_search_defined()) call this%set_default_line_search()
+            call this%get_line_search(ls)
+            opts%ls_max_evals = ls%get_max_fcn_evals()
+            opts%ls_alpha = ls%get_scaling_factor()
+            opts%ls_factor = ls%get_distance_factor()
+        end if
+        opts%max_evals = this%get_max_fcn_evals()
+        opts%ftol = this%get_fcn_tolerance()
+        opts%xtol = this%get_var_tolerance()
+        opts%gtol = this%get_gradient_tolerance()
+        opts%print_status = 0
+        opts%use_line_search = merge(1, 0, this%get_use_line_search())
+        allocate(cib(nprob), st(nprob), fc(n, nprob))
+        xc = x
+        rc = nlh_dq_model_newton_solve(nlh_default_handle(), opts, model%c_handle(), &
+            merge(1_c_int32_t, 0_c_int32_t, model%uses_analytic_jacobian()), xc, fc, cib, st)
+        if (rc /= 0) error stop rc
+        x = xc
+        fvec = fc
+        if (present(status)) status = st
+        if (present(ib)) then
+            do k = 1, nprob
+                ib(k)%iter_count = cib(k)%iter_count
+                ib(k)%fcn_count = cib(k)%fcn_count
+                ib(k)%jacobian_count = cib(k)%jacobian_count
+                ib(k)%gradient_count = 0
+                ib(k)%converge_on_fcn = cib(k)%converge_on_fcn /= 0
+                ib(k)%converge_on_chng = cib(k)%converge_on_chng /= 0
+                ib(k)%converge_on_zero_diff = cib(k)%converge_on_zero_diff /= 0
+            end do
+        end if
     end subroutine
 
     subroutine qns_solve(this, fcn, x, fvec, ib, args)

@@ -141,3 +141,78 @@ def test_fd_jacobian(results):
     E = np.zeros((2, 2), order="F")
     P.polar_jac(np.array([0.5, -0.5]), E, None)
     assert np.abs(J - E).max() <= 1e-4                                # tests/nonlin_test_jacobian.f90 tolerance
+
+
+# ---- device-model extension: set_device_model / device_model_batch / solve_batch -------------------------------------
+EXE_DM = os.path.join(HERE, "fortran", "build", "device_model_suite")
+
+
+def _write_problem_file(path, oracle, seeds, m, n, **gen):
+    gamma = gen.pop("gamma", 0.5)
+    data = [oracle.dq_generate(s, m, n, gamma=gamma, **gen) for s in seeds]          # (A col-major m x n, b, xt, x0)
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<iiid", len(seeds), m, n, gamma))
+        for A, b, xt, x0 in data:
+            fh.write(np.asfortranarray(A).tobytes(order="F"))
+        for A, b, xt, x0 in data:
+            fh.write(np.ascontiguousarray(b).tobytes())
+        for A, b, xt, x0 in data:
+            fh.write(np.ascontiguousarray(x0).tobytes())
+    return gamma, data
+
+
+@pytest.fixture(scope="module")
+def dm_results(oracle, tmp_path_factory):
+    if not os.path.exists(EXE_DM):
+        if not (shutil.which("amdflang") or os.path.exists("/opt/rocm/bin/amdflang")):
+            pytest.skip("no Fortran compiler and no prebuilt tests/fortran/build/device_model_suite")
+        root = os.path.dirname(HERE)
+        subprocess.check_call(["make", "-C", os.path.join(root, "nonlin_amd", "fortran"), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "fortran"), "-s"])
+    d = tmp_path_factory.mktemp("dm")
+    lm_in = _write_problem_file(str(d / "lm.bin"), oracle, [12345 + k for k in range(6)], 512, 64)
+    nt_in = _write_problem_file(str(d / "nt.bin"), oracle, [777 + k for k in range(4)], 48, 48, sigma=0.0, square_shift=True)
+    out = subprocess.run([EXE_DM, str(d / "lm.bin"), str(d / "nt.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    res = {}
+    for line in out.stdout.splitlines():
+        t = line.split()
+        res.setdefault(t[0], []).append({"status": int(t[1]), "counts": (int(t[2]), int(t[3]), int(t[4])),
+                                         "flags": tuple(t[5:8]), "x": np.array([_unhex(h) for h in t[8:]])})
+    return res, lm_in, nt_in
+
+
+def _cmp_dm(r, rc, xo, ibo):
+    assert r["status"] == rc == 0
+    assert r["counts"] == (ibo["iter_count"], ibo["fcn_count"], ibo["jacobian_count"]), (r, ibo)
+    assert r["flags"] == tuple("T" if ibo[k] else "F" for k in ("converge_on_fcn", "converge_on_chng", "converge_on_zero_diff"))
+    assert np.array_equal(r["x"], xo)
+
+
+def test_device_model_least_squares_through_fortran(dm_results, oracle):
+    """vecfcn_helper%set_device_model + least_squares_solver%solve (the reference's own call, the whole iteration on the
+    GPU) and least_squares_solver%solve_batch on six 512 x 64 problems: bit-identical to the CPU oracle."""
+    res, (gamma, data), _ = dm_results
+    sols = [oracle.dq_lm_solve(A, b, gamma, x0, opts=oracle.default_options(max_evals=500)) for A, b, xt, x0 in data]
+    rc, xo, fo, ibo = sols[0][:4]
+    _cmp_dm(res["dm_lm_single"][0], rc, xo, ibo)
+    assert np.array_equal(res["dm_lm_single_fvec"][0]["x"], np.array([fo[0], fo[-1]]))
+    A, b, xt, x0 = data[0]
+    f0 = oracle.dq_residual(A, b, gamma, x0)
+    assert np.array_equal(res["dm_eval"][0]["x"], np.array([f0[0], f0[-1]]))       # obj%fcn of a device model
+    assert len(res["dm_lm_batch"]) == len(data)
+    for k, (rc, xo, fo, ibo, _, _) in enumerate(sols):
+        _cmp_dm(res["dm_lm_batch"][k], rc, xo, ibo)
+
+
+def test_device_model_newton_through_fortran(dm_results, oracle):
+    """newton_solver%solve on a device model (the model's own Jacobian, then forward differences) and solve_batch."""
+    res, _, (gamma, data) = dm_results
+    A, b, xt, x0 = data[0]
+    rc, xo, fo, ibo, _ = oracle.dq_newton_solve(A, b, gamma, x0, analytic=True, opts=oracle.default_options(max_evals=500))
+    _cmp_dm(res["dm_newton_an"][0], rc, xo, ibo)
+    rc, xo, fo, ibo, _ = oracle.dq_newton_solve(A, b, gamma, x0, analytic=False, opts=oracle.default_options(max_evals=500))
+    _cmp_dm(res["dm_newton_fd"][0], rc, xo, ibo)
+    for k, (A, b, xt, x0) in enumerate(data):
+        rc, xo, fo, ibo, _ = oracle.dq_newton_solve(A, b, gamma, x0, analytic=True, opts=oracle.default_options(max_evals=500))
+        _cmp_dm(res["dm_newton_batch"][k], rc, xo, ibo)
