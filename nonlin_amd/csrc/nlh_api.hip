@@ -141,17 +141,17 @@ struct Timed {
 };
 
 // Brackets for the launches of nlh_qrx.hip (another translation unit): which = 0 pivot kernel, 1 trailing pass, 2 rest.
-static void qrx_time_begin(nlh_handle *h, int which)
+static void qrx_time_begin(nlh_handle *h, int which, hipStream_t s)
 {
     const int kid = which == 1 ? NLH_K_QRX_PASS : which == 0 ? NLH_K_QRX_PIVOT : NLH_K_QR;
     h->qrx_open_on = (h->timing >> kid) & 1u;
-    if (h->qrx_open_on) { h->qrx_a = ev_get(h); h->qrx_b = ev_get(h); hipEventRecord(h->qrx_a, h->stream); }
+    if (h->qrx_open_on) { h->qrx_a = ev_get(h); h->qrx_b = ev_get(h); hipEventRecord(h->qrx_a, s); }
     h->qrx_kid = kid;
 }
-static void qrx_time_end(nlh_handle *h, int)
+static void qrx_time_end(nlh_handle *h, int, hipStream_t s)
 {
     if (!h->qrx_open_on) return;
-    hipEventRecord(h->qrx_b, h->stream);
+    hipEventRecord(h->qrx_b, s);
     h->pending.push_back({h->qrx_a, h->qrx_b, h->qrx_kid});
     if (h->pending.size() > 65536) timing_flush(h);
 }
@@ -209,8 +209,6 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    hipFuncSetAttribute((const void *)k_qr_exact, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    hipFuncSetAttribute((const void *)k_qr_exact_lazy<QX_B, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_panel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -542,7 +540,7 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
     int rc;
     const size_t mn = (size_t)nprob * m * n, pm = (size_t)nprob * m, pn = (size_t)nprob * n;
     if ((rc = ensure(h, h->J, sizeof(double) * mn))) return rc;
-    // + a residual column and read-ahead padding behind the last problem (exact QR, k_qr_exact_lazy)
+    // the panel doubles as the exact factorisation's row-major working matrix (nlh_qrx.hip) and as lmsolve's scratch
     if (need_panel && (rc = ensure(h, h->P, sizeof(double) * std::max(mn + pm + (size_t)512 * (n + 1),
                                                                       qrx_matrix_doubles(nprob, m, n))))) return rc;
     if ((rc = ensure(h, h->wa4, sizeof(double) * pm))) return rc;
@@ -578,38 +576,15 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
     const int ft = factor_threads(n);
     const size_t shl = sizeof(double) * (size_t)(6 * n + 72);
     if (o->factor_policy == NLH_FACTOR_EXACT) {
-        // reference operation order: row-major copy of J, exact lmfactor + Q^T f, exact lmpar
+        // reference operation order: exact lmfactor + Q^T f (streaming form, the batch advances through the
+        // Householder steps in lock step: nlh_qrx.hip), exact lmpar
         {
-            Timed t(h, NLH_K_QR);
-            dim3 grid((m + 31) / 32, (n + 31) / 32, nprob);
-            const size_t lds_cap = 158 * 1024;
-            // deferred-update kernel (512 threads, 256 VGPRs each) up to n = 511; the plain one above that
-            const int qt = std::min(ft, 512);
-            const size_t sh8 = sizeof(double) * QlLds<QX_B, 512>::doubles(n, qt);
-            const bool lazy = m >= n && n + 1 <= qt && sh8 <= lds_cap;
-            static const bool use_qrx = !(getenv("NLH_QRX") && atoi(getenv("NLH_QRX")) == 0);
-            if (use_qrx && m >= n) {
-                // streaming form: the batch advances through the Householder steps in lock step (nlh_qrx.hip)
-                int rc;
-                if ((rc = ensure(h, h->qxV, qrx_workspace_bytes(nprob, m, n)))) return rc;
-                QrxTimer tm{h, [](void *c, int which) { qrx_time_begin((nlh_handle *)c, which); },
-                            [](void *c, int which) { qrx_time_end((nlh_handle *)c, which); }};
-                qrx_factor(h->stream, nprob, m, n, w.J, w.P, dfvec, w.R, w.v, w.wa4, w.scratch, dx, w.st, o->factor,
-                           o->gtol, h->qxV.p, &tm);
-            } else if (lazy) {
-                // row stride n + 1 (residual as last column), reflector ring in h->qxV
-                int rc;
-                if ((rc = ensure(h, h->qxV, sizeof(double) * ((size_t)nprob * QX_B * m + 512)))) return rc;
-                hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, n + 1, w.st, (int)ST_NEED_QR);
-                hipLaunchKernelGGL((k_qr_exact_lazy<QX_B, 512>), dim3(nprob), dim3(qt), sh8, h->stream, m, n, w.P, dfvec,
-                                   w.R, w.v, w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, (double *)h->qxV.p,
-                                   (size_t)nprob * m * (n + 1) * sizeof(double) > ((size_t)1 << 30) ? 1 : 0);
-            } else {
-                hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, m, n, w.J, w.P, n, w.st, (int)ST_NEED_QR);
-                size_t sh = sizeof(double) * (size_t)(2 * n + 64 + 3 * NLH_NCH + 8 + QX_VC);
-                hipLaunchKernelGGL(k_qr_exact, dim3(nprob), dim3(ft), sh, h->stream, m, n, w.P, dfvec, w.R, w.v,
-                                   w.wa4, w.scratch, dx, w.st, o->factor, o->gtol, 0);
-            }
+            int rc;
+            if ((rc = ensure(h, h->qxV, qrx_workspace_bytes(nprob, m, n)))) return rc;
+            QrxTimer tm{h, [](void *c, int which, hipStream_t s) { qrx_time_begin((nlh_handle *)c, which, s); },
+                        [](void *c, int which, hipStream_t s) { qrx_time_end((nlh_handle *)c, which, s); }};
+            qrx_factor(h->stream, nprob, m, n, w.J, w.P, dfvec, w.R, w.v, w.wa4, w.scratch, dx, w.st, o->factor,
+                       o->gtol, h->qxV.p, &tm);
         }
         {
             Timed t(h, NLH_K_LMPAR);

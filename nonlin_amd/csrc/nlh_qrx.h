@@ -11,8 +11,8 @@
 // which = 0 pivot / reflector kernel, 1 trailing pass, 2 everything else.
 struct QrxTimer {
     void *ctx;
-    void (*begin)(void *ctx, int which);
-    void (*end)(void *ctx, int which);
+    void (*begin)(void *ctx, int which, hipStream_t s);
+    void (*end)(void *ctx, int which, hipStream_t s);
 };
 
 // Row stride of the row-major working matrix (n columns + the residual, padded to 64 bytes).
@@ -23,7 +23,7 @@ size_t qrx_matrix_doubles(int nprob, int m, int n);
 size_t qrx_workspace_bytes(int nprob, int m, int n);
 
 // Factor every problem whose stage is ST_NEED_QR (st == nullptr: all).  J: column-major m x n per problem;
-// T: row-major scratch (qrx_matrix_doubles); outputs as k_qr_exact_lazy: R (n x n column-major, upper + diagonal),
+// T: row-major scratch (qrx_matrix_doubles); outputs: R (n x n column-major, upper + diagonal),
 // v.ipvt / acnorm / qtf / rdiag, wa4 = Q^T f, and -- when st != nullptr -- the outer-loop head (lm_head) with
 // stage -> ST_QR_READY / ST_DONE.
 void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, double *T, const double *fvec,

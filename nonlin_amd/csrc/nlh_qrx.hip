@@ -156,13 +156,13 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
 // The new reflector goes to slot np of the current bank, or to slot 0 of the other bank when this step's pass
 // flushes (np == QRX_C - 1).
 __global__ void __launch_bounds__(256)
-k_qrx_pivot(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
+k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
 {
     __shared__ double cd[2 * QRX_NE * 256];
     __shared__ double aux[40 + 128];
     __shared__ double red[64];
-    const int p = blockIdx.x;
+    const int p = p0 + blockIdx.x;
     if (st && st[p].stage != ST_NEED_QR) return;
     const int tid = threadIdx.x, BS = blockDim.x, ldp = n + 1;
     int *redi = reinterpret_cast<int *>(red + 32);
@@ -271,7 +271,7 @@ k_qrx_pivot(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int c
 // tile ahead (coalesced 64-byte rows -> broadcast ds_reads); with CPT = 4 a row's nine LDS values serve 256 elements.
 template <int NP, bool FLUSH, int CPT>
 __global__ void __launch_bounds__(64)
-k_qrx_pass(int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
+k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
            double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
            int32_t *__restrict__ srcall, int32_t *__restrict__ slotall, double *__restrict__ rdall,
            double *__restrict__ waall, const QrxStep *__restrict__ stepall, double *__restrict__ Rall,
@@ -286,8 +286,9 @@ k_qrx_pass(int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t t
     // are given ids that agree modulo 8: they share an L2 (reflector tiles, multipliers, the row segment two windows
     // both touch are fetched from the fabric once).
     const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
-    const int p = grp * 8 + (r_ & 7), win = r_ >> 3;
-    if (p >= nprob) return;
+    const int pl = grp * 8 + (r_ & 7), win = r_ >> 3;
+    if (pl >= nprob) return;
+    const int p = p0 + pl;
     if (st && st[p].stage != ST_NEED_QR) return;
     const int lane = threadIdx.x, ldp = n + 1;
     const int wtop = ld - 64 * CPT * win;                               // end (exclusive) of this wave's topmost window
@@ -549,7 +550,7 @@ k_qrx_finish(int m, int n, int ld, int coff, size_t tst, size_t vst, int cur, in
 }
 
 template <int NP, bool FLUSH>
-static void launch_pass(hipStream_t stream, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
+static void launch_pass(hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
                         double *R, double *qtf, const LmState *st)
 {
     // One column per lane (CPT = 1): measured against two and four columns per lane (fewer waves, the LDS row shared by
@@ -557,20 +558,20 @@ static void launch_pass(hipStream_t stream, int nprob, int lo, int m, int n, int
     constexpr int CPT = 1;
     const int nwin = (n + 1 - lo + 64 * CPT - 1) / (64 * CPT);         // live physical columns coff + lo .. coff + n
     const dim3 grid((unsigned)(((nprob + 7) / 8) * 8 * nwin));
-    hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH, CPT>), grid, dim3(64), 0, stream, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+    hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH, CPT>), grid, dim3(64), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                        T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
 }
 
 // np = 0 .. QRX_C - 2: plain pass with np pending updates; np = QRX_C - 1: the flushing pass.
 template <int NP>
-static void dispatch_pass(int np, hipStream_t stream, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst,
+static void dispatch_pass(int np, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst,
                           int j, int cur, double *T, const QrxWs &w, double *R, double *qtf, const LmState *st)
 {
     if constexpr (NP == QRX_C - 1) {
-        launch_pass<NP, true>(stream, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
+        launch_pass<NP, true>(stream, p0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
     } else {
-        if (np == NP) launch_pass<NP, false>(stream, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
-        else dispatch_pass<NP + 1>(np, stream, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
+        if (np == NP) launch_pass<NP, false>(stream, p0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
+        else dispatch_pass<NP + 1>(np, stream, p0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
     }
 }
 
@@ -582,27 +583,31 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     qrx_carve(ws, nprob, m, n, &w);
     const int ld = qrx_ld(n), coff = qrx_coff(n);
     const size_t tst = qrx_tstride(m, n), vst = qrx_vstride(m);
-    auto tb = [&](int which) { if (tm) tm->begin(tm->ctx, which); };
-    auto te = [&](int which) { if (tm) tm->end(tm->ctx, which); };
-    tb(2);
+    auto tb = [&](int which, hipStream_t s) { if (tm) tm->begin(tm->ctx, which, s); };
+    auto te = [&](int which, hipStream_t s) { if (tm) tm->end(tm->ctx, which, s); };
+    tb(2, stream);
     hipLaunchKernelGGL(k_qrx_transpose, dim3((m + 31) / 32, (n + 31) / 32, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, J, T,
                        (const LmState *)st);
     hipLaunchKernelGGL(k_qrx_init, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
-    te(2);
+    te(2, stream);
+    // (Measured and dropped: the two halves of the batch on two streams, half B's pivot kernel under half A's pass, with
+    // events keeping the passes from overlapping each other -- 1035 ms instead of 999 ms per 512 x 4096x256 solve; the
+    // cross-stream event waits cost more than the pivot latency they hide.  Sub-batches on host threads, which need no
+    // cross-stream ordering, do hide it: nlh_api.hip, lm_sub_batches.)
     int cur = 0, np = 0, lo = 1;             // lo: first slot position that can still hold live data (step 0 moves physically)
     for (int j = 0; j < n; ++j) {
         const bool flush = (np == QRX_C - 1);
-        tb(0);
-        hipLaunchKernelGGL(k_qrx_pivot, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
+        tb(0, stream);
+        hipLaunchKernelGGL(k_qrx_pivot, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
                            T, w, R, v, (const LmState *)st);
-        te(0);
-        tb(1);
-        dispatch_pass<0>(np, stream, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, v.qtf, st);
-        te(1);
+        te(0, stream);
+        tb(1, stream);
+        dispatch_pass<0>(np, stream, 0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, v.qtf, st);
+        te(1, stream);
         if (flush) { cur ^= 1; np = 1; lo = j + 1; } else { np += 1; }
     }
-    tb(2);
+    tb(2, stream);
     hipLaunchKernelGGL(k_qrx_finish, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, cur, np, (const double *)T, w, R, v,
                        wa4, scratch, x, st, factor, gtol);
-    te(2);
+    te(2, stream);
 }

@@ -99,11 +99,25 @@ def main():
             r2 = (k["hbm_read_bytes_x2"] + k["hbm_write_bytes"]) / alg
             k["bytes_per_algorithmic_byte_x1"] = r1
             k["bytes_per_algorithmic_byte_x2"] = r2
-            # fewer bytes than the algorithmic ones cannot have moved: that picks the reading of FETCH_SIZE
+            # fewer bytes than the algorithmic ones cannot have moved: that picks the reading of FETCH_SIZE (the
+            # calibration kernel below settles it independently: 0.500 for this access pattern -> x2)
             pick = r1 if k["hbm_read_bytes_x1"] >= 0.98 * alg else r2
             summary.update({"m": m, "n": n, "policy": policy,
                             "roofline_kernel": {"kernel": "k_qrx_pass", "hbm_bytes_per_algorithmic_byte": pick,
                                                 "fetch_size_reading": "x1" if pick == r1 else "x2"}})
+    # calibration run (profiles/ubench/fetch_calib.hip): FETCH_SIZE x 1024 / bytes actually read, 8 and 16 bytes per lane
+    cal = glob.glob(os.path.join(out_dir, "calib", "**", "*counter_collection.csv"), recursive=True)
+    if cal:
+        nbytes = None
+        for line in open(os.path.join(out_dir, "calib.log")):
+            if line.startswith("bytes_read_per_kernel"):
+                nbytes = float(line.split()[1])
+        c = {}
+        for r in csv.DictReader(open(cal[0])):
+            if r["Kernel_Name"].startswith("k_read") and nbytes:
+                c[family(r["Kernel_Name"])] = float(r["Counter_Value"]) * 1024.0 / nbytes
+        summary["fetch_size_calibration"] = {"bytes_read_per_kernel": nbytes, "FETCH_SIZE_bytes_per_byte_read": c,
+                                             "source": "profiles/ubench/fetch_calib.hip (k_read8: the access pattern of k_qrx_pass)"}
     with open(os.path.join(out_dir, "r02_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     print("wrote r02_pmc_summary.json:", json.dumps(summary.get("roofline_kernel")))

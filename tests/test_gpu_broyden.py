@@ -182,3 +182,14 @@ def test_dq_quasi_newton_many_problems_concurrently(ds, oracle):
             assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
         assert np.array_equal(x[p].cpu().numpy(), xo), p
         assert np.array_equal(fvec[p].cpu().numpy(), fo), p
+
+
+def test_host_readme_example_1_counts(oracle):
+    """README.md:34-99 through the drop-in API on the GPU: 11 iterations, 15 function evaluations, 1 Jacobian evaluation
+    (the counts the reference prints), x and f bit-identical to the CPU oracle."""
+    x, f, ib = _solve_host(P.fcn1, 2, (1.0, 1.0), jdelta=20)
+    assert (ib.iter_count, ib.fcn_count, ib.jacobian_count) == (11, 15, 1)
+    rc, xo, fo, ibo = oracle.quasi_newton_solve(lambda a, b: P.fcn1(a, b, None), 2, [1.0, 1.0], jdelta=20)
+    assert rc == 0 and _same(ib, ibo)
+    assert np.array_equal(x, xo) and np.array_equal(f, fo)
+    assert ("%.2e" % f[0], "%.2e" % f[1]) == ("3.23e-12", "7.05e-12")                         # README.md:94

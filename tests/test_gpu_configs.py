@@ -1,7 +1,8 @@
 """BASELINE.json configs 4 and 5 at their stated sizes, under the parity-carrying exact policy (the library default).
 
 The oracle needs ~0.25 s per 2048 x 128 problem and minutes for one 65536 x 512 problem on a host core, so at full size
-the comparison with it is a sample (config 4) or opt-in (config 5, NLH_SLOW_TESTS=1); everything else is held through
+the comparison with it is a sample (config 4) or one solve taking about a minute (config 5; NLH_FAST_TESTS=1 skips it);
+everything else is held through
 properties that do not depend on the size: every problem converges, sharding does not change a bit of any problem,
 the exact and the normal-equations policies agree at the forward-difference noise level, R^T R = P^T J^T J P."""
 import os
@@ -45,8 +46,8 @@ def test_c4_1024_problems_exact_policy_and_sharding_invariance(ds, oracle):
 def test_c5_tall_skinny_65536x512_full_solve(ds, oracle):
     """Config 5: one 65536 x 512 problem, seed 12345.  Exact policy: converges; the normal-equations policy (MFMA J^T J
     contraction) reaches the same point at the forward-difference noise level with the same counts; the Gram matrix of
-    the FD Jacobian agrees with an fp64 reference product.  NLH_SLOW_TESTS=1 adds the bit-for-bit comparison with the
-    oracle (minutes of host time)."""
+    the FD Jacobian agrees with an fp64 reference product; and x, fvec, counts and flags are bit-identical to the CPU
+    oracle's (about a minute of host time; NLH_FAST_TESTS=1 skips that last part)."""
     m, n = 65536, 512
     A, b, xt, x0 = ds.generate(1, m, n, seed0=12345)
     xe = x0.clone()
@@ -67,7 +68,7 @@ def test_c5_tall_skinny_65536x512_full_solve(ds, oracle):
     Gref = torch.matmul(J[0], J[0].T)
     assert float((G[0] - Gref).abs().max() / Gref.abs().max()) < 1e-12
     assert float((g[0] - torch.mv(J[0], f0[0])).abs().max() / g[0].abs().max()) < 1e-11
-    if os.environ.get("NLH_SLOW_TESTS"):
+    if not os.environ.get("NLH_FAST_TESTS"):            # about a minute of host time for the oracle
         rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), 0.5,
                                                    x0[0].cpu().numpy(), opts=oracle.default_options(max_evals=500))
         assert rc == 0 and all(ibe[0][k] == ibo[k] for k in KEYS), (ibe[0], ibo)

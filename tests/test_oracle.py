@@ -1,5 +1,9 @@
-"""CPU tests: pin the oracle (oracle/nonlin_oracle.c) against every known answer the reference
-holds for the hot path and against the reference outputs recorded in SURVEY.md / BASELINE.md."""
+"""CPU tests: pin the oracle (oracle/nonlin_oracle.c) against every known answer the reference holds for the hot
+path (GOLD["reference_held"]: README output, the tolerances of the reference's own tests).
+
+Separately, regression values recorded from a survey-time build of the reference against stand-in linalg modules
+(GOLD["recorded_not_reference_held"], SURVEY.md sections 6 / 8(d)) are checked too; that build cannot be reproduced under
+this project's rules, so those tests are labelled `recorded` and carry no parity claim."""
 import json
 import os
 import struct
@@ -10,7 +14,9 @@ import pytest
 import problems_ref as P
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLD = json.load(open(os.path.join(HERE, "golden", "reference_known_answers.json")))
+_G = json.load(open(os.path.join(HERE, "golden", "reference_known_answers.json")))
+GOLD = _G["reference_held"]
+RECORDED = _G["recorded_not_reference_held"]          # regression values, NOT golden vectors (see the module docstring)
 
 
 def _hex(v):
@@ -30,7 +36,8 @@ def test_norm2_matches_flang_bitwise(oracle):
         assert _hex(oracle.norm2(x)) == c["norm2"]
 
 
-def test_readme_example_2_bit_exact(oracle):
+def test_readme_example_2_printed_digits(oracle):
+    """Reference-held: README.md:165-171 prints c0..c3 with ten decimals and the max residual with five."""
     g = GOLD["readme_example_2"]
     rc, x, f, ib = oracle.lm_solve(lambda xx, ff: P.lsfcn1(xx, ff, None), g["m"], g["n"], g["x0"])
     assert rc == 0
@@ -41,24 +48,30 @@ def test_readme_example_2_bit_exact(oracle):
     assert "%.10f" % x[1] == "%.10f" % pr["c2"]
     assert "%.10f" % x[0] == "%.10f" % pr["c3"]
     assert "%.5f" % np.abs(f).max() == "%.5f" % pr["max_residual"]
-    rec = g["recorded_reference_output"]
-    assert [_hex(v) for v in x] == rec["x_hex"]                 # bit-identical to the reference's answer
+
+
+# ---- recorded, not reference-held: regression values from the survey-time build (no parity claim) -------------------
+def test_recorded_readme_example_2_bits_and_counts(oracle):
+    g = GOLD["readme_example_2"]
+    rc, x, f, ib = oracle.lm_solve(lambda xx, ff: P.lsfcn1(xx, ff, None), g["m"], g["n"], g["x0"])
+    rec = RECORDED["readme_example_2_output"]
+    assert [_hex(v) for v in x] == rec["x_hex"]
     assert np.abs(f).max() == rec["max_abs_f"]
     for k in ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn", "converge_on_chng", "converge_on_zero_diff"):
         assert ib[k] == rec[k]
 
 
-def test_newton_recorded_counts(oracle):
-    g = GOLD["newton_fcn1_analytic_x0_1_1"]
+def test_recorded_newton_counts(oracle):
+    g = RECORDED["newton_fcn1_analytic_x0_1_1"]
     rc, x, f, ib = oracle.newton_solve(lambda a, b: P.fcn1(a, b, None), 2, [1.0, 1.0], jac=lambda a, b: P.jac1(a, b, None))
     assert rc == 0 and list(x) == g["x"] and list(f) == g["f"]
     for k in ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn"):
         assert ib[k] == g[k]
 
 
-@pytest.mark.parametrize("case", GOLD["synthetic_dense_quadratic_counts"]["cases"],
+@pytest.mark.parametrize("case", RECORDED["synthetic_dense_quadratic_counts"]["cases"],
                          ids=lambda c: f"{c['m']}x{c['n']}-{len(c['gen'])}-{len(c['opt'])}")
-def test_synthetic_counts_match_recorded_reference(oracle, case):
+def test_recorded_synthetic_counts(oracle, case):
     A, b, xt, x0 = oracle.dq_generate(12345, case["m"], case["n"], **case["gen"])
     rc, x, f, ib, ncalls, _ = oracle.dq_lm_solve(A, b, case["gen"].get("gamma", 0.5), x0,
                                                  opts=oracle.default_options(max_evals=500, **case["opt"]))
@@ -70,6 +83,7 @@ def test_synthetic_counts_match_recorded_reference(oracle, case):
         assert ncalls == case["callbacks"]
 
 
+# ---- reference-held (continued) ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ic", GOLD["reference_test_tolerances"]["test_least_squares_1"]["ics"])
 @pytest.mark.parametrize("analytic", [True, False])
 def test_least_squares_1_and_4(oracle, ic, analytic):
@@ -338,3 +352,16 @@ def test_bfgs_1_2_3(oracle):
 def test_fd_gradient_matches_analytic(oracle):
     g = oracle.fd_gradient(_rosen, [0.5, 0.5])
     assert np.abs(g - np.array([-51.0, 50.0])).max() <= 1e-5
+
+
+def test_readme_example_1_quasi_newton_counts(oracle):
+    """README.md:34-99 (quasi_newton_solver, x0 = (1, 1), set_jacobian_interval(20), default tolerances): the reference
+    prints `Iterations: 11`, `Function Evaluations: 15`, `Jacobian Evaluations: 1`, solution (5.00000, 3.00000) and
+    residual (0.323E-11, 0.705E-11).  A reference-held pin of qns_solve and, through it, of the restated QR
+    factorisation / rank-1 update / triangular solve of the un-vendored linalg library (the residual digits are the
+    outcome of eleven Broyden updates)."""
+    rc, x, f, ib = oracle.quasi_newton_solve(lambda a, b: P.fcn1(a, b, None), 2, [1.0, 1.0], jdelta=20)
+    assert rc == 0
+    assert (ib["iter_count"], ib["fcn_count"], ib["jacobian_count"]) == (11, 15, 1)          # README.md:95-97
+    assert "%.5f, %.5f" % (x[0], x[1]) == "5.00000, 3.00000"                                  # README.md:93
+    assert ("%.2e" % f[0], "%.2e" % f[1]) == ("3.23e-12", "7.05e-12")                         # 0.323E-11, 0.705E-11 (:94)
