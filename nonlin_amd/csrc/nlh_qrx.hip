@@ -13,13 +13,13 @@
 // beyond LDS + registers (168 MB on the chip) or the Infinity Cache (256 MiB), and a resident subset of
 // problems would leave most SIMDs idle behind the serial row recurrences.  The floor is therefore HBM:
 // 8 * sum_j (m - j)(n - j + 1) bytes per problem (1.06 GB at 4096 x 256).  The kernels are built for that floor:
-//   * the working matrix T is ROW-major (the residual rides along as the last column), one lane owns one
-//     trailing column and walks down the rows: a wave reads 64 consecutive doubles per row through a buffer
-//     descriptor (scalar row offset + per-lane column offset, no address arithmetic), 32 rows of loads in
-//     flight ahead of the arithmetic, one wave per workgroup, no barrier between waves;
-//   * rows END on a 64-column boundary (qrx_coff), so the trailing columns of any step fill whole 64-column
-//     windows counted from the end: every wave-level access is one aligned 512-byte span and a step launches
-//     exactly ceil((n - j) / 64) waves per problem;
+//   * the working matrix T is ROW-BLOCKED (qrx_at: eight rows of a column per 64-byte sector, the residual rides along
+//     as the last column); one lane owns one trailing column and walks down the rows: two rows per 16-byte load through
+//     a buffer descriptor (scalar block offset + per-lane column offset, no address arithmetic), a wave reads 4 KB
+//     contiguous per 8-row block, 32 rows of loads in flight ahead of the arithmetic, one wave per workgroup, no
+//     barrier between waves;
+//   * block rows END on a 64-column boundary (qrx_coff), so the trailing columns of any step fill whole 64-column
+//     windows counted from the end and a step launches exactly ceil(live columns / 64) waves per problem;
 //   * reflector entries are wave-uniform: each wave stages a 64-row tile of them in LDS one tile ahead
 //     (coalesced reads of the slot vectors) and reads a row's entries back as broadcast ds_reads, issued one
 //     row pair ahead of the arithmetic; two rows are processed together so that the dependent mul / sub chains
@@ -41,6 +41,7 @@
 #include "nlh_common.h"
 #include <type_traits>
 #include <cstdlib>
+#include <algorithm>
 
 #ifndef QRX_C
 #define QRX_C 8            // reflector slots per bank = pending updates before a flush + 1
@@ -53,9 +54,13 @@
 #ifndef QRX_AUX_STORE
 #define QRX_AUX_STORE 2   // the flush: non-temporal, the rewritten columns are not read again before the next step
 #endif
+#ifndef QRX_UF
+#define QRX_UF(flush) 16
+#endif
 #define QRX_NE 8           // NORM2 chunk: elements per thread
 
 typedef unsigned int qrx_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int qrx_u32x4 __attribute__((ext_vector_type(4)));
 struct QrxStep { double ajnorm, ajj; int32_t kmax, pad; };
 
 // Physical column of slot k (k = 0 .. n, n = the residual) is k + qrx_coff(n): the row ENDS on a 64-column boundary, so
@@ -64,7 +69,12 @@ struct QrxStep { double ajnorm, ajj; int32_t kmax, pad; };
 static int qrx_coff(int n) { return (64 - ((n + 1) & 63)) & 63; }
 int qrx_ld(int n) { return n + 1 + qrx_coff(n); }
 
-static size_t qrx_tstride(int m, int n) { return (size_t)m * qrx_ld(n); }   // doubles between two problems' matrices
+static size_t qrx_tstride(int m, int n) { return (size_t)((m + 7) & ~7) * qrx_ld(n); }   // doubles between two problems' matrices
+
+// Element (row i, physical column c) of a working matrix.  Row-blocked: eight consecutive rows of a column share one
+// 64-byte sector ((i / 8) * ld + c is the sector index), so a lane reads its column two rows per 16-byte load, a wave
+// reads 4 KB contiguous per row block, and a walk down one column (the pivot gather) costs a sector per 8 elements.
+__host__ __device__ __forceinline__ size_t qrx_at(int i, int c, int ld) { return ((size_t)(i >> 3) * ld + c) * 8 + (i & 7); }
 static size_t qrx_vstride(int m)      // doubles between two slots of a reflector bank
 {
     return ((size_t)m + 7) & ~(size_t)7;
@@ -107,26 +117,27 @@ static size_t qrx_carve(void *base, int nprob, int m, int n, QrxWs *w)
 
 size_t qrx_workspace_bytes(int nprob, int m, int n) { return qrx_carve(nullptr, nprob, m, n, nullptr); }
 
-// Column-major m x n  ->  row-major with row stride ld (32 x 32 tiles through LDS).
+// Column-major m x n  ->  the row-blocked working matrix: eight rows of a column are contiguous in both layouts, so a
+// thread moves one 64-byte sector (consecutive threads: consecutive columns, i.e. contiguous writes).
 __global__ void __launch_bounds__(256)
 k_qrx_transpose(int m, int n, int ld, int coff, size_t tst, const double *__restrict__ J, double *__restrict__ T,
                 const LmState *__restrict__ st)
 {
-    __shared__ double tile[32][33];
-    const int p = blockIdx.z;
+    const int p = blockIdx.y;
     if (st && st[p].stage != ST_NEED_QR) return;
     const double *Jp = J + (size_t)p * m * n;
     double *Tp = T + (size_t)p * tst;
-    const int i0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
-        const int i = i0 + tx, k = k0 + r;
-        tile[r][tx] = (i < m && k < n) ? Jp[(size_t)k * m + i] : 0.0;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int i = i0 + r, k = k0 + tx;
-        if (i < m && k < n) Tp[(size_t)i * ld + coff + k] = tile[tx][r];
+    const int nblk = (m + 7) >> 3;
+    const size_t total = (size_t)nblk * n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(e % n), b = (int)(e / n);
+        const double *src = Jp + (size_t)k * m + (size_t)b * 8;
+        double *dst = Tp + ((size_t)b * ld + coff + k) * 8;
+        double vv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vv[r] = (b * 8 + r < m) ? src[r] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dst[r] = vv[r];
     }
 }
 
@@ -140,9 +151,43 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
     const int tid = threadIdx.x, BS = blockDim.x;
     double *a = T + (size_t)p * tst;
     const double *f = fall + (size_t)p * m;
-    for (int i = tid; i < m; i += BS) a[(size_t)i * ld + coff + n] = f[i];
+    for (int i = tid; i < m; i += BS) a[qrx_at(i, coff + n, ld)] = f[i];
     for (int k = tid; k < n; k += BS) {
-        const double nr = norm2_flang_serial_strided(a + coff + k, ld, m);
+        // flang NORM2 of column k, rows ascending: a sector (8 rows) per load group, the next one in flight
+        double mx = 0.0, sq = 0.0;
+        auto step = [&](double vv) {
+            const double av = fabs(vv);
+            if (mx == 0.0) {
+                mx = av;
+            } else if (av > mx) {
+                const double t = mx / av, tsq = t * t;
+                sq = sq * tsq;
+                sq = sq + tsq;
+                mx = av;
+            } else if (av != 0.0) {
+                const double t = av / mx;
+                sq = sq + t * t;
+            }
+        };
+        const int nblk = (m + 7) >> 3;
+        const double *colp = a + (size_t)(coff + k) * 8;
+        double xa[8], xb[8];
+        auto ld8 = [&](double (&x)[8], int b) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = colp[(size_t)b * ld * 8 + r];
+        };
+        ld8(xa, 0);
+        for (int b = 0; b < nblk; b += 2) {
+            if (b + 1 < nblk) ld8(xb, b + 1);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (b * 8 + r < m) step(xa[r]);
+            if (b + 2 < nblk) ld8(xa, b + 2);
+            if (b + 1 < nblk) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if ((b + 1) * 8 + r < m) step(xb[r]);
+            }
+        }
+        const double nr = mx * sqrt(1.0 + sq);
         v.acnorm[(size_t)p * n + k] = nr;
         w.rdiag[(size_t)p * n + k] = nr;
         w.wa[(size_t)p * n + k] = nr;
@@ -213,19 +258,19 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     }
     const bool move0 = (j == 0 && kmax != 0);                   // see above: slot 0's column takes the pivot column's place
     const int src0 = coff;                                       // physical column of slot 0 at step 0
-    // The pivot column with its pending updates applied, oldest first.  Four rows per thread are loaded together (the
-    // column walk costs a 64-byte sector per element, the pending reflector entries are coalesced) before any is stored.
+    // The pivot column with its pending updates applied, oldest first.  Consecutive threads take consecutive rows (eight
+    // of them share a sector of the row-blocked matrix); four rows per thread are loaded together before any is stored.
     const double *__restrict__ Vc = w.V + ((size_t)p * 2 + cur) * QRX_C * vst;          // slot q at Vc + q * vst
     double *__restrict__ Vn = flush ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
                                     : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
-    double *col = T + (size_t)p * tst + srck;
+    double *Tp = T + (size_t)p * tst;
     for (int i0 = j + tid; i0 < m; i0 += 4 * BS) {
         double e[4], vq[4][QRX_C - 1], mv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = min(i0 + u * BS, m - 1);
-            e[u] = col[(size_t)row * ld];
-            mv[u] = move0 ? col[(size_t)row * ld + (src0 - srck)] : 0.0;
+            e[u] = Tp[qrx_at(row, srck, ld)];
+            mv[u] = move0 ? Tp[qrx_at(row, src0, ld)] : 0.0;
 #pragma unroll
             for (int q = 0; q < QRX_C - 1; ++q) vq[u][q] = (q < np) ? Vc[(size_t)q * vst + row] : 0.0;
         }
@@ -236,7 +281,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
                 if (q < np) e[u] = e[u] - tk[q] * vq[u][q];
             if (i0 + u * BS < m) {
                 Vn[i0 + u * BS] = e[u];
-                if (move0) col[(size_t)(i0 + u * BS) * ld] = mv[u];
+                if (move0) Tp[qrx_at(i0 + u * BS, srck, ld)] = mv[u];
             }
         }
     }
@@ -265,11 +310,11 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
 // Step j, part 2: every trailing column k = j+1 .. n (n = the residual): pending updates, dot product with
 // the reflector in ascending row order (:652-653), multiplier (:654), row j becomes final (R(j,k) / qtf(j)),
 // norm down-date (:656-661).
-// One wave per workgroup; a lane owns CPT columns (lane, lane + 64, ...) and walks down the rows, so a wave reads
-// 64 consecutive doubles per row and column group, with 32 loads per lane in flight ahead of the arithmetic.
-// The reflector entries of a row (wave-uniform) come from an LDS tile of 64 rows that the wave stages for itself one
-// tile ahead (coalesced 64-byte rows -> broadcast ds_reads); with CPT = 4 a row's nine LDS values serve 256 elements.
-template <int NP, bool FLUSH, int CPT>
+// One wave per workgroup; a lane owns one physical column and walks down the rows.  The matrix is row-blocked (qrx_at):
+// a lane reads two rows of its column per 16-byte load, a wave 4 KB contiguous per 8-row block, 32 loads (64 rows) in
+// flight ahead of the arithmetic.  The reflector entries of a row (wave-uniform) come from an LDS tile of 64 rows that
+// the wave stages for itself one tile ahead (coalesced slot vectors in, broadcast ds_reads out).
+template <int NP, bool FLUSH>
 __global__ void __launch_bounds__(64)
 k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
            double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
@@ -277,65 +322,58 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
            double *__restrict__ waall, const QrxStep *__restrict__ stepall, double *__restrict__ Rall,
            double *__restrict__ qtfall, const LmState *__restrict__ st)
 {
-    constexpr int U = 32 / CPT;            // rows per load group
+    constexpr int U = QRX_UF(FLUSH);       // rows per load group (8 or 16 loads per lane; the flush is write-bound and
+                                           // register-hungry: half the read-ahead)
     constexpr int TR = QRX_TR;             // rows per reflector tile
     constexpr int LP = QRX_C;              // LDS row: the pending entries and the new one (NP + 1 <= QRX_C doubles)
     constexpr int NPI = NP < QRX_C ? NP : 0;
     __shared__ double vt[2][TR * LP];
     // Workgroup -> (problem, window): consecutive workgroup ids go to consecutive XCDs, so the windows of one problem
-    // are given ids that agree modulo 8: they share an L2 (reflector tiles, multipliers, the row segment two windows
-    // both touch are fetched from the fabric once).
+    // are given ids that agree modulo 8: they share an L2 (reflector tiles, multipliers are fetched from the fabric once).
     const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
     const int pl = grp * 8 + (r_ & 7), win = r_ >> 3;
     if (pl >= nprob) return;
     const int p = p0 + pl;
     if (st && st[p].stage != ST_NEED_QR) return;
     const int lane = threadIdx.x, ldp = n + 1;
-    const int wtop = ld - 64 * CPT * win;                               // end (exclusive) of this wave's topmost window
     const QrxStep step = stepall[p];
     const bool refl = step.ajnorm != 0.0;
     const double ajj = step.ajj;
     int32_t *srcp = srcall + (size_t)p * ldp;
     int32_t *slotp = slotall + (size_t)p * ld;
     double *tpc = tpall + ((size_t)p * 2 + cur) * QRX_C * ldp;
-    const double *vc = Vall + ((size_t)p * 2 + cur) * QRX_C * vst + j;          // slot q, row j + r at vc[q * vst + r]
-    const double *vo = Vall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst + j;   // slot 0 of the other bank
-    double *Tj = T + (size_t)p * tst + (size_t)j * ld;                  // row j
-    const int nrows = m - j;
+    double *Tp = T + (size_t)p * tst;
+    // rows are counted from the start of row j's 8-row block: rel row r = absolute row jb + r, first live one r0
+    const int jb = j & ~7, r0 = j & 7, mrel = m - jb;
+    const double *vc = Vall + ((size_t)p * 2 + cur) * QRX_C * vst + jb;          // slot q, rel row r at vc[q * vst + r]
+    const double *vo = Vall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst + jb;   // slot 0 of the other bank
 
     // A lane owns a PHYSICAL column; which slot of the permuted matrix that column currently holds comes from the
     // inverse map (the interchange never moves data).  Since the last flush the live columns are coff + lo .. ld - 1
-    // (lo = the step after that flush, 0 before the first one) minus the consumed ones, at most QRX_C - 1 of them,
-    // whose lanes idle: every load is the lane's own column, i.e. one aligned 512-byte span per wave and row.
-    unsigned kc[CPT], pc[CPT];
-    bool act[CPT];
-    double tq[CPT][NP > 0 ? NP : 1], s[CPT], rowj[CPT];
+    // (lo = the step after that flush, 1 before the first one) minus the consumed ones, at most QRX_C - 1 of them,
+    // whose lanes idle: every load is the lane's own column.
+    const int col = ld - 64 * (win + 1) + lane;
+    const int kslot = (col >= coff + lo) ? slotp[col] : -1;
+    const bool act = kslot > j;
+    const int k = act ? kslot : n;                                      // idle lanes: any valid slot for the table reads
+    double tq[NP > 0 ? NP : 1];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        const int col = wtop - 64 * (c + 1) + lane;
-        const int k = (col >= coff + lo) ? slotp[col] : -1;
-        act[c] = k > j;
-        pc[c] = (unsigned)col;
-        kc[c] = act[c] ? (unsigned)k : (unsigned)n;                     // idle lanes: any valid slot for the table reads
-#pragma unroll
-        for (int q = 0; q < NP; ++q) tq[c][q] = tpc[(size_t)q * ldp + kc[c]];
-        s[c] = 0.0;
-    }
-    auto pending = [&](double a, int c, const auto &vr) {
+    for (int q = 0; q < NP; ++q) tq[q] = tpc[(size_t)q * ldp + k];
+    auto pending = [&](double a, const auto &vr) {
         double e = a;
 #pragma unroll
-        for (int q = 0; q < NP; ++q) e = e - tq[c][q] * vr[q];
+        for (int q = 0; q < NP; ++q) e = e - tq[q] * vr[q];
         return e;
     };
+    double rowj;
     {   // row j with its pending updates (becomes final below)
         double v0[NP + 1];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) v0[q] = vc[(size_t)q * vst];
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) rowj[c] = pending(Tj[pc[c]], c, v0);
+        for (int q = 0; q < NP; ++q) v0[q] = vc[(size_t)q * vst + r0];
+        rowj = pending(Tp[qrx_at(j, col, ld)], v0);
     }
 
-    // reflector tile t: lane l fetches the entries of row t*TR + l (one coalesced 512-byte read per slot); the staged
+    // reflector tile t: lane l fetches the entries of rel row t*TR + l (one coalesced 512-byte read per slot); the staged
     // LDS row is [pending v_0 .. v_NP-1, new v]
     double sv[NP + 1];
     auto vfetch = [&](int t) {
@@ -349,31 +387,31 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
 #pragma unroll
         for (int q = 0; q <= NP; ++q) d[q] = sv[q];
     };
-    // Matrix accesses go through a buffer descriptor of this problem's matrix: address = descriptor base + wave-uniform
-    // row offset (scalar register) + per-lane column offset (one VGPR per column for the whole pass); reads past the
-    // last row return zero and are never used.
+    // Matrix accesses go through a buffer descriptor of this problem's matrix from row block jb on: address = descriptor
+    // base + wave-uniform block offset (scalar register) + per-lane column offset (one VGPR for the whole pass) + the
+    // row pair inside the block (immediate); reads past the last block return zero and are never used, idle lanes are
+    // parked past the range and fetch nothing.
+    const int nblk = (mrel + 7) >> 3;
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(Tj, 0, (int)((size_t)nrows * ld * sizeof(double)), 0x00020000);
-    unsigned so[CPT], ko[CPT];
+        __builtin_amdgcn_make_buffer_rsrc(Tp + (size_t)(jb >> 3) * ld * 8, 0, (int)((size_t)nblk * ld * 64), 0x00020000);
+    const unsigned so = act ? (unsigned)col * 64u : 0x80000000u;
+    const unsigned ko = act ? (unsigned)(coff + k) * 64u : 0x80000000u;  // where a flush puts the column (idle lanes: nowhere)
+    const unsigned ldb = (unsigned)ld * 64u;                            // bytes per row block
+    double a0[U], a1[U];
+    auto load = [&](double (&buf)[U], int rbase) {                      // rbase: rel row, a multiple of 8
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        so[c] = act[c] ? pc[c] * 8u : 0x80000000u;      // idle lanes: past the descriptor's range, nothing is fetched
-        ko[c] = (kc[c] + (unsigned)coff) * 8u;
-    }
-    const unsigned ldb = (unsigned)ld * 8u;
-    double a0[U][CPT], a1[U][CPT];
-    auto load = [&](double (&buf)[U][CPT], int r0) {
+        for (int b4 = 0; b4 < U / 8; ++b4) {
+            const unsigned boff = (unsigned)((rbase >> 3) + b4) * ldb;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned roff = (unsigned)(r0 + u) * ldb;
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) {
-                const qrx_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, so[c], roff, QRX_AUX_LOAD);
-                buf[u][c] = __hiloint2double((int)w.y, (int)w.x);
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const qrx_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + 16u * q2, boff, QRX_AUX_LOAD);
+                buf[b4 * 8 + 2 * q2] = __hiloint2double((int)w.y, (int)w.x);
+                buf[b4 * 8 + 2 * q2 + 1] = __hiloint2double((int)w.w, (int)w.z);
             }
         }
     };
-    auto compute = [&](auto guarded, const double (&buf)[U][CPT], int r0, const double *tile, int g) {
+    double s = 0.0;
+    auto compute = [&](auto guarded, const double (&buf)[U], int rbase, const double *tile, int g) {
         constexpr bool GD = decltype(guarded)::value;
         double va[NP + 1], vb[NP + 1];
         auto ldsrow = [&](double (&dst)[NP + 1], int u) {
@@ -381,53 +419,52 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
 #pragma unroll
             for (int q = 0; q <= NP; ++q) dst[q] = vr[q];
         };
-        auto flushrow = [&](const double (&e)[CPT], int row) {
-            const unsigned roff = (unsigned)row * ldb;
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) {
-                if (act[c]) {
-                    qrx_u32x2 w;
-                    w.x = (unsigned)__double2loint(e[c]); w.y = (unsigned)__double2hiint(e[c]);
-                    __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, ko[c], roff, QRX_AUX_STORE);
-                }
-            }
-        };
-        // Two rows at a time with the 2 * CPT update chains interleaved (each chain is a dependent mul / sub
-        // sequence, one wave per SIMD has nobody else to hide that latency); the LDS reads of a row pair are
-        // issued one pair ahead.
+        // Two rows at a time with their update chains interleaved (each chain is a dependent mul / sub sequence, and a
+        // wave alone on its SIMD has nobody else to hide that latency); the LDS reads of a row pair are issued one pair
+        // ahead.  A pair (even row, odd row) is also the 16-byte unit of the flush.
         ldsrow(va, 0);
         ldsrow(vb, 1);
 #pragma unroll
         for (int u = 0; u < U; u += 2) {
-            if (GD && r0 + u >= nrows) break;                           // uniform
-            double e0[CPT], e1[CPT], v0[NP + 1], v1[NP + 1];
+            const int row = rbase + u;
+            if (GD && row >= mrel) break;                               // uniform
+            double v0[NP + 1], v1[NP + 1];
 #pragma unroll
             for (int q = 0; q <= NP; ++q) { v0[q] = va[q]; v1[q] = vb[q]; }
             if (u + 2 < U) { ldsrow(va, u + 2); ldsrow(vb, u + 3); }
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) { e0[c] = buf[u][c]; e1[c] = buf[u + 1][c]; }
+            double e0 = buf[u], e1 = buf[u + 1];
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                double p0[CPT], p1[CPT];
-#pragma unroll
-                for (int c = 0; c < CPT; ++c) { p0[c] = tq[c][q] * v0[q]; p1[c] = tq[c][q] * v1[q]; }
-#pragma unroll
-                for (int c = 0; c < CPT; ++c) { e0[c] = e0[c] - p0[c]; e1[c] = e1[c] - p1[c]; }
+                const double p0_ = tq[q] * v0[q], p1_ = tq[q] * v1[q];
+                e0 = e0 - p0_;
+                e1 = e1 - p1_;
             }
-            double w0[CPT], w1[CPT];
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) { w0[c] = v0[NP] * e0[c]; w1[c] = v1[NP] * e1[c]; }
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) s[c] = s[c] + w0[c];           // :653, rows ascending
-            if (FLUSH) flushrow(e0, r0 + u);
-            if (GD && r0 + u + 1 >= nrows) break;
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) s[c] = s[c] + w1[c];
-            if (FLUSH) flushrow(e1, r0 + u + 1);
+            const double w0 = v0[NP] * e0, w1 = v1[NP] * e1;
+            const bool ok0 = !GD || (row >= r0), ok1 = !GD || (row + 1 >= r0 && row + 1 < mrel);
+            if (ok0) s = s + w0;                                        // :653, rows ascending
+            if (ok1) s = s + w1;
+            if (FLUSH) {
+                const unsigned boff = (unsigned)(row >> 3) * ldb, ioff = (unsigned)(row & 7) * 8u;
+                if (!GD) {                                              // the pair as one 16-byte store
+                    qrx_u32x4 w;
+                    w.x = (unsigned)__double2loint(e0); w.y = (unsigned)__double2hiint(e0);
+                    w.z = (unsigned)__double2loint(e1); w.w = (unsigned)__double2hiint(e1);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, ko + ioff, boff, QRX_AUX_STORE);
+                } else {                                                // first / last tile: row by row
+                    qrx_u32x2 w;
+                    w.x = (unsigned)__double2loint(e0); w.y = (unsigned)__double2hiint(e0);
+                    if (ok0) __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, ko + ioff, boff, QRX_AUX_STORE);
+                    w.x = (unsigned)__double2loint(e1); w.y = (unsigned)__double2hiint(e1);
+                    if (ok1) __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, ko + ioff + 8u, boff, QRX_AUX_STORE);
+                }
+            }
+            // keep a pair's work together: with many pending updates the scheduler otherwise hoists the LDS reads of
+            // many row pairs (NP + 1 values each) and runs out of registers
+            if (NP >= 6) __builtin_amdgcn_sched_barrier(0);
         }
     };
-    const int ntile = (nrows + TR - 1) / TR, nfull = nrows / TR;
-    // Unconditional read-ahead of the reflector rows: rows past the last one belong to the next bank or to the padding
+    const int ntile = (mrel + TR - 1) / TR;
+    // Unconditional read-ahead of the reflector rows: rows past the last one belong to the next slot or to the padding
     // behind the banks and are never used.
     vfetch(0);
     vstore(0);
@@ -438,8 +475,8 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
         const double *tile = vt[t & 1];
         const int rb = t * TR;
         vfetch(t + 1);
-        if (t < nfull) {
-#pragma unroll 1
+        if ((t > 0 || r0 == 0) && rb + TR <= mrel) {                     // every row of the tile is live
+#pragma unroll
             for (int g = 0; g < TR / U; g += 2) {
                 load(a1, rb + (g + 1) * U);
                 compute(plain_t, a0, rb + g * U, tile, g);
@@ -459,45 +496,39 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
         __syncthreads();
     }
 
+    if (!act) return;
     double *tpn = FLUSH ? tpall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * ldp : tpc + (size_t)NPI * ldp;
     double *rdiag = rdall + (size_t)p * n, *wa = waall + (size_t)p * n;
+    const double temp = refl ? s / ajj : 0.0;                           // :654 (residual: w + v*(-s/a) == w - (s/a)*v bit for bit)
+    tpn[k] = temp;
+    if (FLUSH) {                                                        // the column now sits at its slot's own position
+        srcp[k] = coff + k;
+        slotp[coff + k] = k;
+        if (col != coff + k) slotp[col] = -1;
+    }
+    const double rjk = refl ? rowj - temp * ajj : rowj;                 // :655 at i = j: row j is final
+    if (k == n) { qtfall[(size_t)p * n + j] = rjk; return; }
+    Rall[(size_t)p * n * n + (size_t)k * n + j] = rjk;
+    if (!refl) return;
+    double rk = rdiag[k];
+    if (rk != 0.0) {                                                    // :656-661
+        const double t2 = rjk / rk;
+        rk = rk * sqrt(fmax(0.0, 1.0 - t2 * t2));
+        const double q = rk / wa[k];
+        if (!(5.0e-2 * (q * q) > NLH_EPS)) {
+            rk = norm2_flang_serial([&](int i2) {
+                const int row = j + 1 + i2, rel = row - jb;
+                double vr[NP + 1];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        if (!act[c]) continue;
-        const int k = (int)kc[c];
-        const double temp = refl ? s[c] / ajj : 0.0;                    // :654 (residual: see nlh_kernels_exact.h)
-        tpn[k] = temp;
-        if (FLUSH) {                                                    // the column now sits at its slot's own position
-            srcp[k] = coff + k;
-            slotp[coff + k] = k;
-            if ((int)pc[c] != coff + k) slotp[pc[c]] = -1;
+                for (int q2 = 0; q2 < NP; ++q2) vr[q2] = vc[(size_t)q2 * vst + rel];
+                // a flush has just rewritten the column (pending updates applied) at its slot's own position
+                const double e = FLUSH ? Tp[qrx_at(row, coff + k, ld)] : pending(Tp[qrx_at(row, col, ld)], vr);
+                const double vn = FLUSH ? vo[rel] : vc[(size_t)NPI * vst + rel];
+                return e - temp * vn;
+            }, m - j - 1);
+            wa[k] = rk;
         }
-        const double rjk = refl ? rowj[c] - temp * ajj : rowj[c];       // :655 at i = j: row j is final
-        if (k == n) { qtfall[(size_t)p * n + j] = rjk; continue; }
-        Rall[(size_t)p * n * n + (size_t)k * n + j] = rjk;
-        if (!refl) continue;
-        double rk = rdiag[k];
-        if (rk != 0.0) {                                                // :656-661
-            const double t2 = rjk / rk;
-            rk = rk * sqrt(fmax(0.0, 1.0 - t2 * t2));
-            const double q = rk / wa[k];
-            if (!(5.0e-2 * (q * q) > NLH_EPS)) {
-                const double *colp = Tj + pc[c];
-                const double *dstp = Tj + coff + kc[c];
-                rk = norm2_flang_serial([&](int i2) {
-                    const int row = 1 + i2;
-                    double vr[NP + 1];
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) vr[q] = vc[(size_t)q * vst + row];
-                    // a flush has just rewritten the column (pending updates applied) at its own position
-                    const double e = FLUSH ? dstp[(size_t)row * ld] : pending(colp[(size_t)row * ld], c, vr);
-                    const double vn = FLUSH ? vo[row] : vc[(size_t)NPI * vst + row];
-                    return e - temp * vn;
-                }, nrows - 1);
-                wa[k] = rk;
-            }
-            rdiag[k] = rk;
-        }
+        rdiag[k] = rk;
     }
 }
 
@@ -530,7 +561,7 @@ k_qrx_finish(int m, int n, int ld, int coff, size_t tst, size_t vst, int cur, in
         if (i < n) {
             e = qtf[i];
         } else {
-            e = a[(size_t)i * ld + coff + n];
+            e = a[qrx_at(i, coff + n, ld)];
 #pragma unroll
             for (int q = 0; q < QRX_C; ++q)
                 if (q < np) e = e - tk[q] * Vc[(size_t)q * vst + i];
@@ -553,12 +584,11 @@ template <int NP, bool FLUSH>
 static void launch_pass(hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
                         double *R, double *qtf, const LmState *st)
 {
-    // One column per lane (CPT = 1): measured against two and four columns per lane (fewer waves, the LDS row shared by
-    // more elements) on 512 x 4096x256, 1024 x 2048x128 and a single problem, more waves won every time.
-    constexpr int CPT = 1;
-    const int nwin = (n + 1 - lo + 64 * CPT - 1) / (64 * CPT);         // live physical columns coff + lo .. coff + n
+    // One column per lane: measured against two and four columns per lane (fewer waves, the LDS row shared by more
+    // elements) on 512 x 4096x256, 1024 x 2048x128 and a single problem, more waves won every time.
+    const int nwin = (n + 1 - lo + 63) / 64;                            // live physical columns coff + lo .. coff + n
     const dim3 grid((unsigned)(((nprob + 7) / 8) * 8 * nwin));
-    hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH, CPT>), grid, dim3(64), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+    hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH>), grid, dim3(64), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                        T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
 }
 
@@ -586,8 +616,11 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     auto tb = [&](int which, hipStream_t s) { if (tm) tm->begin(tm->ctx, which, s); };
     auto te = [&](int which, hipStream_t s) { if (tm) tm->end(tm->ctx, which, s); };
     tb(2, stream);
-    hipLaunchKernelGGL(k_qrx_transpose, dim3((m + 31) / 32, (n + 31) / 32, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, J, T,
-                       (const LmState *)st);
+    {
+        const size_t total = (size_t)((m + 7) >> 3) * n;
+        const unsigned gx = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_qrx_transpose, dim3(gx, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, J, T, (const LmState *)st);
+    }
     hipLaunchKernelGGL(k_qrx_init, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
     te(2, stream);
     // (Measured and dropped: the two halves of the batch on two streams, half B's pivot kernel under half A's pass, with
