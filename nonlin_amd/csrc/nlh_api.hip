@@ -445,7 +445,8 @@ static void launch_fd(nlh_handle *h, int nprob, int m, int n, const double *P, c
 // bits do not depend on its batch, the round it is active in, the sub-batch or the rank it was dealt to.
 static int gram_splits(int m)
 {
-    const int s = (m + 1023) / 1024;                  // 1024 rows per split
+    const int s = (m + 1023) / 1024;                  // 1024 rows per split (4096 rows per split was measured: no gain for
+                                                      // 512 x 4096x256, and one problem alone 3.3 -> 7.0 ms per solve)
     return s < 1 ? 1 : s;
 }
 
@@ -786,7 +787,8 @@ static int lm_sub_batches(const nlh_options *o, int nprob, int m, int n)
     if (S <= 0) {                                   // auto: >= 128 problems per sub-batch, at most 3 in flight (measured
         S = nprob / 128;                            // on 512 x 4096x256 exact: 1 / 2 / 3 / 4 -> 1032 / 959 / 928 / 1036 ms)
         if (S > 3) S = 3;
-    }
+        if (o->factor_policy != NLH_FACTOR_EXACT) S = 1;   // the normal-equations pipeline has no long latency-bound
+    }                                                      // stage to hide (1 / 2 / 4 -> 40.0 / 40.6 / 41.7 ms)
     if (S > nprob) S = nprob;
     return S < 1 ? 1 : S;
 }
