@@ -413,7 +413,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     double s = 0.0;
     auto compute = [&](auto guarded, const double (&buf)[U], int rbase, const double *tile, int g) {
         constexpr bool GD = decltype(guarded)::value;
-        double va[NP + 1], vb[NP + 1];
+        double va[NP + 1], vb[NP + 1], est[8];
         auto ldsrow = [&](double (&dst)[NP + 1], int u) {
             const double *vr = tile + (g * U + u) * LP;
 #pragma unroll
@@ -445,11 +445,20 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
             if (ok1) s = s + w1;
             if (FLUSH) {
                 const unsigned boff = (unsigned)(row >> 3) * ldb, ioff = (unsigned)(row & 7) * 8u;
-                if (!GD) {                                              // the pair as one 16-byte store
-                    qrx_u32x4 w;
-                    w.x = (unsigned)__double2loint(e0); w.y = (unsigned)__double2hiint(e0);
-                    w.z = (unsigned)__double2loint(e1); w.w = (unsigned)__double2hiint(e1);
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, ko + ioff, boff, QRX_AUX_STORE);
+                if (!GD) {
+                    // a lane's eight rows of a block are one 64-byte sector: collect them and store the sector whole
+                    // (four 16-byte stores back to back), not as four partial writes spread over the block's arithmetic
+                    est[u & 7] = e0;
+                    est[(u & 7) + 1] = e1;
+                    if ((u & 7) == 6) {
+#pragma unroll
+                        for (int q2 = 0; q2 < 4; ++q2) {
+                            qrx_u32x4 w;
+                            w.x = (unsigned)__double2loint(est[2 * q2]); w.y = (unsigned)__double2hiint(est[2 * q2]);
+                            w.z = (unsigned)__double2loint(est[2 * q2 + 1]); w.w = (unsigned)__double2hiint(est[2 * q2 + 1]);
+                            __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, ko + 16u * q2, boff, QRX_AUX_STORE);
+                        }
+                    }
                 } else {                                                // first / last tile: row by row
                     qrx_u32x2 w;
                     w.x = (unsigned)__double2loint(e0); w.y = (unsigned)__double2hiint(e0);
