@@ -240,8 +240,8 @@ __device__ double norm2_flang_block(Get get, int len, double *scratch)
     return r;
 }
 
-// The same NORM2 with a wide chunk: cd holds 2*cap doubles (cap <= EMAX*blockDim), aux 40 + blockDim/2
-// doubles.  The running maximum before every element comes from a wave scan (shuffles) plus one LDS
+// The same NORM2 with a wide chunk: cd holds 2*cap + 4*EMAX doubles (cap <= EMAX*blockDim), aux 40 + blockDim/2 + 4
+// doubles (16-byte aligned; the tails are read-ahead padding of the serial phase).  The running maximum before every element comes from a wave scan (shuffles) plus one LDS
 // exchange, i.e. three barriers per chunk instead of log2(chunk) of them.  The serial recurrence is
 // unchanged, but the one thread that runs it executes as few instructions as possible: every thread
 // flags whether its EMAX consecutive elements are free of a new maximum (all c == 1), and a flagged
@@ -310,30 +310,45 @@ __device__ double norm2_flang_block_wide(Get get, int len, double *cd, int cap, 
                     s = s + dsv[i + u];
                 }
             };
-            double da[EMAX], db[EMAX];
-            int fa = 0, fb = 0;
-            auto load = [&](double (&d)[EMAX], int &f, int r) {
-                f = flags[r];
-                const double2 *src = reinterpret_cast<const double2 *>(dsv + r * EMAX);   // plain runs have E == EMAX
+            if (E == EMAX) {
+                // Four runs per iteration, four register buffers: the LDS reads of a run are issued four runs (32 adds)
+                // before its terms enter the chain, in straight-line code, so the waits are counted ones and the chain
+                // itself is the only latency left (one lgkmcnt(0) per run cost 2/3 of this function's time).  dsv and
+                // flags carry 4 runs / 8 entries of padding behind them for the read-ahead.
+                const int nfast = nrun & ~3;
+                double d0[EMAX], d1[EMAX], d2[EMAX], d3[EMAX];
+                auto loadrun = [&](double (&d)[EMAX], int r) {
+                    const double2 *src = reinterpret_cast<const double2 *>(dsv + r * EMAX);
 #pragma unroll
-                for (int u = 0; u < EMAX / 2; ++u) { const double2 v2 = src[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
-            };
-            auto chain = [&](const double (&d)[EMAX], int f, int r) {
-                if (f) {
+                    for (int u = 0; u < EMAX / 2; ++u) { const double2 v2 = src[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
+                };
+                auto adds = [&](const double (&d)[EMAX]) {
 #pragma unroll
                     for (int u = 0; u < EMAX; ++u) s = s + d[u];
-                } else {
-                    general(r * E, min(E, cl - r * E));
+                };
+                int r = 0;
+                int4 f = make_int4(0, 0, 0, 0);
+                if (nfast > 0) {
+                    loadrun(d0, 0); loadrun(d1, 1); loadrun(d2, 2); loadrun(d3, 3);
+                    f = *reinterpret_cast<const int4 *>(flags);
                 }
-            };
-            if (E == EMAX) {
-                load(da, fa, 0);
-                for (int r = 0; r < nrun; r += 2) {
-                    if (r + 1 < nrun) load(db, fb, r + 1);
-                    chain(da, fa, r);
-                    if (r + 2 < nrun) load(da, fa, r + 2);
-                    if (r + 1 < nrun) chain(db, fb, r + 1);
+                for (; r < nfast; r += 4) {
+                    const int4 fn = *reinterpret_cast<const int4 *>(flags + r + 4);
+                    if (f.x & f.y & f.z & f.w) {
+                        adds(d0); loadrun(d0, r + 4); __builtin_amdgcn_sched_barrier(0);   // keep each reload right behind
+                        adds(d1); loadrun(d1, r + 5); __builtin_amdgcn_sched_barrier(0);   // the adds that free its registers
+                        adds(d2); loadrun(d2, r + 6); __builtin_amdgcn_sched_barrier(0);
+                        adds(d3); loadrun(d3, r + 7); __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        if (f.x) adds(d0); else general(r * E, E);
+                        if (f.y) adds(d1); else general((r + 1) * E, E);
+                        if (f.z) adds(d2); else general((r + 2) * E, E);
+                        if (f.w) adds(d3); else general((r + 3) * E, min(E, cl - (r + 3) * E));
+                        loadrun(d0, r + 4); loadrun(d1, r + 5); loadrun(d2, r + 6); loadrun(d3, r + 7);
+                    }
+                    f = fn;
                 }
+                for (; r < nrun; ++r) general(r * E, min(E, cl - r * E));
             } else {
                 general(0, cl);
             }

@@ -204,8 +204,8 @@ __global__ void __launch_bounds__(256)
 k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
 {
-    __shared__ double cd[2 * QRX_NE * 256];
-    __shared__ double aux[40 + 128];
+    __shared__ __attribute__((aligned(16))) double cd[2 * QRX_NE * 256 + 4 * QRX_NE];
+    __shared__ __attribute__((aligned(16))) double aux[40 + 128 + 4];
     __shared__ double red[64];
     const int p = p0 + blockIdx.x;
     if (st && st[p].stage != ST_NEED_QR) return;
