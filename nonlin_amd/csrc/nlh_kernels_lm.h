@@ -260,7 +260,17 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
     par = fmin(par, paru);
     if (par == 0.0) par = gnorm / dxnorm;
 
+    bool at_fixed_point = false;
     for (int iter = 1;; ++iter) {                              // :522-563
+        // Once an iteration has STARTED with par = +Inf and run to its end, the loop is at a fixed point: the next
+        // iteration starts from the same par = parl = +Inf, the same R and qtb (lmsolve restarts from them), computes
+        // the same x (= 0), sdiag, dxnorm and fp, cannot exit before iter == 10 (fp repeats) and leaves par = +Inf
+        // again.  Everything lmpar returns is therefore already what the tenth iteration would leave, bit for bit;
+        // the remaining (identical) sweeps are skipped.  This is where deviation A sends every problem whose trust
+        // region has shrunk below the residual tail it adds to ||D x||: par explodes super-exponentially (4.2 ->
+        // 1.9e19 -> 8.3e74 -> 7.3e241 -> Inf on the benchmark family) and the reference spends five more sweeps there.
+        if (at_fixed_point && par == __builtin_inf()) break;
+        const bool started_inf = (par == __builtin_inf());
         if (par == 0.0) par = fmax(NLH_DWARF, p001 * paru);
         temp = sqrt(par);
         __syncthreads();
@@ -307,6 +317,7 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
         if (fp > 0.0) parl = fmax(parl, par);                  // :558-559
         if (fp < 0.0) paru = fmin(paru, par);
         par = fmax(parl, par + parc);                          // :562
+        at_fixed_point = started_inf;
     }
     *par_io = par;
     return 0;
