@@ -27,7 +27,7 @@
 //   * column updates are DEFERRED: after step j a trailing column is not rewritten; its multiplier
 //     t_k = s_k / a_jj is kept and later passes apply the pending updates on the fly, oldest first --
 //     e = ((a - t_0 v_0) - t_1 v_1) ... -- the very roundings of the eager update (:655).  Every 7th step
-//     the pass stores e back (flush, non-temporal): 8 B read + 8/7 B written per element and step instead of 24.
+//     the pass stores e back (flush, whole 64-byte sectors): 8 B read + 8/7 B written per element and step instead of 24.
 //     (Measured: 12 or 16 slots per bank are slower -- the extra multiply / subtract pairs cost more than the
 //     flushes they save; a flushing pass runs at 4.8 TB/s, a plain one at 5.7-6.0 TB/s of the 6.3 achievable.)
 //   * the column interchange (:626-637) never moves data: slot k of the permuted matrix carries a source
@@ -49,10 +49,10 @@
 #define QRX_TR 64           // rows per reflector tile of the pass
 #define QRX_PAD_ROWS 160   // read-ahead padding behind the last problem's matrix (a tile + a load group)
 #ifndef QRX_AUX_LOAD
-#define QRX_AUX_LOAD 0    // cache policy of the matrix stream (2 = non-temporal)
-#endif
+#define QRX_AUX_LOAD 0    // cache policy of the matrix stream: default.  Non-temporal loads (2) were measured: 1137 vs 836 ms
+#endif                    // per 512 x 4096x256 solve
 #ifndef QRX_AUX_STORE
-#define QRX_AUX_STORE 2   // the flush: non-temporal, the rewritten columns are not read again before the next step
+#define QRX_AUX_STORE 0   // the flush: default policy (non-temporal stores: 836 vs 828 ms)
 #endif
 #ifndef QRX_UF
 #define QRX_UF(flush) 16
