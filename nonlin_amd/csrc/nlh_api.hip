@@ -409,20 +409,24 @@ static void launch_dq_residual(nlh_handle *h, int nprob, int m, int n, const dou
 
 static void launch_dq_panel(nlh_handle *h, int nprob, int m, int n, const double *A, const double *b,
                             double gamma, const double *x, double *P, const LmState *st, int want,
-                            const double *f0_fused = nullptr)
+                            const double *f0_fused = nullptr, bool to_qrx = false)
 {
     Timed t(h, NLH_K_DQ_PANEL);
     // 32 columns per thread: A is re-read from L2 n/32 times (the kernel is L2->CU bound at 16) and the
     // register budget still leaves 5 waves per SIMD; measured 2.49 ms (16) / 1.97 (32) / 1.95 (48) per
-    // 256 x 4096 x 256 launch.  f0_fused != null: the epilogue writes the Jacobian column instead of the residual.
+    // 256 x 4096 x 256 launch.  f0_fused != null: the epilogue writes the Jacobian column instead of the residual;
+    // to_qrx: in the layout of the exact factorisation's working matrix (P is then that matrix).
     constexpr int JT = 32;
     dim3 grid((m + RB - 1) / RB, (n + JT - 1) / JT, nprob);
     size_t sh = sizeof(double) * (size_t)n;
+    const int tld = to_qrx ? qrx_ld(n) : 0, tcoff = to_qrx ? qrx_ld(n) - (n + 1) : 0;
+    const size_t tst = to_qrx ? qrx_matrix_stride(m, n) : 0;
     if (f0_fused)
-        hipLaunchKernelGGL((k_dq_panel<RB, JT, true>), grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, P, f0_fused, st, want);
+        hipLaunchKernelGGL((k_dq_panel<RB, JT, true>), grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, P, f0_fused, st, want,
+                           tld, tcoff, tst);
     else
         hipLaunchKernelGGL((k_dq_panel<RB, JT, false>), grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, P,
-                           (const double *)nullptr, st, want);
+                           (const double *)nullptr, st, want, 0, 0, (size_t)0);
 }
 
 static void launch_fd(nlh_handle *h, int nprob, int m, int n, const double *P, const double *f0,
@@ -572,7 +576,7 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
 // One pass over the factorisation + lmpar stages for every problem whose Jacobian is in
 // w.J (stage ST_HAVE_JAC or ST_NEED_QR) or whose factors are ready (inner-loop repeat).
 static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, int m, int n, LmWs &w,
-                              double *dx, const double *dfvec, int nact = -1)
+                              double *dx, const double *dfvec, int nact = -1, bool jac_in_qrx_layout = false)
 {
     const int ft = factor_threads(n);
     const size_t shl = sizeof(double) * (size_t)(6 * n + 72);
@@ -584,8 +588,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
             if ((rc = ensure(h, h->qxV, qrx_workspace_bytes(nprob, m, n)))) return rc;
             QrxTimer tm{h, [](void *c, int which, hipStream_t s) { qrx_time_begin((nlh_handle *)c, which, s); },
                         [](void *c, int which, hipStream_t s) { qrx_time_end((nlh_handle *)c, which, s); }};
-            qrx_factor(h->stream, nprob, m, n, w.J, w.P, dfvec, w.R, w.v, w.wa4, w.scratch, dx, w.st, o->factor,
-                       o->gtol, h->qxV.p, &tm);
+            qrx_factor(h->stream, nprob, m, n, jac_in_qrx_layout ? (const double *)nullptr : w.J, w.P, dfvec, w.R, w.v, w.wa4,
+                       w.scratch, dx, w.st, o->factor, o->gtol, h->qxV.p, &tm);
         }
         {
             Timed t(h, NLH_K_LMPAR);
@@ -745,7 +749,10 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     int nact = nprob;                                           // problems still iterating (from the previous round)
     for (int round = 0; round < max_rounds; ++round) {
         // outer-loop head for problems that need a Jacobian (:221): n perturbed evaluations + FD
-        if (o->fuse_fd) {
+        if (o->fuse_fd && o->factor_policy == NLH_FACTOR_EXACT) {
+            // the Jacobian is only ever read by the exact factorisation: written in its working layout, no re-layout pass
+            launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.P, w.st, ST_NEED_JAC, dfvec, true);
+        } else if (o->fuse_fd) {
             launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.J, w.st, ST_NEED_JAC, dfvec);
         } else {
             launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.P, w.st, ST_NEED_JAC);
@@ -753,7 +760,8 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         }
         hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_NEED_JAC,
                            o->factor_policy != NLH_FACTOR_AUTO ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
-        if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec, nact))) return rc;
+        if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec, nact,
+                                     o->fuse_fd && o->factor_policy == NLH_FACTOR_EXACT))) return rc;
         // trial residual (:297-299)
         launch_dq_residual(h, nprob, m, n, dA, db, gamma, w.v.wa2, w.wa4, w.part, w.st, ST_TRIAL_READY);
         hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_TRIAL_READY,

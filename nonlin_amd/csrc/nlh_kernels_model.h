@@ -128,7 +128,8 @@ template <int BS, int JT, bool FUSE>
 __global__ void __launch_bounds__(BS)
 k_dq_panel(int m, int n, const double *__restrict__ A, const double *__restrict__ b,
            double gamma, const double *__restrict__ x, double *__restrict__ P,
-           const double *__restrict__ f0, const LmState *__restrict__ st, int want_stage)
+           const double *__restrict__ f0, const LmState *__restrict__ st, int want_stage,
+           int tld, int tcoff, size_t tst)
 {
     extern __shared__ double smem[];
     const int p = blockIdx.z;
@@ -210,15 +211,20 @@ k_dq_panel(int m, int n, const double *__restrict__ A, const double *__restrict_
     }
     const double bi = b[(size_t)p * m + i];
     const double f0i = FUSE ? f0[(size_t)p * m + i] : 0.0;
-    double *Pp = P + (size_t)p * m * n + i;
+    // tld > 0 (fused form only): the Jacobian goes straight into the exact factorisation's row-blocked working matrix
+    // (nlh_qrx.hip, qrx_at: element (i, c) at ((i / 8) * tld + c) * 8 + i % 8, column j at c = tcoff + j) -- the eight
+    // lanes of a row block complete a 64-byte sector per column -- instead of a column-major J that would then be
+    // re-laid out.
+    double *Pp = tld ? P + (size_t)p * tst + ((size_t)(i >> 3) * tld + tcoff) * 8 + (i & 7) : P + (size_t)p * m * n + i;
+    const size_t cstride = tld ? (size_t)8 : (size_t)m;
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) {
         if (jj < jt) {
             const double u = acc[jj];
             const double r = (u + (gamma * u) * u) - bi;
             // written once, read once by the next kernel: non-temporal, so that it does not displace A (re-read n/JT times)
-            if (FUSE) __builtin_nontemporal_store((r - f0i) / fd_step(xs[j0 + jj]), Pp + (size_t)(j0 + jj) * m);
-            else __builtin_nontemporal_store(r, Pp + (size_t)(j0 + jj) * m);
+            if (FUSE) __builtin_nontemporal_store((r - f0i) / fd_step(xs[j0 + jj]), Pp + (size_t)(j0 + jj) * cstride);
+            else __builtin_nontemporal_store(r, Pp + (size_t)(j0 + jj) * cstride);
         }
     }
 }

@@ -17,12 +17,15 @@ struct QrxTimer {
 
 // Row stride of the row-major working matrix (n columns + the residual, padded to 64 bytes).
 int qrx_ld(int n);
+// Doubles between the working matrices of two consecutive problems.
+size_t qrx_matrix_stride(int m, int n);
 // Doubles the row-major working matrix T needs for nprob problems (incl. read-ahead padding).
 size_t qrx_matrix_doubles(int nprob, int m, int n);
 // Bytes of private workspace (reflector banks, pending multipliers, column map, norms, step records).
 size_t qrx_workspace_bytes(int nprob, int m, int n);
 
-// Factor every problem whose stage is ST_NEED_QR (st == nullptr: all).  J: column-major m x n per problem;
+// Factor every problem whose stage is ST_NEED_QR (st == nullptr: all).  J: column-major m x n per problem, or nullptr when
+// the caller has already written the Jacobian into T in the working layout (qrx_ld / qrx_matrix_stride; k_dq_panel does);
 // T: row-major scratch (qrx_matrix_doubles); outputs: R (n x n column-major, upper + diagonal),
 // v.ipvt / acnorm / qtf / rdiag, wa4 = Q^T f, and -- when st != nullptr -- the outer-loop head (lm_head) with
 // stage -> ST_QR_READY / ST_DONE.

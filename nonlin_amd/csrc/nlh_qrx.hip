@@ -80,6 +80,8 @@ static size_t qrx_vstride(int m)      // doubles between two slots of a reflecto
     return ((size_t)m + 7) & ~(size_t)7;
 }
 
+size_t qrx_matrix_stride(int m, int n) { return qrx_tstride(m, n); }
+
 size_t qrx_matrix_doubles(int nprob, int m, int n)
 {
     return (size_t)nprob * qrx_tstride(m, n) + (size_t)QRX_PAD_ROWS * qrx_ld(n);
@@ -625,7 +627,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     auto tb = [&](int which, hipStream_t s) { if (tm) tm->begin(tm->ctx, which, s); };
     auto te = [&](int which, hipStream_t s) { if (tm) tm->end(tm->ctx, which, s); };
     tb(2, stream);
-    {
+    if (J) {
         const size_t total = (size_t)((m + 7) >> 3) * n;
         const unsigned gx = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(k_qrx_transpose, dim3(gx, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, J, T, (const LmState *)st);
