@@ -589,7 +589,7 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
             QrxTimer tm{h, [](void *c, int which, hipStream_t s) { qrx_time_begin((nlh_handle *)c, which, s); },
                         [](void *c, int which, hipStream_t s) { qrx_time_end((nlh_handle *)c, which, s); }};
             qrx_factor(h->stream, nprob, m, n, jac_in_qrx_layout ? (const double *)nullptr : w.J, w.P, dfvec, w.R, w.v, w.wa4,
-                       w.scratch, dx, w.st, o->factor, o->gtol, h->qxV.p, &tm);
+                       w.scratch, dx, w.st, o->factor, o->gtol, h->qxV.p, &tm, nact);
         }
         {
             Timed t(h, NLH_K_LMPAR);

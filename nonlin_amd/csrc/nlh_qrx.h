@@ -28,7 +28,8 @@ size_t qrx_workspace_bytes(int nprob, int m, int n);
 // the caller has already written the Jacobian into T in the working layout (qrx_ld / qrx_matrix_stride; k_dq_panel does);
 // T: row-major scratch (qrx_matrix_doubles); outputs: R (n x n column-major, upper + diagonal),
 // v.ipvt / acnorm / qtf / rdiag, wa4 = Q^T f, and -- when st != nullptr -- the outer-loop head (lm_head) with
-// stage -> ST_QR_READY / ST_DONE.
+// stage -> ST_QR_READY / ST_DONE.  nact: how many of the nprob problems are expected to be at ST_NEED_QR (<= 0: all) --
+// only picks the kernel variant for nearly empty launches, never the result.
 void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, double *T, const double *fvec,
                 double *R, LmVecs v, double *wa4, double *scratch, const double *x, LmState *st, double factor,
-                double gtol, void *ws, const QrxTimer *tm);
+                double gtol, void *ws, const QrxTimer *tm, int nact);

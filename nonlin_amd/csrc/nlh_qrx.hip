@@ -309,6 +309,59 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     }
 }
 
+// The end of a trailing column's pass, given its dot product s with the reflector: multiplier (:654), row j becomes
+// final (R(j,k) / qtf(j), :655 at i = j), norm down-date (:656-661) with the rare recomputation.
+template <int NP, bool FLUSH>
+__device__ __forceinline__ void
+qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int cur, size_t vst, double s, double rowj, bool refl,
+              double ajj, const double (&tq)[NP > 0 ? NP : 1], const double *__restrict__ Tp, const double *__restrict__ vc,
+              const double *__restrict__ vo, double *__restrict__ tpall, int32_t *__restrict__ srcp, int32_t *__restrict__ slotp,
+              double *__restrict__ rdall, double *__restrict__ waall, double *__restrict__ Rall, double *__restrict__ qtfall)
+{
+    constexpr int NPI = NP < QRX_C ? NP : 0;
+    const int ldp = n + 1, jb = j & ~7;
+    double *tpc = tpall + ((size_t)p * 2 + cur) * QRX_C * ldp;
+    auto pending = [&](double a, const auto &vr) {
+        double e = a;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) e = e - tq[q] * vr[q];
+        return e;
+    };
+    double *tpn = FLUSH ? tpall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * ldp : tpc + (size_t)NPI * ldp;
+    double *rdiag = rdall + (size_t)p * n, *wa = waall + (size_t)p * n;
+    const double temp = refl ? s / ajj : 0.0;                           // :654 (residual: w + v*(-s/a) == w - (s/a)*v bit for bit)
+    tpn[k] = temp;
+    if (FLUSH) {                                                        // the column now sits at its slot's own position
+        srcp[k] = coff + k;
+        slotp[coff + k] = k;
+        if (col != coff + k) slotp[col] = -1;
+    }
+    const double rjk = refl ? rowj - temp * ajj : rowj;                 // :655 at i = j: row j is final
+    if (k == n) { qtfall[(size_t)p * n + j] = rjk; return; }
+    Rall[(size_t)p * n * n + (size_t)k * n + j] = rjk;
+    if (!refl) return;
+    double rk = rdiag[k];
+    if (rk != 0.0) {                                                    // :656-661
+        const double t2 = rjk / rk;
+        rk = rk * sqrt(fmax(0.0, 1.0 - t2 * t2));
+        const double q = rk / wa[k];
+        if (!(5.0e-2 * (q * q) > NLH_EPS)) {
+            rk = norm2_flang_serial([&](int i2) {
+                const int row = j + 1 + i2, rel = row - jb;
+                double vr[NP + 1];
+#pragma unroll
+                for (int q2 = 0; q2 < NP; ++q2) vr[q2] = vc[(size_t)q2 * vst + rel];
+                // a flush has just rewritten the column (pending updates applied) at its slot's own position
+                const double e = FLUSH ? Tp[qrx_at(row, coff + k, ld)] : pending(Tp[qrx_at(row, col, ld)], vr);
+                const double vn = FLUSH ? vo[rel] : vc[(size_t)NPI * vst + rel];
+                return e - temp * vn;
+            }, m - j - 1);
+            wa[k] = rk;
+        }
+        rdiag[k] = rk;
+    }
+}
+
 // Step j, part 2: every trailing column k = j+1 .. n (n = the residual): pending updates, dot product with
 // the reflector in ascending row order (:652-653), multiplier (:654), row j becomes final (R(j,k) / qtf(j)),
 // norm down-date (:656-661).
@@ -317,7 +370,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
 // flight ahead of the arithmetic.  The reflector entries of a row (wave-uniform) come from an LDS tile of 64 rows that
 // the wave stages for itself one tile ahead (coalesced slot vectors in, broadcast ds_reads out).
 template <int NP, bool FLUSH>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (FLUSH && NP >= 4) ? 2 : 4)))
 k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
            double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
            int32_t *__restrict__ srcall, int32_t *__restrict__ slotall, double *__restrict__ rdall,
@@ -361,7 +414,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     double tq[NP > 0 ? NP : 1];
 #pragma unroll
     for (int q = 0; q < NP; ++q) tq[q] = tpc[(size_t)q * ldp + k];
-    auto pending = [&](double a, const auto &vr) {
+    auto pending = [&](double a, const auto &vr) __attribute__((always_inline)) {
         double e = a;
 #pragma unroll
         for (int q = 0; q < NP; ++q) e = e - tq[q] * vr[q];
@@ -378,13 +431,13 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     // reflector tile t: lane l fetches the entries of rel row t*TR + l (one coalesced 512-byte read per slot); the staged
     // LDS row is [pending v_0 .. v_NP-1, new v]
     double sv[NP + 1];
-    auto vfetch = [&](int t) {
+    auto vfetch = [&](int t) __attribute__((always_inline)) {
         const int row = t * TR + lane;
 #pragma unroll
         for (int q = 0; q < NP; ++q) sv[q] = vc[(size_t)q * vst + row];
         sv[NP] = FLUSH ? vo[row] : vc[(size_t)NPI * vst + row];
     };
-    auto vstore = [&](int buf) {
+    auto vstore = [&](int buf) __attribute__((always_inline)) {
         double *d = &vt[buf][lane * LP];
 #pragma unroll
         for (int q = 0; q <= NP; ++q) d[q] = sv[q];
@@ -400,7 +453,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     const unsigned ko = act ? (unsigned)(coff + k) * 64u : 0x80000000u;  // where a flush puts the column (idle lanes: nowhere)
     const unsigned ldb = (unsigned)ld * 64u;                            // bytes per row block
     double a0[U], a1[U];
-    auto load = [&](double (&buf)[U], int rbase) {                      // rbase: rel row, a multiple of 8
+    auto load = [&](double (&buf)[U], int rbase) __attribute__((always_inline)) {                      // rbase: rel row, a multiple of 8
 #pragma unroll
         for (int b4 = 0; b4 < U / 8; ++b4) {
             const unsigned boff = (unsigned)((rbase >> 3) + b4) * ldb;
@@ -413,10 +466,10 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
         }
     };
     double s = 0.0;
-    auto compute = [&](auto guarded, const double (&buf)[U], int rbase, const double *tile, int g) {
+    auto compute = [&](auto guarded, const double (&buf)[U], int rbase, const double *tile, int g) __attribute__((always_inline)) {
         constexpr bool GD = decltype(guarded)::value;
         double va[NP + 1], vb[NP + 1], est[8];
-        auto ldsrow = [&](double (&dst)[NP + 1], int u) {
+        auto ldsrow = [&](double (&dst)[NP + 1], int u) __attribute__((always_inline)) {
             const double *vr = tile + (g * U + u) * LP;
 #pragma unroll
             for (int q = 0; q <= NP; ++q) dst[q] = vr[q];
@@ -482,65 +535,250 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     load(a0, 0);
     __syncthreads();
     std::false_type plain_t; std::true_type guard_t;
-    for (int t = 0; t < ntile; ++t) {
+    // A tile whose rows are all live runs unguarded and fully unrolled; the tile of row j (unless j is a multiple of 8) and the last, partial one run guarded.  The three are separate loops, not branches of one loop body: a
+    // merge of the two forms at the loop's back edge makes the compiler copy the registers of the load group just issued
+    // for the next tile, i.e. wait for it -- one full memory latency per 64 rows.  For the same reason the next tile's
+    // reflector rows go to LDS BEFORE the tile's last load group is issued (the memory counter retires in order).
+    auto tile_plain = [&](int t) __attribute__((always_inline)) {
         const double *tile = vt[t & 1];
         const int rb = t * TR;
         vfetch(t + 1);
-        if ((t > 0 || r0 == 0) && rb + TR <= mrel) {                     // every row of the tile is live
 #pragma unroll
-            for (int g = 0; g < TR / U; g += 2) {
-                load(a1, rb + (g + 1) * U);
-                compute(plain_t, a0, rb + g * U, tile, g);
-                load(a0, rb + (g + 2) * U);
-                compute(plain_t, a1, rb + (g + 1) * U, tile, g + 1);
-            }
-        } else {
+        for (int g = 0; g < TR / U; g += 2) {
+            load(a1, rb + (g + 1) * U);
+            compute(plain_t, a0, rb + g * U, tile, g);
+            if (g + 2 >= TR / U) vstore((t + 1) & 1);
+            load(a0, rb + (g + 2) * U);
+            compute(plain_t, a1, rb + (g + 1) * U, tile, g + 1);
+        }
+        __syncthreads();
+    };
+    auto tile_guard = [&](int t) __attribute__((always_inline)) {
+        const double *tile = vt[t & 1];
+        const int rb = t * TR;
+        vfetch(t + 1);
 #pragma unroll 1
-            for (int g = 0; g < TR / U; g += 2) {
-                load(a1, rb + (g + 1) * U);
-                compute(guard_t, a0, rb + g * U, tile, g);
-                load(a0, rb + (g + 2) * U);
-                compute(guard_t, a1, rb + (g + 1) * U, tile, g + 1);
-            }
+        for (int g = 0; g < TR / U; g += 2) {
+            load(a1, rb + (g + 1) * U);
+            compute(guard_t, a0, rb + g * U, tile, g);
+            load(a0, rb + (g + 2) * U);
+            compute(guard_t, a1, rb + (g + 1) * U, tile, g + 1);
         }
         vstore((t + 1) & 1);
         __syncthreads();
-    }
+    };
+    const int tfull = mrel / TR;                                        // tiles 0 .. tfull-1 end at or before the last row
+    int t = 0;
+    if (r0 != 0) { tile_guard(0); t = 1; }
+#pragma unroll 1
+    for (; t < tfull; ++t) tile_plain(t);
+#pragma unroll 1
+    for (; t < ntile; ++t) tile_guard(t);
 
     if (!act) return;
-    double *tpn = FLUSH ? tpall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * ldp : tpc + (size_t)NPI * ldp;
-    double *rdiag = rdall + (size_t)p * n, *wa = waall + (size_t)p * n;
-    const double temp = refl ? s / ajj : 0.0;                           // :654 (residual: w + v*(-s/a) == w - (s/a)*v bit for bit)
-    tpn[k] = temp;
-    if (FLUSH) {                                                        // the column now sits at its slot's own position
-        srcp[k] = coff + k;
-        slotp[coff + k] = k;
-        if (col != coff + k) slotp[col] = -1;
-    }
-    const double rjk = refl ? rowj - temp * ajj : rowj;                 // :655 at i = j: row j is final
-    if (k == n) { qtfall[(size_t)p * n + j] = rjk; return; }
-    Rall[(size_t)p * n * n + (size_t)k * n + j] = rjk;
-    if (!refl) return;
-    double rk = rdiag[k];
-    if (rk != 0.0) {                                                    // :656-661
-        const double t2 = rjk / rk;
-        rk = rk * sqrt(fmax(0.0, 1.0 - t2 * t2));
-        const double q = rk / wa[k];
-        if (!(5.0e-2 * (q * q) > NLH_EPS)) {
-            rk = norm2_flang_serial([&](int i2) {
-                const int row = j + 1 + i2, rel = row - jb;
-                double vr[NP + 1];
+    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, refl, ajj, tq, Tp, vc, vo, tpall, srcp, slotp,
+                             rdall, waall, Rall, qtfall);
+}
+
+// The same pass for launches too small to fill the chip (a handful of problems still iterating, one problem alone, the
+// last narrow steps): there a lone wave per 64 columns is bound by its own instruction stream -- (2 NP + 2) fp64
+// operations per row and lane, 80 us (NP = 0) to 225 us (flush) per 4096 rows -- while three SIMDs of its CU idle.
+// ROW-PARALLEL form: a workgroup of W waves per (problem, window); waves 1 .. W-1 (producers) walk disjoint
+// 16-row groups, apply the pending updates, multiply by the reflector entry and hand the PRODUCTS over through LDS;
+// wave 0 (the adder) does nothing but the ordered sum s = s + w_i (:652-653), rows ascending -- the only part of the step
+// that is serial by definition (16 cycles per dependent add).  One barrier per round of (W-1) x 16 rows; the adder
+// works one round behind the producers.  Same arithmetic on the same operands in the same order: bit-identical to
+// k_qrx_pass (rows outside the live range contribute +0.0, and a sum that starts at +0.0 can never become -0.0).
+#ifndef QRX_RP6_MAX_WG
+#define QRX_RP6_MAX_WG 256              // ... and of at most this many, with six waves (five producers) instead of four
+#endif
+#ifndef QRX_RP_MAX_WG
+#define QRX_RP_MAX_WG 1024              // launches of at most this many (problem, window) pairs take the row-parallel pass
+#endif
+#define QRX_RP_G 16                     // rows per producer and round (two 8-row blocks)
+#define QRX_RP_D 4                      // rounds per producer tile = row groups in flight per producer
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the matrix loads in flight for the
+// coming rounds (s_waitcnt vmcnt(0)) -- a full memory latency per round.
+__device__ __forceinline__ void qrx_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NP, bool FLUSH, int W>
+__global__ void __launch_bounds__(64 * W)
+k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
+              double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
+              int32_t *__restrict__ srcall, int32_t *__restrict__ slotall, double *__restrict__ rdall,
+              double *__restrict__ waall, const QrxStep *__restrict__ stepall, double *__restrict__ Rall,
+              double *__restrict__ qtfall, const LmState *__restrict__ st)
+{
+    constexpr int NPR = W - 1, G = QRX_RP_G, D = QRX_RP_D, RR = NPR * G, LP = QRX_C;
+    constexpr int NPI = NP < QRX_C ? NP : 0;
+    __shared__ double vt[NPR][2][D * G * LP];
+    __shared__ __attribute__((aligned(16))) double pb[2][RR / 2][64][2];
+    const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
+    const int pl = grp * 8 + (r_ & 7), win = r_ >> 3;
+    if (pl >= nprob) return;
+    const int p = p0 + pl;
+    if (st && st[p].stage != ST_NEED_QR) return;
+    const int lane = threadIdx.x & 63, ldp = n + 1;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block offsets stay scalar
+    const bool adder = (wv == 0);
+    const int pw = adder ? 0 : wv - 1;                                   // producer index
+    const QrxStep step = stepall[p];
+    const bool refl = step.ajnorm != 0.0;
+    const double ajj = step.ajj;
+    int32_t *srcp = srcall + (size_t)p * ldp;
+    int32_t *slotp = slotall + (size_t)p * ld;
+    double *tpc = tpall + ((size_t)p * 2 + cur) * QRX_C * ldp;
+    double *Tp = T + (size_t)p * tst;
+    const int jb = j & ~7, r0 = j & 7, mrel = m - jb;
+    const double *vc = Vall + ((size_t)p * 2 + cur) * QRX_C * vst + jb;
+    const double *vo = Vall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst + jb;
+    const int col = ld - 64 * (win + 1) + lane;
+    const int kslot = (col >= coff + lo) ? slotp[col] : -1;
+    const bool act = kslot > j;
+    const int k = act ? kslot : n;
+    double tq[NP > 0 ? NP : 1];
 #pragma unroll
-                for (int q2 = 0; q2 < NP; ++q2) vr[q2] = vc[(size_t)q2 * vst + rel];
-                // a flush has just rewritten the column (pending updates applied) at its slot's own position
-                const double e = FLUSH ? Tp[qrx_at(row, coff + k, ld)] : pending(Tp[qrx_at(row, col, ld)], vr);
-                const double vn = FLUSH ? vo[rel] : vc[(size_t)NPI * vst + rel];
-                return e - temp * vn;
-            }, m - j - 1);
-            wa[k] = rk;
-        }
-        rdiag[k] = rk;
+    for (int q = 0; q < NP; ++q) tq[q] = tpc[(size_t)q * ldp + k];
+    double rowj = 0.0;
+    if (adder) {                                                        // row j with its pending updates (becomes final in the tail)
+        double e = Tp[qrx_at(j, col, ld)];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) e = e - tq[q] * vc[(size_t)q * vst + r0];
+        rowj = e;
     }
+    const int nblk = (mrel + 7) >> 3;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(Tp + (size_t)(jb >> 3) * ld * 8, 0, (int)((size_t)nblk * ld * 64), 0x00020000);
+    const unsigned so = act ? (unsigned)col * 64u : 0x80000000u;
+    const unsigned ko = act ? (unsigned)(coff + k) * 64u : 0x80000000u;
+    const unsigned ldb = (unsigned)ld * 64u;
+    const int nround = (mrel + RR - 1) / RR;                            // producers: rounds 0 .. nround-1, adder: 1 .. nround
+    const int ntile = (nround + 1 + D - 1) / D;
+
+    // producer side -------------------------------------------------------------------------------------------------
+    // reflector tile kt of producer pw: the D row groups it handles in rounds kt*D .. kt*D + D-1; lane l fetches the
+    // entries of group l / 16, row l % 16 (clamped to the last row: entries past it are never used)
+    double sv[NP + 1];
+    auto vfetch = [&](int kt) __attribute__((always_inline)) {
+        const int row = min((kt * D + (lane >> 4)) * RR + pw * G + (lane & 15), mrel - 1);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) sv[q] = vc[(size_t)q * vst + row];
+        sv[NP] = FLUSH ? vo[row] : vc[(size_t)NPI * vst + row];
+    };
+    auto vstore = [&](int buf) __attribute__((always_inline)) {
+        double *d = &vt[pw][buf][lane * LP];
+#pragma unroll
+        for (int q = 0; q <= NP; ++q) d[q] = sv[q];
+    };
+    double a[D][G];
+    auto load = [&](double (&buf)[G], int t) __attribute__((always_inline)) {                          // the producer's group of round t
+        const int rbase = t * RR + pw * G;
+#pragma unroll
+        for (int b4 = 0; b4 < G / 8; ++b4) {
+            const unsigned boff = (unsigned)((rbase >> 3) + b4) * ldb;
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const qrx_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + 16u * q2, boff, QRX_AUX_LOAD);
+                buf[b4 * 8 + 2 * q2] = __hiloint2double((int)w.y, (int)w.x);
+                buf[b4 * 8 + 2 * q2 + 1] = __hiloint2double((int)w.w, (int)w.z);
+            }
+        }
+    };
+    auto produce = [&](const double (&buf)[G], int t, const double *tile, int i) __attribute__((always_inline)) {
+        const int rbase = t * RR + pw * G;
+        // (Measured and dropped: four rows at a time with the chains pinned in step and the LDS reads a group ahead --
+        // no faster for a lone problem, 3 % slower for a full batch: the producers are not the bottleneck.)
+        double est[8];
+#pragma unroll
+        for (int u = 0; u < G; u += 2) {
+            const int row = rbase + u;
+            double v0[NP + 1], v1[NP + 1];
+#pragma unroll
+            for (int q = 0; q <= NP; ++q) { v0[q] = tile[(i * G + u) * LP + q]; v1[q] = tile[(i * G + u + 1) * LP + q]; }
+            double e0 = buf[u], e1 = buf[u + 1];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const double p0_ = tq[q] * v0[q], p1_ = tq[q] * v1[q];
+                e0 = e0 - p0_;
+                e1 = e1 - p1_;
+            }
+            const bool ok0 = row >= r0 && row < mrel, ok1 = row + 1 >= r0 && row + 1 < mrel;
+            double2 ww;
+            ww.x = ok0 ? v0[NP] * e0 : 0.0;
+            ww.y = ok1 ? v1[NP] * e1 : 0.0;
+            *reinterpret_cast<double2 *>(&pb[t & 1][(pw * G + u) >> 1][lane][0]) = ww;
+            if (FLUSH) {
+                est[u & 7] = e0;
+                est[(u & 7) + 1] = e1;
+                if ((u & 7) == 6) {
+                    const int rb8 = rbase + (u & ~7);
+                    const unsigned boff = (unsigned)(rb8 >> 3) * ldb;
+                    if (rb8 >= r0 && rb8 + 8 <= mrel) {                  // uniform: a whole 64-byte sector per lane
+#pragma unroll
+                        for (int q2 = 0; q2 < 4; ++q2) {
+                            qrx_u32x4 w;
+                            w.x = (unsigned)__double2loint(est[2 * q2]); w.y = (unsigned)__double2hiint(est[2 * q2]);
+                            w.z = (unsigned)__double2loint(est[2 * q2 + 1]); w.w = (unsigned)__double2hiint(est[2 * q2 + 1]);
+                            __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, ko + 16u * q2, boff, QRX_AUX_STORE);
+                        }
+                    } else {                                            // the block of row j, the last block: row by row
+#pragma unroll
+                        for (int q2 = 0; q2 < 8; ++q2) {
+                            qrx_u32x2 w;
+                            w.x = (unsigned)__double2loint(est[q2]); w.y = (unsigned)__double2hiint(est[q2]);
+                            if (rb8 + q2 >= r0 && rb8 + q2 < mrel)
+                                __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, ko + 8u * q2, boff, QRX_AUX_STORE);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // adder side ----------------------------------------------------------------------------------------------------
+    double s = 0.0;
+    auto consume = [&](int half) __attribute__((always_inline)) {
+        double2 ww[RR / 2];
+#pragma unroll
+        for (int pr = 0; pr < RR / 2; ++pr) ww[pr] = *reinterpret_cast<const double2 *>(&pb[half][pr][lane][0]);
+#pragma unroll
+        for (int pr = 0; pr < RR / 2; ++pr) {
+            s = s + ww[pr].x;                                           // :653, rows ascending
+            s = s + ww[pr].y;
+        }
+    };
+
+    // The two roles run separate loops with the same number of barriers (s_barrier counts arrivals, not program
+    // counters): a shared loop body would merge the roles' register states at every round and make the compiler copy --
+    // hence wait for -- the load groups in flight.  Producers run every round unguarded: rounds past the last row yield +0.0.
+    if (adder) {
+        qrx_lds_barrier();
+#pragma unroll 1
+        for (int t = 0; t < ntile * D; ++t) {
+            if (t >= 1 && t <= nround) consume((t - 1) & 1);
+            qrx_lds_barrier();
+        }
+    } else {
+        vfetch(0);
+        vstore(0);
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) load(a[i], i);
+        qrx_lds_barrier();
+#pragma unroll 1
+        for (int kt = 0; kt < ntile; ++kt) {
+            vfetch(kt + 1);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const int t = kt * D + i;
+                load(a[(i + D - 1) % D], t + D - 1);
+                produce(a[i], t, vt[pw][kt & 1], i);
+                if (i == D - 1) vstore((kt + 1) & 1);
+                qrx_lds_barrier();
+            }
+        }
+    }
+    if (!adder || !act) return;
+    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, refl, ajj, tq, Tp, vc, vo, tpall, srcp, slotp,
+                             rdall, waall, Rall, qtfall);
 }
 
 // After the last step: wa4 = Q^T f (:241-253; rows < n are the qtf entries, the rest carries the pending
@@ -592,33 +830,45 @@ k_qrx_finish(int m, int n, int ld, int coff, size_t tst, size_t vst, int cur, in
 }
 
 template <int NP, bool FLUSH>
-static void launch_pass(hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
+static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
                         double *R, double *qtf, const LmState *st)
 {
     // One column per lane: measured against two and four columns per lane (fewer waves, the LDS row shared by more
     // elements) on 512 x 4096x256, 1024 x 2048x128 and a single problem, more waves won every time.
     const int nwin = (n + 1 - lo + 63) / 64;                            // live physical columns coff + lo .. coff + n
     const dim3 grid((unsigned)(((nprob + 7) / 8) * 8 * nwin));
-    hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH>), grid, dim3(64), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
-                       T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+    if (rp == 6)
+        hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 6>), grid, dim3(64 * 6), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+    else if (rp == 4)
+        hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 4>), grid, dim3(64 * 4), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+    else
+        hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH>), grid, dim3(64), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
 }
 
-// np = 0 .. QRX_C - 2: plain pass with np pending updates; np = QRX_C - 1: the flushing pass.
+// A pass with np pending updates; flushing ones exist for np = 1, 3 and QRX_C - 1 (flush periods 2, 4 and QRX_C).
+static constexpr bool qrx_can_flush(int np) { return np == 1 || np == 3 || np == QRX_C - 1; }
+
 template <int NP>
-static void dispatch_pass(int np, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst,
+static void dispatch_pass(int np, bool flush, int rp, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst,
                           int j, int cur, double *T, const QrxWs &w, double *R, double *qtf, const LmState *st)
 {
-    if constexpr (NP == QRX_C - 1) {
-        launch_pass<NP, true>(stream, p0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
-    } else {
-        if (np == NP) launch_pass<NP, false>(stream, p0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
-        else dispatch_pass<NP + 1>(np, stream, p0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
+    if (np == NP) {
+        if (flush) {
+            if constexpr (qrx_can_flush(NP)) launch_pass<NP, true>(rp, stream, p0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
+        } else {
+            if constexpr (NP < QRX_C - 1) launch_pass<NP, false>(rp, stream, p0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
+        }
+    } else if constexpr (NP < QRX_C - 1) {
+        dispatch_pass<NP + 1>(np, flush, rp, stream, p0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, qtf, st);
     }
 }
 
 void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, double *T, const double *fvec,
                 double *R, LmVecs v, double *wa4, double *scratch, const double *x, LmState *st, double factor,
-                double gtol, void *ws, const QrxTimer *tm)
+                double gtol, void *ws, const QrxTimer *tm, int nact)
 {
     QrxWs w;
     qrx_carve(ws, nprob, m, n, &w);
@@ -638,15 +888,25 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     // events keeping the passes from overlapping each other -- 1035 ms instead of 999 ms per 512 x 4096x256 solve; the
     // cross-stream event waits cost more than the pivot latency they hide.  Sub-batches on host threads, which need no
     // cross-stream ordering, do hide it: nlh_api.hip, lm_sub_batches.)
+    static const int forced_period = [] { const char *e = getenv("NLH_QRX_PERIOD"); return e ? atoi(e) : 0; }();
+    const int period = forced_period ? forced_period : QRX_C;
+    static const long rp_env = [] { const char *e = getenv("NLH_QRX_RP"); return e ? atol(e) : -1L; }();
+    const long rp_max = rp_env >= 0 ? rp_env : QRX_RP_MAX_WG;
+    static const long rp6_env = [] { const char *e = getenv("NLH_QRX_RP6"); return e ? atol(e) : -1L; }();
+    const long rp6_max = std::min(rp_max, rp6_env >= 0 ? rp6_env : (long)QRX_RP6_MAX_WG);
+    if (nact <= 0 || nact > nprob) nact = nprob;
     int cur = 0, np = 0, lo = 1;             // lo: first slot position that can still hold live data (step 0 moves physically)
     for (int j = 0; j < n; ++j) {
-        const bool flush = (np == QRX_C - 1);
+        const bool flush = qrx_can_flush(np) && np >= period - 1;
+        const int nwin = (n + 1 - lo + 63) / 64;
+        const long nwg = (long)nact * nwin;
+        const int rp = nwg <= rp6_max ? 6 : nwg <= rp_max ? 4 : 0;        // waves per workgroup of the row-parallel pass, 0: one wave
         tb(0, stream);
         hipLaunchKernelGGL(k_qrx_pivot, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
                            T, w, R, v, (const LmState *)st);
         te(0, stream);
         tb(1, stream);
-        dispatch_pass<0>(np, stream, 0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, v.qtf, st);
+        dispatch_pass<0>(np, flush, rp, stream, 0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, v.qtf, st);
         te(1, stream);
         if (flush) { cur ^= 1; np = 1; lo = j + 1; } else { np += 1; }
     }
