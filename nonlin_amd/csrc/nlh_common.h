@@ -364,6 +364,129 @@ __device__ double norm2_flang_block_wide(Get get, int len, double *cd, int cap, 
     return r;
 }
 
+// The same NORM2 with the serial recurrence spread over the LANES of one wave.  A chunk is 64 runs of EL consecutive
+// elements; run l belongs to lane l of wave 0, which holds its EL terms d_i in registers.  The running sum travels
+// down the lanes: at step l every lane takes its lower neighbour's value (one DPP wave shift) and adds its own EL
+// terms, a straight-line chain of dependent adds with register operands -- lane l's result is the true partial sum
+// after run l, the other lanes' results at that step are never used.  Measured on gfx950 a dependent fp64 add with
+// register operands issues every ~2 ns; a taken branch costs ~13 ns and an LDS round trip ~100 ns, which is what the
+// one-thread forms above spend most of their time on (7.6 ns per element).  A run that contains a new maximum
+// (c_i != 1, flagged by the threads that prepared it) takes the general s <- s*c + d form for that step only.
+// Bit-identical to norm2_flang_block.  BSZ = blockDim.x (64 .. 1024, a power of two), EL a multiple of BSZ / 64 (and of 2);
+// cd: 2 * (64 * EL + 128) doubles of LDS, 16-byte aligned; aux: 40 doubles + BSZ ints.
+__device__ __forceinline__ double nlh_wave_shr1(double t)
+{
+    int lo = __double2loint(t), hi = __double2hiint(t);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);      // wave_shr:1 (lane 0 keeps its value)
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int EL, int BSZ, typename Get>
+__device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *aux)
+{
+    constexpr int CAP = 64 * EL, PADCAP = CAP + 128, E = CAP / BSZ, TPR = EL / E;   // E elements per thread, TPR threads per run
+    static_assert(CAP % BSZ == 0 && EL % E == 0 && E % 2 == 0, "chunk must split evenly");
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int nw = BSZ / 64;
+    double *cs = cd, *dsv = cd + PADCAP, *wmax = aux, *carry = aux + 32;
+    int *tflags = reinterpret_cast<int *>(aux + 40);
+    __syncthreads();
+    if (tid == 0) { carry[0] = 0.0; carry[1] = 0.0; }
+    for (int base = 0; base < len; base += CAP) {
+        const int cl = min(CAP, len - base);
+        const int i0 = tid * E;
+        double a[E], lm = 0.0;
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            a[u] = (i0 + u < cl) ? fabs(get(base + i0 + u)) : 0.0;
+            lm = fmax(lm, a[u]);
+        }
+        double sc = lm;                                              // inclusive prefix maximum over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(sc, off, 64);
+            if (lane >= off) sc = fmax(sc, o);
+        }
+        double ex = __shfl_up(sc, 1, 64);
+        if (lane == 0) ex = 0.0;
+        __syncthreads();                                             // carry of the previous chunk is final
+        if (lane == 63) wmax[wid] = sc;
+        __syncthreads();
+        const double mx_in = carry[0];
+        double prev = fmax(mx_in, ex);
+        for (int w = 0; w < wid; ++w) prev = fmax(prev, wmax[w]);
+        bool plain = true;
+        // element i of the chunk lives at i + 2 * (i / EL): two doubles of padding behind every run, so that the 16-byte
+        // reads of a run's owner fall on other banks than its neighbours'
+        double2 *cdst = reinterpret_cast<double2 *>(cs + i0 + 2 * (i0 / EL));
+        double2 *ddst = reinterpret_cast<double2 *>(dsv + i0 + 2 * (i0 / EL));
+#pragma unroll
+        for (int u = 0; u < E; u += 2) {
+            double cc[2], dd[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double c = 1.0, d = 0.0;
+                const double av = a[u + h];
+                if (prev == 0.0) {
+                    // mx was zero: element becomes the maximum, s untouched
+                } else if (av > prev) {
+                    const double t = prev / av, tsq = t * t;
+                    c = tsq; d = tsq;
+                } else if (av != 0.0) {
+                    const double t = av / prev;
+                    d = t * t;
+                }
+                plain = plain && (c == 1.0);
+                cc[h] = c; dd[h] = d;
+                prev = fmax(prev, av);
+            }
+            cdst[u >> 1] = make_double2(cc[0], cc[1]);
+            ddst[u >> 1] = make_double2(dd[0], dd[1]);
+        }
+        tflags[tid] = plain ? 1 : 0;
+        __syncthreads();
+        if (wid == 0) {
+            const int nl = (cl + EL - 1) / EL;                       // runs in use
+            double d[EL];
+            const double2 *mine = reinterpret_cast<const double2 *>(dsv + lane * (EL + 2));
+#pragma unroll
+            for (int u = 0; u < EL / 2; ++u) { const double2 v2 = mine[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
+            int pl = 1;
+#pragma unroll
+            for (int k = 0; k < TPR; ++k) pl &= tflags[lane * TPR + k];
+            const unsigned long long mask = __ballot(pl != 0);
+            double t = carry[1];
+#pragma unroll 1
+            for (int l = 0; l < nl; ++l) {
+                if (l > 0) t = nlh_wave_shr1(t);
+                if ((mask >> l) & 1ull) {
+#pragma unroll
+                    for (int u = 0; u < EL; ++u) t = t + d[u];
+                } else {
+                    const double *cm = cs + lane * (EL + 2), *dm = dsv + lane * (EL + 2);   // (d[] stays in registers: no dynamic index)
+#pragma unroll 4
+                    for (int u = 0; u < EL; ++u) {
+                        const double c = cm[u];
+                        if (c != 1.0) t = t * c;
+                        t = t + dm[u];
+                    }
+                }
+            }
+            const int lo = __builtin_amdgcn_readlane(__double2loint(t), nl - 1);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(t), nl - 1);
+            double mx = mx_in;
+#pragma unroll
+            for (int w = 0; w < nw; ++w) mx = fmax(mx, wmax[w]);
+            if (lane == 0) { carry[1] = __hiloint2double(hi, lo); carry[0] = mx; }
+        }
+    }
+    __syncthreads();
+    const double r = carry[0] * sqrt(1.0 + carry[1]);
+    __syncthreads();
+    return r;
+}
+
 // Same algorithm, one thread, for short vectors or per-column use.
 template <typename Get>
 __device__ __forceinline__ double norm2_flang_serial(Get get, int len)

@@ -57,7 +57,7 @@
 #ifndef QRX_UF
 #define QRX_UF(flush) 16
 #endif
-#define QRX_NE 8           // NORM2 chunk: elements per thread
+#define QRX_NL 64          // NORM2: elements per lane of the serial phase (chunks of 4096)
 
 typedef unsigned int qrx_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int qrx_u32x4 __attribute__((ext_vector_type(4)));
@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(256)
 k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
 {
-    __shared__ __attribute__((aligned(16))) double cd[2 * QRX_NE * 256 + 4 * QRX_NE];
-    __shared__ __attribute__((aligned(16))) double aux[40 + 128 + 4];
+    __shared__ __attribute__((aligned(16))) double cd[2 * (64 * QRX_NL + 128)];
+    __shared__ __attribute__((aligned(16))) double aux[40 + 128];
     __shared__ double red[64];
     const int p = p0 + blockIdx.x;
     if (st && st[p].stage != ST_NEED_QR) return;
@@ -219,33 +219,65 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     double *tpc = w.tp + ((size_t)p * 2 + cur) * QRX_C * ldp;
     double *R = Rall + (size_t)p * n * n;
 
-    double bv = 0.0;
-    int bk = 0x7fffffff;
-    for (int k = j + tid; k < n; k += BS) {
-        const double d = rdiag[k];
-        if (bk == 0x7fffffff || d > bv) { bv = d; bk = k; }
-    }
-    const int kmax = block_argmax_first(bv, bk, red, redi);
-    const int srck = src[kmax];
+    // Everything the step needs that does not depend on the pivot is fetched up front, alongside the norms the pivot
+    // search looks at: with at most BS candidate columns each thread also brings its candidate's source column, output
+    // index and pending multipliers, and the winner publishes them through LDS -- the gather below then starts one
+    // memory latency after the kernel does, instead of four dependent ones (norms -> src[kmax] -> ... ).
+    const bool onecand = (n - j <= BS);
     int32_t *slotof = w.slotof + (size_t)p * ld;
+    double bv = 0.0, my_tk[QRX_C - 1];
+    int bk = 0x7fffffff, my_src = 0, my_ipvt = 0;
+    if (onecand) {
+        const int k = j + tid;
+        if (k < n) {
+            bv = rdiag[k]; bk = k;
+            my_src = src[k]; my_ipvt = ipvt[k];
+#pragma unroll
+            for (int q = 0; q < QRX_C - 1; ++q) my_tk[q] = (q < np) ? tpc[(size_t)q * ldp + k] : 0.0;
+        }
+    } else {
+        for (int k = j + tid; k < n; k += BS) {
+            const double d = rdiag[k];
+            if (bk == 0x7fffffff || d > bv) { bv = d; bk = k; }
+        }
+    }
+    // slot j's own entries (tid 0 does the interchange bookkeeping)
+    double rd_j = 0.0, wa_j = 0.0;
+    int src_j = 0, ipvt_j = 0, src_0 = 0;
+    if (tid == 0) { rd_j = rdiag[j]; wa_j = wa[j]; src_j = src[j]; ipvt_j = ipvt[j]; src_0 = src[0]; }
+    const int kmax = block_argmax_first(bv, bk, red, redi);
+    double *pub = red + 40;                                      // [0 .. QRX_C-2] multipliers, then src, ipvt (as ints)
+    int *pubi = reinterpret_cast<int *>(pub + QRX_C);
+    if (onecand) {
+        if (j + tid == kmax) {
+#pragma unroll
+            for (int q = 0; q < QRX_C - 1; ++q) pub[q] = my_tk[q];
+            pubi[0] = my_src; pubi[1] = my_ipvt;
+        }
+    } else if (tid == 0) {
+        pubi[0] = src[kmax]; pubi[1] = ipvt[kmax];
+    } else if (tid <= np) {
+        pub[tid - 1] = tpc[(size_t)(tid - 1) * ldp + kmax];
+    }
+    __syncthreads();
+    const int srck = pubi[0];
     double tk[QRX_C];
 #pragma unroll
-    for (int q = 0; q < QRX_C; ++q) tk[q] = (q < np) ? tpc[(size_t)q * ldp + kmax] : 0.0;
-    __syncthreads();
+    for (int q = 0; q < QRX_C; ++q) tk[q] = (q < QRX_C - 1 && q < np) ? pub[q] : 0.0;
     if (kmax != j) {
         if (tid == 0) {
-            rdiag[kmax] = rdiag[j];
-            wa[kmax] = wa[j];
-            const int32_t t = ipvt[j]; ipvt[j] = ipvt[kmax]; ipvt[kmax] = t;
+            rdiag[kmax] = rd_j;
+            wa[kmax] = wa_j;
+            ipvt[j] = pubi[1]; ipvt[kmax] = ipvt_j;
             if (j == 0) {
                 // first step only: a physical interchange (slot 0's column is copied over the consumed pivot column in the
                 // gather below), so that the live columns are coff + 1 .. from the start -- with n + 1 = 1 (mod 64) a
                 // live column at coff + 0 would cost every pass of the first cycle a whole extra 64-column window
-                slotof[src[0]] = -1;
+                slotof[src_0] = -1;
                 slotof[srck] = kmax;
             } else {
-                src[kmax] = src[j];                              // slot kmax now lives where slot j's data is
-                slotof[src[j]] = kmax;
+                src[kmax] = src_j;                               // slot kmax now lives where slot j's data is
+                slotof[src_j] = kmax;
                 slotof[srck] = -1;                               // the pivot column is consumed
             }
         }
@@ -266,6 +298,10 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     double *__restrict__ Vn = flush ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
                                     : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
     double *Tp = T + (size_t)p * tst;
+    // The gathered column also goes to LDS (the region NORM2 later fills with its coefficients: it reads every element
+    // before it writes any) when it fits one NORM2 chunk, so that the norm does not start with another trip to memory.
+    const bool staged = (m - j <= 64 * QRX_NL);
+    double *stage = cd;
     for (int i0 = j + tid; i0 < m; i0 += 4 * BS) {
         double e[4], vq[4][QRX_C - 1], mv[4];
 #pragma unroll
@@ -283,25 +319,33 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
                 if (q < np) e[u] = e[u] - tk[q] * vq[u][q];
             if (i0 + u * BS < m) {
                 Vn[i0 + u * BS] = e[u];
+                if (staged) stage[i0 + u * BS - j] = e[u];
                 if (move0) Tp[qrx_at(i0 + u * BS, srck, ld)] = mv[u];
             }
         }
     }
     __syncthreads();
-    double ajnorm = norm2_flang_block_wide<QRX_NE>([&](int i) { return Vn[j + i]; }, m - j, cd, QRX_NE * BS, aux);   // :642
+    const double ejj = staged ? stage[0] : Vn[j];                 // the diagonal entry before scaling (read before NORM2 reuses the region)
+    double ajnorm = staged ? norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return stage[i]; }, m - j, cd, aux)
+                           : norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return Vn[j + i]; }, m - j, cd, aux);   // :642
     double ajj = 0.0;
     if (ajnorm != 0.0) {
-        if (Vn[j] < 0.0) ajnorm = -ajnorm;                       // :644
-        __syncthreads();
-        for (int i = j + tid; i < m; i += BS) {                   // :645-646
-            double t = Vn[i] / ajnorm;
-            if (i == j) t = t + 1.0;
-            Vn[i] = t;
+        if (ejj < 0.0) ajnorm = -ajnorm;                         // :644
+        // :645-646; eight rows per thread are loaded together before any is stored: the compiler must assume that the
+        // store of one row aliases the load of the next, and a row-at-a-time loop pays a memory latency per row
+        for (int i0 = j + tid; i0 < m; i0 += 8 * BS) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = Vn[min(i0 + u * BS, m - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                t[u] = t[u] / ajnorm;
+                if (i0 + u * BS == j) { t[u] = t[u] + 1.0; ajj = t[u]; }
+                if (i0 + u * BS < m) Vn[i0 + u * BS] = t[u];
+            }
         }
-        __syncthreads();
-        ajj = Vn[j];
     }
-    if (tid == 0) {
+    if (tid == 0) {                                              // thread 0 scaled row j
         QrxStep s;
         s.ajnorm = ajnorm; s.ajj = ajj; s.kmax = kmax; s.pad = 0;
         w.step[p] = s;
@@ -588,7 +632,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
 // wave 0 (the adder) does nothing but the ordered sum s = s + w_i (:652-653), rows ascending -- the only part of the step
 // that is serial by definition (16 cycles per dependent add).  One barrier per round of (W-1) x 16 rows; the adder
 // works one round behind the producers.  Same arithmetic on the same operands in the same order: bit-identical to
-// k_qrx_pass (rows outside the live range contribute +0.0, and a sum that starts at +0.0 can never become -0.0).
+// k_qrx_pass.
 #ifndef QRX_RP6_MAX_WG
 #define QRX_RP6_MAX_WG 256              // ... and of at most this many, with six waves (five producers) instead of four
 #endif
@@ -702,10 +746,9 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
                 e0 = e0 - p0_;
                 e1 = e1 - p1_;
             }
-            const bool ok0 = row >= r0 && row < mrel, ok1 = row + 1 >= r0 && row + 1 < mrel;
-            double2 ww;
-            ww.x = ok0 ? v0[NP] * e0 : 0.0;
-            ww.y = ok1 ? v1[NP] * e1 : 0.0;
+            double2 ww;                                                 // rows outside the live range: garbage the adder skips
+            ww.x = v0[NP] * e0;
+            ww.y = v1[NP] * e1;
             *reinterpret_cast<double2 *>(&pb[t & 1][(pw * G + u) >> 1][lane][0]) = ww;
             if (FLUSH) {
                 est[u & 7] = e0;
@@ -746,15 +789,28 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
             s = s + ww[pr].y;
         }
     };
+    auto consume_edge = [&](int half, int rbase) __attribute__((always_inline)) {    // the round of row j, the last round
+#pragma unroll 1
+        for (int pr = 0; pr < RR / 2; ++pr) {
+            const double2 ww = *reinterpret_cast<const double2 *>(&pb[half][pr][lane][0]);
+            const int row = rbase + 2 * pr;
+            if (row >= r0 && row < mrel) s = s + ww.x;                  // uniform
+            if (row + 1 >= r0 && row + 1 < mrel) s = s + ww.y;
+        }
+    };
 
     // The two roles run separate loops with the same number of barriers (s_barrier counts arrivals, not program
     // counters): a shared loop body would merge the roles' register states at every round and make the compiler copy --
-    // hence wait for -- the load groups in flight.  Producers run every round unguarded: rounds past the last row yield +0.0.
+    // hence wait for -- the load groups in flight.  Producers run every round unguarded; the adder skips the rows outside the live range.
     if (adder) {
         qrx_lds_barrier();
 #pragma unroll 1
         for (int t = 0; t < ntile * D; ++t) {
-            if (t >= 1 && t <= nround) consume((t - 1) & 1);
+            if (t >= 1 && t <= nround) {
+                const int rbase = (t - 1) * RR;
+                if (rbase >= r0 && rbase + RR <= mrel) consume((t - 1) & 1);
+                else consume_edge((t - 1) & 1, rbase);
+            }
             qrx_lds_barrier();
         }
     } else {

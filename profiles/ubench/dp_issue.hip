@@ -20,6 +20,33 @@ __global__ void __launch_bounds__(1024) k_chain(double *out, int n, double x)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// one chain, unrolled 64x: the latency of a dependent fp64 add without loop overhead
+__global__ void __launch_bounds__(64) k_dep(double *out, int n, double x)
+{
+    double a = threadIdx.x * 1e-9;
+    for (int i = 0; i < n; i += 64) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) a = a + x;
+    }
+    out[threadIdx.x] = a;
+}
+// the same with an LDS operand per add (the adder of k_qrx_pass_rp / the NORM2 serial phase)
+__global__ void __launch_bounds__(64) k_dep_lds(double *out, int n, double x)
+{
+    __shared__ double buf[64 * 64];
+    for (int i = threadIdx.x; i < 64 * 64; i += 64) buf[i] = x;
+    __syncthreads();
+    double a = threadIdx.x * 1e-9;
+    for (int i = 0; i < n; i += 64) {
+        double w[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) w[u] = buf[u * 64 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) a = a + w[u];
+    }
+    out[threadIdx.x] = a;
+}
+
 template <int K, bool MUL>
 static void run(int threads, int blocks, double *d)
 {
@@ -40,6 +67,18 @@ int main()
     for (int threads : {64, 256, 512, 1024}) {
         run<1, false>(threads, 1, d); run<2, false>(threads, 1, d); run<4, false>(threads, 1, d); run<8, false>(threads, 1, d);
         run<16, false>(threads, 1, d);
+    }
+    {
+        const int n = 1 << 22;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int which = 0; which < 2; ++which) {
+            if (which == 0) hipLaunchKernelGGL(k_dep, dim3(1), dim3(64), 0, 0, d, 64, 1.0000001); else hipLaunchKernelGGL(k_dep_lds, dim3(1), dim3(64), 0, 0, d, 64, 1.0000001);
+            hipEventRecord(e0);
+            if (which == 0) hipLaunchKernelGGL(k_dep, dim3(1), dim3(64), 0, 0, d, n, 1.0000001); else hipLaunchKernelGGL(k_dep_lds, dim3(1), dim3(64), 0, 0, d, n, 1.0000001);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("dependent add, unrolled 64x%s: %7.3f ns per add\n", which ? ", LDS operand" : "", ms * 1e6 / n);
+        }
     }
     run<1, true>(64, 1, d); run<4, true>(64, 1, d); run<8, true>(64, 1, d);
     run<4, false>(256, 256, d); run<4, false>(512, 256, d); run<8, false>(1024, 256, d);
