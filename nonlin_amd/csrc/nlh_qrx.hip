@@ -730,12 +730,16 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
     };
     auto produce = [&](const double (&buf)[G], int t, const double *tile, int i) __attribute__((always_inline)) {
         const int rbase = t * RR + pw * G;
-        // (Measured and dropped: four rows at a time with the chains pinned in step and the LDS reads a group ahead --
-        // no faster for a lone problem, 3 % slower for a full batch: the producers are not the bottleneck.)
+        // (Measured and dropped.  Four rows at a time with the chains pinned in step and the LDS reads a group ahead: no
+        // faster for a lone problem, 3 % slower for a full batch.  Reflector entries kept across the lanes and pulled out
+        // with a DPP64 row broadcast instead of the LDS broadcast read: equal for a lone problem -- 7 extra VALU moves per
+        // row replace 7 LDS reads --, 3 % slower for a full batch.  A product ring three rounds deep with LDS counters
+        // instead of the barrier per round: no faster.  Cycle counters in the kernel: at NP = 6 a producer spends ~100 cycles
+        // per row, i.e. its 13 fp64 operations + LDS reads at the VALU's 4 cycles per wave instruction; a fifth and sixth wave
+        // share a SIMD with another and finish last.  The split over three producers is what this form can give.)
         double est[8];
 #pragma unroll
         for (int u = 0; u < G; u += 2) {
-            const int row = rbase + u;
             double v0[NP + 1], v1[NP + 1];
 #pragma unroll
             for (int q = 0; q <= NP; ++q) { v0[q] = tile[(i * G + u) * LP + q]; v1[q] = tile[(i * G + u + 1) * LP + q]; }
@@ -945,7 +949,6 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     // cross-stream event waits cost more than the pivot latency they hide.  Sub-batches on host threads, which need no
     // cross-stream ordering, do hide it: nlh_api.hip, lm_sub_batches.)
     static const int forced_period = [] { const char *e = getenv("NLH_QRX_PERIOD"); return e ? atoi(e) : 0; }();
-    const int period = forced_period ? forced_period : QRX_C;
     static const long rp_env = [] { const char *e = getenv("NLH_QRX_RP"); return e ? atol(e) : -1L; }();
     const long rp_max = rp_env >= 0 ? rp_env : QRX_RP_MAX_WG;
     static const long rp6_env = [] { const char *e = getenv("NLH_QRX_RP6"); return e ? atol(e) : -1L; }();
@@ -953,10 +956,13 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     if (nact <= 0 || nact > nprob) nact = nprob;
     int cur = 0, np = 0, lo = 1;             // lo: first slot position that can still hold live data (step 0 moves physically)
     for (int j = 0; j < n; ++j) {
-        const bool flush = qrx_can_flush(np) && np >= period - 1;
         const int nwin = (n + 1 - lo + 63) / 64;
         const long nwg = (long)nact * nwin;
         const int rp = nwg <= rp6_max ? 6 : nwg <= rp_max ? 4 : 0;        // waves per workgroup of the row-parallel pass, 0: one wave
+        // a launch that leaves most of the chip idle is bound by the instruction stream of its few waves, not by HBM:
+        // flush every 3rd step there (at most 3 pending updates per row instead of 7; lone problem: 111 -> 103 ms)
+        const int period = forced_period ? forced_period : (rp == 6 ? 4 : QRX_C);
+        const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
         hipLaunchKernelGGL(k_qrx_pivot, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
                            T, w, R, v, (const LmState *)st);
