@@ -31,8 +31,21 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
                             double *sbuf /* LDS, n doubles, EXACT only */)
 {
     const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
-    for (int j = 0; j < n; ++j) {                              // :710-714
-        for (int i = j + tid; i < n; i += BS) r[(size_t)j * ldr + i] = r[(size_t)i * ldr + j];
+    // :710-714, the upper triangle copied into the lower one: eight elements per thread are loaded before any is stored
+    // (sources and destinations never overlap, but the compiler cannot know; element by element, every store would
+    // wait for its own load: n memory latencies in the column-by-column form)
+    for (int e0 = tid; e0 < n * n; e0 += 8 * BS) {
+        double t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * BS, j = e / n, i = e - j * n;
+            t8[u] = (e < n * n && i > j) ? r[(size_t)i * ldr + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * BS, j = e / n, i = e - j * n;
+            if (e < n * n && i > j) r[(size_t)j * ldr + i] = t8[u];
+        }
     }
     for (int j = tid; j < n; j += BS) { x[j] = r[(size_t)j * ldr + j]; wa[j] = qtb[j]; qtbp[j] = 0.0; }
     for (int e = tid; e < n * n; e += BS) Wrows[e] = 0.0;       // sdiag(j:n) = zero, per elimination (:722)

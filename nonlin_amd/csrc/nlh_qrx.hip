@@ -653,7 +653,8 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
               double *__restrict__ waall, const QrxStep *__restrict__ stepall, double *__restrict__ Rall,
               double *__restrict__ qtfall, const LmState *__restrict__ st)
 {
-    constexpr int NPR = W - 1, G = QRX_RP_G, D = QRX_RP_D, RR = NPR * G, LP = QRX_C;
+    constexpr int NPR = W - 1, G = QRX_RP_G, D = QRX_RP_D, RR = NPR * G, LP = 8;
+    static_assert(NP < 8, "the row-parallel pass stages at most eight entries per row");
     constexpr int NPI = NP < QRX_C ? NP : 0;
     __shared__ double vt[NPR][2][D * G * LP];
     __shared__ __attribute__((aligned(16))) double pb[2][RR / 2][64][2];
@@ -897,19 +898,22 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     // elements) on 512 x 4096x256, 1024 x 2048x128 and a single problem, more waves won every time.
     const int nwin = (n + 1 - lo + 63) / 64;                            // live physical columns coff + lo .. coff + n
     const dim3 grid((unsigned)(((nprob + 7) / 8) * 8 * nwin));
+    if constexpr (NP >= 8) rp = 0;
+    if constexpr (NP < 8) {
     if (rp == 6)
         hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 6>), grid, dim3(64 * 6), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
     else if (rp == 4)
         hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 4>), grid, dim3(64 * 4), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
-    else
+    }
+    if (rp == 0)
         hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH>), grid, dim3(64), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
 }
 
 // A pass with np pending updates; flushing ones exist for np = 1, 3 and QRX_C - 1 (flush periods 2, 4 and QRX_C).
-static constexpr bool qrx_can_flush(int np) { return np == 1 || np == 3 || np == QRX_C - 1; }
+static constexpr bool qrx_can_flush(int np) { return np == 1 || np == 3 || (QRX_C > 8 && np == 7) || np == QRX_C - 1; }
 
 template <int NP>
 static void dispatch_pass(int np, bool flush, int rp, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst,
@@ -961,7 +965,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         const int rp = nwg <= rp6_max ? 6 : nwg <= rp_max ? 4 : 0;        // waves per workgroup of the row-parallel pass, 0: one wave
         // a launch that leaves most of the chip idle is bound by the instruction stream of its few waves, not by HBM:
         // flush every 3rd step there (at most 3 pending updates per row instead of 7; lone problem: 111 -> 103 ms)
-        const int period = forced_period ? forced_period : (rp == 6 ? 4 : QRX_C);
+        const int period = forced_period ? forced_period : (rp == 6 ? 4 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
         const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
         hipLaunchKernelGGL(k_qrx_pivot, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
