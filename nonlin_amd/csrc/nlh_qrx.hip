@@ -35,7 +35,8 @@
 //     slot j's source and pending multipliers.  The flush writes every slot to its own position.
 // Launches per step: k_qrx_pivot (one workgroup per problem: pivot search, bookkeeping, gather of the pivot
 // column with its pending updates, NORM2 -- a serial chain of m - j adds --, scaling -> reflector) and
-// k_qrx_pass (lane per trailing column).  The driver keeps several sub-batches in flight on private streams
+// k_qrx_pass (lane per trailing column; k_qrx_pass_rp, the row-parallel form, when the launch cannot fill the chip:
+// a few problems still iterating, one problem alone, the last narrow steps).  The driver keeps several sub-batches in flight on private streams
 // (nlh_api.hip, lm_sub_batches) so that one sub-batch's pivot kernels run under another's passes.
 #include "nlh_qrx.h"
 #include "nlh_common.h"
@@ -630,7 +631,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
 // ROW-PARALLEL form: a workgroup of W waves per (problem, window); waves 1 .. W-1 (producers) walk disjoint
 // 16-row groups, apply the pending updates, multiply by the reflector entry and hand the PRODUCTS over through LDS;
 // wave 0 (the adder) does nothing but the ordered sum s = s + w_i (:652-653), rows ascending -- the only part of the step
-// that is serial by definition (16 cycles per dependent add).  One barrier per round of (W-1) x 16 rows; the adder
+// that is serial by definition (a dependent fp64 add with register operands issues every ~2 ns: profiles/ubench/dp_issue.hip).  One barrier per round of (W-1) x 16 rows; the adder
 // works one round behind the producers.  Same arithmetic on the same operands in the same order: bit-identical to
 // k_qrx_pass.
 #ifndef QRX_RP6_MAX_WG
