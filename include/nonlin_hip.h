@@ -261,6 +261,12 @@ int nlh_chol_factor(nlh_handle *h, int32_t nprob, int32_t n, double *dG, const d
 int nlh_qr_factor(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, double *dJ,
                   const double *df, int32_t *dipvt, double *drdiag, double *dacnorm,
                   double *dqtf, double *dwa4);
+/* The same factorisation in the reference's OPERATION ORDER (what NLH_FACTOR_EXACT runs inside the LM solve:
+ * streaming lock-step Householder steps, nlh_qrx.hip): bit-identical to the CPU path.  dJ [nprob][n][m] is not
+ * modified; dR [nprob][n][n] column-major receives R (strict upper triangle + diagonal = rdiag); requires m >= n. */
+int nlh_lmfactor_exact(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dJ,
+                       const double *df, double *dR, int32_t *dipvt, double *drdiag, double *dacnorm,
+                       double *dqtf, double *dwa4);
 /* lmpar (:394-566, including its two deviations from MINPACK) on an n-by-n R
  * (leading dimension ldr) for every problem.  dtailsq[k] = sum of squares of the
  * caller's wa4(n+1:m).  Outputs: dpar (in/out), dxstep [nprob][n], dsdiag [nprob][n]. */

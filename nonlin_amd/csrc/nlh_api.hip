@@ -2502,6 +2502,27 @@ int nlh_qr_factor(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, double *dJ
     return 0;
 }
 
+// lmfactor + Q^T f in the reference's operation order (the factorisation the exact LM policy runs): nlh_qrx.hip on
+// caller-supplied matrices, every problem factored.  dJ: [nprob][n][m] column-major, not modified.
+int nlh_lmfactor_exact(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dJ, const double *df,
+                       double *dR, int32_t *dipvt, double *drdiag, double *dacnorm, double *dqtf, double *dwa4)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (nprob <= 0) return 0;
+    if (m < n || n < 1) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->P, sizeof(double) * qrx_matrix_doubles(nprob, m, n)))) return rc;
+    if ((rc = ensure(h, h->qxV, qrx_workspace_bytes(nprob, m, n)))) return rc;
+    LmVecs v;
+    memset(&v, 0, sizeof v);
+    v.ipvt = dipvt; v.acnorm = dacnorm; v.qtf = dqtf; v.rdiag = drdiag;
+    qrx_factor(h->stream, nprob, m, n, dJ, (double *)h->P.p, df, dR, v, dwa4, dwa4, (const double *)nullptr, (LmState *)nullptr,
+               100.0, 0.0, h->qxV.p, (const QrxTimer *)nullptr, nprob);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 // lmpar on caller-supplied factors (parity tests): wraps lmpar_dev.
 }  // extern "C"
 

@@ -206,6 +206,24 @@ class DeviceSolver:
                      "nlh_qr_factor")
         return ipvt, rdiag, acnorm, qtf, wa4
 
+    def lmfactor_exact(self, J, f):
+        """lmfactor + Q^T f in the reference's operation order (the exact LM policy's factorisation, bit-identical to
+        the CPU path).  J [nprob, n, m] (column-major problems, not modified), f [nprob, m], m >= n.
+        Returns (R [nprob, n, n] column-major: R[p].T is R with rdiag on the diagonal, ipvt0, rdiag, acnorm, qtf, wa4)."""
+        nprob, n, m = J.shape
+        _chk(J, (nprob, n, m), "J"); _chk(f, (nprob, m), "f")
+        dev = J.device
+        R = torch.zeros((nprob, n, n), dtype=torch.float64, device=dev)
+        ipvt = torch.empty((nprob, n), dtype=torch.int32, device=dev)
+        rdiag = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        acnorm = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        qtf = torch.empty((nprob, n), dtype=torch.float64, device=dev)
+        wa4 = torch.empty((nprob, m), dtype=torch.float64, device=dev)
+        self.h.check(self.lib.nlh_lmfactor_exact(self.h.ptr, nprob, m, n, J.data_ptr(), f.data_ptr(), R.data_ptr(),
+                                                 ipvt.data_ptr(), rdiag.data_ptr(), acnorm.data_ptr(), qtf.data_ptr(),
+                                                 wa4.data_ptr()), "nlh_lmfactor_exact")
+        return R, ipvt, rdiag, acnorm, qtf, wa4
+
     def lmpar(self, R, ipvt, diag, qtf, delta, tailsq, par):
         """R [nprob, n, ldr] column-major n-by-n blocks with leading dimension ldr."""
         nprob, n, ldr = R.shape

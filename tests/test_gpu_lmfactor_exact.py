@@ -1,0 +1,111 @@
+"""The exact policy's factorisation on its own (nlh_lmfactor_exact = nlh_qrx.hip: lmfactor + Q^T f of
+src/nonlin_least_squares.f90:569-667 / :241-253 in the reference's operation order) against the CPU oracle, BIT FOR BIT,
+on matrices built to reach the corners the random LM problems rarely visit: graded rows (a new running maximum inside
+every NORM2 run), graded and permuted columns (non-trivial pivoting), duplicate columns (ties: lowest index wins), zero
+and dependent columns (zero reflectors), exact zeros, sizes on both sides of the kernels' internal limits (more than 256
+candidate columns, columns longer than one NORM2 chunk), and the same matrix in batches that select each of the three
+forms of the trailing pass (six-wave and four-wave row-parallel, one wave per window)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _qtf_reference(a, rdiag, f):
+    """Q^T f as lss_solve forms it (:241-253): ascending dot product, no fused operations (Python floats)."""
+    m, n = a.shape
+    w = [float(v) for v in f]
+    qtf = np.zeros(n)
+    for j in range(n):
+        ajj = float(a[j, j])
+        if ajj != 0.0:
+            col = a[j:, j]
+            s = 0.0
+            for i in range(m - j):
+                s = s + float(col[i]) * w[j + i]
+            t = -s / ajj
+            for i in range(m - j):
+                w[j + i] = w[j + i] + float(col[i]) * t
+        qtf[j] = w[j]
+    return qtf, np.array(w)
+
+
+def _matrix(kind, m, n, rng):
+    a = rng.standard_normal((m, n))
+    if kind == "random":
+        pass
+    elif kind == "graded_rows":              # |row i| grows: every element is a new maximum of the running NORM2
+        a *= (1.0 + 1e-3) ** np.arange(m)[:, None]
+    elif kind == "graded_rows_down":
+        a *= (1.0 + 1e-3) ** (-np.arange(m))[:, None]
+    elif kind == "graded_cols":              # column norms spread over 12 decades, shuffled
+        a *= 10.0 ** (-12.0 * rng.permutation(n) / max(n - 1, 1))[None, :]
+    elif kind == "duplicates":               # pairs of identical columns: ties in the pivot search, dependent columns
+        a[:, 1::2] = a[:, 0:n - 1:2][:, : a[:, 1::2].shape[1]]
+    elif kind == "zero_cols":
+        a[:, rng.choice(n, size=max(1, n // 5), replace=False)] = 0.0
+    elif kind == "sparse":                   # three quarters exact zeros, a few all-zero rows
+        a[rng.random((m, n)) < 0.75] = 0.0
+        a[rng.choice(m, size=m // 10, replace=False), :] = 0.0
+    elif kind == "rank_one":
+        a = np.outer(rng.standard_normal(m), rng.standard_normal(n))
+    else:
+        raise ValueError(kind)
+    return np.asfortranarray(a)
+
+
+def _check(ds, oracle, a, f, copies=1):
+    m, n = a.shape
+    J = torch.tensor(np.ascontiguousarray(a.T)[None].repeat(copies, axis=0), device="cuda:0")
+    F = torch.tensor(np.ascontiguousarray(f)[None].repeat(copies, axis=0), device="cuda:0")
+    R, ipvt, rdiag, acnorm, qtf, wa4 = ds.lmfactor_exact(J, F)
+    ao, ip, rd, acn = oracle.lmfactor(a)
+    qt, w = _qtf_reference(ao, rd, f)
+    for p in sorted({0, copies // 2, copies - 1}):
+        assert np.array_equal(ipvt[p].cpu().numpy(), ip)
+        assert np.array_equal(rdiag[p].cpu().numpy(), rd)
+        assert np.array_equal(acnorm[p].cpu().numpy(), acn)
+        Rg = R[p].cpu().numpy().T                                  # column-major n x n
+        up = np.triu_indices(n, 1)
+        assert np.array_equal(Rg[up], ao[:n, :n][up])
+        assert np.array_equal(np.diag(Rg), rd)
+        assert np.array_equal(qtf[p].cpu().numpy(), qt)
+        assert np.array_equal(wa4[p].cpu().numpy(), w)
+    if copies > 1:                                                 # every copy the same bits
+        for t in (R, ipvt, rdiag, acnorm, qtf, wa4):
+            assert bool((t == t[0:1]).all())
+
+
+KINDS = ["random", "graded_rows", "graded_rows_down", "graded_cols", "duplicates", "zero_cols", "sparse", "rank_one"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("m,n", [(300, 37), (130, 129), (64, 64), (21, 4)])
+def test_lmfactor_exact_bitwise_adversarial(ds, oracle, kind, m, n):
+    rng = np.random.default_rng(hash((kind, m, n)) % (2 ** 31))
+    a = _matrix(kind, m, n, rng)
+    f = rng.standard_normal(m)
+    _check(ds, oracle, a, f)
+
+
+@pytest.mark.parametrize("kind", ["graded_rows", "duplicates", "graded_cols"])
+@pytest.mark.parametrize("m,n", [(4500, 40), (700, 300)])
+def test_lmfactor_exact_bitwise_beyond_internal_limits(ds, oracle, kind, m, n):
+    """m - j > 4096: the pivot column does not fit one NORM2 chunk; n - j > 256: more candidate columns than threads."""
+    rng = np.random.default_rng(7 + m + n)
+    a = _matrix(kind, m, n, rng)
+    f = rng.standard_normal(m)
+    _check(ds, oracle, a, f)
+
+
+@pytest.mark.parametrize("copies", [1, 40, 300, 1100])
+def test_lmfactor_exact_every_pass_form(ds, oracle, copies):
+    """The same graded 520 x 70 matrix (two 64-column windows) in batches of 1 / 40 / 300 / 1100: 2 .. 2200 (problem, window)
+    pairs per launch select the six-wave, the four-wave and the one-wave form of the trailing pass; all the same bits."""
+    rng = np.random.default_rng(99)
+    a = _matrix("graded_rows", 520, 70, rng)
+    a[:, 5] = a[:, 3]
+    a[:, 11] = 0.0
+    f = rng.standard_normal(520)
+    _check(ds, oracle, a, f, copies=copies)
