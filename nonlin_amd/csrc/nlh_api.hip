@@ -521,11 +521,10 @@ static void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_
         else
             hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
         if (n - nb > 0)
-            hipLaunchKernelGGL(k_lu_swap, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
+            hipLaunchKernelGGL(k_lu_swap_trsm, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
                                (const int32_t *)dipvt, jb, nb);
         const int nt = n - jb - nb;
         if (nt > 0) {
-            hipLaunchKernelGGL(k_lu_trsm, dim3((nt + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA, jb, nb);
             hipLaunchKernelGGL(k_lu_gemm, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, h->stream, n, dA, jb, nb);
         }
         jb += nb;

@@ -72,42 +72,71 @@ k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ 
             if (q != j) { const double t = bs[j]; bs[j] = bs[q]; bs[q] = t; }
         }
     __syncthreads();
-    // Each thread owns row tid (+ BS, ...).  Its entry of the next column is fetched before the barrier of the
-    // current step, so a step costs a barrier and an LDS update rather than a global load issued after it.
+    // Each thread owns row tid (+ BS, ...).  Its entries of the next LUS_PF columns are fetched while the current
+    // LUS_PF steps run, so a step costs a barrier and an LDS update, not a trip to L2 (one column ahead was not
+    // enough: a step is shorter than the latency).
+    constexpr int PF = 8;
     {
-        double pre = (tid > 0 && tid < n) ? a[tid] : 0.0;          // column 0
-        for (int j = 0; j < n; ++j) {                              // L y = P b (unit diagonal)
-            const double cur = pre;
-            if (j + 1 < n) pre = (tid > j + 1 && tid < n) ? a[(size_t)(j + 1) * n + tid] : 0.0;
-            const double bj = bs[j];
-            if (bj != 0.0) {
-                const double *cj = a + (size_t)j * n;
-                if (tid > j && tid < n) bs[tid] = bs[tid] - bj * cur;
-                for (int i = tid + BS; i < n; i += BS)
-                    if (i > j) bs[i] = bs[i] - bj * cj[i];
+        double cur[PF], nxt[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) nxt[u] = (u < n && tid > u && tid < n) ? a[(size_t)u * n + tid] : 0.0;
+        for (int j0 = 0; j0 < n; j0 += PF) {                       // L y = P b (unit diagonal)
+#pragma unroll
+            for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int jn = j0 + PF + u;
+                nxt[u] = (jn < n && tid > jn && tid < n) ? a[(size_t)jn * n + tid] : 0.0;
             }
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int j = j0 + u;
+                if (j < n) {                                       // uniform
+                    const double bj = bs[j];
+                    if (bj != 0.0) {
+                        const double *cj = a + (size_t)j * n;
+                        if (tid > j && tid < n) bs[tid] = bs[tid] - bj * cur[u];
+                        for (int i = tid + BS; i < n; i += BS)
+                            if (i > j) bs[i] = bs[i] - bj * cj[i];
+                    }
+                    __syncthreads();
+                }
+            }
         }
     }
     {
-        const int jl = n - 1;
-        double pre = (tid < jl) ? a[(size_t)jl * n + tid] : 0.0, dpre = a[(size_t)jl * n + jl];
-        for (int j = n - 1; j >= 0; --j) {                         // U x = y
-            const double cur = pre, dcur = dpre;
-            if (j > 0) {
-                pre = (tid < j - 1) ? a[(size_t)(j - 1) * n + tid] : 0.0;
-                dpre = a[(size_t)(j - 1) * n + j - 1];
+        double cur[PF], nxt[PF], dcur[PF], dnxt[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int j = n - 1 - u;
+            nxt[u] = (j >= 0 && tid < j) ? a[(size_t)j * n + tid] : 0.0;
+            dnxt[u] = (j >= 0) ? a[(size_t)j * n + j] : 1.0;
+        }
+        for (int j0 = n - 1; j0 >= 0; j0 -= PF) {                  // U x = y
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { cur[u] = nxt[u]; dcur[u] = dnxt[u]; }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int jn = j0 - PF - u;
+                nxt[u] = (jn >= 0 && tid < jn) ? a[(size_t)jn * n + tid] : 0.0;
+                dnxt[u] = (jn >= 0) ? a[(size_t)jn * n + jn] : 1.0;
             }
-            const double bjr = bs[j];
-            if (bjr != 0.0) {
-                const double *cj = a + (size_t)j * n;
-                const double bj = bjr / dcur;
-                __syncthreads();
-                if (tid < j) bs[tid] = bs[tid] - bj * cur;
-                for (int i = tid + BS; i < j; i += BS) bs[i] = bs[i] - bj * cj[i];
-                if (tid == 0) bs[j] = bj;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int j = j0 - u;
+                if (j >= 0) {                                      // uniform
+                    const double bjr = bs[j];
+                    if (bjr != 0.0) {
+                        const double *cj = a + (size_t)j * n;
+                        const double bj = bjr / dcur[u];
+                        __syncthreads();
+                        if (tid < j) bs[tid] = bs[tid] - bj * cur[u];
+                        for (int i = tid + BS; i < j; i += BS) bs[i] = bs[i] - bj * cj[i];
+                        if (tid == 0) bs[j] = bj;
+                    }
+                    __syncthreads();
+                }
             }
-            __syncthreads();
         }
     }
     for (int i = tid; i < n; i += BS) b[i] = bs[i];
@@ -176,20 +205,73 @@ k_lu_panel(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int
 }
 
 // The same panel factorisation with the panel held in registers: thread r owns row jb + r of the nb <= LU_PNB panel
-// columns (rows = n - jb <= LU_PROWS = blockDim).  A column step is: wave arg-max of |a(r, c)| and a 16-entry scan of
-// the per-wave results (first maximum), the pivot row and row c published through LDS, the two owners exchanging
-// rows, then every thread scales its multiplier and updates the rest of its row -- two barriers per column, no
-// global or LDS traffic for the panel body.  Identical operation sequence per element (pivot search, in-panel
-// interchange, reciprocal scaling, a(i,k) -= l(i) u(j,k) for j ascending): bit-identical to the unblocked loop.
+// columns (rows = n - jb <= LU_PROWS = blockDim).  A column step is: the first maximum of |a(r, c)| -- DPP reductions
+// inside every wave (no LDS round trips), then 16-lane DPP reductions of the per-wave results --, the pivot row
+// (with the reciprocal of the pivot) and row c published through LDS, the two owners exchanging rows, then every
+// thread scales its multiplier and updates the rest of its row -- two barriers per column, no global or LDS traffic
+// for the panel body.  What a step costs is the instruction count of sixteen waves on four SIMDs: with the arg-max
+// through six shuffle levels, every thread scanning the sixteen per-wave results and every thread dividing by the
+// pivot a step took 3.3 us (n = 1024); in this form ~1 us.  Identical operation sequence per element (pivot search,
+// in-panel interchange, reciprocal scaling, a(i,k) -= l(i) u(j,k) for j ascending): bit-identical to the unblocked loop.
 #define LU_PNB 16
 #define LU_PROWS 1024
+
+// First maximum = the largest value, and among the lanes that hold it the smallest index: a max-reduction of the
+// values followed by a min-reduction of the candidate indices (three and two instructions per DPP step instead of
+// the dozen a (value, index) pair comparison takes).  Lanes without a candidate pass value -1 and index 0x7fffffff.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double lu_dpp_max_step(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, BANK_MASK, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, BANK_MASK, false);
+    return fmax(v, __hiloint2double(ohi, olo));
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int lu_dpp_min_step(int i)
+{
+    return min(i, __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, BANK_MASK, false));
+}
+// reductions over a 16-lane row (result in lane 15 of the row) and over the wave (result in lane 63)
+__device__ __forceinline__ double lu_row16_max(double v)
+{
+    v = lu_dpp_max_step<0x111, 0xf, 0xf>(v);       // row_shr:1
+    v = lu_dpp_max_step<0x112, 0xf, 0xf>(v);       // row_shr:2
+    v = lu_dpp_max_step<0x114, 0xf, 0xf>(v);       // row_shr:4
+    return lu_dpp_max_step<0x118, 0xf, 0xf>(v);    // row_shr:8
+}
+__device__ __forceinline__ int lu_row16_min(int i)
+{
+    i = lu_dpp_min_step<0x111, 0xf, 0xf>(i);
+    i = lu_dpp_min_step<0x112, 0xf, 0xf>(i);
+    i = lu_dpp_min_step<0x114, 0xf, 0xf>(i);
+    return lu_dpp_min_step<0x118, 0xf, 0xf>(i);
+}
+__device__ __forceinline__ double lu_uniform_lane(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// wave-uniform (value, index) of the first maximum over the wave's lanes
+__device__ __forceinline__ void lu_wave_first_max(double v, int idx, double &vmax, int &imin)
+{
+    double t = lu_row16_max(v);
+    t = lu_dpp_max_step<0x142, 0xa, 0xf>(t);       // row_bcast:15 into rows 1 and 3
+    t = lu_dpp_max_step<0x143, 0xc, 0xf>(t);       // row_bcast:31 into rows 2 and 3: lane 63 has the wave's
+    vmax = lu_uniform_lane(t, 63);
+    int c = (v == vmax) ? idx : 0x7fffffff;
+    c = lu_row16_min(c);
+    c = lu_dpp_min_step<0x142, 0xa, 0xf>(c);
+    c = lu_dpp_min_step<0x143, 0xc, 0xf>(c);
+    imin = __builtin_amdgcn_readlane(c, 63);
+}
+
 __global__ void __launch_bounds__(1024)
 k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
                int jb, int nb)
 {
     __shared__ double redv[2][16];
     __shared__ int redi[2][16];
-    __shared__ double prow[2][LU_PNB], crow[2][LU_PNB];
+    __shared__ double prow[2][LU_PNB + 1], crow[2][LU_PNB];      // prow[.][LU_PNB]: 1 / pivot
     const int p = blockIdx.x, r = threadIdx.x, lane = r & 63, wid = r >> 6, nw = (blockDim.x + 63) >> 6;
     const int rows = n - jb;
     double *a = Aall + (size_t)p * n * n;
@@ -205,27 +287,21 @@ k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
             // first maximum of |a(r, c)| over r >= c
             double v = (mine && r >= c) ? fabs(row[c]) : -1.0;
             int idx = (mine && r >= c) ? r : 0x7fffffff;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ov = __shfl_down(v, off, 64);
-                const int oi = __shfl_down(idx, off, 64);
-                const bool take = (oi != 0x7fffffff) && (idx == 0x7fffffff || ov > v || (ov == v && oi < idx));
-                if (take) { v = ov; idx = oi; }
-            }
-            if (lane == 0) { redv[par][wid] = v; redi[par][wid] = idx; }
+            double wmax;
+            int widx;
+            lu_wave_first_max(v, idx, wmax, widx);
+            if (lane == 0) { redv[par][wid] = wmax; redi[par][wid] = widx; }
             __syncthreads();
-            double bv = redv[par][0];
-            int piv = redi[par][0];
-            for (int w = 1; w < nw; ++w) {
-                const double ov = redv[par][w];
-                const int oi = redi[par][w];
-                const bool take = (oi != 0x7fffffff) && (piv == 0x7fffffff || ov > bv || (ov == bv && oi < piv));
-                if (take) { bv = ov; piv = oi; }
-            }
+            // the per-wave results, one per lane of a 16-lane row (every row of every wave does the same)
+            const double cv = (lane & 15) < nw ? redv[par][lane & 15] : -1.0;
+            const int ci = (lane & 15) < nw ? redi[par][lane & 15] : 0x7fffffff;
+            const double bv = lu_uniform_lane(lu_row16_max(cv), 15);
+            const int piv = __builtin_amdgcn_readlane(lu_row16_min((cv == bv) ? ci : 0x7fffffff), 15);
             // the pivot row and row c through LDS
             if (r == piv) {
 #pragma unroll
                 for (int k = 0; k < LU_PNB; ++k) prow[par][k] = row[k];
+                prow[par][LU_PNB] = 1.0 / row[c];                // (Inf for a zero pivot: not used then)
             }
             if (r == c) {
 #pragma unroll
@@ -245,7 +321,7 @@ k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
                     }
                 }
                 if (mine && r > c) {
-                    const double rcp = 1.0 / apj;
+                    const double rcp = prow[par][LU_PNB];
                     const double lij = row[c] * rcp;
                     row[c] = lij;
 #pragma unroll
@@ -268,38 +344,35 @@ k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
     }
 }
 
-// Deferred row interchanges of panel [jb, jb+nb) applied to every column outside the panel.
+// A thread per column outside the panel: the deferred row interchanges of panel [jb, jb+nb), then -- right of the
+// panel -- the column's part of the block row: u(j,k) final after the updates of the earlier panel columns (unit lower
+// triangular solve, j ascending).  One launch for both: these kernels are launch-latency-bound (n = 1024: 64 panels x
+// three launches of 5 - 12 us each were a third of the factorisation).
 __global__ void __launch_bounds__(256)
-k_lu_swap(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipvt_all, int jb, int nb)
-{
-    const int p = blockIdx.y;
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n - nb) return;
-    if (k >= jb) k += nb;                          // skip the panel's own columns
-    double *ck = Aall + (size_t)p * n * n + (size_t)k * n;
-    const int32_t *ipvt = ipvt_all + (size_t)p * n;
-    for (int j = jb; j < jb + nb; ++j) {
-        const int q = ipvt[j];
-        if (q != j) { const double t = ck[j]; ck[j] = ck[q]; ck[q] = t; }
-    }
-}
-
-// Block row: for every column k right of the panel, rows jb..jb+nb: u(j,k) final after the updates
-// of the earlier panel columns (unit lower triangular solve, j ascending).
-__global__ void __launch_bounds__(256)
-k_lu_trsm(int n, double *__restrict__ Aall, int jb, int nb)
+k_lu_swap_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipvt_all, int jb, int nb)
 {
     __shared__ double L11[LU_NB * LU_NB];          // L11[i + j*LU_NB], i > j used
+    __shared__ int32_t piv[LU_NB];
     const int p = blockIdx.y;
     double *a = Aall + (size_t)p * n * n;
     for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) {
         const int i = e % nb, j = e / nb;
         L11[i + j * LU_NB] = a[(size_t)(jb + j) * n + jb + i];
     }
+    if (threadIdx.x < nb) piv[threadIdx.x] = ipvt_all[(size_t)p * n + jb + threadIdx.x];
     __syncthreads();
-    const int k = jb + nb + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    double *ck = a + (size_t)k * n + jb;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n - nb) return;
+    if (k >= jb) k += nb;                          // skip the panel's own columns
+    double *ck = a + (size_t)k * n;
+    // (Measured and dropped: composing the interchanges once per workgroup and loading all touched rows before storing
+    // any -- two trips to memory instead of a dependent one per interchange -- is slower: 3.44 vs 3.23 ms at n = 1024.)
+    for (int j = 0; j < nb; ++j) {
+        const int q = piv[j];
+        if (q != jb + j) { const double t = ck[jb + j]; ck[jb + j] = ck[q]; ck[q] = t; }
+    }
+    if (k < jb + nb) return;                       // left of the panel: interchanges only
+    ck += jb;
     double u[LU_NB];
 #pragma unroll
     for (int i = 0; i < LU_NB; ++i) u[i] = (i < nb) ? ck[i] : 0.0;
