@@ -517,7 +517,8 @@ static void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_
         const int pw = lds ? LU_PNB : LU_NB;
         const int nb = (n - jb < pw) ? (n - jb) : pw;
         if (lds)
-            hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
+            // one thread per panel row: waves without rows would still run the step's instruction stream and barriers
+            hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(std::min(1024, (n - jb + 63) & ~63)), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
         else
             hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
         if (n - nb > 0)
