@@ -53,8 +53,8 @@
 #define QRX_AUX_LOAD 0    // cache policy of the matrix stream: default.  Non-temporal loads (2) were measured: 1137 vs 836 ms
 #endif                    // per 512 x 4096x256 solve
 #ifndef QRX_AUX_STORE
-#define QRX_AUX_STORE 0   // the flush: default policy (non-temporal stores: 836 vs 828 ms)
-#endif
+#define QRX_AUX_STORE 1   // the flush: sc0 (measured, 512 x 4096x256 on one box: default policy 727 ms, sc0 714, nt 740,
+#endif                    // sc0 sc1 847, sc0 sc1 nt 1217)
 #ifndef QRX_UF
 #define QRX_UF(flush) 16
 #endif
