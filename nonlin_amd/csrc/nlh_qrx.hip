@@ -58,7 +58,8 @@
 #ifndef QRX_UF
 #define QRX_UF(flush) 16
 #endif
-#define QRX_NL 64          // NORM2: elements per lane of the serial phase (chunks of 4096)
+// NORM2 of the pivot kernel: elements per lane of the serial phase = chunk / 64.  64 (chunks of 4096) when columns are
+// longer than 2048, 32 otherwise: half the LDS and 64 registers less, four workgroups per CU instead of two.
 
 typedef unsigned int qrx_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int qrx_u32x4 __attribute__((ext_vector_type(4)));
@@ -203,6 +204,7 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
 // Step j, part 1: pivot (:622-637), the pivot column with its pending updates -> reflector (:642-646).
 // The new reflector goes to slot np of the current bank, or to slot 0 of the other bank when this step's pass
 // flushes (np == QRX_C - 1).
+template <int QRX_NL>
 __global__ void __launch_bounds__(256)
 k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
@@ -969,8 +971,12 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         const int period = forced_period ? forced_period : (rp == 6 ? 4 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
         const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
-        hipLaunchKernelGGL(k_qrx_pivot, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
-                           T, w, R, v, (const LmState *)st);
+        if (m <= 2048)
+            hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
+                               T, w, R, v, (const LmState *)st);
+        else
+            hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
+                               T, w, R, v, (const LmState *)st);
         te(0, stream);
         tb(1, stream);
         dispatch_pass<0>(np, flush, rp, stream, 0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, v.qtf, st);
