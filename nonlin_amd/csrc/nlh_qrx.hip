@@ -228,13 +228,20 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     // memory latency after the kernel does, instead of four dependent ones (norms -> src[kmax] -> ... ).
     const bool onecand = (n - j <= BS);
     int32_t *slotof = w.slotof + (size_t)p * ld;
+    // The pass before this step flushed: every live slot k >= j now sits at its own position coff + k, everything left
+    // of that is consumed.  (The flushing pass itself must not write the maps, see qrx_pass_tail.)
+    const bool fresh = (flush & 2) != 0;
+    if (fresh) {
+        for (int c = tid; c < ld; c += BS) slotof[c] = (c - coff >= j && c - coff <= n) ? c - coff : -1;
+        for (int k = j + tid; k <= n; k += BS) src[k] = coff + k;
+    }
     double bv = 0.0, my_tk[QRX_C - 1];
     int bk = 0x7fffffff, my_src = 0, my_ipvt = 0;
     if (onecand) {
         const int k = j + tid;
         if (k < n) {
             bv = rdiag[k]; bk = k;
-            my_src = src[k]; my_ipvt = ipvt[k];
+            my_src = fresh ? coff + k : src[k]; my_ipvt = ipvt[k];
 #pragma unroll
             for (int q = 0; q < QRX_C - 1; ++q) my_tk[q] = (q < np) ? tpc[(size_t)q * ldp + k] : 0.0;
         }
@@ -247,7 +254,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     // slot j's own entries (tid 0 does the interchange bookkeeping)
     double rd_j = 0.0, wa_j = 0.0;
     int src_j = 0, ipvt_j = 0, src_0 = 0;
-    if (tid == 0) { rd_j = rdiag[j]; wa_j = wa[j]; src_j = src[j]; ipvt_j = ipvt[j]; src_0 = src[0]; }
+    if (tid == 0) { rd_j = rdiag[j]; wa_j = wa[j]; src_j = fresh ? coff + j : src[j]; ipvt_j = ipvt[j]; src_0 = src[0]; }
     const int kmax = block_argmax_first(bv, bk, red, redi);
     double *pub = red + 40;                                      // [0 .. QRX_C-2] multipliers, then src, ipvt (as ints)
     int *pubi = reinterpret_cast<int *>(pub + QRX_C);
@@ -258,7 +265,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
             pubi[0] = my_src; pubi[1] = my_ipvt;
         }
     } else if (tid == 0) {
-        pubi[0] = src[kmax]; pubi[1] = ipvt[kmax];
+        pubi[0] = fresh ? coff + kmax : src[kmax]; pubi[1] = ipvt[kmax];
     } else if (tid <= np) {
         pub[tid - 1] = tpc[(size_t)(tid - 1) * ldp + kmax];
     }
@@ -298,7 +305,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     // The pivot column with its pending updates applied, oldest first.  Consecutive threads take consecutive rows (eight
     // of them share a sector of the row-blocked matrix); four rows per thread are loaded together before any is stored.
     const double *__restrict__ Vc = w.V + ((size_t)p * 2 + cur) * QRX_C * vst;          // slot q at Vc + q * vst
-    double *__restrict__ Vn = flush ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
+    double *__restrict__ Vn = (flush & 1) ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
                                     : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
     double *Tp = T + (size_t)p * tst;
     // The gathered column also goes to LDS (the region NORM2 later fills with its coefficients: it reads every element
@@ -362,7 +369,7 @@ template <int NP, bool FLUSH>
 __device__ __forceinline__ void
 qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int cur, size_t vst, double s, double rowj, bool refl,
               double ajj, const double (&tq)[NP > 0 ? NP : 1], const double *__restrict__ Tp, const double *__restrict__ vc,
-              const double *__restrict__ vo, double *__restrict__ tpall, int32_t *__restrict__ srcp, int32_t *__restrict__ slotp,
+              const double *__restrict__ vo, double *__restrict__ tpall,
               double *__restrict__ rdall, double *__restrict__ waall, double *__restrict__ Rall, double *__restrict__ qtfall)
 {
     constexpr int NPI = NP < QRX_C ? NP : 0;
@@ -378,11 +385,10 @@ qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int 
     double *rdiag = rdall + (size_t)p * n, *wa = waall + (size_t)p * n;
     const double temp = refl ? s / ajj : 0.0;                           // :654 (residual: w + v*(-s/a) == w - (s/a)*v bit for bit)
     tpn[k] = temp;
-    if (FLUSH) {                                                        // the column now sits at its slot's own position
-        srcp[k] = coff + k;
-        slotp[coff + k] = k;
-        if (col != coff + k) slotp[col] = -1;
-    }
+    // (A flush has put the column at its slot's own position coff + k.  The slot maps are NOT touched here: another
+    // workgroup of this very launch may not have read its lanes' entries yet -- with more workgroups than the chip holds
+    // at once, or rows so few that a workgroup ends before a later one starts, it would take the moved column for a live
+    // one still waiting for its pending updates.  The next step's pivot kernel resets the maps instead.)
     const double rjk = refl ? rowj - temp * ajj : rowj;                 // :655 at i = j: row j is final
     if (k == n) { qtfall[(size_t)p * n + j] = rjk; return; }
     Rall[(size_t)p * n * n + (size_t)k * n + j] = rjk;
@@ -441,7 +447,6 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     const QrxStep step = stepall[p];
     const bool refl = step.ajnorm != 0.0;
     const double ajj = step.ajj;
-    int32_t *srcp = srcall + (size_t)p * ldp;
     int32_t *slotp = slotall + (size_t)p * ld;
     double *tpc = tpall + ((size_t)p * 2 + cur) * QRX_C * ldp;
     double *Tp = T + (size_t)p * tst;
@@ -623,7 +628,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     for (; t < ntile; ++t) tile_guard(t);
 
     if (!act) return;
-    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, refl, ajj, tq, Tp, vc, vo, tpall, srcp, slotp,
+    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, refl, ajj, tq, Tp, vc, vo, tpall,
                              rdall, waall, Rall, qtfall);
 }
 
@@ -673,7 +678,6 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
     const QrxStep step = stepall[p];
     const bool refl = step.ajnorm != 0.0;
     const double ajj = step.ajj;
-    int32_t *srcp = srcall + (size_t)p * ldp;
     int32_t *slotp = slotall + (size_t)p * ld;
     double *tpc = tpall + ((size_t)p * 2 + cur) * QRX_C * ldp;
     double *Tp = T + (size_t)p * tst;
@@ -841,7 +845,7 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
         }
     }
     if (!adder || !act) return;
-    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, refl, ajj, tq, Tp, vc, vo, tpall, srcp, slotp,
+    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, refl, ajj, tq, Tp, vc, vo, tpall,
                              rdall, waall, Rall, qtfall);
 }
 
@@ -961,6 +965,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     static const long rp6_env = [] { const char *e = getenv("NLH_QRX_RP6"); return e ? atol(e) : -1L; }();
     const long rp6_max = std::min(rp_max, rp6_env >= 0 ? rp6_env : (long)QRX_RP6_MAX_WG);
     if (nact <= 0 || nact > nprob) nact = nprob;
+    bool prev_flushed = false;
     int cur = 0, np = 0, lo = 1;             // lo: first slot position that can still hold live data (step 0 moves physically)
     for (int j = 0; j < n; ++j) {
         const int nwin = (n + 1 - lo + 63) / 64;
@@ -972,15 +977,16 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
         if (m <= 2048)
-            hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
+            hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, (flush ? 1 : 0) | (prev_flushed ? 2 : 0),
                                T, w, R, v, (const LmState *)st);
         else
-            hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, flush ? 1 : 0,
+            hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, (flush ? 1 : 0) | (prev_flushed ? 2 : 0),
                                T, w, R, v, (const LmState *)st);
         te(0, stream);
         tb(1, stream);
         dispatch_pass<0>(np, flush, rp, stream, 0, nprob, lo, m, n, ld, coff, tst, vst, j, cur, T, w, R, v.qtf, st);
         te(1, stream);
+        prev_flushed = flush;
         if (flush) { cur ^= 1; np = 1; lo = j + 1; } else { np += 1; }
     }
     tb(2, stream);

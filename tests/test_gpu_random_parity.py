@@ -39,3 +39,38 @@ def test_exact_policy_random_sweep(ds, oracle):
                 assert ibs[p][k] == ibo[k], (where, k, ibs[p], ibo)
             assert np.array_equal(x[p].cpu().numpy(), xo, equal_nan=True), where
             assert np.array_equal(fvec[p].cpu().numpy(), fo, equal_nan=True), where
+
+
+@pytest.mark.parametrize("m,n,base,copies,gen,sub_batches", [
+    (319, 255, 3, 500, dict(sigma=0.0), 0),
+    (319, 255, 3, 500, dict(sigma=0.0), 1),
+    (301, 300, 3, 150, dict(gamma=10.0, sigma=1.0, spread=50.0), 0),
+    (152, 150, 3, 500, dict(gamma=10.0, sigma=1.0, spread=50.0), 0),
+])
+def test_exact_policy_more_workgroups_than_the_chip_holds(ds, oracle, m, n, base, copies, gen, sub_batches):
+    """A few short problems replicated into a batch whose launches have far more workgroups than the chip holds at once
+    and rows so few that a workgroup can end before a later one of the same launch starts: every copy must carry the
+    bits of its original, and the originals the oracle's.  (Found by a soak run: the flushing pass used to update the
+    slot maps in place, and a late workgroup of the same launch could read the updated entry -- different bits in a few
+    copies per thousand, hundreds with several sub-batches in flight.)"""
+    A, b, xt, x0 = ds.generate(base, m, n, seed0=5927, square_shift=(m == n), **gen)
+    A = A.repeat(copies, 1, 1).contiguous()
+    b = b.repeat(copies, 1).contiguous()
+    x0 = x0.repeat(copies, 1).contiguous()
+    nprob = base * copies
+    me = 40 * (n + 1)
+    for trial in range(2):
+        x = x0.clone()
+        fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=me, factor_policy=2, sub_batches=sub_batches))
+        xs, fs = x.cpu().numpy(), fvec.cpu().numpy()
+        for p0 in range(base):
+            assert bool((xs[p0::base] == xs[p0]).all() | np.isnan(xs[p0]).any()), (trial, p0)
+            assert bool((fs[p0::base] == fs[p0]).all() | np.isnan(fs[p0]).any()), (trial, p0)
+            assert all(status[p] == status[p0] and all(ibs[p][k] == ibs[p0][k] for k in KEYS) for p in range(p0, nprob, base))
+            if trial == 0:
+                Ah = np.asfortranarray(A[p0].cpu().numpy().T)
+                rc, xo, fo, ibo = oracle.dq_lm_solve(Ah, b[p0].cpu().numpy(), 0.5, x0[p0].cpu().numpy(),
+                                                     opts=oracle.default_options(max_evals=me))[:4]
+                assert status[p0] == rc
+                assert all(ibs[p0][k] == ibo[k] for k in KEYS)
+                assert np.array_equal(xs[p0], xo, equal_nan=True) and np.array_equal(fs[p0], fo, equal_nan=True)
