@@ -33,6 +33,10 @@
 //   * the column interchange (:626-637) never moves data: slot k of the permuted matrix carries a source
 //     column index src[k]; the pivot column is consumed into the reflector and slot kmax simply inherits
 //     slot j's source and pending multipliers.  The flush writes every slot to its own position.
+//   * RULE: no workgroup of a pass writes anything another workgroup of the same launch reads.  Workgroups of one
+//     launch need not run at the same time (more of them than the chip holds, or rows so few that one ends before a
+//     later one starts).  The slot maps in particular are written only by the pivot kernel (one workgroup per
+//     problem): after a flush the NEXT pivot kernel resets them to the identity (its `fresh` flag).
 // Launches per step: k_qrx_pivot (one workgroup per problem: pivot search, bookkeeping, gather of the pivot
 // column with its pending updates, NORM2 -- a serial chain of m - j adds --, scaling -> reflector) and
 // k_qrx_pass (lane per trailing column; k_qrx_pass_rp, the row-parallel form, when the launch cannot fill the chip:

@@ -13,7 +13,7 @@ from oracle import pyoracle as oracle
 oracle.lib()
 ds = DeviceSolver(0)
 KEYS = ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn", "converge_on_chng", "converge_on_zero_diff")
-SIZES = [1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 63, 64, 65, 95, 96, 97, 100, 127, 128, 129, 150, 200, 255, 256, 257, 300]
+SIZES = [int(v) for v in os.environ["SOAK_SIZES"].split(",")] if os.environ.get("SOAK_SIZES") else [1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 63, 64, 65, 95, 96, 97, 100, 127, 128, 129, 150, 200, 255, 256, 257, 300]
 rng = random.Random(int(os.environ.get("SOAK_SEED", "11")))
 t_end = time.time() + float(os.environ.get("SOAK_SECONDS", "300"))
 case = 0; bad = 0
