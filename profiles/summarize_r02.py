@@ -34,7 +34,7 @@ def family(name):
     name = re.sub(r"^void ", "", name)
     m = re.match(r"([A-Za-z_0-9:]+)", name)
     fam = m.group(1) if m else name
-    return "k_qrx_pass" if fam == "k_qrx_pass_rp" else fam      # the two forms of the trailing pass are one roofline kernel
+    return "k_qrx_pass" if fam in ("k_qrx_pass_rp", "k_qrx_pass_col") else fam      # the forms of the trailing pass are one roofline kernel
 
 
 def qr_pass_bytes(m, n):
