@@ -3,8 +3,8 @@
 The random parity sweep of tests/test_gpu_random_parity.py for as long as SOAK_SECONDS allows, with the base problems also
 replicated into batches of up to 1500 -- launches with more workgroups than the chip holds, every form of the trailing
 pass, several sub-batches in flight.  Every copy must carry the bits of the CPU oracle's solution of its original
-(x, fvec, status, all counts).  Round 2: 551 cases found the slot-map race DESIGN.md section 2 describes; 773 cases after
-the fix: no mismatch."""
+(x, fvec, status, all counts).  Round 2: 551 cases found the slot-map race DESIGN.md section 2 describes; 3,159 cases after
+the fix (four seeds): no mismatch."""
 import os, sys, time, random
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
