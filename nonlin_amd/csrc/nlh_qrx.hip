@@ -316,8 +316,14 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     // before it writes any) when it fits one NORM2 chunk, so that the norm does not start with another trip to memory.
     const bool staged = (m - j <= 64 * QRX_NL);
     double *stage = cd;
-    for (int i0 = j + tid; i0 < m; i0 += 4 * BS) {
-        double e[4], vq[4][QRX_C - 1], mv[4];
+    // ... and in that case every thread KEEPS its rows (at most 64 * QRX_NL / 256 of them) in registers for the scaling
+    // below: the raw column then never goes to memory -- one write of the reflector instead of write, read, write.
+    constexpr int KEEP = 64 * QRX_NL / 256;                      // rows per thread when staged (16 or 8), four per iteration
+    double keep[KEEP];
+#pragma unroll
+    for (int u = 0; u < KEEP; ++u) keep[u] = 0.0;
+    auto gather4 = [&](int i0, double (&e)[4]) __attribute__((always_inline)) {
+        double vq[4][QRX_C - 1], mv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = min(i0 + u * BS, m - 1);
@@ -331,11 +337,30 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
 #pragma unroll
             for (int q = 0; q < QRX_C - 1; ++q)
                 if (q < np) e[u] = e[u] - tk[q] * vq[u][q];
-            if (i0 + u * BS < m) {
-                Vn[i0 + u * BS] = e[u];
-                if (staged) stage[i0 + u * BS - j] = e[u];
-                if (move0) Tp[qrx_at(i0 + u * BS, srck, ld)] = mv[u];
+            if (move0 && i0 + u * BS < m) Tp[qrx_at(i0 + u * BS, srck, ld)] = mv[u];
+        }
+    };
+    if (staged) {
+#pragma unroll
+        for (int it = 0; it < KEEP / 4; ++it) {
+            const int i0 = j + tid + it * 4 * BS;
+            if (i0 < m) {                                        // (not uniform: the last iteration is ragged)
+                double e[4];
+                gather4(i0, e);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    keep[it * 4 + u] = e[u];
+                    if (i0 + u * BS < m) stage[i0 + u * BS - j] = e[u];
+                }
             }
+        }
+    } else {
+        for (int i0 = j + tid; i0 < m; i0 += 4 * BS) {
+            double e[4];
+            gather4(i0, e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * BS < m) Vn[i0 + u * BS] = e[u];
         }
     }
     __syncthreads();
@@ -343,7 +368,26 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     double ajnorm = staged ? norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return stage[i]; }, m - j, cd, aux)
                            : norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return Vn[j + i]; }, m - j, cd, aux);   // :642
     double ajj = 0.0;
-    if (ajnorm != 0.0) {
+    if (staged) {
+        // :645-646 from the registers (ajnorm == 0: the column is zero; the reflector slot still gets the column)
+        if (ajnorm != 0.0 && ejj < 0.0) ajnorm = -ajnorm;         // :644
+#pragma unroll
+        for (int it = 0; it < KEEP / 4; ++it) {
+            const int i0 = j + tid + it * 4 * BS;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * BS;
+                if (i < m) {
+                    double t = keep[it * 4 + u];
+                    if (ajnorm != 0.0) {
+                        t = t / ajnorm;
+                        if (i == j) { t = t + 1.0; ajj = t; }
+                    }
+                    Vn[i] = t;
+                }
+            }
+        }
+    } else if (ajnorm != 0.0) {
         if (ejj < 0.0) ajnorm = -ajnorm;                         // :644
         // :645-646; eight rows per thread are loaded together before any is stored: the compiler must assume that the
         // store of one row aliases the load of the next, and a row-at-a-time loop pays a memory latency per row
