@@ -210,7 +210,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("NLH_BENCH_BATCH", "512")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("NLH_BENCH_BATCH", "2048")),
                     help="problems per GPU per step (weak scaling)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--total-problems", type=int, default=8192, help="problems in all (strong scaling)")

@@ -16,11 +16,11 @@ run_cfg() {   # tag, bench args
     done
     grep "^{\"metric\"" "$OUT/$tag.stats.log" > "$OUT/r02_${tag}_bench_under_rocprof.json"
 }
-run_cfg c2 --batch 512                                  # headline: 512 x 4096x256, exact policy
+run_cfg c2 --batch 2048                                 # headline: 2048 x 4096x256, exact policy
 run_cfg c4 --mrows 2048 --ncols 128 --batch 1024        # config 4: 1024 x 2048x128, exact policy
 run_cfg c5 --mrows 65536 --ncols 512 --batch 1          # config 5: one 65536x512 problem, exact policy
 run_cfg c5auto --mrows 65536 --ncols 512 --batch 1 --policy 0   # config 5, normal-equations policy: FD column + MFMA J^T J kernels
-run_cfg c2auto --batch 512 --policy 0                   # the opt-in fast policy at the headline shape
+run_cfg c2auto --batch 2048 --policy 0                  # the opt-in fast policy at the headline shape
 # FETCH_SIZE calibration for the 8-byte-per-lane streaming pattern of k_qrx_pass (known byte count)
 ( cd profiles/ubench && hipcc -O3 --offload-arch=gfx950 -o fetch_calib fetch_calib.hip > /dev/null 2>&1 )
 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/calib" -o r02 -- profiles/ubench/fetch_calib > "$OUT/calib.log" 2>&1

@@ -25,8 +25,8 @@ import subprocess
 import sys
 from collections import defaultdict
 
-CFG = {"c2": (4096, 256, 512, 2), "c4": (2048, 128, 1024, 2), "c5": (65536, 512, 1, 2),
-       "c5auto": (65536, 512, 1, 0), "c2auto": (4096, 256, 512, 0)}
+CFG = {"c2": (4096, 256, 2048, 2), "c4": (2048, 128, 1024, 2), "c5": (65536, 512, 1, 2),
+       "c5auto": (65536, 512, 1, 0), "c2auto": (4096, 256, 2048, 0)}
 
 
 def family(name):
