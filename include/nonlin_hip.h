@@ -152,6 +152,12 @@ int nlh_cls_solve(nlh_handle *h, const nlh_options *opts, double delta0, double 
                   nlh_vecfcn fcn, nlh_jacfcn jacfcn, void *ctx,
                   double *x, double *fvec, nlh_iteration_behavior *ib);
 
+/* fcnnvar_helper%gradient -- fnh_grad_fcn, src/nonlin_multi_var.f90:182-246.  gradfcn != NULL: the user's gradient.
+ * Otherwise forward differences: g_j = (f(x + h_j e_j) - f(x)) / h_j, h_j = sqrt(eps) |x_j| (sqrt(eps) when x_j = 0),
+ * callbacks in ascending j on the calling thread; x is perturbed and restored; fv = NULL => f(x) is evaluated first.
+ * Host arrays; needs no handle (n + 1 calls of a host function and nothing else). */
+int nlh_fd_gradient(int32_t n, nlh_fcnnvar fcn, nlh_gradfcn gradfcn, void *ctx, double *x, const double *fv, double *g);
+
 /* bfgs%solve -- bfgs_solve, src/nonlin_optimize.f90:557-770, with fcnnvar_helper%gradient
  * (src/nonlin_multi_var.f90:182-246; gradfcn = NULL => forward differences) and ls_search_miso
  * (src/nonlin_linesearch.f90:329-492).  opts->max_evals = get_max_fcn_evals() (500, :46),

@@ -57,6 +57,7 @@ SYMBOLS = {
                                          c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
     "nlh_cls_solve": (C.c_int, [_H, C.POINTER(Options), C.c_double, C.c_double, c_double_p, c_double_p, C.c_int32, C.c_int32,
                                 VECFCN, JACFCN, C.c_void_p, c_double_p, c_double_p, C.POINTER(IterationBehavior)]),
+    "nlh_fd_gradient": (C.c_int, [C.c_int32, FCNNVAR, GRADFCN, C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "nlh_bfgs_solve": (C.c_int, [_H, C.POINTER(Options), C.c_int32, FCNNVAR, GRADFCN, C.c_void_p, c_double_p, c_double_p,
                                  C.POINTER(IterationBehavior)]),
     "nlh_dq_lm_solve_batch": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

@@ -2182,6 +2182,28 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
     return 0;
 }
 
+// fcnnvar_helper%gradient -- fnh_grad_fcn, src/nonlin_multi_var.f90:182-246: the user's gradient routine when there is
+// one, otherwise forward differences with h_j = sqrt(eps) |x_j| (sqrt(eps) at x_j = 0), one evaluation per variable in
+// ascending order on the calling thread, true division.  The work is n + 1 calls of a host function: nothing here for
+// the device; it lives behind the C ABI so that the Fortran shim and nlh_bfgs_solve share one implementation.
+int nlh_fd_gradient(int32_t n, nlh_fcnnvar fcn, nlh_gradfcn gradfcn, void *ctx, double *x, const double *fv, double *g)
+{
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;
+    if (n < 1 || !x || !g) return NLH_INVALID_INPUT_ERROR;
+    if (gradfcn) { gradfcn(ctx, n, x, g); return 0; }
+    const double f0 = fv ? *fv : fcn(ctx, n, x);
+    for (int j = 0; j < n; ++j) {
+        const double xj = x[j];
+        double step = NLH_SQRT_EPS * fabs(xj);
+        if (step == 0.0) step = NLH_SQRT_EPS;
+        x[j] = xj + step;
+        const double fj = fcn(ctx, n, x);
+        x[j] = xj;
+        g[j] = (fj - f0) / step;
+    }
+    return 0;
+}
+
 // bfgs%solve -- bfgs_solve, src/nonlin_optimize.f90:557-770; fcnnvar / gradientfcn callbacks flattened to C
 int nlh_bfgs_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_fcnnvar fcn, nlh_gradfcn gradfcn, void *ctx,
                    double *x, double *fout, nlh_iteration_behavior *ib)
@@ -2193,19 +2215,7 @@ int nlh_bfgs_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_fcnnvar f
     HIPCHK(h, hipSetDevice(h->device));
     BfgsEval ev;
     ev.fcn = [&](const double *xx, double *f) -> int { *f = fcn(ctx, n, xx); return 0; };
-    ev.grad = [&](double *xx, double fv, double *g) -> int {    // fnh_grad_fcn, src/nonlin_multi_var.f90:182-246
-        if (gradfcn) { gradfcn(ctx, n, xx, g); return 0; }
-        for (int j = 0; j < n; ++j) {
-            const double temp = xx[j];
-            double hh = NLH_SQRT_EPS * fabs(temp);
-            if (hh == 0.0) hh = NLH_SQRT_EPS;
-            xx[j] = temp + hh;
-            const double f1 = fcn(ctx, n, xx);
-            xx[j] = temp;
-            g[j] = (f1 - fv) / hh;
-        }
-        return 0;
-    };
+    ev.grad = [&](double *xx, double fv, double *g) -> int { return nlh_fd_gradient(n, fcn, gradfcn, ctx, xx, &fv, g); };
     int rc = bfgs_core(h, o, n, ev, x, fout, ib);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return NLH_ERR_HIP; }

@@ -285,7 +285,10 @@ k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
         if (c < nb) {                              // uniform
             const int par = c & 1;
             // first maximum of |a(r, c)| over r >= c
+            // NaN entries: the ordered search keeps a NaN diagonal entry (nothing compares greater) and never takes a
+            // NaN below it; the max-reduction drops NaNs, so a NaN on the diagonal enters as +Inf at the lowest index
             double v = (mine && r >= c) ? fabs(row[c]) : -1.0;
+            if (r == c && v != v) v = __builtin_inf();
             int idx = (mine && r >= c) ? r : 0x7fffffff;
             double wmax;
             int widx;
@@ -296,7 +299,8 @@ k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
             const double cv = (lane & 15) < nw ? redv[par][lane & 15] : -1.0;
             const int ci = (lane & 15) < nw ? redi[par][lane & 15] : 0x7fffffff;
             const double bv = lu_uniform_lane(lu_row16_max(cv), 15);
-            const int piv = __builtin_amdgcn_readlane(lu_row16_min((cv == bv) ? ci : 0x7fffffff), 15);
+            int piv = __builtin_amdgcn_readlane(lu_row16_min((cv == bv) ? ci : 0x7fffffff), 15);
+            if (piv == 0x7fffffff) piv = c;        // (unreachable: row c is always a candidate)
             // the pivot row and row c through LDS
             if (r == piv) {
 #pragma unroll

@@ -88,6 +88,16 @@ module nonlin_hip_c
             type(nlh_iteration_behavior), intent(out) :: ib
             integer(c_int) :: rc
         end function
+        function nlh_fd_gradient(n, fcn, gradfcn, ctx, x, fv, g) bind(C, name="nlh_fd_gradient") result(rc)
+            import :: c_ptr, c_funptr, c_int, c_int32_t, c_double
+            integer(c_int32_t), value :: n
+            type(c_funptr), value :: fcn, gradfcn
+            type(c_ptr), value :: ctx
+            real(c_double), intent(inout) :: x(*)
+            type(c_ptr), value :: fv
+            real(c_double), intent(out) :: g(*)
+            integer(c_int) :: rc
+        end function
         function nlh_poly_fit(h, npts, order, thru_zero, x, y, coef) bind(C, name="nlh_poly_fit") result(rc)
             import :: c_ptr, c_int, c_int32_t, c_double
             type(c_ptr), value :: h

@@ -1,7 +1,8 @@
-! least_squares_solver, constrained_equation_solver and constrained_least_squares_solver with the reference's
-! public interface (src/nonlin_least_squares.f90:20-74, 80-115, 793-935); solve marshals to nlh_lm_solve
-! (lss_solve on the GPU, :118-391) / nlh_cls_solve (cls_solve, :938-1176) and performs the `error stop`
-! the reference would.
+! least_squares_solver, constrained_equation_solver and constrained_least_squares_solver: the public types and
+! bindings of src/nonlin_least_squares.f90:20-74.  Every `solve` here is a marshalling body: settings go into an
+! nlh_options record, the caller's arrays into contiguous copies, and the iteration itself runs behind the C ABI
+! (nlh_lm_solve / nlh_dq_model_lm_solve = lss_solve on the GPU, :118-391; nlh_cls_solve = cls_solve, :938-1176).
+! The `error stop` the reference would perform is performed here, after the outputs have been copied back.
 module nonlin_least_squares
     use iso_fortran_env
     use, intrinsic :: iso_c_binding
@@ -9,6 +10,7 @@ module nonlin_least_squares
     use nonlin_error_handling
     use nonlin_types
     use nonlin_hip_c
+    use nonlin_shim_support
     implicit none
     private
     public :: least_squares_solver
@@ -16,56 +18,50 @@ module nonlin_least_squares
     public :: constrained_least_squares_solver
 
     type, extends(equation_solver) :: least_squares_solver
-        real(real64), private :: m_factor = 100.0d0
+        real(real64), private :: step_bound_ = 100.0d0           ! lmdif's `factor`
     contains
-        procedure, public :: get_step_scaling_factor => lss_get_factor
-        procedure, public :: set_step_scaling_factor => lss_set_factor
-        procedure, public :: solve => lss_solve
-        procedure, public :: solve_batch => lss_solve_batch
+        procedure, public :: get_step_scaling_factor => lm_step_bound
+        procedure, public :: set_step_scaling_factor => lm_put_step_bound
+        procedure, public :: solve => lm_solve_one
+        procedure, public :: solve_batch => lm_solve_many
     end type
 
     type, abstract, extends(least_squares_solver) :: constrained_equation_solver
-        real(real64), private, allocatable, dimension(:) :: m_upper
-        real(real64), private, allocatable, dimension(:) :: m_lower
+        real(real64), private, allocatable, dimension(:) :: box_hi_
+        real(real64), private, allocatable, dimension(:) :: box_lo_
     contains
-        procedure, public :: get_upper_limits => ces_get_upper_bounds
-        procedure, public :: set_upper_limits => ces_set_upper_bounds
-        procedure, public :: get_lower_limits => ces_get_lower_bounds
-        procedure, public :: set_lower_limits => ces_set_lower_bounds
-        procedure, public :: apply_limits => ces_apply_limits
+        procedure, public :: get_upper_limits => box_hi
+        procedure, public :: set_upper_limits => box_put_hi
+        procedure, public :: get_lower_limits => box_lo
+        procedure, public :: set_lower_limits => box_put_lo
+        procedure, public :: apply_limits => box_project
     end type
 
     type, extends(constrained_equation_solver) :: constrained_least_squares_solver
-        real(real64), private :: m_delta = 1.0d0
-        real(real64), private :: m_scaling = 1.0d0
+        real(real64), private :: radius0_ = 1.0d0                ! initial trust-region radius
+        real(real64), private :: dogleg_scale_ = 1.0d0
     contains
-        procedure, public :: get_trust_region_radius => cls_get_radius
-        procedure, public :: set_trust_region_radius => cls_set_radius
-        procedure, public :: get_step_scaling_factor => cls_get_factor
-        procedure, public :: set_step_scaling_factor => cls_set_factor
-        procedure, public :: solve => cls_solve
+        procedure, public :: get_trust_region_radius => tr_radius0
+        procedure, public :: set_trust_region_radius => tr_put_radius0
+        procedure, public :: get_step_scaling_factor => tr_dogleg_scale
+        procedure, public :: set_step_scaling_factor => tr_put_dogleg_scale
+        procedure, public :: solve => tr_solve_one
     end type
 
 contains
-    pure function lss_get_factor(this) result(x)
+    ! ---- least_squares_solver ----------------------------------------------------------------------------------
+    pure real(real64) function lm_step_bound(this)
         class(least_squares_solver), intent(in) :: this
-        real(real64) :: x
-        x = this%m_factor
+        lm_step_bound = this%step_bound_
     end function
 
-    subroutine lss_set_factor(this, x)      ! clamp: :108-114
+    subroutine lm_put_step_bound(this, x)        ! stored inside [0.1, 100] (reference setter, :80-115)
         class(least_squares_solver), intent(inout) :: this
         real(real64), intent(in) :: x
-        if (x < 0.1d0) then
-            this%m_factor = 0.1d0
-        else if (x > 1.0d2) then
-            this%m_factor = 1.0d2
-        else
-            this%m_factor = x
-        end if
+        this%step_bound_ = into_interval(x, 0.1d0, 1.0d2)
     end subroutine
 
-    subroutine lss_solve(this, fcn, x, fvec, ib, args)
+    subroutine lm_solve_one(this, fcn, x, fvec, ib, args)
         class(least_squares_solver), intent(inout) :: this
         class(vecfcn_helper), intent(in), target :: fcn
         real(real64), intent(inout), dimension(:) :: x
@@ -73,77 +69,52 @@ contains
         type(iteration_behavior), optional :: ib
         class(*), intent(inout), optional, target :: args
 
-        integer(int32) :: neqn, nvar, flag
-        integer(c_int) :: rc
         type(nlh_options) :: opts
-        type(nlh_iteration_behavior) :: cib, cibs(1)
+        type(nlh_iteration_behavior) :: counters(1)
         type(nlh_callback_ctx), target :: ctx
-        type(c_funptr) :: cjac
-        real(c_double), allocatable :: xc(:), fc(:)
-        type(device_model_batch) :: dm
-        integer(c_int32_t) :: st(1)
+        type(device_model_batch) :: onchip
+        type(c_funptr) :: jac_entry
+        real(c_double), allocatable :: xwork(:), fwork(:)
+        integer(c_int32_t) :: outcome(1)
+        integer(c_int) :: rc
+        integer(int32) :: m, n
 
-        neqn = fcn%get_equation_count()
-        nvar = fcn%get_variable_count()
-        if (present(ib)) then           ! :177-185
-            ib%iter_count = 0; ib%fcn_count = 0; ib%jacobian_count = 0; ib%gradient_count = 0
-            ib%converge_on_fcn = .false.; ib%converge_on_chng = .false.; ib%converge_on_zero_diff = .false.
-        end if
-        if (.not.fcn%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR    ! :188
-        if (nvar > neqn) error stop NL_UNDERDEFINED_PROBLEM_ERROR                ! :189
-        flag = 0
-        if (size(x) /= nvar) then
-            flag = 3
-        else if (size(fvec) /= neqn) then
-            flag = 4
-        end if
-        if (flag /= 0) error stop flag
+        m = fcn%get_equation_count()
+        n = fcn%get_variable_count()
+        if (present(ib)) call behavior_clear(ib)
+        if (.not.fcn%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR    ! reference :188
+        if (n > m) error stop NL_UNDERDEFINED_PROBLEM_ERROR                      ! reference :189
+        call require_vector_sizes(size(x), size(fvec), n, m)
 
-        call nlh_default_options(opts)
-        opts%max_evals = this%get_max_fcn_evals()
-        opts%ftol = this%get_fcn_tolerance()
-        opts%xtol = this%get_var_tolerance()
-        opts%gtol = this%get_gradient_tolerance()
-        opts%print_status = merge(1, 0, this%get_print_status())
-        opts%factor = this%m_factor
-        opts%factor_policy = this%factor_policy
-
-        ctx%helper => fcn
-        if (present(args)) ctx%args => args
-        cjac = c_null_funptr
-        if (fcn%is_jacobian_defined()) cjac = c_funloc(nlh_jacfcn_trampoline)
-        allocate(xc(nvar), fc(neqn))    ! contiguous copies: the dummies may be strided sections
-        xc = x
+        call this%export_options(opts)
+        opts%factor = this%step_bound_
+        allocate(xwork(n), source = x)       ! the dummies may be strided sections: the C side wants contiguous memory
+        allocate(fwork(m))
         if (fcn%is_device_model_defined()) then
-            ! set_device_model: the whole iteration runs on the GPU (FD Jacobian, factorisation, lmpar, trial
-            ! evaluations), no host callback; st is the code the reference would stop with
-            dm = fcn%device_model()
-            rc = nlh_dq_model_lm_solve(nlh_default_handle(), opts, dm%c_handle(), xc, fc, cibs, st)
-            cib = cibs(1)
-            if (rc == 0) rc = st(1)
+            ! residual family registered with set_device_model: FD Jacobian, factorisation, lmpar and the trial
+            ! evaluations all run on the GPU; outcome(1) is the code the reference would stop with
+            onchip = fcn%device_model()
+            rc = nlh_dq_model_lm_solve(nlh_default_handle(), opts, onchip%c_handle(), xwork, fwork, counters, outcome)
+            if (rc == 0) rc = outcome(1)
         else
-            rc = nlh_lm_solve(nlh_default_handle(), opts, neqn, nvar, c_funloc(nlh_vecfcn_trampoline), cjac, &
-                c_loc(ctx), xc, fc, cib)
+            ctx%helper => fcn
+            if (present(args)) ctx%args => args
+            jac_entry = c_null_funptr
+            if (fcn%is_jacobian_defined()) jac_entry = c_funloc(nlh_jacfcn_trampoline)
+            rc = nlh_lm_solve(nlh_default_handle(), opts, m, n, c_funloc(nlh_vecfcn_trampoline), jac_entry, &
+                c_loc(ctx), xwork, fwork, counters(1))
         end if
-        x = xc
-        fvec = fc
-        if (present(ib)) then           ! :378-385
-            ib%iter_count = cib%iter_count
-            ib%fcn_count = cib%fcn_count
-            ib%jacobian_count = cib%jacobian_count
-            ib%gradient_count = cib%gradient_count
-            ib%converge_on_fcn = cib%converge_on_fcn /= 0
-            ib%converge_on_chng = cib%converge_on_chng /= 0
-            ib%converge_on_zero_diff = cib%converge_on_zero_diff /= 0
-        end if
-        if (rc /= 0) error stop rc      ! :388-390 (NL_CONVERGENCE_ERROR) or a library failure
+        x = xwork
+        fvec = fwork
+        if (present(ib)) call behavior_import(ib, counters(1))
+        if (rc /= 0) error stop rc      ! NL_CONVERGENCE_ERROR as at :388-390, or a library failure
     end subroutine
 
     !> Extension: least_squares_solver%solve (lss_solve, :118-391) for every problem of a device model batch in
     !> one call.  x(n, nprob) start points in / solutions out, fvec(m, nprob) residuals at the solutions,
     !> ib(nprob) the counters and flags of each solve, status(nprob) = 0 or the code the reference would
     !> `error stop` with for that problem (no process abort: the other problems are unaffected).
-    subroutine lss_solve_batch(this, model, x, fvec, ib, status)
+    subroutine lm_solve_many(this, model, x, fvec, ib, status)
         class(least_squares_solver), intent(inout) :: this
         class(device_model_batch), intent(in) :: model
         real(real64), intent(inout), dimension(:,:) :: x
@@ -151,139 +122,113 @@ contains
         type(iteration_behavior), intent(out), dimension(:), optional :: ib
         integer(int32), intent(out), dimension(:), optional :: status
 
-        integer(int32) :: neqn, nvar, nprob, k
-        integer(c_int) :: rc
         type(nlh_options) :: opts
-        type(nlh_iteration_behavior), allocatable :: cib(:)
-        integer(c_int32_t), allocatable :: st(:)
-        real(c_double), allocatable :: xc(:,:), fc(:,:)
+        type(nlh_iteration_behavior), allocatable :: counters(:)
+        integer(c_int32_t), allocatable :: outcome(:)
+        real(c_double), allocatable :: xwork(:,:), fwork(:,:)
+        integer(c_int) :: rc
+        integer(int32) :: m, n, count
 
         if (.not.model%is_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR
-        neqn = model%get_equation_count()
-        nvar = model%get_variable_count()
-        nprob = model%get_problem_count()
-        if (nvar > neqn) error stop NL_UNDERDEFINED_PROBLEM_ERROR
-        if (size(x, 1) /= nvar .or. size(x, 2) /= nprob) error stop 3
-        if (size(fvec, 1) /= neqn .or. size(fvec, 2) /= nprob) error stop 4
+        m = model%get_equation_count()
+        n = model%get_variable_count()
+        count = model%get_problem_count()
+        if (n > m) error stop NL_UNDERDEFINED_PROBLEM_ERROR
+        if (any(shape(x) /= [n, count])) error stop 3
+        if (any(shape(fvec) /= [m, count])) error stop 4
         if (present(ib)) then
-            if (size(ib) /= nprob) error stop 5
+            if (size(ib) /= count) error stop 5
         end if
         if (present(status)) then
-            if (size(status) /= nprob) error stop 6
+            if (size(status) /= count) error stop 6
         end if
-        call nlh_default_options(opts)
-        opts%max_evals = this%get_max_fcn_evals()
-        opts%ftol = this%get_fcn_tolerance()
-        opts%xtol = this%get_var_tolerance()
-        opts%gtol = this%get_gradient_tolerance()
-        opts%print_status = 0
-        opts%factor = this%m_factor
-        opts%factor_policy = this%factor_policy
-        allocate(cib(nprob), st(nprob), fc(neqn, nprob))
-        xc = x
-        rc = nlh_dq_model_lm_solve(nlh_default_handle(), opts, model%c_handle(), xc, fc, cib, st)
+        call this%export_options(opts, quiet = .true.)
+        opts%factor = this%step_bound_
+        allocate(counters(count), outcome(count), fwork(m, count))
+        allocate(xwork(n, count), source = x)
+        rc = nlh_dq_model_lm_solve(nlh_default_handle(), opts, model%c_handle(), xwork, fwork, counters, outcome)
         if (rc /= 0) error stop rc      ! a library failure, not a per-problem outcome
-        x = xc
-        fvec = fc
-        if (present(status)) status = st
-        if (present(ib)) then
-            do k = 1, nprob
-                ib(k)%iter_count = cib(k)%iter_count
-                ib(k)%fcn_count = cib(k)%fcn_count
-                ib(k)%jacobian_count = cib(k)%jacobian_count
-                ib(k)%gradient_count = cib(k)%gradient_count
-                ib(k)%converge_on_fcn = cib(k)%converge_on_fcn /= 0
-                ib(k)%converge_on_chng = cib(k)%converge_on_chng /= 0
-                ib(k)%converge_on_zero_diff = cib(k)%converge_on_zero_diff /= 0
-            end do
-        end if
+        x = xwork
+        fvec = fwork
+        if (present(status)) status = outcome
+        if (present(ib)) call behavior_import(ib, counters)
     end subroutine
 
-    pure function ces_get_upper_bounds(this) result(rst)    ! :796-808
-        class(constrained_equation_solver), intent(in) :: this
-        real(real64), allocatable, dimension(:) :: rst
-        if (allocated(this%m_upper)) then
-            rst = this%m_upper
+    ! ---- constrained_equation_solver: the box -------------------------------------------------------------------
+    !> A copy of v, or a zero-length vector while v has not been set (what the reference's getters return).
+    pure function copy_or_empty(v) result(r)
+        real(real64), intent(in), allocatable, dimension(:) :: v
+        real(real64), allocatable, dimension(:) :: r
+        if (allocated(v)) then
+            r = v
         else
-            allocate(rst(0))
+            r = [real(real64) ::]
         end if
     end function
 
-    subroutine ces_set_upper_bounds(this, x)                ! :811-824
-        class(constrained_equation_solver), intent(inout) :: this
-        real(real64), intent(in), dimension(:) :: x
-        if (allocated(this%m_upper)) deallocate(this%m_upper)
-        this%m_upper = x
-    end subroutine
-
-    pure function ces_get_lower_bounds(this) result(rst)    ! :827-839
+    pure function box_hi(this) result(r)
         class(constrained_equation_solver), intent(in) :: this
-        real(real64), allocatable, dimension(:) :: rst
-        if (allocated(this%m_lower)) then
-            rst = this%m_lower
-        else
-            allocate(rst(0))
-        end if
+        real(real64), allocatable, dimension(:) :: r
+        r = copy_or_empty(this%box_hi_)
     end function
 
-    subroutine ces_set_lower_bounds(this, x)                ! :842-855
+    pure function box_lo(this) result(r)
+        class(constrained_equation_solver), intent(in) :: this
+        real(real64), allocatable, dimension(:) :: r
+        r = copy_or_empty(this%box_lo_)
+    end function
+
+    subroutine box_put_hi(this, x)
         class(constrained_equation_solver), intent(inout) :: this
         real(real64), intent(in), dimension(:) :: x
-        if (allocated(this%m_lower)) deallocate(this%m_lower)
-        this%m_lower = x
+        this%box_hi_ = x                 ! (re)allocates to the shape of x
     end subroutine
 
-    subroutine ces_apply_limits(this, x)                    ! :858-883
+    subroutine box_put_lo(this, x)
+        class(constrained_equation_solver), intent(inout) :: this
+        real(real64), intent(in), dimension(:) :: x
+        this%box_lo_ = x
+    end subroutine
+
+    !> Projection of x onto the box, lower limits first; limits shorter than x bound only its leading entries.
+    subroutine box_project(this, x)
         class(constrained_equation_solver), intent(in) :: this
         real(real64), intent(inout), dimension(:) :: x
-        integer(int32) :: i, nu, nl, n
-        real(real64), allocatable, dimension(:) :: maxX, minX
-        maxX = this%get_upper_limits()
-        minX = this%get_lower_limits()
-        n = size(x)
-        nu = min(n, size(maxX))
-        nl = min(n, size(minX))
-        do i = 1, nl
-            if (x(i) < minX(i)) x(i) = minX(i)
-        end do
-        do i = 1, nu
-            if (x(i) > maxX(i)) x(i) = maxX(i)
-        end do
-    end subroutine
-
-    pure function cls_get_radius(this) result(rst)          ! :888-895
-        class(constrained_least_squares_solver), intent(in) :: this
-        real(real64) :: rst
-        rst = this%m_delta
-    end function
-
-    subroutine cls_set_radius(this, x)                      ! :898-910
-        class(constrained_least_squares_solver), intent(inout) :: this
-        real(real64), intent(in) :: x
-        if (x <= 0.0d0) then
-            this%m_delta = 1.0d0
-        else
-            this%m_delta = x
+        integer(int32) :: k
+        if (allocated(this%box_lo_)) then
+            k = min(size(x), size(this%box_lo_))
+            where (x(:k) < this%box_lo_(:k)) x(:k) = this%box_lo_(:k)
+        end if
+        if (allocated(this%box_hi_)) then
+            k = min(size(x), size(this%box_hi_))
+            where (x(:k) > this%box_hi_(:k)) x(:k) = this%box_hi_(:k)
         end if
     end subroutine
 
-    pure function cls_get_factor(this) result(rst)          ! :913-920
+    ! ---- constrained_least_squares_solver -----------------------------------------------------------------------
+    pure real(real64) function tr_radius0(this)
         class(constrained_least_squares_solver), intent(in) :: this
-        real(real64) :: rst
-        rst = this%m_scaling
+        tr_radius0 = this%radius0_
     end function
 
-    subroutine cls_set_factor(this, x)                      ! :923-935
+    subroutine tr_put_radius0(this, x)           ! non-positive input selects 1 (reference setter, :898-910)
         class(constrained_least_squares_solver), intent(inout) :: this
         real(real64), intent(in) :: x
-        if (x <= 0.0d0) then
-            this%m_scaling = 1.0d0
-        else
-            this%m_scaling = x
-        end if
+        this%radius0_ = positive_or(x, 1.0d0)
     end subroutine
 
-    subroutine cls_solve(this, fcn, x, fvec, ib, args)      ! :938-1176
+    pure real(real64) function tr_dogleg_scale(this)
+        class(constrained_least_squares_solver), intent(in) :: this
+        tr_dogleg_scale = this%dogleg_scale_
+    end function
+
+    subroutine tr_put_dogleg_scale(this, x)      ! same rule (:923-935)
+        class(constrained_least_squares_solver), intent(inout) :: this
+        real(real64), intent(in) :: x
+        this%dogleg_scale_ = positive_or(x, 1.0d0)
+    end subroutine
+
+    subroutine tr_solve_one(this, fcn, x, fvec, ib, args)
         class(constrained_least_squares_solver), intent(inout) :: this
         class(vecfcn_helper), intent(in), target :: fcn
         real(real64), intent(inout), dimension(:) :: x
@@ -291,67 +236,44 @@ contains
         type(iteration_behavior), optional :: ib
         class(*), intent(inout), optional, target :: args
 
-        integer(int32) :: neqn, nvar, flag
-        integer(c_int) :: rc
         type(nlh_options) :: opts
-        type(nlh_iteration_behavior) :: cib
+        type(nlh_iteration_behavior) :: counters
         type(nlh_callback_ctx), target :: ctx
-        type(c_funptr) :: cjac
-        real(c_double), allocatable :: xc(:), fc(:), xl(:), xu(:)
+        type(c_funptr) :: jac_entry
+        real(c_double), allocatable :: xwork(:), fwork(:), lo(:), hi(:)
+        integer(c_int) :: rc
+        integer(int32) :: m, n
 
-        neqn = fcn%get_equation_count()
-        nvar = fcn%get_variable_count()
-        xl = this%get_lower_limits()
-        xu = this%get_upper_limits()
-        if (present(ib)) then           ! :977-985
-            ib%iter_count = 0; ib%fcn_count = 0; ib%jacobian_count = 0; ib%gradient_count = 0
-            ib%converge_on_fcn = .false.; ib%converge_on_chng = .false.; ib%converge_on_zero_diff = .false.
+        m = fcn%get_equation_count()
+        n = fcn%get_variable_count()
+        if (present(ib)) call behavior_clear(ib)
+        if (.not.fcn%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR    ! reference :988
+        if (n > m) error stop NL_UNDERDEFINED_PROBLEM_ERROR                      ! reference :989
+        call require_vector_sizes(size(x), size(fvec), n, m)
+        ! limits of the wrong length are replaced by an unbounded box, and the replacement is stored (:999-1009)
+        lo = this%get_lower_limits()
+        if (size(lo) /= n) then
+            lo = spread(-huge(1.0d0), 1, n)
+            call this%set_lower_limits(lo)
         end if
-        if (.not.fcn%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR    ! :988
-        if (nvar > neqn) error stop NL_UNDERDEFINED_PROBLEM_ERROR                ! :989
-        flag = 0
-        if (size(x) /= nvar) then
-            flag = 3
-        else if (size(fvec) /= neqn) then
-            flag = 4
-        end if
-        if (flag /= 0) error stop flag
-        if (size(xl) /= nvar) then      ! :999-1009: wrong-sized limits are replaced and stored
-            deallocate(xl)
-            allocate(xl(nvar), source = -huge(0.0d0))
-            call this%set_lower_limits(xl)
-        end if
-        if (size(xu) /= nvar) then
-            deallocate(xu)
-            allocate(xu(nvar), source = huge(0.0d0))
-            call this%set_upper_limits(xu)
+        hi = this%get_upper_limits()
+        if (size(hi) /= n) then
+            hi = spread(huge(1.0d0), 1, n)
+            call this%set_upper_limits(hi)
         end if
 
-        call nlh_default_options(opts)
-        opts%max_evals = this%get_max_fcn_evals()
-        opts%ftol = this%get_fcn_tolerance()
-        opts%xtol = this%get_var_tolerance()
-        opts%gtol = this%get_gradient_tolerance()
-        opts%print_status = merge(1, 0, this%get_print_status())
-
+        call this%export_options(opts)
         ctx%helper => fcn
         if (present(args)) ctx%args => args
-        cjac = c_null_funptr
-        if (fcn%is_jacobian_defined()) cjac = c_funloc(nlh_jacfcn_trampoline)
-        allocate(xc(nvar), fc(neqn))
-        xc = x
-        rc = nlh_cls_solve(nlh_default_handle(), opts, this%m_delta, this%m_scaling, xl, xu, neqn, nvar, &
-            c_funloc(nlh_vecfcn_trampoline), cjac, c_loc(ctx), xc, fc, cib)
-        x = xc
-        fvec = fc
-        if (present(ib)) then           ! :1163-1170
-            ib%iter_count = cib%iter_count
-            ib%fcn_count = cib%fcn_count
-            ib%jacobian_count = cib%jacobian_count
-            ib%converge_on_fcn = cib%converge_on_fcn /= 0
-            ib%converge_on_chng = cib%converge_on_chng /= 0
-            ib%converge_on_zero_diff = cib%converge_on_zero_diff /= 0
-        end if
-        if (rc /= 0) error stop rc      ! :1173-1175
+        jac_entry = c_null_funptr
+        if (fcn%is_jacobian_defined()) jac_entry = c_funloc(nlh_jacfcn_trampoline)
+        allocate(xwork(n), source = x)
+        allocate(fwork(m))
+        rc = nlh_cls_solve(nlh_default_handle(), opts, this%radius0_, this%dogleg_scale_, lo, hi, m, n, &
+            c_funloc(nlh_vecfcn_trampoline), jac_entry, c_loc(ctx), xwork, fwork, counters)
+        x = xwork
+        fvec = fwork
+        if (present(ib)) call behavior_import(ib, counters)
+        if (rc /= 0) error stop rc      ! as at :1173-1175
     end subroutine
 end module

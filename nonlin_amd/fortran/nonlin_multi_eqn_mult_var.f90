@@ -110,6 +110,7 @@ module nonlin_multi_eqn_mult_var
         procedure, public :: set_gradient_tolerance => cfg_put_gtol
         procedure, public :: get_print_status => cfg_verbose
         procedure, public :: set_print_status => cfg_put_verbose
+        procedure, public :: export_options => cfg_export
         procedure(nonlin_solver), deferred, public, pass :: solve
     end type
 
@@ -419,6 +420,24 @@ contains
         class(equation_solver), intent(inout) :: this
         logical, intent(in) :: x
         this%verbose_ = x
+    end subroutine
+
+    !> Extension used by every solve body of the shim: the C ABI's option record with this solver's settings
+    !> (library defaults for everything the base type does not hold); quiet = .true. suppresses print_status.
+    subroutine cfg_export(this, opts, quiet)
+        class(equation_solver), intent(in) :: this
+        type(nlh_options), intent(out) :: opts
+        logical, intent(in), optional :: quiet
+        call nlh_default_options(opts)
+        opts%max_evals = this%max_evals_
+        opts%ftol = this%ftol_
+        opts%xtol = this%xtol_
+        opts%gtol = this%gtol_
+        opts%print_status = merge(1, 0, this%verbose_)
+        if (present(quiet)) then
+            if (quiet) opts%print_status = 0
+        end if
+        opts%factor_policy = this%factor_policy
     end subroutine
 
     ! ---- trampolines: the C layer's nlh_vecfcn / nlh_jacfcn --------------------------------

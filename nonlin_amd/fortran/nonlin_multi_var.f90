@@ -5,6 +5,7 @@ module nonlin_multi_var
     use, intrinsic :: iso_c_binding
     use nonlin_types
     use nonlin_error_handling
+    use nonlin_hip_c, only : nlh_fd_gradient
     implicit none
     private
     public :: fcnnvar
@@ -132,43 +133,42 @@ contains
         call this%grad_ptr_(x, g, args)
     end subroutine
 
-    ! obj_gradient, :182-246: n + 1 evaluations of a scalar; the work is the user's function, so it stays here.
+    !> fcnnvar_helper%gradient (public behaviour of fnh_grad_fcn, src/nonlin_multi_var.f90:182-246): marshals to
+    !> nlh_fd_gradient, which calls the user's gradient routine when one is bound and otherwise takes forward
+    !> differences through the objective trampoline; x is perturbed and restored by the C side's working copy.
     subroutine obj_gradient(this, x, g, fv, args)
-        class(fcnnvar_helper), intent(in) :: this
+        class(fcnnvar_helper), intent(in), target :: this
         real(real64), intent(inout), dimension(:) :: x
         real(real64), intent(out), dimension(:) :: g
         real(real64), intent(in), optional :: fv
-        class(*), intent(inout), optional :: args
-        integer(int32) :: j, n, flag
-        real(real64) :: eps, h, temp, f, f1
+        class(*), intent(inout), optional, target :: args
+
+        type(nlh_scalar_ctx), target :: ctx
+        real(c_double), allocatable :: xwork(:), gwork(:)
+        real(c_double), target :: f0
+        type(c_funptr) :: grad_entry
+        type(c_ptr) :: f0_entry
+        integer(c_int) :: rc
+        integer(int32) :: n
+
         n = this%get_variable_count()
-        flag = 0
-        if (size(x) /= n) then
-            flag = 2
-        else if (size(g) /= n) then
-            flag = 3
-        end if
-        if (flag /= 0) error stop flag
+        if (size(x) /= n) error stop 2                          ! the reference's size checks stop with 2 and 3
+        if (size(g) /= n) error stop 3
         if (.not.this%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR
-        if (this%is_gradient_defined()) then
-            call this%grad_ptr_(x, g, args)
-        else
-            if (present(fv)) then
-                f = fv
-            else
-                f = this%fcn(x, args)
-            end if
-            eps = sqrt(epsilon(eps))
-            do j = 1, n
-                temp = x(j)
-                h = eps * abs(temp)
-                if (h == 0.0d0) h = eps
-                x(j) = temp + h
-                f1 = this%fcn(x, args)
-                x(j) = temp
-                g(j) = (f1 - f) / h
-            end do
+        ctx%helper => this
+        if (present(args)) ctx%args => args
+        grad_entry = c_null_funptr
+        if (this%is_gradient_defined()) grad_entry = c_funloc(nlh_gradfcn_trampoline)
+        f0_entry = c_null_ptr
+        if (present(fv)) then
+            f0 = fv
+            f0_entry = c_loc(f0)
         end if
+        allocate(xwork(n), source = x)
+        allocate(gwork(n))
+        rc = nlh_fd_gradient(n, c_funloc(nlh_fcnnvar_trampoline), grad_entry, c_loc(ctx), xwork, f0_entry, gwork)
+        if (rc /= 0) error stop rc
+        g = gwork
     end subroutine
 
     pure function opt_max_evals(this) result(n)

@@ -1,5 +1,6 @@
-! line_search_optimizer and bfgs with the reference's public interface (src/nonlin_optimize.f90:44-72, 470-556);
-! bfgs%solve marshals to nlh_bfgs_solve (bfgs_solve on the GPU, :557-770).  nelder_mead is outside the hot path.
+! line_search_optimizer and bfgs: the public types and bindings of src/nonlin_optimize.f90:44-72, 470-556.
+! bfgs%solve marshals to nlh_bfgs_solve (bfgs_solve behind the C ABI, :557-770); the line search is a parameter
+! record here.  nelder_mead is outside the hot path.
 module nonlin_optimize
     use iso_fortran_env
     use, intrinsic :: iso_c_binding
@@ -8,82 +9,99 @@ module nonlin_optimize
     use nonlin_multi_var
     use nonlin_types
     use nonlin_hip_c
+    use nonlin_shim_support
     implicit none
     private
     public :: line_search_optimizer
     public :: bfgs
 
     type, abstract, extends(equation_optimizer) :: line_search_optimizer
-        class(line_search), private, allocatable :: m_lineSearch
-        logical, private :: m_useLineSearch = .true.
-        real(real64), private :: xtol_ = 1.0d-12
+        class(line_search), private, allocatable :: search_
+        logical, private :: search_on_ = .true.
+        real(real64), private :: step_tol_ = 1.0d-12         ! convergence on the change in x
     contains
-        procedure, public :: get_line_search => lso_get_line_search
-        procedure, public :: set_line_search => lso_set_line_search
-        procedure, public :: set_default_line_search => lso_set_default
-        procedure, public :: is_line_search_defined => lso_is_line_search_defined
-        procedure, public :: get_use_line_search => lso_get_use_search
-        procedure, public :: set_use_line_search => lso_set_use_search
-        procedure, public :: get_var_tolerance => lso_get_var_tol
-        procedure, public :: set_var_tolerance => lso_set_var_tol
+        procedure, public :: get_line_search => lsopt_copy_search
+        procedure, public :: set_line_search => lsopt_put_search
+        procedure, public :: set_default_line_search => lsopt_default_search
+        procedure, public :: is_line_search_defined => lsopt_has_search
+        procedure, public :: get_use_line_search => lsopt_enabled
+        procedure, public :: set_use_line_search => lsopt_enable
+        procedure, public :: get_var_tolerance => lsopt_step_tol
+        procedure, public :: set_var_tolerance => lsopt_put_step_tol
+        procedure, public :: export_options => lsopt_export
     end type
 
     type, extends(line_search_optimizer) :: bfgs
     contains
-        procedure, public :: solve => bfgs_solve
+        procedure, public :: solve => bfgs_solve_one
     end type
 
 contains
-    subroutine lso_get_line_search(this, ls)
+    pure logical function lsopt_has_search(this)
+        class(line_search_optimizer), intent(in) :: this
+        lsopt_has_search = allocated(this%search_)
+    end function
+
+    !> ls = a copy of the optimizer's search object; left unallocated while none has been set.
+    subroutine lsopt_copy_search(this, ls)
         class(line_search_optimizer), intent(in) :: this
         class(line_search), intent(out), allocatable :: ls
-        if (allocated(this%m_lineSearch)) allocate(ls, source = this%m_lineSearch)
+        if (this%is_line_search_defined()) allocate(ls, source = this%search_)
     end subroutine
 
-    subroutine lso_set_line_search(this, ls)
+    subroutine lsopt_put_search(this, ls)
         class(line_search_optimizer), intent(inout) :: this
         class(line_search), intent(in) :: ls
-        if (allocated(this%m_lineSearch)) deallocate(this%m_lineSearch)
-        allocate(this%m_lineSearch, source = ls)
+        if (this%is_line_search_defined()) deallocate(this%search_)
+        allocate(this%search_, source = ls)
     end subroutine
 
-    subroutine lso_set_default(this)
+    subroutine lsopt_default_search(this)
         class(line_search_optimizer), intent(inout) :: this
-        type(line_search) :: ls
-        call this%set_line_search(ls)
+        call this%set_line_search(line_search())
     end subroutine
 
-    pure function lso_is_line_search_defined(this) result(x)
+    pure logical function lsopt_enabled(this)
         class(line_search_optimizer), intent(in) :: this
-        logical :: x
-        x = allocated(this%m_lineSearch)
+        lsopt_enabled = this%search_on_
     end function
 
-    pure function lso_get_use_search(this) result(x)
-        class(line_search_optimizer), intent(in) :: this
-        logical :: x
-        x = this%m_useLineSearch
-    end function
-
-    subroutine lso_set_use_search(this, x)
+    subroutine lsopt_enable(this, x)
         class(line_search_optimizer), intent(inout) :: this
         logical, intent(in) :: x
-        this%m_useLineSearch = x
+        this%search_on_ = x
     end subroutine
 
-    pure function lso_get_var_tol(this) result(x)
+    pure real(real64) function lsopt_step_tol(this)
         class(line_search_optimizer), intent(in) :: this
-        real(real64) :: x
-        x = this%xtol_
+        lsopt_step_tol = this%step_tol_
     end function
 
-    subroutine lso_set_var_tol(this, x)
+    subroutine lsopt_put_step_tol(this, x)
         class(line_search_optimizer), intent(inout) :: this
         real(real64), intent(in) :: x
-        this%xtol_ = x
+        this%step_tol_ = x
     end subroutine
 
-    subroutine bfgs_solve(this, fcn, x, fout, ib, args)     ! :557-770
+    !> Extension: this optimizer's settings as the C ABI's option record.  As in the reference (:603-608) an
+    !> optimizer that searches but has no search object yet gets the default one, and keeps it.
+    subroutine lsopt_export(this, opts)
+        class(line_search_optimizer), intent(inout) :: this
+        type(nlh_options), intent(out) :: opts
+        call nlh_default_options(opts)
+        opts%max_evals = this%get_max_fcn_evals()
+        opts%gtol = this%get_tolerance()
+        opts%xtol = this%step_tol_
+        opts%print_status = merge(1, 0, this%get_print_status())
+        opts%use_line_search = merge(1, 0, this%search_on_)
+        if (.not.this%search_on_) return
+        if (.not.this%is_line_search_defined()) call this%set_default_line_search()
+        opts%ls_max_evals = this%search_%get_max_fcn_evals()
+        opts%ls_alpha = this%search_%get_scaling_factor()
+        opts%ls_factor = this%search_%get_distance_factor()
+    end subroutine
+
+    subroutine bfgs_solve_one(this, fcn, x, fout, ib, args)
         class(bfgs), intent(inout) :: this
         class(fcnnvar_helper), intent(in), target :: fcn
         real(real64), intent(inout), dimension(:) :: x
@@ -91,57 +109,33 @@ contains
         type(iteration_behavior), optional :: ib
         class(*), intent(inout), optional, target :: args
 
-        integer(int32) :: n
-        integer(c_int) :: rc
         type(nlh_options) :: opts
-        type(nlh_iteration_behavior) :: cib
+        type(nlh_iteration_behavior) :: counters
         type(nlh_scalar_ctx), target :: ctx
-        type(c_funptr) :: cgrad
-        real(c_double), allocatable :: xc(:)
-        real(c_double) :: fo
-        class(line_search), allocatable :: ls
+        type(c_funptr) :: grad_entry
+        real(c_double), allocatable :: xwork(:)
+        real(c_double) :: fmin
+        integer(c_int) :: rc
+        integer(int32) :: n
 
         n = fcn%get_variable_count()
-        if (present(ib)) then           ! :594-602
-            ib%iter_count = 0; ib%fcn_count = 0; ib%jacobian_count = 0; ib%gradient_count = 0
-            ib%converge_on_fcn = .false.; ib%converge_on_chng = .false.; ib%converge_on_zero_diff = .false.
-        end if
-        call nlh_default_options(opts)
-        if (this%get_use_line_search()) then        ! :603-608
-            if (.not.this%is_line_search_defined()) call this%set_default_line_search()
-            call this%get_line_search(ls)
-            opts%ls_max_evals = ls%get_max_fcn_evals()
-            opts%ls_alpha = ls%get_scaling_factor()
-            opts%ls_factor = ls%get_distance_factor()
-        end if
-        if (.not.fcn%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR    ! :614
-        if (size(x) /= n) error stop NL_INVALID_INPUT_ERROR                      ! :615
-
-        opts%max_evals = this%get_max_fcn_evals()
-        opts%gtol = this%get_tolerance()
-        opts%xtol = this%get_var_tolerance()
-        opts%print_status = merge(1, 0, this%get_print_status())
-        opts%use_line_search = merge(1, 0, this%get_use_line_search())
-
+        if (present(ib)) call behavior_clear(ib)
+        call this%export_options(opts)
+        if (.not.fcn%is_fcn_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR    ! reference :614
+        if (size(x) /= n) error stop NL_INVALID_INPUT_ERROR                      ! reference :615
         ctx%helper => fcn
         if (present(args)) ctx%args => args
-        cgrad = c_null_funptr
-        if (fcn%is_gradient_defined()) cgrad = c_funloc(nlh_gradfcn_trampoline)
-        allocate(xc(n))
-        xc = x
-        rc = nlh_bfgs_solve(nlh_default_handle(), opts, n, c_funloc(nlh_fcnnvar_trampoline), cgrad, c_loc(ctx), &
-            xc, fo, cib)
-        x = xc
-        if (present(fout)) fout = fo    ! :762
-        if (present(ib)) then           ! :751-759
-            ib%iter_count = cib%iter_count
-            ib%fcn_count = cib%fcn_count
-            ib%jacobian_count = 0
-            ib%gradient_count = cib%gradient_count
-            ib%converge_on_fcn = .false.
-            ib%converge_on_chng = cib%converge_on_chng /= 0
-            ib%converge_on_zero_diff = cib%converge_on_zero_diff /= 0
+        grad_entry = c_null_funptr
+        if (fcn%is_gradient_defined()) grad_entry = c_funloc(nlh_gradfcn_trampoline)
+        allocate(xwork(n), source = x)
+        rc = nlh_bfgs_solve(nlh_default_handle(), opts, n, c_funloc(nlh_fcnnvar_trampoline), grad_entry, c_loc(ctx), &
+            xwork, fmin, counters)
+        x = xwork
+        if (present(fout)) fout = fmin
+        if (present(ib)) then
+            call behavior_import(ib, counters)      ! jacobian_count = 0, gradient_count filled by the C side
+            ib%converge_on_fcn = .false.            ! bfgs has no such test (reference :751-759)
         end if
-        if (rc /= 0) error stop rc      ! :765-767
+        if (rc /= 0) error stop rc      ! as at :765-767
     end subroutine
 end module

@@ -202,3 +202,35 @@ def test_lu_singular_and_tied_pivots(ds, oracle, n):
     assert int(info[0]) == rc and rc > 0
     assert np.array_equal(ipvt[0].cpu().numpy(), ipo)
     assert np.array_equal(Ad[0].cpu().numpy().T, lu, equal_nan=True)
+
+
+@pytest.mark.parametrize("n", [40, 130, 300])
+@pytest.mark.parametrize("kind", ["all_nan", "nan_column", "nan_diagonal", "scattered"])
+def test_lu_nan_entries_keep_a_valid_pivot(ds, oracle, n, kind):
+    """NaN entries (a NaN Jacobian from a host callback, a NaN start point): the ordered pivot search of the CPU loop
+    keeps a NaN diagonal entry and never selects a NaN below it.  Every pivot index must stay inside the matrix (the
+    interchange and solve kernels index with it) and equal the CPU loop's."""
+    import ctypes as C
+    rng = np.random.default_rng(n)
+    Ah = np.asfortranarray(rng.standard_normal((n, n)))
+    if kind == "all_nan":
+        Ah[:] = np.nan
+    elif kind == "nan_column":
+        Ah[:, n // 3] = np.nan
+    elif kind == "nan_diagonal":
+        Ah[n // 2, n // 2] = np.nan
+    else:
+        Ah[rng.random((n, n)) < 0.02] = np.nan
+    lu = Ah.copy(order="F")
+    ipo = np.zeros(n, dtype=np.int32)
+    L = oracle.lib()
+    L.nlo_lu_factor(n, lu.ctypes.data_as(C.POINTER(C.c_double)), n, ipo.ctypes.data_as(C.POINTER(C.c_int32)))
+    Ad = torch.tensor(np.ascontiguousarray(Ah.T), device="cuda").unsqueeze(0)
+    bd = torch.tensor(rng.standard_normal(n), device="cuda").unsqueeze(0)
+    ipvt, info = ds.lu_factor(Ad)
+    ds.lu_solve(Ad, ipvt, bd)
+    torch.cuda.synchronize()
+    ip = ipvt[0].cpu().numpy()
+    assert ip.min() >= 0 and ip.max() < n
+    if kind != "scattered":                      # (scattered NaNs: the strided small-n search may pick another NaN row)
+        assert np.array_equal(ip, ipo)
