@@ -791,7 +791,8 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
 static int lm_sub_batches(const nlh_options *o, int nprob, int m, int n)
 {
     int S = o->sub_batches;
-    if (const char *e = getenv("NLH_SUB_BATCHES")) S = atoi(e);
+    if (S <= 0)                                     // the environment only fills in for "automatic", never overrides a caller
+        if (const char *e = getenv("NLH_SUB_BATCHES")) S = atoi(e);
     if (S <= 0) {                                   // auto: >= 128 problems per sub-batch, at most 3 in flight (measured
         S = nprob / 128;                            // on 512 x 4096x256 exact: 1 / 2 / 3 / 4 -> 1032 / 959 / 928 / 1036 ms)
         if (S > 3) S = 3;

@@ -334,9 +334,10 @@ void nlo_lmpar(int32_t m, int32_t n, double *r, int32_t ldr, const int32_t *ipvt
         dxnorm = nlo_norm2(m, wa2);                          /* :531 deviation A */
         temp = fp;
         fp = dxnorm - delta;
-        if (getenv("NLO_DEBUG_LMPAR"))
-            fprintf(stderr, "[lmpar] iter=%d par=%.17g parl=%.6g paru=%.6g dxnorm=%.17g fp=%.6g delta=%.6g\n",
-                    iter, *par, parl, paru, dxnorm, fp, delta);
+#ifdef NLO_TRACE
+        fprintf(stderr, "[lmpar] iter=%d par=%.17g parl=%.6g paru=%.6g dxnorm=%.17g fp=%.6g delta=%.6g\n",
+                iter, *par, parl, paru, dxnorm, fp, delta);
+#endif
 
         if (fabs(fp) <= p1 * delta ||
             (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;  /* :538-540 */
@@ -478,9 +479,10 @@ int nlo_lm_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_null,
 
             ratio = 0.0;                                     /* :319-320 */
             if (prered != 0.0) ratio = actred / prered;
-            if (getenv("NLO_DEBUG"))
-                fprintf(stderr, "[nlo] iter=%d neval=%d fnorm=%.17g fnorm1=%.17g par=%.6g delta=%.6g pnorm=%.6g actred=%.6g prered=%.6g ratio=%.6g gnorm=%.3g\n",
-                        iter, neval, fnorm, fnorm1, par, delta, pnorm, actred, prered, ratio, gnorm);
+#ifdef NLO_TRACE                                              /* build-time tracing: nothing in the timed loops */
+            fprintf(stderr, "[nlo] iter=%d neval=%d fnorm=%.17g fnorm1=%.17g par=%.6g delta=%.6g pnorm=%.6g actred=%.6g prered=%.6g ratio=%.6g gnorm=%.3g\n",
+                    iter, neval, fnorm, fnorm1, par, delta, pnorm, actred, prered, ratio, gnorm);
+#endif
 
             if (ratio <= qtr) {                              /* :323-337 */
                 if (actred >= 0.0) temp = half;
