@@ -26,6 +26,7 @@
 #include "nlh_kernels_factor.h"
 #include "nlh_kernels_lm.h"
 #include "nlh_kernels_lu.h"
+#include "nlh_kernels_newton.h"
 #include "nlh_kernels_broyden.h"
 #include "nlh_kernels_bfgs.h"
 #include "nlh_kernels_exact.h"
@@ -503,11 +504,12 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
 static int factor_threads(int n) { return n >= 96 ? 1024 : 256; }
 
 // lu_factor: unblocked single-workgroup kernel for small n, blocked multi-kernel path otherwise.
-static void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipvt, int32_t *dinfo)
+static void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipvt, int32_t *dinfo,
+                             const LmState *st = nullptr, int want = -1)
 {
     Timed t(h, NLH_K_LU);
     if (n < 128) {
-        hipLaunchKernelGGL(k_lu_factor, dim3(nprob), dim3(n >= 96 ? 1024 : 256), 0, h->stream, n, dA, dipvt, dinfo);
+        hipLaunchKernelGGL(k_lu_factor, dim3(nprob), dim3(n >= 96 ? 1024 : 256), 0, h->stream, n, dA, dipvt, dinfo, st, want);
         return;
     }
     if (dinfo) hipMemsetAsync(dinfo, 0, sizeof(int32_t) * (size_t)nprob, h->stream);
@@ -518,15 +520,16 @@ static void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_
         const int nb = (n - jb < pw) ? (n - jb) : pw;
         if (lds)
             // one thread per panel row: waves without rows would still run the step's instruction stream and barriers
-            hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(std::min(1024, (n - jb + 63) & ~63)), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
+            hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(std::min(1024, (n - jb + 63) & ~63)), 0, h->stream, n, dA, dipvt, dinfo, jb, nb,
+                               st, want);
         else
-            hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb);
+            hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb, st, want);
         if (n - nb > 0)
             hipLaunchKernelGGL(k_lu_swap_trsm, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
-                               (const int32_t *)dipvt, jb, nb);
+                               (const int32_t *)dipvt, jb, nb, st, want);
         const int nt = n - jb - nb;
         if (nt > 0) {
-            hipLaunchKernelGGL(k_lu_gemm, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, h->stream, n, dA, jb, nb);
+            hipLaunchKernelGGL(k_lu_gemm, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, h->stream, n, dA, jb, nb, st, want);
         }
         jb += nb;
     }
@@ -1116,14 +1119,16 @@ static int newton_core(nlh_handle *h, const nlh_options *o, int n, NewtonEval &e
             HIPCHK(h, hipMemcpyAsync(dfvec, fvec, sizeof(double) * n, hipMemcpyHostToDevice, s));
             {
                 Timed t(h, NLH_K_JTF);
-                hipLaunchKernelGGL(k_jtf_exact, dim3((n + 255) / 256), dim3(256), 0, s, n, n, dJ, dfvec, dgrad);
+                hipLaunchKernelGGL(k_jtf_exact, dim3((n + 255) / 256, 1), dim3(256), 0, s, n, n, (const double *)dJ, (const double *)dfvec, dgrad,
+                                   (const LmState *)nullptr, -1);
             }
             // LU of a copy (:570) and solve for -fvec (:577)
             HIPCHK(h, hipMemcpyAsync(dLU, dJ, sizeof(double) * nn, hipMemcpyDeviceToDevice, s));
             launch_lu_factor(h, 1, n, dLU, dipvt, (int32_t *)nullptr);
             for (int i = 0; i < n; ++i) rhs[i] = -fvec[i];
             HIPCHK(h, hipMemcpyAsync(drhs, rhs.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, s, n, dLU, dipvt, drhs);
+            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, s, n, (const double *)dLU, (const int32_t *)dipvt, drhs,
+                               (const LmState *)nullptr, -1);
             HIPCHK(h, hipMemcpyAsync(dir.data(), drhs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipMemcpyAsync(grad.data(), dgrad, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipStreamSynchronize(s));
@@ -1914,62 +1919,95 @@ int nlh_newton_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_vecfcn 
     return rc;
 }
 
+// newton_solver%solve for a batch of device-model problems: the lock-step state machine of nlh_kernels_newton.h.  A round
+// serves every problem in whatever stage it is: the ones that want a Jacobian get J (analytic or forward differences),
+// grad = J^T F in the reference's row order, the LU of J in place (the reference factors a copy; J is not read again in
+// the iteration), the direction and the set-up of the line search; the ones with a trial point get F(x) and one turn of
+// the search loop / the convergence test.  One 8-byte read-back per round.
 int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t n, const double *dA,
                               const double *db, double gamma, int32_t analytic, double *dx, double *dfvec,
                               nlh_iteration_behavior *ib, int32_t *status)
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
-    if (!o || n < 1) return NLH_INVALID_INPUT_ERROR;
+    if (!o || n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
-    // one problem per call; run_problems deals the problems to worker threads with private handles
-    auto solve_one = [&](nlh_handle *h, int p) -> int {
-        int rc;
-        const size_t nn = (size_t)n * n;
-        if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
-        if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
-        if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
-        hipStream_t s = h->stream;
-        std::vector<double> x(n), f(n);
-        const double *A = dA + (size_t)p * nn, *b = db + (size_t)p * n;
-        double *dxp = dx + (size_t)p * n, *dfp = dfvec + (size_t)p * n;
-        double *dxs = (double *)h->xdev.p, *dfs = (double *)h->wa4.p;
-        HIPCHK(h, hipMemcpyAsync(x.data(), dxp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipStreamSynchronize(s));
-        NewtonEval ev;
-        ev.fcn = [&](const double *xx, double *ff) -> int {
-            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
-            launch_dq_residual(h, 1, n, n, A, b, gamma, dxs, dfs, nullptr, nullptr, -1);
-            HIPCHK(h, hipMemcpyAsync(ff, dfs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
-            HIPCHK(h, hipStreamSynchronize(s));
-            return 0;
-        };
-        ev.jac = [&](double *xx, const double *f0, double *dJ) -> int {
-            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    int rc;
+    const size_t nn = (size_t)n * n, np = (size_t)nprob;
+    if ((rc = ensure(h, h->J, sizeof(double) * nn * np))) return rc;
+    if (!analytic && (rc = ensure(h, h->P, sizeof(double) * nn * np))) return rc;
+    if ((rc = ensure(h, h->vecs, sizeof(double) * 3 * n * np))) return rc;
+    if ((rc = ensure(h, h->ipvt, sizeof(int32_t) * n * np))) return rc;
+    if ((rc = ensure(h, h->state, sizeof(LmState) * np))) return rc;
+    if ((rc = ensure(h, h->misc, sizeof(NtState) * np + 64))) return rc;
+    if ((rc = ensure_pinned(h, sizeof(NtState) * np + 64))) return rc;
+    double *dJ = (double *)h->J.p, *dP = (double *)h->P.p;
+    double *dxold = (double *)h->vecs.p, *ddir = dxold + (size_t)n * np, *dgrad = ddir + (size_t)n * np;
+    int32_t *dipvt = (int32_t *)h->ipvt.p;
+    LmState *st = (LmState *)h->state.p;
+    int32_t *dcounts = (int32_t *)h->misc.p;
+    NtState *ns = (NtState *)((char *)h->misc.p + 64);
+    int32_t *hcounts = (int32_t *)h->pinned;
+    NtState *hns = (NtState *)((char *)h->pinned + 64);
+    hipStream_t s = h->stream;
+    NtOpts no;
+    no.ftol = o->ftol; no.xtol = o->xtol; no.gtol = o->gtol; no.ls_alpha = o->ls_alpha; no.ls_factor = o->ls_factor;
+    no.max_evals = o->max_evals; no.ls_max_evals = o->ls_max_evals; no.use_line_search = o->use_line_search ? 1 : 0; no.pad = 0;
+    const int pb = (nprob + 255) / 256;
+    const bool echo = o->print_status && nprob == 1;             // the status block is a single solve's (:611-613)
+
+    // (:535 asks for a Jacobian before fvec is defined and discards it: nothing observable for a device model.)
+    hipLaunchKernelGGL(k_nt_reset, dim3(pb), dim3(256), 0, s, nprob, st, ns);
+    launch_dq_residual(h, nprob, n, n, dA, db, gamma, dx, dfvec, nullptr, st, NT_START);       // :538
+    hipLaunchKernelGGL(k_nt_start, dim3(nprob), dim3(256), 0, s, n, no, (const double *)dx, (const double *)dfvec, st, ns);
+    int need_jac = nprob, trial = 0;                             // upper bounds until the first read-back
+    // a round advances every live problem by one evaluation at least, and a solve makes at most max_evals + ls_max_evals
+    const long max_rounds = (long)o->max_evals + (long)o->ls_max_evals + 8;
+    for (long round = 0; round < max_rounds; ++round) {
+        if (need_jac > 0) {
             if (analytic) {
                 Timed t(h, NLH_K_DQ_JACOBIAN);
-                hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((n + RB - 1) / RB, 1), dim3(RB), sizeof(double) * n, s,
-                                   n, n, A, gamma, dxs, dJ);
-            } else {
-                HIPCHK(h, hipMemcpyAsync(dfs, f0, sizeof(double) * n, hipMemcpyHostToDevice, s));
-                launch_dq_panel(h, 1, n, n, A, b, gamma, dxs, (double *)h->P.p, nullptr, -1);
-                launch_fd(h, 1, n, n, (const double *)h->P.p, dfs, dxs, dJ, nullptr, -1);
+                hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((n + RB - 1) / RB, nprob), dim3(RB), sizeof(double) * n, s,
+                                   n, n, dA, gamma, (const double *)dx, dJ, (const LmState *)st, (int)NT_NEED_JAC);
+            } else {                                             // vfh_jac_fcn: n perturbed evaluations, (f1 - f0) / h
+                launch_dq_panel(h, nprob, n, n, dA, db, gamma, dx, dP, st, NT_NEED_JAC);
+                launch_fd(h, nprob, n, n, dP, dfvec, dx, dJ, st, NT_NEED_JAC);
             }
-            return 0;
-        };
-        nlh_iteration_behavior lib;
-        memset(&lib, 0, sizeof lib);
-        rc = newton_core(h, o, n, ev, x.data(), f.data(), &lib);
-        if (rc < 0) return rc;
-        if (ib) ib[p] = lib;
-        if (status) status[p] = rc;
-        HIPCHK(h, hipMemcpyAsync(dxp, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipMemcpyAsync(dfp, f.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+            {
+                Timed t(h, NLH_K_JTF);                           // :565-567
+                hipLaunchKernelGGL(k_jtf_exact, dim3((n + 255) / 256, nprob), dim3(256), 0, s, n, n, (const double *)dJ,
+                                   (const double *)dfvec, dgrad, (const LmState *)st, (int)NT_NEED_JAC);
+            }
+            hipLaunchKernelGGL(k_nt_rhs, dim3((n + 255) / 256, nprob), dim3(256), 0, s, n, (const double *)dfvec, ddir,
+                               (const LmState *)st);
+            launch_lu_factor(h, nprob, n, dJ, dipvt, nullptr, st, NT_NEED_JAC);          // :570
+            hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, s, n, (const double *)dJ,
+                               (const int32_t *)dipvt, ddir, (const LmState *)st, (int)NT_NEED_JAC);   // :577
+            hipLaunchKernelGGL(k_nt_step_begin, dim3(nprob), dim3(256), 0, s, n, no, dx, dxold, ddir, (const double *)dgrad, st, ns);
+        }
+        launch_dq_residual(h, nprob, n, n, dA, db, gamma, dx, dfvec, nullptr, st, NT_TRIAL);
+        hipLaunchKernelGGL(k_nt_trial, dim3(nprob), dim3(256), 0, s, n, no, dx, (const double *)dxold, (const double *)ddir,
+                           (const double *)dgrad, (const double *)dfvec, st, ns);
+        hipLaunchKernelGGL(k_nt_count, dim3(1), dim3(256), 0, s, nprob, (const LmState *)st, dcounts);
+        HIPCHK(h, hipMemcpyAsync(hcounts, dcounts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (echo) HIPCHK(h, hipMemcpyAsync(hns, ns, sizeof(NtState), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
-        return 0;
-    };
-    const int rcb = run_problems(h, nprob, solve_one);
-    if (rcb) return rcb;
+        if (echo && hns[0].print_due) print_status(hns[0].iter, hns[0].neval, hns[0].njac, hns[0].xnorm, hns[0].fnorm);
+        need_jac = hcounts[0]; trial = hcounts[1];
+        if (need_jac == 0 && trial == 0) break;
+    }
+    HIPCHK(h, hipMemcpyAsync(hns, ns, sizeof(NtState) * np, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
+    for (int p = 0; p < nprob; ++p) {
+        const NtState &q = hns[p];
+        if (ib) {                                                // :624-632
+            ib[p].iter_count = q.iter; ib[p].fcn_count = q.neval; ib[p].jacobian_count = q.njac; ib[p].gradient_count = 0;
+            ib[p].converge_on_fcn = q.fcnvrg; ib[p].converge_on_chng = q.xcnvrg; ib[p].converge_on_zero_diff = q.gcnvrg;
+        }
+        const bool finished = q.rc || q.flag || q.fcnvrg || q.xcnvrg;
+        if (status) status[p] = q.rc ? q.rc : ((q.flag || !finished) ? NLH_CONVERGENCE_ERROR : 0);       // :635-637
+    }
+    (void)trial;
     return 0;
 }
 
@@ -2054,7 +2092,7 @@ int nlh_dq_quasi_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t
             if (analytic) {
                 Timed t(h, NLH_K_DQ_JACOBIAN);
                 hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((n + RB - 1) / RB, 1), dim3(RB), sizeof(double) * n, s,
-                                   n, n, A, gamma, dxs, dJ);
+                                   n, n, A, gamma, (const double *)dxs, dJ, (const LmState *)nullptr, -1);
             } else {
                 HIPCHK(h, hipMemcpyAsync(dfs, f0, sizeof(double) * n, hipMemcpyHostToDevice, s));
                 launch_dq_panel(h, 1, n, n, A, b, gamma, dxs, (double *)h->P.p, nullptr, -1);
@@ -2455,7 +2493,7 @@ int nlh_dq_jacobian(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const do
     {
         Timed t(h, NLH_K_DQ_JACOBIAN);
         hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((m + RB - 1) / RB, nprob), dim3(RB), sizeof(double) * n, h->stream,
-                           m, n, dA, gamma, dx, dJ);
+                           m, n, dA, gamma, dx, dJ, (const LmState *)nullptr, -1);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -2592,7 +2630,8 @@ int nlh_lu_solve(nlh_handle *h, int32_t nprob, int32_t n, const double *dLU, con
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
     HIPCHK(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, h->stream, n, dLU, dipvt, db);
+    hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, h->stream, n, dLU, dipvt, db,
+                       (const LmState *)nullptr, -1);
     HIPCHK(h, hipGetLastError());
     return 0;
 }

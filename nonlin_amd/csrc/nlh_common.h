@@ -487,85 +487,6 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
     return r;
 }
 
-// The same NORM2 run by ONE WAVE out of registers alone: the form for a launch with one wave per problem, where a
-// batch of problems keeps every SIMD of the chip busy with chains (norm2_flang_block_lanes gives a whole 256-thread
-// workgroup to one chain).  Lane l owns the EL consecutive elements of run l of a 64 * EL chunk: it loads them itself,
-// the running maximum before the run comes from a wave scan, the coefficients (c_i, d_i) are formed in registers, and
-// the running sum travels down the lanes exactly as above.  A run that contains a new maximum takes the general
-// s <- s c + d form for its step (s * 1.0 == s bit for bit, so the multiply needs no test).  get(i) must be callable by
-// every lane for any i < len.  Bit-identical to norm2_flang_block.
-template <int EL, typename Get>
-__device__ __forceinline__ double norm2_flang_wave(Get get, int len)
-{
-    const int lane = threadIdx.x & 63;
-    double mx_in = 0.0, s_in = 0.0;
-    for (int base = 0; base < len; base += 64 * EL) {
-        const int cl = min(64 * EL, len - base), i0 = lane * EL;
-        double c[EL], d[EL], lm = 0.0;
-#pragma unroll
-        for (int u = 0; u < EL; ++u) {
-            d[u] = (i0 + u < cl) ? fabs(get(base + i0 + u)) : 0.0;        // |x| first, the coefficient d_i in place below
-            lm = fmax(lm, d[u]);
-        }
-        double sc = lm;                                                  // inclusive prefix maximum over the lanes
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double o = __shfl_up(sc, off, 64);
-            if (lane >= off) sc = fmax(sc, o);
-        }
-        double prev = __shfl_up(sc, 1, 64);
-        if (lane == 0) prev = 0.0;
-        prev = fmax(mx_in, prev);                                        // running maximum before this lane's run
-        bool plain = true;
-#pragma unroll
-        for (int u = 0; u < EL; ++u) {
-            const double av = d[u];
-            double cc = 1.0, dd = 0.0;
-            if (prev == 0.0) {
-                // mx was zero: the element becomes the maximum, s untouched
-            } else if (av > prev) {
-                const double t = prev / av, tsq = t * t;
-                cc = tsq; dd = tsq;
-            } else if (av != 0.0) {
-                const double t = av / prev;
-                dd = t * t;
-            }
-            plain = plain && (cc == 1.0);
-            c[u] = cc;
-            d[u] = dd;
-            prev = fmax(prev, av);
-        }
-        const unsigned long long mask = __ballot(plain);
-        const int nl = (cl + EL - 1) / EL;                               // runs in use
-        double t = s_in;
-#ifdef NLH_EXP_NORM_NOCHAIN
-        for (int u = 0; u < EL; ++u) t = t + d[u] * c[u];
-        if (false)
-#endif
-#pragma unroll 1
-        for (int l = 0; l < nl; ++l) {
-            if (l > 0) t = nlh_wave_shr1(t);
-            if ((mask >> l) & 1ull) {
-#pragma unroll
-                for (int u = 0; u < EL; ++u) t = t + d[u];
-            } else {
-#pragma unroll
-                for (int u = 0; u < EL; ++u) {
-                    t = t * c[u];
-                    t = t + d[u];
-                }
-            }
-        }
-        const int lo = __builtin_amdgcn_readlane(__double2loint(t), nl - 1);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(t), nl - 1);
-        s_in = __hiloint2double(hi, lo);
-        const int mlo = __builtin_amdgcn_readlane(__double2loint(sc), 63);
-        const int mhi = __builtin_amdgcn_readlane(__double2hiint(sc), 63);
-        mx_in = fmax(mx_in, __hiloint2double(mhi, mlo));
-    }
-    return mx_in * sqrt(1.0 + s_in);
-}
-
 // Same algorithm, one thread, for short vectors or per-column use.
 template <typename Get>
 __device__ __forceinline__ double norm2_flang_serial(Get get, int len)

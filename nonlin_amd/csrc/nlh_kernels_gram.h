@@ -392,10 +392,15 @@ k_jtf(int m, int n, const double *__restrict__ J, const double *__restrict__ f,
 // rows ascending, separate multiply and add.  The Newton line search feeds dot(grad, dir) into the backtracking
 // formula, so a reordered sum changes the accepted step in its last bits.
 __global__ void __launch_bounds__(256)
-k_jtf_exact(int m, int n, const double *__restrict__ J, const double *__restrict__ f, double *__restrict__ g)
+k_jtf_exact(int m, int n, const double *__restrict__ Jall, const double *__restrict__ fall, double *__restrict__ gall,
+            const LmState *__restrict__ st, int want)
 {
+    const int p = blockIdx.y;                                     // problems of a batch: J [p][n][m], f [p][m], g [p][n]
+    if (st && st[p].stage != want) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    const double *J = Jall + (size_t)p * m * n, *f = fall + (size_t)p * m;
+    double *g = gall + (size_t)p * n;
     const double *col = J + (size_t)j * m;
     double s = 0.0;
     int i = 0;

@@ -8,11 +8,13 @@
 #include "nlh_common.h"
 
 __global__ void __launch_bounds__(1024)
-k_lu_factor(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info)
+k_lu_factor(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
+            const LmState *__restrict__ st, int want)
 {
     __shared__ double red[64];
     int *redi = reinterpret_cast<int *>(red + 32);
     const int p = blockIdx.x;
+    if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
     const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
     double *a = Aall + (size_t)p * n * n;
     int32_t *ipvt = ipvt_all + (size_t)p * n;
@@ -57,10 +59,11 @@ k_lu_factor(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, in
 // Solve LU x = b in place (dynamic LDS: n doubles).
 __global__ void __launch_bounds__(1024)
 k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ ipvt_all,
-           double *__restrict__ ball)
+           double *__restrict__ ball, const LmState *__restrict__ st, int want)
 {
     extern __shared__ double bs[];
     const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
     const double *a = LUall + (size_t)p * n * n;
     const int32_t *ipvt = ipvt_all + (size_t)p * n;
     double *b = ball + (size_t)p * n;
@@ -154,11 +157,12 @@ k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ 
 
 __global__ void __launch_bounds__(1024)
 k_lu_panel(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
-           int jb, int nb)
+           int jb, int nb, const LmState *__restrict__ st, int want)
 {
     __shared__ double red[64];
     int *redi = reinterpret_cast<int *>(red + 32);
     const int p = blockIdx.x;
+    if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
     const int tid = threadIdx.x, BS = blockDim.x;
     double *a = Aall + (size_t)p * n * n;
     int32_t *ipvt = ipvt_all + (size_t)p * n;
@@ -267,12 +271,13 @@ __device__ __forceinline__ void lu_wave_first_max(double v, int idx, double &vma
 
 __global__ void __launch_bounds__(1024)
 k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
-               int jb, int nb)
+               int jb, int nb, const LmState *__restrict__ st, int want)
 {
     __shared__ double redv[2][16];
     __shared__ int redi[2][16];
     __shared__ double prow[2][LU_PNB + 1], crow[2][LU_PNB];      // prow[.][LU_PNB]: 1 / pivot
     const int p = blockIdx.x, r = threadIdx.x, lane = r & 63, wid = r >> 6, nw = (blockDim.x + 63) >> 6;
+    if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
     const int rows = n - jb;
     double *a = Aall + (size_t)p * n * n;
     int32_t *ipvt = ipvt_all + (size_t)p * n;
@@ -353,11 +358,13 @@ k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
 // triangular solve, j ascending).  One launch for both: these kernels are launch-latency-bound (n = 1024: 64 panels x
 // three launches of 5 - 12 us each were a third of the factorisation).
 __global__ void __launch_bounds__(256)
-k_lu_swap_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipvt_all, int jb, int nb)
+k_lu_swap_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipvt_all, int jb, int nb,
+               const LmState *__restrict__ st, int want)
 {
     __shared__ double L11[LU_NB * LU_NB];          // L11[i + j*LU_NB], i > j used
     __shared__ int32_t piv[LU_NB];
     const int p = blockIdx.y;
+    if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
     double *a = Aall + (size_t)p * n * n;
     for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) {
         const int i = e % nb, j = e / nb;
@@ -397,11 +404,12 @@ k_lu_swap_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipv
 // Trailing update A22 -= L21 U12 on 64x64 tiles; each thread owns a 4x4 register tile and
 // subtracts the nb products in j order (separate multiply and subtract).
 __global__ void __launch_bounds__(256)
-k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb)
+k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__restrict__ st, int want)
 {
     __shared__ double Ls[LU_NB * 64];              // Ls[j*64 + r]
     __shared__ double Us[LU_NB * 64];              // Us[j*64 + c]
     const int p = blockIdx.z;
+    if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
     double *a = Aall + (size_t)p * n * n;
     const int t0 = jb + nb;
     const int r0 = t0 + blockIdx.x * 64, c0 = t0 + blockIdx.y * 64;

@@ -276,10 +276,11 @@ k_fd_jacobian(int m, int n, const double *__restrict__ P, const double *__restri
 template <int BS>
 __global__ void __launch_bounds__(BS)
 k_dq_jacobian(int m, int n, const double *__restrict__ A, double gamma,
-              const double *__restrict__ x, double *__restrict__ J)
+              const double *__restrict__ x, double *__restrict__ J, const LmState *__restrict__ st, int want)
 {
     extern __shared__ double smem[];
     const int p = blockIdx.y;
+    if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
     double *xs = smem;
     const double *Ap = A + (size_t)p * m * n;
     const double *xp = x + (size_t)p * n;

@@ -63,15 +63,12 @@
 #ifndef QRX_UF
 #define QRX_UF(flush) 16
 #endif
-#ifndef QRX_XSTORE
-#define QRX_XSTORE 0      // 1: the flush stores whole 128-byte lines (a sector per lane goes through LDS, every store
-#endif                    // instruction of the wave writes 1 KB contiguous) instead of 16 bytes per lane at a 64-byte stride
-#ifndef QRX_FLUSH_WAVES
-#define QRX_FLUSH_WAVES 2
-#endif
-#ifndef QRX_EXP_NOSTORE
-#define QRX_EXP_NOSTORE 0 // timing experiments only: the flush computes but does not store (wrong results)
-#endif
+// The flushing pass, measured at 2048 x 4096x256, full width (profiles/ubench/rw_stream.hip, w_stream.hip reproduce the
+// memory-system side): 8.7 ms against 2.9 ms for a plain pass; without its stores 3.3 ms.  A write-only stream in the
+// flush's shape (16 bytes per lane at a 64-byte stride) runs at 3.7 TB/s, line-contiguous stores at 5.5 TB/s -- but a
+// kernel that reads AND writes in place reaches 4.8-5.0 TB/s of combined traffic whichever shape its stores have
+// (read-only: 6.1 TB/s), and the flush with its sectors transposed through LDS into 1 KB-contiguous stores took the
+// same 8.7 ms.  What a flush costs is set by mixed read/write traffic; the lever is fewer flushes (QRX_C).
 // NORM2 of the pivot kernel: elements per lane of the serial phase = chunk / 64.  64 (chunks of 4096) when columns are
 // longer than 2048, 32 otherwise: half the LDS and 64 registers less, four workgroups per CU instead of two.
 
@@ -421,175 +418,6 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     }
 }
 
-// The same step split in two launches, for batches: k_qrx_pivot above gives a 256-thread workgroup (69 KB of LDS, 220
-// registers per lane) to every problem and keeps it for the whole serial NORM2 chain, so a CU holds two problems and a
-// batch of 2048 takes four rounds of ~48 us during which HBM idles.  Here the bandwidth part and the latency part each
-// get the shape they need:
-//   k_qrx_pivot_gather  256 threads per problem, no LDS beyond the search scratch, few registers (8 workgroups per CU):
-//                       pivot search (:622-625), interchange bookkeeping (:626-637), the pivot column with its pending
-//                       updates applied (oldest first) written RAW into the reflector slot -- HBM-bound (the column's
-//                       sectors and np reflector vectors per problem);
-//   k_qrx_pivot_norm    ONE WAVE per problem (norm2_flang_wave: registers only, 12 waves per CU, i.e. the whole batch
-//                       of 2048 chains in flight at once): NORM2 of the raw column (:642), sign (:644),
-//                       scaling into the reflector (:645-646), rdiag(j) (:665).
-// Same operations on the same operands in the same order as k_qrx_pivot: bit-identical.
-__global__ void __launch_bounds__(256)
-k_qrx_pivot_gather(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
-                   double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
-{
-    __shared__ double red[64];
-    const int p = blockIdx.x;
-    if (st && st[p].stage != ST_NEED_QR) return;
-    const int tid = threadIdx.x, BS = blockDim.x, ldp = n + 1;
-    int *redi = reinterpret_cast<int *>(red + 32);
-    double *rdiag = w.rdiag + (size_t)p * n, *wa = w.wa + (size_t)p * n;
-    int32_t *src = w.src + (size_t)p * ldp;
-    int32_t *ipvt = v.ipvt + (size_t)p * n;
-    double *tpc = w.tp + ((size_t)p * 2 + cur) * QRX_C * ldp;
-    double *R = Rall + (size_t)p * n * n;
-    const bool onecand = (n - j <= BS);
-    int32_t *slotof = w.slotof + (size_t)p * ld;
-    const bool fresh = (flush & 2) != 0;                         // the pass before this step flushed: identity maps again
-    if (fresh) {
-        for (int c = tid; c < ld; c += BS) slotof[c] = (c - coff >= j && c - coff <= n) ? c - coff : -1;
-        for (int k = j + tid; k <= n; k += BS) src[k] = coff + k;
-    }
-    double bv = 0.0, my_tk[QRX_C - 1];
-    int bk = 0x7fffffff, my_src = 0, my_ipvt = 0;
-    if (onecand) {
-        const int k = j + tid;
-        if (k < n) {
-            bv = rdiag[k]; bk = k;
-            my_src = fresh ? coff + k : src[k]; my_ipvt = ipvt[k];
-#pragma unroll
-            for (int q = 0; q < QRX_C - 1; ++q) my_tk[q] = (q < np) ? tpc[(size_t)q * ldp + k] : 0.0;
-        }
-    } else {
-        for (int k = j + tid; k < n; k += BS) {
-            const double d = rdiag[k];
-            if (bk == 0x7fffffff || d > bv) { bv = d; bk = k; }
-        }
-    }
-    double rd_j = 0.0, wa_j = 0.0;
-    int src_j = 0, ipvt_j = 0, src_0 = 0;
-    if (tid == 0) { rd_j = rdiag[j]; wa_j = wa[j]; src_j = fresh ? coff + j : src[j]; ipvt_j = ipvt[j]; src_0 = src[0]; }
-    const int kmax = block_argmax_first(bv, bk, red, redi);
-    double *pub = red + 40;
-    int *pubi = reinterpret_cast<int *>(pub + QRX_C);
-    if (onecand) {
-        if (j + tid == kmax) {
-#pragma unroll
-            for (int q = 0; q < QRX_C - 1; ++q) pub[q] = my_tk[q];
-            pubi[0] = my_src; pubi[1] = my_ipvt;
-        }
-    } else if (tid == 0) {
-        pubi[0] = fresh ? coff + kmax : src[kmax]; pubi[1] = ipvt[kmax];
-    } else if (tid <= np) {
-        pub[tid - 1] = tpc[(size_t)(tid - 1) * ldp + kmax];
-    }
-    __syncthreads();
-    const int srck = pubi[0];
-    double tk[QRX_C];
-#pragma unroll
-    for (int q = 0; q < QRX_C; ++q) tk[q] = (q < QRX_C - 1 && q < np) ? pub[q] : 0.0;
-    if (kmax != j) {
-        if (tid == 0) {
-            rdiag[kmax] = rd_j;
-            wa[kmax] = wa_j;
-            ipvt[j] = pubi[1]; ipvt[kmax] = ipvt_j;
-            if (j == 0) {                                        // first step: a physical interchange, see k_qrx_pivot
-                slotof[src_0] = -1;
-                slotof[srck] = kmax;
-            } else {
-                src[kmax] = src_j;
-                slotof[src_j] = kmax;
-                slotof[srck] = -1;
-            }
-        }
-        if (tid < np) tpc[(size_t)tid * ldp + kmax] = tpc[(size_t)tid * ldp + j];
-        for (int i = tid; i < j; i += BS) {
-            const double t = R[(size_t)j * n + i];
-            R[(size_t)j * n + i] = R[(size_t)kmax * n + i];
-            R[(size_t)kmax * n + i] = t;
-        }
-    } else if (tid == 0) {
-        slotof[srck] = -1;
-    }
-    if (tid == 0) {                                              // what the norm kernel needs besides the column
-        QrxStep sp;
-        sp.ajnorm = 0.0; sp.ajj = 0.0; sp.kmax = kmax; sp.pad = 0;
-        w.step[p] = sp;
-    }
-    const bool move0 = (j == 0 && kmax != 0);
-    const int src0 = coff;
-    const double *__restrict__ Vc = w.V + ((size_t)p * 2 + cur) * QRX_C * vst;
-    double *__restrict__ Vn = (flush & 1) ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
-                                    : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
-    double *Tp = T + (size_t)p * tst;
-    // four rows per thread are loaded together (with the np reflector entries of each) before any is stored
-    for (int i0 = j + tid; i0 < m; i0 += 4 * BS) {
-        double e[4], vq[4][QRX_C - 1], mv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = min(i0 + u * BS, m - 1);
-            e[u] = Tp[qrx_at(row, srck, ld)];
-            mv[u] = move0 ? Tp[qrx_at(row, src0, ld)] : 0.0;
-#pragma unroll
-            for (int q = 0; q < QRX_C - 1; ++q) vq[u][q] = (q < np) ? Vc[(size_t)q * vst + row] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int q = 0; q < QRX_C - 1; ++q)
-                if (q < np) e[u] = e[u] - tk[q] * vq[u][q];
-            if (i0 + u * BS < m) {
-                if (move0) Tp[qrx_at(i0 + u * BS, srck, ld)] = mv[u];
-                Vn[i0 + u * BS] = e[u];
-            }
-        }
-    }
-}
-
-#define QRX_NORM_EL 32
-__global__ void __launch_bounds__(64)
-k_qrx_pivot_norm(int m, int n, size_t vst, int j, int cur, int np, int flush, QrxWs w, const LmState *__restrict__ st)
-{
-    const int p = blockIdx.x;
-    if (st && st[p].stage != ST_NEED_QR) return;
-    const int lane = threadIdx.x;
-    double *__restrict__ Vn = (flush & 1) ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
-                                    : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
-    const double *col = Vn + j;
-    double ajnorm = norm2_flang_wave<QRX_NORM_EL>([&](int i) { return col[i]; }, m - j);      // :642
-    const double ejj = col[0];
-    double ajj = 0.0;
-#ifdef NLH_EXP_NORM_NOSCALE
-    if (ajnorm == 123.456) {
-#else
-    if (ajnorm != 0.0) {
-#endif
-        if (ejj < 0.0) ajnorm = -ajnorm;                         // :644
-        // :645-646; eight rows per lane are loaded together before any is stored (the store of one row may alias the
-        // load of the next as far as the compiler knows)
-        for (int i0 = j + lane; i0 < m; i0 += 8 * 64) {
-            double t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = Vn[min(i0 + u * 64, m - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                t[u] = t[u] / ajnorm;
-                if (i0 + u * 64 == j) { t[u] = t[u] + 1.0; ajj = t[u]; }
-                if (i0 + u * 64 < m) Vn[i0 + u * 64] = t[u];
-            }
-        }
-    }
-    if (lane == 0) {                                             // lane 0 scaled row j
-        QrxStep *sp = w.step + p;
-        sp->ajnorm = ajnorm; sp->ajj = ajj;
-        w.rdiag[(size_t)p * n + j] = -ajnorm;                    // :665
-    }
-}
-
 // The end of a trailing column's pass, given its dot product s with the reflector: multiplier (:654), row j becomes
 // final (R(j,k) / qtf(j), :655 at i = j), norm down-date (:656-661) with the rare recomputation.
 template <int NP, bool FLUSH>
@@ -650,7 +478,7 @@ qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int 
 // flight ahead of the arithmetic.  The reflector entries of a row (wave-uniform) come from an LDS tile of 64 rows that
 // the wave stages for itself one tile ahead (coalesced slot vectors in, broadcast ds_reads out).
 template <int NP, bool FLUSH>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (FLUSH && NP >= 4) ? QRX_FLUSH_WAVES : 4)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (FLUSH && NP >= 4) ? 2 : 4)))
 k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
            double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
            int32_t *__restrict__ srcall, int32_t *__restrict__ slotall, double *__restrict__ rdall,
@@ -663,7 +491,6 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     constexpr int LP = QRX_C;              // LDS row: the pending entries and the new one (NP + 1 <= QRX_C doubles)
     constexpr int NPI = NP < QRX_C ? NP : 0;
     __shared__ double vt[2][TR * LP];
-    __shared__ __attribute__((aligned(16))) double xst[(FLUSH && QRX_XSTORE) ? 64 * 8 : 2];
     // Workgroup -> (problem, window): consecutive workgroup ids go to consecutive XCDs, so the windows of one problem
     // are given ids that agree modulo 8: they share an L2 (reflector tiles, multipliers are fetched from the fabric once).
     const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
@@ -732,23 +559,6 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     const unsigned so = act ? (unsigned)col * 64u : 0x80000000u;
     const unsigned ko = act ? (unsigned)(coff + k) * 64u : 0x80000000u;  // where a flush puts the column (idle lanes: nowhere)
     const unsigned ldb = (unsigned)ld * 64u;                            // bytes per row block
-    // Line-contiguous flush: a column that is flushed where it was read (the usual case) goes out with its window, 1 KB
-    // contiguous per store instruction: piece q of the window's 4 KB row block, lane l writing bytes q*1024 + 16 l, i.e.
-    // row pair l % 4 of window column 16 q + l / 4.  Columns that move (slots displaced by an interchange since the
-    // last flush: their destination is a consumed position nobody reads) are stored by their own lanes as before.
-    unsigned xo[4] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
-    unsigned kod = 0x80000000u;
-    bool anydisp = false;
-    if (FLUSH && QRX_XSTORE) {
-        const bool stay = act && (coff + k == col);
-        const unsigned long long okm = __ballot(stay);
-        const unsigned col0b = (unsigned)(ld - 64 * (win + 1)) * 64u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            xo[q] = ((okm >> (q * 16 + (lane >> 2))) & 1ull) ? col0b + (unsigned)q * 1024u + (unsigned)lane * 16u : 0x80000000u;
-        kod = (act && !stay) ? ko : 0x80000000u;
-        anydisp = __ballot(act && !stay) != 0ull;
-    }
     double a0[U], a1[U];
     auto load = [&](double (&buf)[U], int rbase) __attribute__((always_inline)) {                      // rbase: rel row, a multiple of 8
 #pragma unroll
@@ -802,28 +612,13 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
                     // (four 16-byte stores back to back), not as four partial writes spread over the block's arithmetic
                     est[u & 7] = e0;
                     est[(u & 7) + 1] = e1;
-                    if ((u & 7) == 6 && !QRX_EXP_NOSTORE) {
-                        if (QRX_XSTORE) {
-                            double2 *xs = reinterpret_cast<double2 *>(xst);
-#pragma unroll
-                            for (int q2 = 0; q2 < 4; ++q2) xs[lane * 4 + q2] = make_double2(est[2 * q2], est[2 * q2 + 1]);
-#pragma unroll
-                            for (int q2 = 0; q2 < 4; ++q2) {
-                                const double2 v2 = xs[q2 * 64 + lane];
-                                qrx_u32x4 w;
-                                w.x = (unsigned)__double2loint(v2.x); w.y = (unsigned)__double2hiint(v2.x);
-                                w.z = (unsigned)__double2loint(v2.y); w.w = (unsigned)__double2hiint(v2.y);
-                                __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, xo[q2], boff, QRX_AUX_STORE);
-                            }
-                        }
-                        if (!QRX_XSTORE || anydisp) {
+                    if ((u & 7) == 6) {
 #pragma unroll
                         for (int q2 = 0; q2 < 4; ++q2) {
                             qrx_u32x4 w;
                             w.x = (unsigned)__double2loint(est[2 * q2]); w.y = (unsigned)__double2hiint(est[2 * q2]);
                             w.z = (unsigned)__double2loint(est[2 * q2 + 1]); w.w = (unsigned)__double2hiint(est[2 * q2 + 1]);
-                            __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, (QRX_XSTORE ? kod : ko) + 16u * q2, boff, QRX_AUX_STORE);
-                        }
+                            __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, ko + 16u * q2, boff, QRX_AUX_STORE);
                         }
                     }
                 } else {                                                // first / last tile: row by row
@@ -901,9 +696,6 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
 // that is serial by definition (a dependent fp64 add with register operands issues every ~2 ns: profiles/ubench/dp_issue.hip).  One barrier per round of (W-1) x 16 rows; the adder
 // works one round behind the producers.  Same arithmetic on the same operands in the same order: bit-identical to
 // k_qrx_pass.
-#ifndef QRX_SPLIT_MIN_NACT
-#define QRX_SPLIT_MIN_NACT 256          // factorisations of at least this many problems take the two-launch pivot step
-#endif
 #ifndef QRX_RP6_MAX_WG
 #define QRX_RP6_MAX_WG 256              // ... and of at most this many, with six waves (five producers) instead of four
 #endif
@@ -1388,10 +1180,6 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         te(2, stream);
         return;
     }
-    // Pivot step as two launches (gather; one wave per problem for the norm) once the batch has more problems than the
-    // one-workgroup-per-problem form keeps on the chip at a time
-    static const int split_env = [] { const char *e = getenv("NLH_QRX_SPLIT"); return e ? atoi(e) : -1; }();
-    const int split_min = split_env >= 0 ? split_env : QRX_SPLIT_MIN_NACT;
     bool prev_flushed = false;
     int cur = 0, np = 0, lo = 1;             // lo: first slot position that can still hold live data (step 0 moves physically)
     for (int j = 0; j < n; ++j) {
@@ -1404,11 +1192,13 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
         const int pf = (flush ? 1 : 0) | (prev_flushed ? 2 : 0);
-        if (nact >= split_min) {
-            hipLaunchKernelGGL(k_qrx_pivot_gather, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, j, cur, np, pf,
-                               T, w, R, v, (const LmState *)st);
-            hipLaunchKernelGGL(k_qrx_pivot_norm, dim3(nprob), dim3(64), 0, stream, m, n, vst, j, cur, np, pf, w, (const LmState *)st);
-        } else if (m <= 2048)
+        // (Measured and dropped: the step as two lean launches -- a 102-register gather kernel, eight workgroups per CU,
+        // and a NORM2 kernel with ONE WAVE per problem working out of registers, so that all 2048 chains of a batch are in
+        // flight at once instead of 512 per round.  Bit-identical, but no faster: gather 98 us (HBM-bound: the column's
+        // sectors and np reflector vectors, ~210 KB per problem) + norm 88 us (46 us loading and preparing coefficients
+        // with a lane per 64-element run, 24 us the chains -- two per SIMD --, 24 us scaling: the column makes three more
+        // trips through memory than in the fused kernel) against 191 us for this kernel's four rounds.)
+        if (m <= 2048)
             hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
                                T, w, R, v, (const LmState *)st);
         else

@@ -507,3 +507,28 @@ def test_fused_fd_epilogue_is_bitwise_the_two_kernel_path(ds, m, n, policy):
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+
+
+@pytest.mark.parametrize("n,nprob,analytic,spread", [(64, 48, True, 0.3), (200, 24, False, 0.3), (129, 40, True, 2.0),
+                                                     (256, 64, True, 0.3)])
+def test_dq_newton_lockstep_batch_bitwise(ds, oracle, n, nprob, analytic, spread):
+    """The lock-step Newton state machine (nlh_kernels_newton.h) on a batch whose problems do NOT march together: some
+    converge in a few iterations, some backtrack, a large spread makes some stop in the line search.  Every problem must
+    carry the bits, counts, flags and status the CPU path gives it alone (a problem's arithmetic never depends on which
+    other problems share its round)."""
+    A, b, xt, x0 = ds.generate(nprob, n, n, seed0=4711, sigma=0.0, spread=spread, square_shift=True)
+    x = x0.clone()
+    fvec, ibs, status = ds.newton_solve_batch(A, b, 0.5, x, analytic=analytic, opts=ds.options(max_evals=60))
+    xs, fs = x.cpu().numpy(), fvec.cpu().numpy()
+    iters = set()
+    for p in range(nprob):
+        Ah = np.asfortranarray(A[p].cpu().numpy().T)
+        rc, xo, fo, ibo, _ = oracle.dq_newton_solve(Ah, b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(), analytic=analytic,
+                                                    opts=oracle.default_options(max_evals=60))
+        assert status[p] == rc, (p, status[p], rc)
+        for k in COUNT_KEYS:
+            assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
+        assert np.array_equal(xs[p], xo), p
+        assert np.array_equal(fs[p], fo), p
+        iters.add((ibo["iter_count"], ibo["fcn_count"]))
+    assert len(iters) > 1                    # the batch really was heterogeneous
