@@ -399,8 +399,13 @@ def main():
     naccept = 0
     bad = 0
     last_ibs = None
+    gathered = None
     for _ in range(args.steps):
         ibs, status = step()
+        if world > 1:
+            # the gather end of the sharded batch belongs to the step: every problem's x and fvec, in global
+            # problem order, on every rank (RCCL all_gather of equal-sized padded shards)
+            gathered = sharding.gather_results(torch.cat([x, fv[0]], dim=1), nprob_total, rank, world)
         njac += sum(ib["jacobian_count"] for ib in ibs)
         naccept += sum(ib["iter_count"] - 1 for ib in ibs)
         bad += sum(1 for s in status if s != 0)
@@ -417,11 +422,14 @@ def main():
     elapsed = float(tt[0])
     njac_all, naccept_all, bad_all = (float(v) for v in cnt.tolist())
 
-    # gather per-problem results (counts + an x checksum) in global problem order on every rank: the "gather" end
+    # per-problem counts in global problem order (reporting only; x and fvec were gathered inside the timed steps)
     rows = torch.tensor([[ib["iter_count"], ib["fcn_count"], ib["jacobian_count"]] for ib in last_ibs],
                         dtype=torch.float64, device=dev).reshape(B, 3)
-    rows = torch.cat([rows, x.sum(dim=1, keepdim=True)], dim=1)
     allrows = sharding.gather_results(rows, nprob_total, rank, world)
+    gather_ok = None
+    if gathered is not None:                                     # this rank's own rows came back where they belong
+        mine = torch.tensor(sharding.shard_indices(nprob_total, rank, world), device=dev)
+        gather_ok = bool(torch.equal(gathered[mine, :n], x)) and bool(torch.equal(gathered[mine, n:], fv[0]))
 
     roof_ms, roof_launches = ds.h.timing(roof_kernel)
     roof_samples = ds.h.timing_samples(roof_kernel) if args.sub_batches == 1 else []
@@ -478,7 +486,9 @@ def main():
                 "problems_total": nprob_total, "problems_rank0": B, "m": m, "n": n, "max_fcn_evals": max_evals,
                 "factor_policy": POLICY_NAMES[args.policy],
                 "sub_batches_in_flight": args.sub_batches,
-                "parallelism": f"independent problems, block-cyclic over {world} rank(s)",
+                "parallelism": f"independent problems, block-cyclic over {world} rank(s)"
+                               + ("; x and fvec all-gathered over RCCL inside every timed step" if world > 1 else ""),
+                "gather_check": gather_ok,
                 "accepted_steps_per_s": naccept_all / elapsed,
                 "non_converged": int(bad_all),
                 "iters_first_problem": [int(v) for v in allrows[0, :3].tolist()],

@@ -217,6 +217,25 @@ int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *opts, int32_t npro
 typedef struct nlh_dq_model nlh_dq_model;
 int  nlh_dq_model_create(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *A, const double *b,
                          double gamma, nlh_dq_model **model);
+
+/* ---- several GPUs behind the boundary (SURVEY.md 8(b) `nlx_init(device, comm)`, 8(e); replaces nothing in the
+ * reference, whose solvers are single-threaded -- this is how `solver%solve_batch` reaches every GPU of the node from ONE
+ * process).  A device set owns one handle (own stream, own workspaces) per entry of its device list.  A model created
+ * ON a set is dealt over the entries block-cyclically (problem k -> entry k mod ndev: iteration counts differ per
+ * problem), and every nlh_dq_model_* call on it runs one host thread per entry: independent problems, no collective,
+ * the same bits as on one device.  devices == NULL or ndev <= 0: every visible device; an id may repeat (two shares
+ * on one GPU).  The handle argument of nlh_dq_model_eval / _lm_solve / _newton_solve is ignored (may be NULL) for a
+ * model created on a set.  (One process per GPU over RCCL is the other way to use several GPUs: nonlin_amd/sharding.py,
+ * bench.py --gpus N.) ---- */
+typedef struct nlh_device_set nlh_device_set;
+int  nlh_device_set_create(nlh_device_set **set, const int32_t *devices, int32_t ndev);
+void nlh_device_set_destroy(nlh_device_set *set);
+int32_t nlh_device_set_size(const nlh_device_set *set);
+nlh_handle *nlh_device_set_handle(nlh_device_set *set, int32_t i);        /* entry i's handle (owned by the set) */
+const char *nlh_device_set_last_error(const nlh_device_set *set);
+int  nlh_dq_model_create_on(nlh_device_set *set, int32_t nprob, int32_t m, int32_t n, const double *A, const double *b,
+                            double gamma, nlh_dq_model **model);
+int32_t nlh_dq_model_device_count(const nlh_dq_model *model);             /* shares the model is dealt into */
 void nlh_dq_model_destroy(nlh_dq_model *model);
 void nlh_dq_model_shape(const nlh_dq_model *model, int32_t *nprob, int32_t *m, int32_t *n);
 /* vecfcn (src/nonlin_multi_eqn_mult_var.f90:14-25) of the model, every problem */

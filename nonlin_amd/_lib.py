@@ -102,6 +102,14 @@ SYMBOLS = {
     "nlh_poly_fit": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "nlh_poly_fit_batch": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlh_dq_model_create": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_double, C.POINTER(C.c_void_p)]),
+    "nlh_device_set_create": (C.c_int, [C.POINTER(C.c_void_p), c_int32_p, C.c_int32]),
+    "nlh_device_set_destroy": (None, [C.c_void_p]),
+    "nlh_device_set_size": (C.c_int32, [C.c_void_p]),
+    "nlh_device_set_handle": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "nlh_device_set_last_error": (C.c_char_p, [C.c_void_p]),
+    "nlh_dq_model_create_on": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_double,
+                                         C.POINTER(C.c_void_p)]),
+    "nlh_dq_model_device_count": (C.c_int32, [C.c_void_p]),
     "nlh_dq_model_destroy": (None, [C.c_void_p]),
     "nlh_dq_model_shape": (None, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p]),
     "nlh_dq_model_eval": (C.c_int, [_H, C.c_void_p, c_double_p, c_double_p]),

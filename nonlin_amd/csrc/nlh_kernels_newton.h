@@ -6,7 +6,7 @@
 // (src/nonlin_helper.f90:36-124) -- runs here, one workgroup per problem, in the reference's operation order: every dot
 // product is ONE ordered chain of adds (it runs down the lanes of a wave, sixteen terms per lane), NORM2 is the flang
 // runtime's algorithm, maxima are exact in any order.  Given bit-identical J, LU and residual kernels, every accept /
-// backtrack decision and every iterate is bit-identical to the host loop (newton_core) and to the CPU oracle.
+// backtrack decision and every iterate is bit-identical to the host loop (newton_core) and to the CPU path.
 #pragma once
 #include "nlh_common.h"
 

@@ -30,6 +30,13 @@ class DeviceSolver:
         self.h = _lib.Handle(device, stream)
         self.lib = self.h.lib
 
+    def check(self, rc, what):
+        return self.h.check(rc, what)
+
+    def model(self, A, b, gamma):
+        """A device residual model behind host arrays on this solver's device (HostModel)."""
+        return HostModel(self, A, b, gamma)
+
     # -- inputs -------------------------------------------------------------
     def generate(self, nprob, m, n, seed0=12345, gamma=0.5, sigma=1e-3, spread=0.3, square_shift=False,
                  seed_stride=1):
@@ -298,3 +305,110 @@ class DeviceSolver:
         self.h.check(self.lib.nlh_lu_solve(self.h.ptr, nprob, n, LU.data_ptr(), ipvt.data_ptr(), b.data_ptr()),
                      "nlh_lu_solve")
         return b
+
+
+class HostModel:
+    """A device residual model behind HOST arrays (nlh_dq_model): the boundary object the Fortran shim's
+    `device_model_batch` wraps.  A [nprob, n, m] (each problem column-major m x n), b [nprob, m] are numpy arrays;
+    the copies live on one device (`owner` a DeviceSolver) or are dealt over the devices of a DeviceSet."""
+
+    def __init__(self, owner, A, b, gamma):
+        import numpy as np
+        self.owner = owner
+        self.lib = owner.lib
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        self.nprob, self.n, self.m = A.shape
+        if b.shape != (self.nprob, self.m):
+            raise ValueError("b must be [nprob, m]")
+        self._md = C.c_void_p()
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        if isinstance(owner, DeviceSet):
+            rc = self.lib.nlh_dq_model_create_on(owner.ptr, self.nprob, self.m, self.n, dp(A), dp(b), float(gamma), C.byref(self._md))
+        else:
+            rc = self.lib.nlh_dq_model_create(owner.h.ptr, self.nprob, self.m, self.n, dp(A), dp(b), float(gamma), C.byref(self._md))
+        owner.check(rc, "nlh_dq_model_create")
+        if rc != 0:
+            raise RuntimeError(f"nlh_dq_model_create: {rc}")
+
+    @property
+    def shares(self):
+        return int(self.lib.nlh_dq_model_device_count(self._md))
+
+    def _solve(self, fn, x, opts, *extra):
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        f = np.empty((self.nprob, self.m))
+        ib = (_lib.IterationBehavior * self.nprob)()
+        st = (C.c_int32 * self.nprob)()
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        hptr = None if isinstance(self.owner, DeviceSet) else self.owner.h.ptr
+        rc = fn(hptr, C.byref(opts if opts is not None else _lib.default_options()), self._md, *extra, dp(x), dp(f), ib, st)
+        self.owner.check(rc, fn.__name__)
+        if rc != 0:
+            raise RuntimeError(f"{fn.__name__}: {rc}")
+        return x, f, [ib[p].as_dict() for p in range(self.nprob)], [int(st[p]) for p in range(self.nprob)]
+
+    def lm_solve(self, x, opts=None):
+        """least_squares_solver%solve on every problem: returns (x, fvec, iteration behaviours, status codes)."""
+        return self._solve(self.lib.nlh_dq_model_lm_solve, x, opts)
+
+    def newton_solve(self, x, analytic=True, opts=None):
+        return self._solve(self.lib.nlh_dq_model_newton_solve, x, opts, 1 if analytic else 0)
+
+    def close(self):
+        if getattr(self, "_md", None) is not None and self._md.value:
+            self.lib.nlh_dq_model_destroy(self._md)
+            self._md = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceSet:
+    """nlh_device_set: one handle per listed device inside ONE process; models created on it are dealt over the devices
+    block-cyclically and solved by one host thread per device (no collective).  devices=None: every visible device;
+    an id may repeat (two shares on one GPU)."""
+
+    def __init__(self, devices=None):
+        self.lib = _lib.load()
+        if self.lib.nlh_device_count() <= 0:
+            raise _lib.NonlinHipUnavailable("no HIP device visible: the nonlin_amd compute path needs a GPU "
+                                          "(there is no CPU fallback)")
+        self._s = C.c_void_p()
+        if devices is None:
+            rc = self.lib.nlh_device_set_create(C.byref(self._s), None, 0)
+        else:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            rc = self.lib.nlh_device_set_create(C.byref(self._s), arr, len(devices))
+        if rc != 0:
+            raise _lib.NonlinHipUnavailable(f"nlh_device_set_create failed with {rc}")
+
+    @property
+    def ptr(self):
+        return self._s
+
+    def __len__(self):
+        return int(self.lib.nlh_device_set_size(self._s))
+
+    def check(self, rc, what):
+        if rc < 0:
+            raise RuntimeError(f"{what}: library error {rc}: {self.lib.nlh_device_set_last_error(self._s).decode()}")
+        return rc
+
+    def model(self, A, b, gamma):
+        return HostModel(self, A, b, gamma)
+
+    def close(self):
+        if getattr(self, "_s", None) is not None and self._s.value:
+            self.lib.nlh_device_set_destroy(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -144,6 +144,36 @@ module nonlin_hip_c
             type(c_ptr), intent(out) :: model
             integer(c_int) :: rc
         end function
+        ! ---- several GPUs behind the boundary (include/nonlin_hip.h: nlh_device_set_*) ----
+        function nlh_device_set_create(set, devices, ndev) bind(C, name="nlh_device_set_create") result(rc)
+            import :: c_ptr, c_int, c_int32_t
+            type(c_ptr), intent(out) :: set
+            integer(c_int32_t), intent(in) :: devices(*)
+            integer(c_int32_t), value :: ndev
+            integer(c_int) :: rc
+        end function
+        subroutine nlh_device_set_destroy(set) bind(C, name="nlh_device_set_destroy")
+            import :: c_ptr
+            type(c_ptr), value :: set
+        end subroutine
+        function nlh_device_set_size(set) bind(C, name="nlh_device_set_size") result(n)
+            import :: c_ptr, c_int32_t
+            type(c_ptr), value :: set
+            integer(c_int32_t) :: n
+        end function
+        function nlh_device_count() bind(C, name="nlh_device_count") result(n)
+            import :: c_int
+            integer(c_int) :: n
+        end function
+        function nlh_dq_model_create_on(set, nprob, m, n, a, b, gamma, model) bind(C, name="nlh_dq_model_create_on") result(rc)
+            import :: c_ptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: set
+            integer(c_int32_t), value :: nprob, m, n
+            real(c_double), intent(in) :: a(*), b(*)
+            real(c_double), value :: gamma
+            type(c_ptr), intent(out) :: model
+            integer(c_int) :: rc
+        end function
         subroutine nlh_dq_model_destroy(model) bind(C, name="nlh_dq_model_destroy")
             import :: c_ptr
             type(c_ptr), value :: model
@@ -180,8 +210,60 @@ module nonlin_hip_c
     end interface
 
     type(c_ptr), save, private :: default_handle = c_null_ptr
+    type(c_ptr), save, private :: default_set = c_null_ptr
+    logical, save, private :: default_set_decided = .false.
 
 contains
+    !> Extension: the GPUs that device_model_batch%create deals a batch over (solve_batch then runs one host thread
+    !> per GPU inside this process).  devices = device ids, 0-based; an empty list selects every visible GPU.  Without
+    !> this call the environment variable NLH_DEVICES decides ("all", or a comma-separated id list); unset: one GPU
+    !> (device 0, the default handle).  Models created earlier keep the devices they were created on.
+    subroutine nlh_use_devices(devices)
+        integer(c_int32_t), intent(in), dimension(:) :: devices
+        integer(c_int) :: rc
+        integer(c_int32_t) :: none(1)
+        none = 0
+        if (size(devices) > 0) then
+            rc = nlh_device_set_create(default_set, devices, int(size(devices), c_int32_t))
+        else
+            rc = nlh_device_set_create(default_set, none, 0_c_int32_t)
+        end if
+        if (rc /= 0) then
+            print '(A,I0,A)', "nonlin_hip: nlh_device_set_create returned ", rc, " (no such HIP device?)"
+            error stop 1
+        end if
+        default_set_decided = .true.
+    end subroutine
+
+    !> The device set models are dealt over, or c_null_ptr when a single GPU (the default handle) is in use.
+    function nlh_default_device_set() result(set)
+        type(c_ptr) :: set
+        character(len=256) :: spec
+        integer :: length, stat, i, k, cnt
+        integer(c_int32_t) :: ids(64)
+        if (.not.default_set_decided) then
+            default_set_decided = .true.
+            call get_environment_variable("NLH_DEVICES", spec, length, stat)
+            if (stat == 0 .and. length > 0) then
+                cnt = 0
+                if (spec(1:length) /= "all") then
+                    k = 1
+                    do i = 1, length + 1
+                        if (i > length .or. spec(i:min(i, length)) == ",") then
+                            if (i > k .and. cnt < size(ids)) then
+                                cnt = cnt + 1
+                                read (spec(k:i - 1), *) ids(cnt)
+                            end if
+                            k = i + 1
+                        end if
+                    end do
+                end if
+                call nlh_use_devices(ids(1:cnt))
+            end if
+        end if
+        set = default_set
+    end function
+
     !> Lazily created process-wide handle on device 0, default stream.
     function nlh_default_handle() result(h)
         type(c_ptr) :: h

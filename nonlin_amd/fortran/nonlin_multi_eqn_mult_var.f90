@@ -18,6 +18,7 @@ module nonlin_multi_eqn_mult_var
     public :: nlh_callback_ctx
     public :: device_model_batch
     public :: NLH_MODEL_DENSE_QUADRATIC
+    public :: nlh_use_devices
     public :: nlh_vecfcn_trampoline
     public :: nlh_jacfcn_trampoline
 
@@ -203,8 +204,13 @@ contains
         call this%destroy()
         ac = a                                               ! contiguous copies: the dummies may be sections
         bc = b
-        rc = nlh_dq_model_create(nlh_default_handle(), int(size(a, 3), c_int32_t), int(size(a, 1), c_int32_t), &
-            int(size(a, 2), c_int32_t), ac, bc, gamma, this%model_)
+        if (c_associated(nlh_default_device_set())) then         ! nlh_use_devices / NLH_DEVICES: dealt over several GPUs
+            rc = nlh_dq_model_create_on(nlh_default_device_set(), int(size(a, 3), c_int32_t), int(size(a, 1), c_int32_t), &
+                int(size(a, 2), c_int32_t), ac, bc, gamma, this%model_)
+        else
+            rc = nlh_dq_model_create(nlh_default_handle(), int(size(a, 3), c_int32_t), int(size(a, 1), c_int32_t), &
+                int(size(a, 2), c_int32_t), ac, bc, gamma, this%model_)
+        end if
         if (rc /= 0) error stop rc
         this%neqn_ = size(a, 1)
         this%nvar_ = size(a, 2)

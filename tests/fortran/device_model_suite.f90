@@ -76,6 +76,16 @@ contains
             call report("dm_lm_batch", ibs(k), st(k), x(:,k))
         end do
         call batch%destroy()
+        ! the same batch dealt over a device set inside this process (here: two shares on GPU 0; on a multi-GPU node
+        ! nlh_use_devices([0, 1, ...]) or NLH_DEVICES=all): every problem must come back with the same bits
+        call nlh_use_devices([0, 0])
+        call batch%create(NLH_MODEL_DENSE_QUADRATIC, a, b, gamma)
+        x = x0
+        call lm%solve_batch(batch, x, f, ibs, st)
+        do k = 1, nprob
+            call report("dm_lm_batch_set", ibs(k), st(k), x(:,k))
+        end do
+        call batch%destroy()
     end subroutine
 
     subroutine run_newton(path)

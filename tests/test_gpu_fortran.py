@@ -203,6 +203,10 @@ def test_device_model_least_squares_through_fortran(dm_results, oracle):
     assert len(res["dm_lm_batch"]) == len(data)
     for k, (rc, xo, fo, ibo, _, _) in enumerate(sols):
         _cmp_dm(res["dm_lm_batch"][k], rc, xo, ibo)
+    # nlh_use_devices([0, 0]): the batch dealt over a device set inside the Fortran process (two shares on GPU 0)
+    assert len(res["dm_lm_batch_set"]) == len(data)
+    for k, (rc, xo, fo, ibo, _, _) in enumerate(sols):
+        _cmp_dm(res["dm_lm_batch_set"][k], rc, xo, ibo)
 
 
 def test_device_model_newton_through_fortran(dm_results, oracle):
