@@ -543,11 +543,13 @@ struct LmWs {
     int nblk;
 };
 
-static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool need_panel)
+static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool need_panel, bool need_J = true)
 {
     int rc;
     const size_t mn = (size_t)nprob * m * n, pm = (size_t)nprob * m, pn = (size_t)nprob * n;
-    if ((rc = ensure(h, h->J, sizeof(double) * mn))) return rc;
+    // need_J = false: the exact policy with the fused FD epilogue writes the Jacobian straight into the factorisation's
+    // working matrix (the panel buffer) and nothing reads a column-major J: 17 GB less at 2048 x 4096x256
+    if (need_J && (rc = ensure(h, h->J, sizeof(double) * mn))) return rc;
     // the panel doubles as the exact factorisation's row-major working matrix (nlh_qrx.hip) and as lmsolve's scratch
     if (need_panel && (rc = ensure(h, h->P, sizeof(double) * std::max(mn + pm + (size_t)512 * (n + 1),
                                                                       qrx_matrix_doubles(nprob, m, n))))) return rc;
@@ -733,7 +735,8 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     int rc;
     HIPCHK(h, hipSetDevice(h->device));
     LmWs w;
-    if ((rc = lm_workspace(h, nprob, m, n, w, true))) return rc;
+    const bool jac_in_place = o->fuse_fd && o->factor_policy == NLH_FACTOR_EXACT;
+    if ((rc = lm_workspace(h, nprob, m, n, w, true, !jac_in_place))) return rc;
     if ((rc = ensure_pinned(h, sizeof(LmState) * (size_t)nprob + 64))) return rc;
     int *d_active = (int *)(w.info + nprob);
     int *h_active = (int *)h->pinned;
@@ -749,6 +752,8 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         hipLaunchKernelGGL(k_lm_init, dim3(pb), dim3(256), 0, h->stream, nprob, w.nblk, w.part, w.st, first_stage);
 
     const int max_rounds = o->max_evals + 8;
+    const bool echo = o->print_status && nprob == 1;
+    int last_printed_iter = -1;
     int nact = nprob;                                           // problems still iterating (from the previous round)
     for (int round = 0; round < max_rounds; ++round) {
         // outer-loop head for problems that need a Jacobian (:221): n perturbed evaluations + FD
@@ -772,7 +777,14 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         lm_update(h, o, nprob, m, n, w, dx, dfvec);
         hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, h->stream, nprob, w.st, d_active);
         HIPCHK(h, hipMemcpyAsync(h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (echo) HIPCHK(h, hipMemcpyAsync(h_state, w.st, sizeof(LmState), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        // a single solve with print_status set: the reference's status block at the end of every outer iteration that
+        // goes on (:372-374), printed from the state that came back with the count
+        if (echo && h_state[0].stage == ST_NEED_JAC && h_state[0].iter != last_printed_iter) {
+            print_status(h_state[0].iter, h_state[0].neval, h_state[0].njac, h_state[0].xnorm, h_state[0].fnorm);
+            last_printed_iter = h_state[0].iter;
+        }
         if (*h_active == 0) break;
         nact = *h_active;
     }

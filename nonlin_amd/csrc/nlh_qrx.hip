@@ -157,6 +157,28 @@ k_qrx_transpose(int m, int n, int ld, int coff, size_t tst, const double *__rest
 }
 
 // wa4 = fvec as column n (:241), initial column norms (:611-616), identity maps.
+// Initial column norms (:611-616) for a HANDFUL of problems: a workgroup per column (the serial recurrence of flang's
+// NORM2 down the lanes of a wave, as in the pivot kernel) instead of a thread per column -- one 65536 x 512 problem:
+// 25 ms -> well under a millisecond.  Same algorithm on the same elements in the same order: the same bits.
+__global__ void __launch_bounds__(256)
+k_qrx_init_norms(int m, int n, int ld, int coff, size_t tst, const double *__restrict__ T, QrxWs w, LmVecs v,
+                 const LmState *__restrict__ st)
+{
+    __shared__ __attribute__((aligned(16))) double cd[2 * (64 * 64 + 128)];
+    __shared__ __attribute__((aligned(16))) double aux[40 + 128];
+    const int p = blockIdx.y, k = blockIdx.x;
+    if (st && st[p].stage != ST_NEED_QR) return;
+    const double *a = T + (size_t)p * tst;
+    const double nr = norm2_flang_block_lanes<64, 256>([&](int i) { return a[qrx_at(i, coff + k, ld)]; }, m, cd, aux);
+    if (threadIdx.x == 0) {
+        v.acnorm[(size_t)p * n + k] = nr;
+        w.rdiag[(size_t)p * n + k] = nr;
+        w.wa[(size_t)p * n + k] = nr;
+        v.ipvt[(size_t)p * n + k] = k;
+    }
+}
+
+template <bool NORMS>
 __global__ void __launch_bounds__(256)
 k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, const double *__restrict__ fall, QrxWs w, LmVecs v,
            const LmState *__restrict__ st)
@@ -167,7 +189,7 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
     double *a = T + (size_t)p * tst;
     const double *f = fall + (size_t)p * m;
     for (int i = tid; i < m; i += BS) a[qrx_at(i, coff + n, ld)] = f[i];
-    for (int k = tid; k < n; k += BS) {
+    for (int k = tid; NORMS && k < n; k += BS) {
         // flang NORM2 of column k, rows ascending: a sector (8 rows) per load group, the next one in flight
         double mx = 0.0, sq = 0.0;
         auto step = [&](double vv) {
@@ -422,8 +444,8 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
 // final (R(j,k) / qtf(j), :655 at i = j), norm down-date (:656-661) with the rare recomputation.
 template <int NP, bool FLUSH>
 __device__ __forceinline__ void
-qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int cur, size_t vst, double s, double rowj, bool refl,
-              double ajj, const double (&tq)[NP > 0 ? NP : 1], const double *__restrict__ Tp, const double *__restrict__ vc,
+qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int cur, size_t vst, double s, double rowj, double rk, double wak,
+              bool refl, double ajj, const double (&tq)[NP > 0 ? NP : 1], const double *__restrict__ Tp, const double *__restrict__ vc,
               const double *__restrict__ vo, double *__restrict__ tpall,
               double *__restrict__ rdall, double *__restrict__ waall, double *__restrict__ Rall, double *__restrict__ qtfall)
 {
@@ -448,11 +470,12 @@ qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int 
     if (k == n) { qtfall[(size_t)p * n + j] = rjk; return; }
     Rall[(size_t)p * n * n + (size_t)k * n + j] = rjk;
     if (!refl) return;
-    double rk = rdiag[k];
+    // rk = rdiag(k), wak = wa(k): fetched by the caller at the start of the pass (only this column's owner ever writes
+    // them), so that the tail is not two dependent trips to memory
     if (rk != 0.0) {                                                    // :656-661
         const double t2 = rjk / rk;
         rk = rk * sqrt(fmax(0.0, 1.0 - t2 * t2));
-        const double q = rk / wa[k];
+        const double q = rk / wak;
         if (!(5.0e-2 * (q * q) > NLH_EPS)) {
             rk = norm2_flang_serial([&](int i2) {
                 const int row = j + 1 + i2, rel = row - jb;
@@ -527,6 +550,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
         for (int q = 0; q < NP; ++q) e = e - tq[q] * vr[q];
         return e;
     };
+    const double rk0 = (act && k < n) ? rdall[(size_t)p * n + k] : 0.0, wa0 = (act && k < n) ? waall[(size_t)p * n + k] : 1.0;
     double rowj;
     {   // row j with its pending updates (becomes final below)
         double v0[NP + 1];
@@ -683,7 +707,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     for (; t < ntile; ++t) tile_guard(t);
 
     if (!act) return;
-    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, refl, ajj, tq, Tp, vc, vo, tpall,
+    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq, Tp, vc, vo, tpall,
                              rdall, waall, Rall, qtfall);
 }
 
@@ -746,6 +770,8 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
     double tq[NP > 0 ? NP : 1];
 #pragma unroll
     for (int q = 0; q < NP; ++q) tq[q] = tpc[(size_t)q * ldp + k];
+    const double rk0 = (adder && act && k < n) ? rdall[(size_t)p * n + k] : 0.0;
+    const double wa0 = (adder && act && k < n) ? waall[(size_t)p * n + k] : 1.0;
     double rowj = 0.0;
     if (adder) {                                                        // row j with its pending updates (becomes final in the tail)
         double e = Tp[qrx_at(j, col, ld)];
@@ -900,7 +926,7 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
         }
     }
     if (!adder || !act) return;
-    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, refl, ajj, tq, Tp, vc, vo, tpall,
+    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq, Tp, vc, vo, tpall,
                              rdall, waall, Rall, qtfall);
 }
 
@@ -944,6 +970,12 @@ k_qrx_pass_col(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, do
     // sum as +0.0 terms in front.
     const int r0 = j & 7, len = m - jb;
     const double *colp = Tp + qrx_at(jb, col, ld);                      // rel row r of this column at colp[(r >> 3) * ld * 8 + (r & 7)]
+    // what thread 0's tail will need, fetched now: row j of the column, the column's down-dated norm and its reference
+    double rowj0 = 0.0, rk0 = 0.0, wa0 = 1.0;
+    if (tid == 0) {
+        rowj0 = Tp[qrx_at(j, col, ld)];
+        if (k < n) { rk0 = rdall[(size_t)p * n + k]; wa0 = waall[(size_t)p * n + k]; }
+    }
     const size_t blk = (size_t)ld * 8;
     const bool one_chunk = len <= CAP;
     // s = sum_i v_i a_i, rows ascending, one chunk of CAP rows at a time
@@ -1000,8 +1032,7 @@ k_qrx_pass_col(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, do
     // multiplier, row j of R / qtf, norm down-date (with its rare recomputation, which reads the column as it still is)
     if (tid == 0) {
         const double tq1[1] = {0.0};
-        const double rowj = Tp[qrx_at(j, col, ld)];
-        qrx_pass_tail<0, false>(p, j, k, col, m, n, ld, coff, 0, vst, s, rowj, refl, ajj, tq1, Tp, vbank + jb, vbank + jb, tpall,
+        qrx_pass_tail<0, false>(p, j, k, col, m, n, ld, coff, 0, vst, s, rowj0, rk0, wa0, refl, ajj, tq1, Tp, vbank + jb, vbank + jb, tpall,
                                 rdall, waall, Rall, qtfall);
     }
     __syncthreads();
@@ -1144,7 +1175,14 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         const unsigned gx = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(k_qrx_transpose, dim3(gx, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, J, T, (const LmState *)st);
     }
-    hipLaunchKernelGGL(k_qrx_init, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
+    if (nact <= 0 || nact > nprob) nact = nprob;
+    if (nact <= QRX_COL_MAX_NACT) {                              // a handful of problems: a workgroup per column for the norms
+        hipLaunchKernelGGL(k_qrx_init<false>, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
+        hipLaunchKernelGGL(k_qrx_init_norms, dim3(n, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, (const double *)T, w, v,
+                           (const LmState *)st);
+    } else {
+        hipLaunchKernelGGL(k_qrx_init<true>, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
+    }
     te(2, stream);
     // (Measured and dropped: the two halves of the batch on two streams, half B's pivot kernel under half A's pass, with
     // events keeping the passes from overlapping each other -- 1035 ms instead of 999 ms per 512 x 4096x256 solve; the
@@ -1155,7 +1193,6 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     const long rp_max = rp_env >= 0 ? rp_env : QRX_RP_MAX_WG;
     static const long rp6_env = [] { const char *e = getenv("NLH_QRX_RP6"); return e ? atol(e) : -1L; }();
     const long rp6_max = std::min(rp_max, rp6_env >= 0 ? rp6_env : (long)QRX_RP6_MAX_WG);
-    if (nact <= 0 || nact > nprob) nact = nprob;
     static const int col_env = [] { const char *e = getenv("NLH_QRX_COL"); return e ? atoi(e) : -1; }();
     if (nact <= (col_env >= 0 ? col_env : QRX_COL_MAX_NACT)) {
         // a handful of problems: a workgroup per trailing column, eager updates, never a pending one (k_qrx_pass_col)

@@ -1,52 +1,24 @@
 """Soak run (not collected by pytest; run it on a GPU box:  SOAK_SECONDS=600 SOAK_SEED=23 python tests/soak_exact_policy.py).
 
-The random parity sweep of tests/test_gpu_random_parity.py for as long as SOAK_SECONDS allows, with the base problems also
-replicated into batches of up to 1500 -- launches with more workgroups than the chip holds, every form of the trailing
-pass, several sub-batches in flight.  Every copy must carry the bits of the CPU oracle's solution of its original
-(x, fvec, status, all counts).  Round 2: 551 cases found the slot-map race DESIGN.md section 2 describes; 3,159 cases after
-the fix (four seeds): no mismatch."""
+tests/soak_cases.py's replicated-batch sweep for as long as SOAK_SECONDS allows (its first 200 cases with seed 11 are the
+collected test test_exact_policy_soak_slice).  Round 2: 551 cases found the slot-map race DESIGN.md section 2 describes;
+3,159 cases after the fix (four seeds): no mismatch."""
 import os, sys, time, random
 sys.path.insert(0, os.getcwd())
-import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from nonlin_amd.device import DeviceSolver
 from oracle import pyoracle as oracle
+import soak_cases
 oracle.lib()
 ds = DeviceSolver(0)
-KEYS = ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn", "converge_on_chng", "converge_on_zero_diff")
-SIZES = [int(v) for v in os.environ["SOAK_SIZES"].split(",")] if os.environ.get("SOAK_SIZES") else [1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 63, 64, 65, 95, 96, 97, 100, 127, 128, 129, 150, 200, 255, 256, 257, 300]
+sizes = [int(v) for v in os.environ["SOAK_SIZES"].split(",")] if os.environ.get("SOAK_SIZES") else soak_cases.SIZES
 rng = random.Random(int(os.environ.get("SOAK_SEED", "11")))
 t_end = time.time() + float(os.environ.get("SOAK_SECONDS", "300"))
 case = 0; bad = 0
 while time.time() < t_end:
-    n = rng.choice(SIZES)
-    m = n + rng.choice([0, 1, 2, 7, 31, 64, 100, 500, 1500, 4200])
-    base = rng.choice([1, 2, 3])
-    reps = rng.choice([1, 1, 1, 20, 150, 500]) if m * n < 200000 else 1
-    gen = rng.choice([{}, dict(sigma=0.0), dict(gamma=2.0, sigma=0.1, spread=5.0), dict(gamma=10.0, sigma=1.0, spread=50.0)])
-    opt = rng.choice([{}, dict(factor=0.1), dict(factor=1.0)])
-    seed = rng.randrange(1, 100000)
-    A, b, xt, x0 = ds.generate(base, m, n, seed0=seed, square_shift=(m == n), **gen)
-    if rng.random() < 0.2 and n >= 4:
-        A[0, 1, :] = A[0, 0, :]; x0[0, 1] = x0[0, 0]
-    if rng.random() < 0.1 and n >= 4:
-        A[0, 2, :] = 0.0
-    if reps > 1:
-        A = A.repeat(reps, 1, 1).contiguous(); b = b.repeat(reps, 1).contiguous(); x0 = x0.repeat(reps, 1).contiguous()
-    nprob = base * reps
-    x = x0.clone()
-    me = 40 * (n + 1)
-    fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=me, factor_policy=2, **opt))
-    xs = x.cpu().numpy(); fs = fvec.cpu().numpy()
-    for p0 in range(base):
-        Ah = np.asfortranarray(A[p0].cpu().numpy().T)
-        rc, xo, fo, ibo = oracle.dq_lm_solve(Ah, b[p0].cpu().numpy(), 0.5, x0[p0].cpu().numpy(),
-                                             opts=oracle.default_options(max_evals=me, **opt))[:4]
-        for p in range(p0, nprob, base):
-            ok = status[p] == rc and all(ibs[p][k] == ibo[k] for k in KEYS) and \
-                np.array_equal(xs[p], xo, equal_nan=True) and np.array_equal(fs[p], fo, equal_nan=True)
-            if not ok:
-                bad += 1
-                print("MISMATCH", dict(case=case, m=m, n=n, p=p, base=base, reps=reps, gen=gen, opt=opt, seed=seed), flush=True)
-                break
+    what, miss = soak_cases.run_case(ds, oracle, rng, sizes)
+    if miss:
+        bad += 1
+        print("MISMATCH", dict(miss, case=case), flush=True)
     case += 1
 print("soak:", case, "cases,", bad, "mismatches", flush=True)

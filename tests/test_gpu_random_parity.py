@@ -41,6 +41,21 @@ def test_exact_policy_random_sweep(ds, oracle):
             assert np.array_equal(fvec[p].cpu().numpy(), fo, equal_nan=True), where
 
 
+def test_exact_policy_soak_slice(ds, oracle):
+    """The first 200 cases (seed 11) of the replicated-batch soak (tests/soak_cases.py, tests/soak_exact_policy.py): random
+    base problems alone or replicated into batches of up to 1500 copies, so that launches have more workgroups than the
+    chip holds and every form of the trailing pass and the sub-batch driver are exercised; every copy must carry the
+    oracle's bits.  This is the sweep that found the slot-map race of round 2."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import soak_cases
+    rng = random.Random(11)
+    for case in range(200):
+        what, miss = soak_cases.run_case(ds, oracle, rng)
+        assert miss is None, dict(miss, case=case)
+
+
 @pytest.mark.parametrize("m,n,base,copies,gen,sub_batches", [
     (319, 255, 3, 500, dict(sigma=0.0), 0),
     (319, 255, 3, 500, dict(sigma=0.0), 1),

@@ -532,3 +532,54 @@ def test_dq_newton_lockstep_batch_bitwise(ds, oracle, n, nprob, analytic, spread
         assert np.array_equal(fs[p], fo), p
         iters.add((ibo["iter_count"], ibo["fcn_count"]))
     assert len(iters) > 1                    # the batch really was heterogeneous
+
+
+def test_print_status_of_a_device_model_solve_matches_the_host_loop(ds, oracle, capfd):
+    """set_print_status(.true.) on a single device-model solve: the lock-step drivers print the reference's status block
+    (src/nonlin_helper.f90:17-33) after every outer iteration that goes on, as the host-callback loop does -- the same
+    text, since both run the same arithmetic.  (Batches stay silent: the block belongs to one solve.)"""
+    import ctypes
+    import nonlin_amd as nl
+    libc = ctypes.CDLL(None)
+
+    def captured():
+        libc.fflush(None)                 # the library prints through C stdio
+        return capfd.readouterr().out
+    m, n = 96, 12
+    A, b, xt, x0 = ds.generate(1, m, n, seed0=99, spread=2.0)
+    Ah, bh = np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy()
+    o = ds.options(max_evals=200)
+    o.print_status = 1
+    captured()
+    x = x0.clone()
+    ds.lm_solve_batch(A, b, 0.5, x, o)
+    dev_out = captured()
+    obj = nl.vecfcn_helper()
+    obj.set_fcn(lambda xx, ff, args=None: ff.__setitem__(slice(None), oracle.dq_residual(Ah, bh, 0.5, np.array(xx))), m, n)
+    s = nl.least_squares_solver()
+    s.factor_policy = 2
+    s.set_max_fcn_evals(200)
+    s.set_print_status(True)
+    xh, fh, ib = x0[0].cpu().numpy().copy(), np.zeros(m), nl.iteration_behavior()
+    s.solve(obj, xh, fh, ib)
+    host_out = captured()
+    assert "Iteration:" in host_out and dev_out == host_out
+    assert np.array_equal(x[0].cpu().numpy(), xh)
+    # Newton: same comparison against the host loop with an analytic Jacobian callback
+    n = 24
+    A, b, xt, x0 = ds.generate(1, n, n, seed0=3, sigma=0.0, spread=1.0, square_shift=True)
+    Ah, bh = np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy()
+    x = x0.clone()
+    ds.newton_solve_batch(A, b, 0.5, x, analytic=True, opts=o)
+    dev_out = captured()
+    obj = nl.vecfcn_helper()
+    obj.set_fcn(lambda xx, ff, args=None: ff.__setitem__(slice(None), oracle.dq_residual(Ah, bh, 0.5, np.array(xx))), n, n)
+    obj.set_jacobian(lambda xx, JJ, args=None: JJ.__setitem__((slice(None), slice(None)), oracle.dq_jacobian(Ah, bh, 0.5, np.array(xx))))
+    s = nl.newton_solver()
+    s.set_max_fcn_evals(200)
+    s.set_print_status(True)
+    xh, fh = x0[0].cpu().numpy().copy(), np.zeros(n)
+    s.solve(obj, xh, fh, nl.iteration_behavior())
+    host_out = captured()
+    assert "Iteration:" in host_out and dev_out == host_out
+    assert np.array_equal(x[0].cpu().numpy(), xh)
