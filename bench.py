@@ -222,6 +222,21 @@ def other_paths(ds):
         ro, tc = cpu(lambda: csolve(Ah, bh, 0.5, xh, opts=O.default_options(max_evals=500)))
         rows.append({"path": name, "gpu_ms": 1e3 * tg, "cpu_oracle_ms": 1e3 * tc, "iterations": ibs[0]["iter_count"],
                      "bitwise_equal": bool(np.array_equal(ro[1], xg[0][0].cpu().numpy()))})
+    # a BATCH of Newton problems: the lock-step device state machine (nlh_kernels_newton.h); CPU: the first 8 on one core
+    nb, n = 256, 256
+    A, b, xt, x0 = ds.generate(nb, n, n, seed0=12345, sigma=0.0, square_shift=True)
+
+    def run_newton_batch():
+        xg[0] = x0.clone()
+        return ds.newton_solve_batch(A, b, 0.5, xg[0], analytic=True, opts=ds.options(max_evals=500))
+    (_, ibs, st), tg = timed(run_newton_batch)
+    nc = 8
+    ro, tc = cpu(lambda: [O.dq_newton_solve(np.asfortranarray(A[q].cpu().numpy().T), b[q].cpu().numpy(), 0.5, x0[q].cpu().numpy(),
+                                            opts=O.default_options(max_evals=500)) for q in range(nc)])
+    rows.append({"path": f"newton_solver (LU), analytic Jacobian, batch of {nb} x n={n} (lock-step state machine)",
+                 "gpu_ms": 1e3 * tg, "cpu_oracle_ms": 1e3 * tc * nb / nc, "cpu_sample": f"{nc} problems, scaled to {nb}",
+                 "iterations": ibs[0]["iter_count"], "solves_per_s": nb / tg,
+                 "bitwise_equal": bool(all(np.array_equal(ro[q][1], xg[0][q].cpu().numpy()) for q in range(nc)))})
     m, n = 4096, 256
     A, b, xt, x0 = ds.generate(1, m, n, seed0=12345)
     Ah, bh, xh = np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), x0[0].cpu().numpy()
@@ -456,13 +471,17 @@ def main():
         # applied) committed under profiles/: bytes moved per algorithmic byte, scaled to this run's average launch.
         traffic, traffic_src = None, None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            pmc_file = next(f for f in ("r03_pmc_summary.json", "r02_pmc_summary.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            prof = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             if (prof["m"], prof["n"], prof.get("policy")) == (m, n, args.policy):
                 ratio = prof["roofline_kernel"]["hbm_bytes_per_algorithmic_byte"]
                 traffic = ratio * unit_bytes * njac / max(roof_launches, 1)
-                traffic_src = ("profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                               f"command at commit {prof.get('commit', '?')}): measured bytes per algorithmic byte x this "
-                               "run's algorithmic bytes per average launch")
+                same = prof.get("problems") in (None, B) and args.sub_batches == 1
+                traffic_src = (f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                               f"command at commit {prof.get('commit', '?')}, {prof.get('problems', '?')} problems): measured "
+                               "bytes per algorithmic byte x this run's algorithmic bytes per average launch"
+                               + ("" if same else "; EXTRAPOLATED: this run's batch / sub-batch count differs from the profiled one"))
         except Exception:
             traffic = None
         out = {
@@ -560,6 +579,14 @@ def main():
                     nj += sum(i["jacobian_count"] for i in ibq)
                 return nj / tq, xq, ibq, tq / nrep
 
+            # what the HIP-event brackets of the timed region cost: the same lock-step batch with no kernel group timed
+            vq, xq_, _, _ = run_policy(ds.options(max_evals=max_evals, factor_policy=args.policy, sub_batches=args.sub_batches),
+                                       nrep=min(args.steps, 3))
+            out["roofline"]["event_bracketing"] = {
+                "note": "the timed steps bracket every launch of the roofline kernel with a HIP event pair on the launch stream "
+                        "(its per-launch durations are measured live, as `roofline.achieved` requires); the same steps without "
+                        "any bracket:", "value_without_brackets": vq, "unit": "LM iterations/s",
+                "overhead_frac": max(0.0, 1.0 - out["value"] / vq)}
             # the library's default options (several sub-batches in flight): same bits, the product's own throughput
             v, xd, _, _ = run_policy(ds.options(max_evals=max_evals), nrep=min(args.steps, 3))
             out["default_options"] = {"value": v, "unit": "LM iterations/s", "identical_x": bool(torch.equal(xd, x)),
@@ -589,6 +616,9 @@ def main():
         if world == 1 and args.other_paths:
             out["other_paths"] = other_paths(ds)
         if cpu is not None:
+            cpu["gpu_over_one_core"] = out["value"] / cpu["value"]
+            if isinstance(cpu.get("all_cores"), dict) and "value" in cpu["all_cores"]:
+                cpu["all_cores"]["gpu_over_all_cores"] = out["value"] / cpu["all_cores"]["value"]
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:

@@ -1218,7 +1218,7 @@ static const int QN_MAX_ROWS = 18000;  // k_qn_house_dot keeps the reflector (ro
 // B (column-major) -> Q, R: Householder QR with Q formed (qr_factor(b, q = q, r = r), :289)
 // Householder steps on the row-major work array [A | E] (rows x ncA | rows x ncE); vbuf slot 0 must hold column 0 of A.
 static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int ncE, double *dA, double *dE,
-                               double *vbuf, double *wbuf, double *st)
+                               double *vbuf, double *wbuf, double *st, const LmState *gst = nullptr, int gwant = -1)
 {
     // vbuf: [nprob][2][rows]; wbuf: room for [nprob][2][ncA + ncE]; st: room for [nprob][2][4]
     hipStream_t s = h->stream;
@@ -1231,14 +1231,14 @@ static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int 
         for (int j = 0; j < steps; ++j) {
             if (skinny)
                 hipLaunchKernelGGL(k_qn_house_fused<4>, dim3((nc + 3) / 4, nprob), dim3(256), sh3, s,
-                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant);
             else
                 hipLaunchKernelGGL(k_qn_house_fused<16>, dim3((nc + 15) / 16, nprob), dim3(256), sh3, s,
-                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant);
         }
         const int jl = steps - 1, slot = jl & 1;
         hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - jl + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
-                           rows, ncA, ncE, jl, dA, dE, vbuf, wbuf + (size_t)slot * nc, st + (size_t)slot * 4, 2 * nc, 8, 1);
+                           rows, ncA, ncE, jl, dA, dE, vbuf, wbuf + (size_t)slot * nc, st + (size_t)slot * 4, 2 * nc, 8, 1, gst, gwant);
         return;
     }
     const bool wide = rows <= QN_DOT2_MAXROWS;          // workgroup-wide loads (reflector + two product tiles in LDS)
@@ -1246,46 +1246,47 @@ static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int 
     for (int j = 0; j < steps; ++j) {
         if (wide)
             hipLaunchKernelGGL(k_qn_house_dot2, dim3((nc + QN_DOT2_CG - 1) / QN_DOT2_CG, nprob), dim3(256), sh2, s,
-                               rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+                               rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant);
         else
             hipLaunchKernelGGL(k_qn_house_dot, dim3((nc + QN_DOT_BS - 1) / QN_DOT_BS, nprob), dim3(QN_DOT_BS),
-                               sizeof(double) * rows, s, rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st);
+                               sizeof(double) * rows, s, rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant);
         hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - j + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
-                           rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, nc, 4, 0);
+                           rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, nc, 4, 0, gst, gwant);
     }
 }
 
-static void launch_qn_qr(nlh_handle *h, int nprob, int n, const double *dB, double *dQ, double *dRt, double *dvb)
+static void launch_qn_qr(nlh_handle *h, int nprob, int n, const double *dB, double *dQ, double *dRt, double *dvb,
+                         const LmState *gst = nullptr, int gwant = -1)
 {
     // dvb: per problem 2n (reflector column, two slots) + 2 x 2n (w, two slots) + 2 x 4 (tau, scal, beta)
     hipStream_t s = h->stream;
     double *vbuf = dvb, *wbuf = dvb + (size_t)nprob * 2 * n, *st = wbuf + (size_t)nprob * 4 * n;
     {
         dim3 grid((n + 31) / 32, (n + 31) / 32, nprob);
-        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, n, n, dB, dRt, n, (const LmState *)nullptr, -1);
+        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, n, n, dB, dRt, n, gst, gwant);
     }
-    hipLaunchKernelGGL(k_qn_qr_init, dim3(std::min(1024, (n * n + 255) / 256), nprob), dim3(256), 0, s, n, dRt, dQ, vbuf);
-    launch_house_steps(h, nprob, n, n, n, dRt, dQ, vbuf, wbuf, st);
+    hipLaunchKernelGGL(k_qn_qr_init, dim3(std::min(1024, (n * n + 255) / 256), nprob), dim3(256), 0, s, n, dRt, dQ, vbuf, gst, gwant);
+    launch_house_steps(h, nprob, n, n, n, dRt, dQ, vbuf, wbuf, st, gst, gwant);
 }
 
 // Q1 R1 = Q R + u v^T (qr_rank1_update(q, r, s, dx), :307).  dwcs: 3n doubles per problem of scratch.
 static void launch_qn_update(nlh_handle *h, int nprob, int n, double *dQ, double *dRt, const double *du,
-                             const double *dv, double *dwcs)
+                             const double *dv, double *dwcs, const LmState *gst = nullptr, int gwant = -1)
 {
     hipStream_t s = h->stream;
     double *dw = dwcs, *dc = dwcs + (size_t)nprob * n, *dsn = dc + (size_t)nprob * n;
-    hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, nprob), dim3(256), 0, s, n, n, dQ, du, dw, 1.0);
-    hipLaunchKernelGGL(k_qn_fold, dim3(nprob), dim3(64), 0, s, n, dw, dc, dsn);
+    hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, nprob), dim3(256), 0, s, n, n, dQ, du, dw, 1.0, gst, gwant);
+    hipLaunchKernelGGL(k_qn_fold, dim3(nprob), dim3(64), 0, s, n, dw, dc, dsn, gst, gwant);
     const dim3 g1((n + 255) / 256, nprob);
-    hipLaunchKernelGGL(k_qn_rot_q, g1, dim3(256), sizeof(double) * 2 * n, s, n, dQ, dc, dsn, 1);
-    hipLaunchKernelGGL(k_qn_hess_r, g1, dim3(256), sizeof(double) * 2 * n, s, n, dRt, dc, dsn, dw, dv);
+    hipLaunchKernelGGL(k_qn_rot_q, g1, dim3(256), sizeof(double) * 2 * n, s, n, dQ, dc, dsn, 1, gst, gwant);
+    hipLaunchKernelGGL(k_qn_hess_r, g1, dim3(256), sizeof(double) * 2 * n, s, n, dRt, dc, dsn, dw, dv, gst, gwant);
     if (n <= 1024) {
         const int bs = std::min(1024, ((n + 63) / 64) * 64);
-        hipLaunchKernelGGL(k_qn_retri<1>, dim3(nprob), dim3(bs), sizeof(double) * 2 * n, s, n, dRt, dc, dsn);
+        hipLaunchKernelGGL(k_qn_retri<1>, dim3(nprob), dim3(bs), sizeof(double) * 2 * n, s, n, dRt, dc, dsn, gst, gwant);
     } else {
-        hipLaunchKernelGGL(k_qn_retri<4>, dim3(nprob), dim3(1024), sizeof(double) * 2 * n, s, n, dRt, dc, dsn);
+        hipLaunchKernelGGL(k_qn_retri<4>, dim3(nprob), dim3(1024), sizeof(double) * 2 * n, s, n, dRt, dc, dsn, gst, gwant);
     }
-    hipLaunchKernelGGL(k_qn_rot_q, g1, dim3(256), sizeof(double) * 2 * n, s, n, dQ, dc, dsn, 0);
+    hipLaunchKernelGGL(k_qn_rot_q, g1, dim3(256), sizeof(double) * 2 * n, s, n, dQ, dc, dsn, 0, gst, gwant);
 }
 
 static int quasi_newton_core(nlh_handle *h, const nlh_options *o, int jdelta, int n, NewtonEval &ev, double *x,
@@ -1331,16 +1332,16 @@ static int quasi_newton_core(nlh_handle *h, const nlh_options *o, int jdelta, in
                 const double x2 = h_dot(n, dx.data(), dx.data());
                 HIPCHK(h, hipMemcpyAsync(ddx, dx.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
                 HIPCHK(h, hipMemcpyAsync(ddf, df.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(k_qn_resid, dim3((n + 255) / 256, 1), dim3(256), sizeof(double) * n, s, n, dB, ddx, ddf, x2, dsv);
-                hipLaunchKernelGGL(k_qn_rank1, dim3((n + 255) / 256, n, 1), dim3(256), 0, s, n, dB, dsv, ddx);
+                hipLaunchKernelGGL(k_qn_resid, dim3((n + 255) / 256, 1), dim3(256), sizeof(double) * n, s, n, dB, ddx, ddf, x2, (const double *)nullptr, dsv, (const LmState *)nullptr, -1);
+                hipLaunchKernelGGL(k_qn_rank1, dim3((n + 255) / 256, n, 1), dim3(256), 0, s, n, dB, dsv, ddx, (const LmState *)nullptr, -1);
                 launch_qn_update(h, 1, n, dQ, dRt, dsv, ddx, dwcs);
                 jcount += 1;
             }
             // grad = B^T f (:313), step = -R^-1 Q^T f (:322-328)
             HIPCHK(h, hipMemcpyAsync(dfv, fvec, sizeof(double) * n, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, 1), dim3(256), 0, s, n, n, dB, dfv, dgrad, 1.0);
-            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, 1), dim3(256), 0, s, n, n, dQ, dfv, dstep, -1.0);
-            hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dRt, dstep, (size_t)n * n, (size_t)n);
+            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, 1), dim3(256), 0, s, n, n, dB, dfv, dgrad, 1.0, (const LmState *)nullptr, -1);
+            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, 1), dim3(256), 0, s, n, n, dQ, dfv, dstep, -1.0, (const LmState *)nullptr, -1);
+            hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dRt, dstep, (size_t)n * n, (size_t)n, (const LmState *)nullptr, -1);
             HIPCHK(h, hipMemcpyAsync(dx.data(), dgrad, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipMemcpyAsync(df.data(), dstep, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipStreamSynchronize(s));
@@ -1530,8 +1531,8 @@ static int cls_core(nlh_handle *h, const nlh_options *o, double delta0, double s
         hipLaunchKernelGGL(k_qn_col0, dim3((m + 255) / 256, 1), dim3(256), 0, s, m, n, dW, vbuf);
         launch_house_steps(h, 1, m, n, 1, dW, dE, vbuf, wbuf, st);
         HIPCHK(h, hipMemcpyAsync(dstep, dE, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dW, dstep, (size_t)m * n, (size_t)n);
-        hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, 1), dim3(256), 0, s, m, n, dJ, dfv, dgv, 1.0);
+        hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n, dW, dstep, (size_t)m * n, (size_t)n, (const LmState *)nullptr, -1);
+        hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, 1), dim3(256), 0, s, m, n, dJ, dfv, dgv, 1.0, (const LmState *)nullptr, -1);
         HIPCHK(h, hipMemcpyAsync(u.data(), dstep, sizeof(double) * n, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(g.data(), dgv, sizeof(double) * n, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
@@ -1805,7 +1806,7 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
             for (int i = 0; i < n; ++i) u[i] = -g[i];
             HIPCHK(h, hipMemcpyAsync(dout, u.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_bf_solve_upper_t, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dR, dout);
-            hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dR, dout, (size_t)n * n, (size_t)n);
+            hipLaunchKernelGGL(k_qn_solve_upper, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dR, dout, (size_t)n * n, (size_t)n, (const LmState *)nullptr, -1);
             HIPCHK(h, hipMemcpyAsync(dx.data(), dout, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipStreamSynchronize(s));
@@ -1931,29 +1932,39 @@ int nlh_newton_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_vecfcn 
     return rc;
 }
 
-// newton_solver%solve for a batch of device-model problems: the lock-step state machine of nlh_kernels_newton.h.  A round
-// serves every problem in whatever stage it is: the ones that want a Jacobian get J (analytic or forward differences),
-// grad = J^T F in the reference's row order, the LU of J in place (the reference factors a copy; J is not read again in
-// the iteration), the direction and the set-up of the line search; the ones with a trial point get F(x) and one turn of
-// the search loop / the convergence test.  One 8-byte read-back per round.
-int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t n, const double *dA,
-                              const double *db, double gamma, int32_t analytic, double *dx, double *dfvec,
-                              nlh_iteration_behavior *ib, int32_t *status)
+// newton_solver%solve / quasi_newton_solver%solve for a batch of device-model problems: the lock-step state machine of
+// nlh_kernels_newton.h.  A round serves every problem in whatever stage it is.  Newton: the ones that want a Jacobian
+// get J (analytic or forward differences), grad = J^T F in the reference's row order, the LU of J in place (the
+// reference factors a copy; J is not read again in the iteration), the direction and the set-up of the line search.
+// Quasi-Newton (broyden): an iteration starts either from a fresh Jacobian B and its QR factors with Q formed (:284-292)
+// or from Broyden's rank-one update of B, Q and R (:294-310); then grad = B^T F, step = -R^-1 Q^T F (:313-328).  The ones
+// with a trial point get F(x) and one turn of the search loop / the convergence test.  One 12-byte read-back per round.
+static int square_lockstep(nlh_handle *h, const nlh_options *o, bool broyden, int jdelta, int32_t nprob, int32_t n,
+                           const double *dA, const double *db, double gamma, int32_t analytic, double *dx, double *dfvec,
+                           nlh_iteration_behavior *ib, int32_t *status)
 {
-    if (!h) return NLH_ERR_BAD_HANDLE;
-    if (!o || n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
+    if (broyden && n > QN_MAX_N) return NLH_ARRAY_SIZE_ERROR;
     const size_t nn = (size_t)n * n, np = (size_t)nprob;
     if ((rc = ensure(h, h->J, sizeof(double) * nn * np))) return rc;
     if (!analytic && (rc = ensure(h, h->P, sizeof(double) * nn * np))) return rc;
-    if ((rc = ensure(h, h->vecs, sizeof(double) * 3 * n * np))) return rc;
+    if ((rc = ensure(h, h->vecs, sizeof(double) * (broyden ? 17 : 3) * n * np + sizeof(double) * 16 * np))) return rc;
     if ((rc = ensure(h, h->ipvt, sizeof(int32_t) * n * np))) return rc;
     if ((rc = ensure(h, h->state, sizeof(LmState) * np))) return rc;
     if ((rc = ensure(h, h->misc, sizeof(NtState) * np + 64))) return rc;
     if ((rc = ensure_pinned(h, sizeof(NtState) * np + 64))) return rc;
-    double *dJ = (double *)h->J.p, *dP = (double *)h->P.p;
+    if (broyden) {
+        if ((rc = ensure(h, h->qnQ, sizeof(double) * nn * np))) return rc;
+        if ((rc = ensure(h, h->qnR, sizeof(double) * nn * np))) return rc;
+    }
+    double *dJ = (double *)h->J.p, *dP = (double *)h->P.p;       // J: the Jacobian / its LU; quasi-Newton: B
     double *dxold = (double *)h->vecs.p, *ddir = dxold + (size_t)n * np, *dgrad = ddir + (size_t)n * np;
+    // quasi-Newton only: F(xold), dx, df, s, the update's scratch (3n), the QR's reflector / w slots (6n + 8), x2
+    double *dfvold = dgrad + (size_t)n * np, *dddx = dfvold + (size_t)n * np, *dddf = dddx + (size_t)n * np;
+    double *dsv = dddf + (size_t)n * np, *dwcs = dsv + (size_t)n * np, *dvb = dwcs + 3 * (size_t)n * np;
+    double *dx2 = dvb + (6 * (size_t)n + 8) * np;
+    double *dQ = (double *)h->qnQ.p, *dRt = (double *)h->qnR.p;
     int32_t *dipvt = (int32_t *)h->ipvt.p;
     LmState *st = (LmState *)h->state.p;
     int32_t *dcounts = (int32_t *)h->misc.p;
@@ -1963,27 +1974,32 @@ int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob
     hipStream_t s = h->stream;
     NtOpts no;
     no.ftol = o->ftol; no.xtol = o->xtol; no.gtol = o->gtol; no.ls_alpha = o->ls_alpha; no.ls_factor = o->ls_factor;
-    no.max_evals = o->max_evals; no.ls_max_evals = o->ls_max_evals; no.use_line_search = o->use_line_search ? 1 : 0; no.pad = 0;
+    no.max_evals = o->max_evals; no.ls_max_evals = o->ls_max_evals; no.use_line_search = o->use_line_search ? 1 : 0;
+    no.broyden = broyden ? 1 : 0; no.jdelta = jdelta; no.pad = 0;
     const int pb = (nprob + 255) / 256;
     const bool echo = o->print_status && nprob == 1;             // the status block is a single solve's (:611-613)
+    auto jacobian = [&]() {                                      // for the problems in stage NT_NEED_JAC
+        if (analytic) {
+            Timed t(h, NLH_K_DQ_JACOBIAN);
+            hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((n + RB - 1) / RB, nprob), dim3(RB), sizeof(double) * n, s,
+                               n, n, dA, gamma, (const double *)dx, dJ, (const LmState *)st, (int)NT_NEED_JAC);
+        } else {                                                 // vfh_jac_fcn: n perturbed evaluations, (f1 - f0) / h
+            launch_dq_panel(h, nprob, n, n, dA, db, gamma, dx, dP, st, NT_NEED_JAC);
+            launch_fd(h, nprob, n, n, dP, dfvec, dx, dJ, st, NT_NEED_JAC);
+        }
+    };
 
-    // (:535 asks for a Jacobian before fvec is defined and discards it: nothing observable for a device model.)
+    // (ns_solve :535 asks for a Jacobian before fvec is defined and discards it: nothing observable for a device model.)
     hipLaunchKernelGGL(k_nt_reset, dim3(pb), dim3(256), 0, s, nprob, st, ns);
-    launch_dq_residual(h, nprob, n, n, dA, db, gamma, dx, dfvec, nullptr, st, NT_START);       // :538
+    launch_dq_residual(h, nprob, n, n, dA, db, gamma, dx, dfvec, nullptr, st, NT_START);       // :538 / :261
     hipLaunchKernelGGL(k_nt_start, dim3(nprob), dim3(256), 0, s, n, no, (const double *)dx, (const double *)dfvec, st, ns);
-    int need_jac = nprob, trial = 0;                             // upper bounds until the first read-back
-    // a round advances every live problem by one evaluation at least, and a solve makes at most max_evals + ls_max_evals
-    const long max_rounds = (long)o->max_evals + (long)o->ls_max_evals + 8;
+    int need_jac = nprob, update = 0;                            // upper bounds until the first read-back
+    // a round advances every live problem by one evaluation at least (or, quasi-Newton, turns an iteration without a
+    // descent direction into a restart: bounded by 10 max_evals + 100 iterations as in the host loop)
+    const long max_rounds = broyden ? 11L * o->max_evals + (long)o->ls_max_evals + 128 : (long)o->max_evals + (long)o->ls_max_evals + 8;
     for (long round = 0; round < max_rounds; ++round) {
-        if (need_jac > 0) {
-            if (analytic) {
-                Timed t(h, NLH_K_DQ_JACOBIAN);
-                hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((n + RB - 1) / RB, nprob), dim3(RB), sizeof(double) * n, s,
-                                   n, n, dA, gamma, (const double *)dx, dJ, (const LmState *)st, (int)NT_NEED_JAC);
-            } else {                                             // vfh_jac_fcn: n perturbed evaluations, (f1 - f0) / h
-                launch_dq_panel(h, nprob, n, n, dA, db, gamma, dx, dP, st, NT_NEED_JAC);
-                launch_fd(h, nprob, n, n, dP, dfvec, dx, dJ, st, NT_NEED_JAC);
-            }
+        if (!broyden && need_jac > 0) {
+            jacobian();
             {
                 Timed t(h, NLH_K_JTF);                           // :565-567
                 hipLaunchKernelGGL(k_jtf_exact, dim3((n + 255) / 256, nprob), dim3(256), 0, s, n, n, (const double *)dJ,
@@ -1994,33 +2010,68 @@ int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob
             launch_lu_factor(h, nprob, n, dJ, dipvt, nullptr, st, NT_NEED_JAC);          // :570
             hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, s, n, (const double *)dJ,
                                (const int32_t *)dipvt, ddir, (const LmState *)st, (int)NT_NEED_JAC);   // :577
-            hipLaunchKernelGGL(k_nt_step_begin, dim3(nprob), dim3(256), 0, s, n, no, dx, dxold, ddir, (const double *)dgrad, st, ns);
+            hipLaunchKernelGGL(k_nt_step_begin, dim3(nprob), dim3(256), 0, s, n, no, (int)NT_NEED_JAC, dx, dxold, ddir, (const double *)dgrad,
+                               (const double *)dfvec, (double *)nullptr, st, ns);
+        }
+        if (broyden && (need_jac > 0 || update > 0)) {
+            if (need_jac > 0) {                                  // :284-292: B = J(x), QR with Q formed
+                jacobian();
+                launch_qn_qr(h, nprob, n, dJ, dQ, dRt, dvb, st, NT_NEED_JAC);
+                hipLaunchKernelGGL(k_nt_advance, dim3(pb), dim3(256), 0, s, nprob, st, (int)NT_NEED_JAC, (int)NT_DIR);
+            }
+            if (update > 0) {                                    // :294-310: B += s dx^T, Q R <- Q R + s dx^T
+                hipLaunchKernelGGL(k_qn_prep, dim3(nprob), dim3(256), 0, s, n, (const double *)dx, (const double *)dxold,
+                                   (const double *)dfvec, (const double *)dfvold, dddx, dddf, dx2, (const LmState *)st);
+                hipLaunchKernelGGL(k_qn_resid, dim3((n + 255) / 256, nprob), dim3(256), sizeof(double) * n, s, n, (const double *)dJ,
+                                   (const double *)dddx, (const double *)dddf, 0.0, (const double *)dx2, dsv, (const LmState *)st, (int)NT_UPDATE);
+                hipLaunchKernelGGL(k_qn_rank1, dim3((n + 255) / 256, n, nprob), dim3(256), 0, s, n, dJ, (const double *)dsv,
+                                   (const double *)dddx, (const LmState *)st, (int)NT_UPDATE);
+                launch_qn_update(h, nprob, n, dQ, dRt, dsv, dddx, dwcs, st, NT_UPDATE);
+                hipLaunchKernelGGL(k_nt_advance, dim3(pb), dim3(256), 0, s, nprob, st, (int)NT_UPDATE, (int)NT_DIR);
+            }
+            // grad = B^T F (:313), step = -R^-1 Q^T F (:322-328)
+            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, nprob), dim3(256), 0, s, n, n, (const double *)dJ, (const double *)dfvec,
+                               dgrad, 1.0, (const LmState *)st, (int)NT_DIR);
+            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, nprob), dim3(256), 0, s, n, n, (const double *)dQ, (const double *)dfvec,
+                               ddir, -1.0, (const LmState *)st, (int)NT_DIR);
+            hipLaunchKernelGGL(k_qn_solve_upper, dim3(nprob), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n, s, n,
+                               (const double *)dRt, ddir, nn, (size_t)n, (const LmState *)st, (int)NT_DIR);
+            hipLaunchKernelGGL(k_nt_step_begin, dim3(nprob), dim3(256), 0, s, n, no, (int)NT_DIR, dx, dxold, ddir, (const double *)dgrad,
+                               (const double *)dfvec, dfvold, st, ns);
         }
         launch_dq_residual(h, nprob, n, n, dA, db, gamma, dx, dfvec, nullptr, st, NT_TRIAL);
         hipLaunchKernelGGL(k_nt_trial, dim3(nprob), dim3(256), 0, s, n, no, dx, (const double *)dxold, (const double *)ddir,
                            (const double *)dgrad, (const double *)dfvec, st, ns);
         hipLaunchKernelGGL(k_nt_count, dim3(1), dim3(256), 0, s, nprob, (const LmState *)st, dcounts);
-        HIPCHK(h, hipMemcpyAsync(hcounts, dcounts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(hcounts, dcounts, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (echo) HIPCHK(h, hipMemcpyAsync(hns, ns, sizeof(NtState), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
         if (echo && hns[0].print_due) print_status(hns[0].iter, hns[0].neval, hns[0].njac, hns[0].xnorm, hns[0].fnorm);
-        need_jac = hcounts[0]; trial = hcounts[1];
-        if (need_jac == 0 && trial == 0) break;
+        need_jac = hcounts[0]; update = hcounts[2];
+        if (need_jac == 0 && update == 0 && hcounts[1] == 0) break;
     }
     HIPCHK(h, hipMemcpyAsync(hns, ns, sizeof(NtState) * np, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     for (int p = 0; p < nprob; ++p) {
         const NtState &q = hns[p];
-        if (ib) {                                                // :624-632
+        if (ib) {                                                // :624-632 / :414-422
             ib[p].iter_count = q.iter; ib[p].fcn_count = q.neval; ib[p].jacobian_count = q.njac; ib[p].gradient_count = 0;
             ib[p].converge_on_fcn = q.fcnvrg; ib[p].converge_on_chng = q.xcnvrg; ib[p].converge_on_zero_diff = q.gcnvrg;
         }
         const bool finished = q.rc || q.flag || q.fcnvrg || q.xcnvrg;
-        if (status) status[p] = q.rc ? q.rc : ((q.flag || !finished) ? NLH_CONVERGENCE_ERROR : 0);       // :635-637
+        if (status) status[p] = q.rc ? q.rc : ((q.flag || !finished) ? NLH_CONVERGENCE_ERROR : 0);       // :635-637 / :425-427
     }
-    (void)trial;
     return 0;
+}
+
+int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t n, const double *dA,
+                              const double *db, double gamma, int32_t analytic, double *dx, double *dfvec,
+                              nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!o || n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
+    return square_lockstep(h, o, false, 0, nprob, n, dA, db, gamma, analytic, dx, dfvec, ib, status);
 }
 
 // quasi_newton_solver%solve -- qns_solve, src/nonlin_solve.f90:156-427
@@ -2075,58 +2126,8 @@ int nlh_dq_quasi_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t
                                     double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
-    if (!o || n < 1) return NLH_INVALID_INPUT_ERROR;
-    HIPCHK(h, hipSetDevice(h->device));
-    // one problem per call; run_problems deals the problems to worker threads with private handles
-    auto solve_one = [&](nlh_handle *h, int p) -> int {
-        int rc;
-        const size_t nn = (size_t)n * n;
-        if ((rc = ensure(h, h->P, sizeof(double) * nn))) return rc;
-        if ((rc = ensure(h, h->xdev, sizeof(double) * n))) return rc;
-        if ((rc = ensure(h, h->wa4, sizeof(double) * n))) return rc;
-        hipStream_t s = h->stream;
-        std::vector<double> x(n), f(n);
-        const double *A = dA + (size_t)p * nn, *b = db + (size_t)p * n;
-        double *dxp = dx + (size_t)p * n, *dfp = dfvec + (size_t)p * n;
-        double *dxs = (double *)h->xdev.p, *dfs = (double *)h->wa4.p;
-        HIPCHK(h, hipMemcpyAsync(x.data(), dxp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipStreamSynchronize(s));
-        NewtonEval ev;
-        ev.fcn = [&](const double *xx, double *ff) -> int {
-            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
-            launch_dq_residual(h, 1, n, n, A, b, gamma, dxs, dfs, nullptr, nullptr, -1);
-            HIPCHK(h, hipMemcpyAsync(ff, dfs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
-            HIPCHK(h, hipStreamSynchronize(s));
-            return 0;
-        };
-        ev.jac = [&](double *xx, const double *f0, double *dJ) -> int {
-            HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
-            if (analytic) {
-                Timed t(h, NLH_K_DQ_JACOBIAN);
-                hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((n + RB - 1) / RB, 1), dim3(RB), sizeof(double) * n, s,
-                                   n, n, A, gamma, (const double *)dxs, dJ, (const LmState *)nullptr, -1);
-            } else {
-                HIPCHK(h, hipMemcpyAsync(dfs, f0, sizeof(double) * n, hipMemcpyHostToDevice, s));
-                launch_dq_panel(h, 1, n, n, A, b, gamma, dxs, (double *)h->P.p, nullptr, -1);
-                launch_fd(h, 1, n, n, (const double *)h->P.p, dfs, dxs, dJ, nullptr, -1);
-            }
-            return 0;
-        };
-        nlh_iteration_behavior lib;
-        memset(&lib, 0, sizeof lib);
-        rc = quasi_newton_core(h, o, jdelta, n, ev, x.data(), f.data(), &lib);
-        if (rc < 0) return rc;
-        if (ib) ib[p] = lib;
-        if (status) status[p] = rc;
-        HIPCHK(h, hipMemcpyAsync(dxp, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipMemcpyAsync(dfp, f.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipStreamSynchronize(s));
-        return 0;
-    };
-    const int rcb = run_problems(h, nprob, solve_one);
-    if (rcb) return rcb;
-    HIPCHK(h, hipGetLastError());
-    return 0;
+    if (!o || n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
+    return square_lockstep(h, o, true, jdelta, nprob, n, dA, db, gamma, analytic, dx, dfvec, ib, status);   // the same state machine
 }
 
 // constrained_least_squares_solver%solve -- cls_solve, src/nonlin_least_squares.f90:938-1176
@@ -2829,7 +2830,7 @@ int nlh_solve_upper(nlh_handle *h, int32_t nprob, int32_t n, const double *dRt, 
     if (n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(k_qn_solve_upper, dim3(nprob), dim3(std::min(1024, ((n + 63) / 64) * 64)), sizeof(double) * n,
-                       h->stream, n, dRt, dx, (size_t)n * n, (size_t)n);
+                       h->stream, n, dRt, dx, (size_t)n * n, (size_t)n, (const LmState *)nullptr, -1);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -2887,7 +2888,7 @@ int nlh_poly_fit_batch(nlh_handle *h, int32_t nprob, int32_t npts, int32_t order
     hipLaunchKernelGGL(k_qn_col0, dim3((npts + 255) / 256, nprob), dim3(256), 0, s, npts, ncols, dA, vbuf);
     launch_house_steps(h, nprob, npts, ncols, 1, dA, rhs, vbuf, wbuf, st);
     hipLaunchKernelGGL(k_qn_solve_upper, dim3(nprob), dim3(64), sizeof(double) * ncols, s, ncols, dA, rhs,
-                       (size_t)npts * ncols, (size_t)npts);
+                       (size_t)npts * ncols, (size_t)npts, (const LmState *)nullptr, -1);
     if (thru_zero) HIPCHK(h, hipMemsetAsync(dcoef, 0, sizeof(double) * (size_t)nprob * (order + 1), s));
     HIPCHK(h, hipMemcpy2DAsync(dcoef + (thru_zero ? 1 : 0), sizeof(double) * (order + 1), rhs, sizeof(double) * npts,
                                sizeof(double) * ncols, nprob, hipMemcpyDeviceToDevice, s));

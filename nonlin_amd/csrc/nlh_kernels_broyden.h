@@ -29,9 +29,11 @@ __device__ __forceinline__ void givens_dev(double f, double g, double &c, double
 
 // Q <- I, and the first reflector's column: vbuf[i] = A(i,0).
 __global__ void __launch_bounds__(256)
-k_qn_qr_init(int n, const double *__restrict__ Rt, double *__restrict__ Q, double *__restrict__ vbuf)
+k_qn_qr_init(int n, const double *__restrict__ Rt, double *__restrict__ Q, double *__restrict__ vbuf,
+        const LmState *__restrict__ gst, int gwant)
 {
     const int p = blockIdx.y;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     const size_t nn = (size_t)n * n;
     double *Qp = Q + p * nn;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nn; e += (size_t)gridDim.x * 256)
@@ -54,11 +56,13 @@ k_qn_qr_init(int n, const double *__restrict__ Rt, double *__restrict__ Q, doubl
 // ncE = 1 (E = the right-hand side f, which becomes Q^T f).
 __global__ void __launch_bounds__(QN_DOT_BS)
 k_qn_house_dot(int rows, int ncA, int ncE, int j, const double *__restrict__ Aall, const double *__restrict__ Eall,
-               const double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st)
+               const double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st,
+        const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double vs[];                 // rows: reflector, rows j+1 .. rows-1
     __shared__ double sq_sh;
     const int p = blockIdx.y, tid = threadIdx.x;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     const double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
     const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
     for (int i0 = j + 1 + tid; i0 < rows; i0 += 8 * QN_DOT_BS) {      // 8 loads in flight per thread
@@ -122,13 +126,15 @@ k_qn_house_dot(int rows, int ncA, int ncE, int j, const double *__restrict__ Aal
 #define QN_DOT2_TR 256
 __global__ void __launch_bounds__(256)
 k_qn_house_dot2(int rows, int ncA, int ncE, int j, const double *__restrict__ Aall, const double *__restrict__ Eall,
-                const double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st)
+                const double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st,
+        const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double sm2[];
     double *vs = sm2;                                   // rows (index = row)
     double *prod = sm2 + rows;                          // [2][QN_DOT2_TR][QN_DOT2_CG]
     __shared__ double sq_sh;
     const int p = blockIdx.y, tid = threadIdx.x;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     const double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
     const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
     for (int i0 = j + 1 + tid; i0 < rows; i0 += 8 * 256) {
@@ -221,7 +227,8 @@ k_qn_house_dot2(int rows, int ncA, int ncE, int j, const double *__restrict__ Aa
 template <int CG>
 __global__ void __launch_bounds__(256)
 k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
-                 double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st)
+                 double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st,
+        const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double sm3[];
     double *vsp = sm3;                                  // previous reflector, scaled (rows >= j)
@@ -230,6 +237,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     double *prod = sm3 + 2 * (size_t)rows;              // [2][TR][CG]
     __shared__ double sq_sh, alpha_sh;
     const int p = blockIdx.y, tid = threadIdx.x, nc = ncA + ncE, jp = j - 1;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
     const double *vprev_g = vbuf + ((size_t)p * 2 + (jp & 1)) * rows;
     double *vcur_g = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
@@ -354,9 +362,11 @@ __global__ void __launch_bounds__(256)
 k_qn_house_apply(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
                  double *__restrict__ vbuf, const double *__restrict__ wbuf, const double *__restrict__ st,
                  int wps /* w doubles per problem */, int sps /* st doubles per problem */,
-                 int fixcol /* 1 after k_qn_house_fused: column j was never stored during step j, finish it here */)
+                 int fixcol /* 1 after k_qn_house_fused: column j was never stored during step j, finish it here */,
+        const LmState *__restrict__ gst, int gwant)
 {
     const int p = blockIdx.z;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
     const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
     double *vnext = vbuf + ((size_t)p * 2 + ((j + 1) & 1)) * rows;
@@ -433,10 +443,12 @@ k_matvec_cm(int m, int n, const double *__restrict__ J, const double *__restrict
 // s = (df - B dx) / x2   (:301-302): thread per row, sum over columns ascending.
 __global__ void __launch_bounds__(256)
 k_qn_resid(int n, const double *__restrict__ B, const double *__restrict__ dx, const double *__restrict__ df,
-           double x2, double *__restrict__ s)
+           double x2, const double *__restrict__ x2all /* per problem, or NULL: x2 */, double *__restrict__ s,
+        const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double xs[];
     const int p = blockIdx.y;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     for (int k = threadIdx.x; k < n; k += 256) xs[k] = dx[(size_t)p * n + k];
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -452,14 +464,16 @@ k_qn_resid(int n, const double *__restrict__ B, const double *__restrict__ dx, c
         for (int u = 0; u < 8; ++u) t = t + v[u] * xs[j + u];
     }
     for (; j < n; ++j) t = t + b[(size_t)j * n] * xs[j];
-    s[(size_t)p * n + i] = (df[(size_t)p * n + i] - t) / x2;
+    s[(size_t)p * n + i] = (df[(size_t)p * n + i] - t) / (x2all ? x2all[p] : x2);
 }
 
 // B += s dx^T  (rank1_update, :306)
 __global__ void __launch_bounds__(256)
-k_qn_rank1(int n, double *__restrict__ B, const double *__restrict__ s, const double *__restrict__ dx)
+k_qn_rank1(int n, double *__restrict__ B, const double *__restrict__ s, const double *__restrict__ dx,
+        const LmState *__restrict__ gst, int gwant)
 {
     const int p = blockIdx.z;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
     if (i >= n) return;
     double *b = B + (size_t)p * n * n + (size_t)j * n + i;
@@ -472,10 +486,12 @@ k_qn_rank1(int n, double *__restrict__ B, const double *__restrict__ s, const do
 // in flight during the sums.
 __global__ void __launch_bounds__(256)
 k_qn_colsdot(int m, int n, const double *__restrict__ M, const double *__restrict__ f, double *__restrict__ out,
-             double sign)
+             double sign,
+        const LmState *__restrict__ gst, int gwant)
 {
     __shared__ double prod[2][16 * 257];
     const int p = blockIdx.y, t = threadIdx.x;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     const int k0 = blockIdx.x * 16;
     const double *Mp = M + (size_t)p * m * n;
     const double *fp = f + (size_t)p * m;
@@ -515,9 +531,11 @@ k_qn_colsdot(int m, int n, const double *__restrict__ M, const double *__restric
 }
 
 // DQRTV1: rotations folding w into w(0), generated from the bottom (one thread per problem).
-__global__ void k_qn_fold(int n, double *__restrict__ w, double *__restrict__ c, double *__restrict__ s)
+__global__ void k_qn_fold(int n, double *__restrict__ w, double *__restrict__ c, double *__restrict__ s,
+        const LmState *__restrict__ gst, int gwant)
 {
     const int p = blockIdx.x;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     if (threadIdx.x != 0) return;
     double *wp = w + (size_t)p * n, *cp = c + (size_t)p * n, *sp = s + (size_t)p * n;
     double rr = wp[n - 1];
@@ -532,10 +550,12 @@ __global__ void k_qn_fold(int n, double *__restrict__ w, double *__restrict__ c,
 
 // DQROT: rotations on adjacent columns of Q, thread per row.  backward: pairs n-2 .. 0, else 0 .. n-2.
 __global__ void __launch_bounds__(256)
-k_qn_rot_q(int n, double *__restrict__ Q, const double *__restrict__ c, const double *__restrict__ s, int backward)
+k_qn_rot_q(int n, double *__restrict__ Q, const double *__restrict__ c, const double *__restrict__ s, int backward,
+        const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double cs[];                 // c[n], s[n]
     const int p = blockIdx.y;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     for (int k = threadIdx.x; k < n; k += 256) { cs[k] = c[(size_t)p * n + k]; cs[n + k] = s[(size_t)p * n + k]; }
     __syncthreads();
     const int row = blockIdx.x * 256 + threadIdx.x;
@@ -565,10 +585,12 @@ k_qn_rot_q(int n, double *__restrict__ Q, const double *__restrict__ c, const do
 // DQRQH + the first-row update: R -> upper Hessenberg, then R(0,:) += w0 v^T.  Thread per column.
 __global__ void __launch_bounds__(256)
 k_qn_hess_r(int n, double *__restrict__ Rt, const double *__restrict__ c, const double *__restrict__ s,
-            const double *__restrict__ w, const double *__restrict__ v)
+            const double *__restrict__ w, const double *__restrict__ v,
+        const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double cs[];
     const int p = blockIdx.y;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     for (int k = threadIdx.x; k < n; k += 256) { cs[k] = c[(size_t)p * n + k]; cs[n + k] = s[(size_t)p * n + k]; }
     __syncthreads();
     const int col = blockIdx.x * 256 + threadIdx.x;
@@ -596,10 +618,12 @@ k_qn_hess_r(int n, double *__restrict__ Rt, const double *__restrict__ c, const 
 // then every later column applies it.  c, s receive the rotations (dynamic LDS: 2n doubles).
 template <int NC>
 __global__ void __launch_bounds__(1024)
-k_qn_retri(int n, double *__restrict__ Rt, double *__restrict__ c, double *__restrict__ s)
+k_qn_retri(int n, double *__restrict__ Rt, double *__restrict__ c, double *__restrict__ s,
+        const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double cs[];
     const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     double *R = Rt + (size_t)p * n * n;
     double t[NC], nx[NC];
 #pragma unroll
@@ -648,10 +672,12 @@ k_qn_retri(int n, double *__restrict__ Rt, double *__restrict__ c, double *__res
 
 // x <- R^-1 x, column oriented (DTRSV 'U','N','N'); R row-major.  Dynamic LDS: n doubles.
 __global__ void __launch_bounds__(1024)
-k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall, size_t stride_r, size_t stride_x)
+k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall, size_t stride_r, size_t stride_x,
+        const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double bs[];
     const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     const double *R = Rt + (size_t)p * stride_r;   // leading n x n block, row-major with leading dimension n
     double *x = xall + (size_t)p * stride_x;
     for (int i = tid; i < n; i += BS) bs[i] = x[i];

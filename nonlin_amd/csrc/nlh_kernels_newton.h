@@ -12,8 +12,11 @@
 
 enum NtStage : int32_t {
     NT_START = 20,      // F(x0) evaluated, start-up logic due (:538-553)
-    NT_NEED_JAC = 21,   // iteration head: Jacobian, gradient, LU, direction, then the step set-up (:556-589)
+    NT_NEED_JAC = 21,   // iteration head: Jacobian, gradient, LU, direction, then the step set-up (:556-589);
+                        // quasi-Newton: an iteration that starts from a fresh Jacobian and its QR factors (:284-292)
     NT_TRIAL = 22,      // x holds a trial point: F(x) due, then the search / convergence logic
+    NT_UPDATE = 23,     // quasi-Newton: an iteration that starts with Broyden's rank-one update of B, Q, R (:294-310)
+    NT_DIR = 24,        // quasi-Newton: factors current, gradient / step / search set-up due (:313-351)
     NT_DONE = ST_DONE
 };
 
@@ -26,12 +29,16 @@ struct NtState {
     int32_t flag;                     // max_evals reached (:616-619): reported as NL_CONVERGENCE_ERROR
     int32_t rc;                       // code of an `error stop` inside the iteration (0: none)
     int32_t print_due;                // the reference would print its status block now (:611-613)
+    int32_t restart;                  // quasi-Newton: this iteration started from a fresh Jacobian
+    int32_t jcount;                   // quasi-Newton: updates since the last fresh Jacobian
     int32_t pad;
 };
 
 struct NtOpts {
     double ftol, xtol, gtol, ls_alpha, ls_factor;
-    int32_t max_evals, ls_max_evals, use_line_search, pad;
+    int32_t max_evals, ls_max_evals, use_line_search;
+    int32_t broyden;                  // 0: ns_solve; 1: qns_solve (src/nonlin_solve.f90:156-427) on the same search / test kernels
+    int32_t jdelta, pad;              // quasi-Newton: iterations between fresh Jacobians
 };
 
 // min_backtrack_search, src/nonlin_linesearch.f90:495-551 (host and device: the same expressions)
@@ -125,6 +132,7 @@ k_nt_reset(int nprob, LmState *__restrict__ st, NtState *__restrict__ ns)
     z.alam = z.alam1 = z.f1 = z.slope = z.alamin = 0.0;
     z.iter = z.neval = z.njac = z.ls_iter = z.ls_neval = 0;
     z.fcnvrg = z.xcnvrg = z.gcnvrg = z.flag = z.rc = z.print_due = z.pad = 0;
+    z.restart = 1; z.jcount = 0;
     ns[p] = z;
     st[p].stage = NT_START;
 }
@@ -167,23 +175,68 @@ k_nt_rhs(int n, const double *__restrict__ fall, double *__restrict__ rall, cons
     if (i < n) rall[(size_t)p * n + i] = -fall[(size_t)p * n + i];
 }
 
-// :573-589 after the LU solve: xold, fold, the step-length guards, the set-up of ls_search_mimo (:249-265) and the first
-// trial point
+// quasi-Newton, an update iteration's head (:294-296): df = F(x) - F(xold), dx = x - xold, x2 = dx.dx (ordered)
 __global__ void __launch_bounds__(256)
-k_nt_step_begin(int n, NtOpts o, double *__restrict__ xall, double *__restrict__ xoldall, double *__restrict__ dirall,
-                const double *__restrict__ gradall, LmState *__restrict__ st, NtState *__restrict__ ns)
+k_qn_prep(int n, const double *__restrict__ xall, const double *__restrict__ xoldall, const double *__restrict__ fall,
+          const double *__restrict__ fvoldall, double *__restrict__ ddxall, double *__restrict__ ddfall,
+          double *__restrict__ x2all, const LmState *__restrict__ st)
+{
+    __shared__ __attribute__((aligned(16))) double buf[NT_CHUNK];
+    __shared__ double xch[2];
+    const int p = blockIdx.x;
+    if (st[p].stage != NT_UPDATE) return;
+    const int tid = threadIdx.x, BS = blockDim.x;
+    const double *x = xall + (size_t)p * n, *xold = xoldall + (size_t)p * n, *fv = fall + (size_t)p * n, *fvold = fvoldall + (size_t)p * n;
+    double *ddx = ddxall + (size_t)p * n, *ddf = ddfall + (size_t)p * n;
+    for (int i = tid; i < n; i += BS) { ddf[i] = fv[i] - fvold[i]; ddx[i] = x[i] - xold[i]; }
+    const double x2 = nt_ordered_sum(n, [&](int i) { return ddx[i] * ddx[i]; }, buf, xch);
+    if (tid == 0) x2all[p] = x2;
+}
+
+__global__ void __launch_bounds__(256)
+k_nt_advance(int nprob, LmState *__restrict__ st, int from, int to)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nprob && st[p].stage == from) st[p].stage = to;
+}
+
+// :573-589 after the LU solve (quasi-Newton: :316-351 after grad = B^T F and step = -R^-1 Q^T F): xold, fold, the
+// step-length guards, the set-up of ls_search_mimo (:249-265) and the first trial point
+__global__ void __launch_bounds__(256)
+k_nt_step_begin(int n, NtOpts o, int want, double *__restrict__ xall, double *__restrict__ xoldall, double *__restrict__ dirall,
+                const double *__restrict__ gradall, const double *__restrict__ fall, double *__restrict__ fvoldall,
+                LmState *__restrict__ st, NtState *__restrict__ ns)
 {
     __shared__ __attribute__((aligned(16))) double buf[NT_CHUNK];
     __shared__ double xch[2], red[8];
     __shared__ double scratch[3 * NLH_NCH + 8];
     const int p = blockIdx.x;
-    if (st[p].stage != NT_NEED_JAC) return;
+    if (st[p].stage != want) return;
     const int tid = threadIdx.x, BS = blockDim.x;
     double *x = xall + (size_t)p * n, *xold = xoldall + (size_t)p * n, *dir = dirall + (size_t)p * n;
     const double *grad = gradall + (size_t)p * n;
     NtState *s = ns + p;
     const double stpmax = s->stpmax;
+    // the counters of this iteration's head: iter (loop top); Newton: a Jacobian every iteration; quasi-Newton: a
+    // Jacobian when the iteration restarted (:284-292), one more update since the last one otherwise (:310)
+    const int njac_inc = o.broyden ? (s->restart ? 1 : 0) : 1;
+    const int jcount = o.broyden ? (s->restart ? 0 : s->jcount + 1) : 0;
     for (int i = tid; i < n; i += BS) xold[i] = x[i];                 // :573-574
+    if (o.broyden) {
+        const double *fv = fall + (size_t)p * n;
+        double *fvold = fvoldall + (size_t)p * n;
+        for (int i = tid; i < n; i += BS) fvold[i] = fv[i];           // :317
+        const double temp = nt_ordered_sum(n, [&](int i) { return grad[i] * dir[i]; }, buf, xch);   // :332
+        if (temp >= 0.0) {                                            // :333-339: not a descent direction: start over
+            if (tid == 0) {
+                s->iter += 1; s->njac += njac_inc; s->jcount = jcount; s->fold = s->f;
+                s->restart = 1; s->print_due = 1;
+                if (s->iter > 10 * o.max_evals + 100) { s->flag = 1; st[p].stage = NT_DONE; }     // the reference would spin here
+                else st[p].stage = NT_NEED_JAC;
+            }
+            return;
+        }
+    }
     if (o.use_line_search) {
         const double temp = nt_ordered_sum(n, [&](int i) { return dir[i] * dir[i]; }, buf, xch);   // :581 (squared length, kept)
         if (temp > stpmax) {
@@ -201,14 +254,14 @@ k_nt_step_begin(int n, NtOpts o, double *__restrict__ xall, double *__restrict__
         }
         const double slope = nt_ordered_sum(n, [&](int i) { return grad[i] * dir[i]; }, buf, xch); // linesearch :249
         if (slope >= 0.0) {                                           // :250-253: error stop
-            if (tid == 0) { s->iter += 1; s->njac += 1; s->fold = s->f; s->rc = 206; st[p].stage = NT_DONE; }
+            if (tid == 0) { s->iter += 1; s->njac += njac_inc; s->jcount = jcount; s->fold = s->f; s->rc = 206; st[p].stage = NT_DONE; }
             return;
         }
         const double test = nt_block_max(n, [&](int i) { return fabs(dir[i]) / fmax(fabs(xold[i]), 1.0); }, red);
         const double alam = 1.0;
         for (int i = tid; i < n; i += BS) x[i] = xold[i] + alam * dir[i];
         if (tid == 0) {
-            s->iter += 1; s->njac += 1; s->fold = s->f; s->print_due = 0;
+            s->iter += 1; s->njac += njac_inc; s->jcount = jcount; s->fold = s->f; s->print_due = 0;
             s->slope = slope;
             s->alamin = (2.0 * NLH_EPS) / test;
             s->alam = alam; s->alam1 = 0.0; s->f1 = 0.0;
@@ -217,7 +270,7 @@ k_nt_step_begin(int n, NtOpts o, double *__restrict__ xall, double *__restrict__
         }
     } else {                                                          // :591-595
         for (int i = tid; i < n; i += BS) x[i] = x[i] + dir[i];
-        if (tid == 0) { s->iter += 1; s->njac += 1; s->fold = s->f; s->print_due = 0; st[p].stage = NT_TRIAL; }
+        if (tid == 0) { s->iter += 1; s->njac += njac_inc; s->jcount = jcount; s->fold = s->f; s->print_due = 0; st[p].stage = NT_TRIAL; }
     }
 }
 
@@ -286,12 +339,12 @@ k_nt_trial(int n, NtOpts o, double *__restrict__ xall, const double *__restrict_
         xnorm = nt_block_max(n, [&](int i) { return fabs(x[i] - xold[i]) / fmax(fabs(x[i]), 1.0); }, red);
         if (xnorm < o.xtol) {
             xc = 1; check = 1;
-        } else {
+        } else if (!o.broyden) {
             const double den = fmax(f, 0.5 * (double)n);
             const double tg = nt_block_max(n, [&](int i) { return fabs(grad[i]) * fmax(fabs(x[i]), 1.0) / den; }, red);
             if (tg < o.gtol) gc = 1;
-        }
-    }
+        }                                                             // (qns_solve tests the gradient only when the search reports a
+    }                                                                 //  zero slope, which ls_search_mimo never does: :360-367)
     if (tid == 0) {
         s->f = f; s->neval = neval;
         s->fcnvrg = fc; s->xcnvrg = xc; s->gcnvrg = gc;
@@ -301,9 +354,11 @@ k_nt_trial(int n, NtOpts o, double *__restrict__ xall, const double *__restrict_
         } else if (gc) {
             s->rc = 207; st[p].stage = NT_DONE;                       // :604-608
         } else {
-            s->print_due = 1;                                         // :611-613
-            if (neval >= o.max_evals) { s->flag = 1; st[p].stage = NT_DONE; }   // :616-619
-            else st[p].stage = NT_NEED_JAC;
+            s->print_due = 1;                                         // :611-613 / :398-400
+            const int restart = o.broyden ? (s->jcount >= o.jdelta ? 1 : 0) : 1;     // :368-391
+            s->restart = restart;
+            if (neval >= o.max_evals) { s->flag = 1; st[p].stage = NT_DONE; }   // :616-619 / :403-406
+            else st[p].stage = restart ? NT_NEED_JAC : NT_UPDATE;
         }
     }
 }
@@ -311,17 +366,19 @@ k_nt_trial(int n, NtOpts o, double *__restrict__ xall, const double *__restrict_
 __global__ void __launch_bounds__(256)
 k_nt_count(int nprob, const LmState *__restrict__ st, int32_t *__restrict__ counts)
 {
-    __shared__ int c[2];
-    if (threadIdx.x < 2) c[threadIdx.x] = 0;
+    __shared__ int c[3];
+    if (threadIdx.x < 3) c[threadIdx.x] = 0;
     __syncthreads();
-    int a = 0, b = 0;
+    int a = 0, b = 0, u = 0;
     for (int p = threadIdx.x; p < nprob; p += blockDim.x) {
         const int sg = st[p].stage;
         a += (sg == NT_NEED_JAC);
         b += (sg == NT_TRIAL);
+        u += (sg == NT_UPDATE);
     }
     if (a) atomicAdd(&c[0], a);
     if (b) atomicAdd(&c[1], b);
+    if (u) atomicAdd(&c[2], u);
     __syncthreads();
-    if (threadIdx.x < 2) counts[threadIdx.x] = c[threadIdx.x];
+    if (threadIdx.x < 3) counts[threadIdx.x] = c[threadIdx.x];
 }

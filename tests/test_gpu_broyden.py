@@ -193,3 +193,27 @@ def test_host_readme_example_1_counts(oracle):
     assert rc == 0 and _same(ib, ibo)
     assert np.array_equal(x, xo) and np.array_equal(f, fo)
     assert ("%.2e" % f[0], "%.2e" % f[1]) == ("3.23e-12", "7.05e-12")                         # README.md:94
+
+
+@pytest.mark.parametrize("n,nprob,analytic,spread,jdelta", [(64, 40, True, 0.03, 5), (96, 24, False, 0.1, 5), (129, 32, True, 0.3, 2),
+                                                            (200, 16, True, 1.0, 5)])
+def test_quasi_newton_lockstep_batch_bitwise(ds, oracle, n, nprob, analytic, spread, jdelta):
+    """quasi_newton_solver on a batch through the lock-step state machine (nlh_kernels_newton.h, broyden mode): problems
+    that restart, update and back-track at different times share every launch.  Each must carry the bits, counts, flags
+    and status the CPU path gives it alone."""
+    A, b, xt, x0 = ds.generate(nprob, n, n, seed0=911, sigma=0.0, spread=spread, square_shift=True)
+    x = x0.clone()
+    fvec, ibs, status = ds.quasi_newton_solve_batch(A, b, 0.5, x, analytic=analytic, opts=ds.options(max_evals=80), jdelta=jdelta)
+    xs, fs = x.cpu().numpy(), fvec.cpu().numpy()
+    seen = set()
+    for p in range(nprob):
+        Ah = np.asfortranarray(A[p].cpu().numpy().T)
+        rc, xo, fo, ibo, _ = oracle.dq_quasi_newton_solve(Ah, b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(), analytic=analytic,
+                                                          opts=oracle.default_options(max_evals=80), jdelta=jdelta)
+        assert status[p] == rc, (p, status[p], rc)
+        for k in ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn", "converge_on_chng", "converge_on_zero_diff"):
+            assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
+        assert np.array_equal(xs[p], xo, equal_nan=True), p
+        assert np.array_equal(fs[p], fo, equal_nan=True), p
+        seen.add((ibo["iter_count"], ibo["fcn_count"], ibo["jacobian_count"]))
+    assert len(seen) > 1
