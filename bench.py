@@ -91,6 +91,25 @@ def _physical_cores():
     return (pick or allowed), model
 
 
+def _cpu_quota():
+    """CPUs this container may actually use at once (cgroup CPU quota), or None when unlimited / unknown: a box can show
+    256 logical CPUs and schedule 16 of them."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]              # cgroup v2
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())           # cgroup v1
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _cpu_worker(cpu, ks, m, n, ready, go, out):
     """Long-lived worker of the all-cores leg: pinned to one physical core, generates its problems BEFORE the clock
     starts, waits for the common start signal, solves them back to back."""
@@ -109,11 +128,13 @@ def _cpu_worker(cpu, ks, m, n, ready, go, out):
     ready.release()
     go.wait()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     njac = 0
     for A, b, xt, x0 in probs:
         rc, x, f, ib, nc, _ = O.dq_lm_solve(A, b, GAMMA, x0, opts=O.default_options(max_evals=500))
         njac += ib["jacobian_count"]
     t1 = time.perf_counter()
+    cpu1 = time.process_time()                                     # CPU time the solves really got (quota, steal)
     # bandwidth probe (after the solves, all workers at once): numpy copies, read + write bytes
     go2 = time.perf_counter()
     reps = 0
@@ -121,7 +142,7 @@ def _cpu_worker(cpu, ks, m, n, ready, go, out):
         np.copyto(dst, buf)
         reps += 1
     t2 = time.perf_counter()
-    out.put((njac, t0, t1, 2.0 * buf.nbytes * reps / (t2 - go2)))
+    out.put((njac, t0, t1, 2.0 * buf.nbytes * reps / (t2 - go2), cpu1 - cpu0))
 
 
 def cpu_all_cores(m, n, one_core_rate, per_worker=4):
@@ -130,6 +151,9 @@ def cpu_all_cores(m, n, one_core_rate, per_worker=4):
     import multiprocessing as mp
     ctx = mp.get_context("fork")
     cpus, model = _physical_cores()
+    quota = _cpu_quota()
+    if quota is not None and quota < len(cpus):                      # more workers than the quota only time-slice
+        cpus = cpus[:max(1, int(quota))]
     W = len(cpus)
     ready, go, out = ctx.Semaphore(0), ctx.Event(), ctx.Queue()
     procs = [ctx.Process(target=_cpu_worker, args=(cpus[w], list(range(w * per_worker, (w + 1) * per_worker)), m, n,
@@ -146,8 +170,10 @@ def cpu_all_cores(m, n, one_core_rate, per_worker=4):
     njac = sum(r[0] for r in res)
     rate = njac / wall
     eff = rate / (W * one_core_rate)
+    cpu_s = sum(r[4] for r in res)
     d = {"value": rate, "unit": "LM iterations/s", "cores": W, "cpu_model": model,
-         "logical_cpus_available": len(os.sched_getaffinity(0)),
+         "logical_cpus_available": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota,
+         "worker_cpu_seconds_over_wall_seconds": cpu_s / wall,
          "sample": f"{W * per_worker} problems: {per_worker} per worker, one pinned worker process per physical core, problems "
                    f"generated before the clock, {wall:.1f} s wall (first start to last finish)",
          "parallel_efficiency_vs_one_core": eff,
@@ -155,9 +181,11 @@ def cpu_all_cores(m, n, one_core_rate, per_worker=4):
     if eff < 0.5:
         # a 4096x256 solve streams an 8 MiB Jacobian (plus its 8 MiB model matrix) through every Householder step:
         # with all cores busy the working sets leave the caches and the host's memory bandwidth is shared
-        d["note"] = ("below half of cores x one-core rate: each solve streams its 8 MiB working matrix n times per "
-                     "factorisation; with every core active that traffic goes to DRAM (see copy_bandwidth_GBs_all_workers: "
-                     "read+write bytes/s of simultaneous 32 MiB numpy copies, one per worker)")
+        d["note"] = ("below half of cores x one-core rate.  worker_cpu_seconds_over_wall_seconds says how many cores the "
+                     "workers were actually given (a container CPU quota or a busy host caps it below `cores`); beyond that, "
+                     "each solve streams its 8 MiB working matrix n times per factorisation and with every core active that "
+                     "traffic goes to DRAM (copy_bandwidth_GBs_all_workers: read+write bytes/s of simultaneous 32 MiB numpy "
+                     "copies, one per worker)")
     return d
 
 

@@ -49,8 +49,10 @@
 #include <algorithm>
 
 #ifndef QRX_C
-#define QRX_C 12           // reflector slots per bank = pending updates before a flush + 1 (measured, 2048 x 4096x256,
-                           // ms per factorisation of the batch: 8: 560, 9: 539, 10: 545, 12: 539, 14: 540, 16: 573, 20: 609)
+#define QRX_C 10           // reflector slots per bank = pending updates before a flush + 1 (measured, 2048 x 4096x256,
+                           // ms per factorisation of the batch, windows as separate workgroups: 8: 560, 9: 539, 10: 545,
+                           // 12: 539, 14: 540, 16: 573, 20: 609; windows as the waves of one workgroup, which makes
+                           // the flushing passes 10-20 % cheaper: 8: 520, 10: 510, 12: 525, 14: 522)
 #endif
 #define QRX_TR 64           // rows per reflector tile of the pass
 #define QRX_PAD_ROWS 160   // read-ahead padding behind the last problem's matrix (a tile + a load group)
@@ -500,8 +502,14 @@ qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int 
 // a lane reads two rows of its column per 16-byte load, a wave 4 KB contiguous per 8-row block, 32 loads (64 rows) in
 // flight ahead of the arithmetic.  The reflector entries of a row (wave-uniform) come from an LDS tile of 64 rows that
 // the wave stages for itself one tile ahead (coalesced slot vectors in, broadcast ds_reads out).
-template <int NP, bool FLUSH>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (FLUSH && NP >= 4) ? 2 : 4)))
+// SHARE: the windows of a problem are the WAVES OF ONE WORKGROUP (64 nwin threads), kept together by one LDS-only barrier
+// per 64-row tile, so that they ask for a reflector tile -- (NP + 1) / 64 of a window's matrix bytes -- at the same
+// time and the fabric delivers it once per problem, not once per window (as separate workgroups the sibling waves
+// drift apart by more than the few microseconds a line survives in an L2 that streams 750 GB/s: the counters showed
+// 1.18x the algorithmic bytes read).
+#define QRX_SHARE_MAXWIN 4
+template <int NP, bool FLUSH, bool SHARE>
+__global__ void __launch_bounds__(SHARE ? 64 * QRX_SHARE_MAXWIN : 64) __attribute__((amdgpu_waves_per_eu(1, (FLUSH && NP >= 4) ? 2 : 4)))
 k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
            double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
            int32_t *__restrict__ srcall, int32_t *__restrict__ slotall, double *__restrict__ rdall,
@@ -517,17 +525,24 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     // Workgroup -> (problem, window): consecutive workgroup ids go to consecutive XCDs, so the windows of one problem
     // are given ids that agree modulo 8: they share an L2 (reflector tiles, multipliers are fetched from the fabric once).
     const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
-    const int pl = grp * 8 + (r_ & 7), win = r_ >> 3;
+    const int pl = SHARE ? b_ : grp * 8 + (r_ & 7);
+    const int win = SHARE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : r_ >> 3;
     if (pl >= nprob) return;
     const int p = p0 + pl;
     if (st && st[p].stage != ST_NEED_QR) return;
-    const int lane = threadIdx.x, ldp = n + 1;
+    const int lane = threadIdx.x & 63, ldp = n + 1;
     const QrxStep step = stepall[p];
     const bool refl = step.ajnorm != 0.0;
     const double ajj = step.ajj;
     int32_t *slotp = slotall + (size_t)p * ld;
     double *tpc = tpall + ((size_t)p * 2 + cur) * QRX_C * ldp;
     double *Tp = T + (size_t)p * tst;
+    // tile barrier: with one wave per workgroup the compiler's __syncthreads (no s_barrier, counted waits) is what the
+    // loops below were tuned with; shared tiles need a real barrier, ordering LDS traffic only (never the matrix loads)
+    auto tile_barrier = [&]() __attribute__((always_inline)) {
+        if (SHARE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+    };
     // rows are counted from the start of row j's 8-row block: rel row r = absolute row jb + r, first live one r0
     const int jb = j & ~7, r0 = j & 7, mrel = m - jb;
     const double *vc = Vall + ((size_t)p * 2 + cur) * QRX_C * vst + jb;          // slot q, rel row r at vc[q * vst + r]
@@ -561,6 +576,10 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
 
     // reflector tile t: lane l fetches the entries of rel row t*TR + l (one coalesced 512-byte read per slot); the staged
     // LDS row is [pending v_0 .. v_NP-1, new v]
+    // (SHARE: every wave still fetches and stores the whole tile -- the same values to the same LDS words, a benign
+    // duplication: what the shared workgroup buys is that its waves ask for the same lines within a barrier interval of
+    // each other, so the L2 serves three of the four requests.  Dealing the staging to the waves -- by slot or by tile --
+    // was tried: any wave-dependent condition around these loads makes the compiler spill the row loops, 10x slower.)
     double sv[NP + 1];
     auto vfetch = [&](int t) __attribute__((always_inline)) {
         const int row = t * TR + lane;
@@ -568,8 +587,8 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
         for (int q = 0; q < NP; ++q) sv[q] = vc[(size_t)q * vst + row];
         sv[NP] = FLUSH ? vo[row] : vc[(size_t)NPI * vst + row];
     };
-    auto vstore = [&](int buf) __attribute__((always_inline)) {
-        double *d = &vt[buf][lane * LP];
+    auto vstore = [&](int t) __attribute__((always_inline)) {           // tile t -> vt[t & 1]
+        double *d = &vt[t & 1][lane * LP];
 #pragma unroll
         for (int q = 0; q <= NP; ++q) d[q] = sv[q];
     };
@@ -664,7 +683,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     vfetch(0);
     vstore(0);
     load(a0, 0);
-    __syncthreads();
+    tile_barrier();
     std::false_type plain_t; std::true_type guard_t;
     // A tile whose rows are all live runs unguarded and fully unrolled; the tile of row j (unless j is a multiple of 8) and the last, partial one run guarded.  The three are separate loops, not branches of one loop body: a
     // merge of the two forms at the loop's back edge makes the compiler copy the registers of the load group just issued
@@ -678,11 +697,11 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
         for (int g = 0; g < TR / U; g += 2) {
             load(a1, rb + (g + 1) * U);
             compute(plain_t, a0, rb + g * U, tile, g);
-            if (g + 2 >= TR / U) vstore((t + 1) & 1);
+            if (g + 2 >= TR / U) vstore(t + 1);
             load(a0, rb + (g + 2) * U);
             compute(plain_t, a1, rb + (g + 1) * U, tile, g + 1);
         }
-        __syncthreads();
+        tile_barrier();
     };
     auto tile_guard = [&](int t) __attribute__((always_inline)) {
         const double *tile = vt[t & 1];
@@ -695,8 +714,8 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
             load(a0, rb + (g + 2) * U);
             compute(guard_t, a1, rb + (g + 1) * U, tile, g + 1);
         }
-        vstore((t + 1) & 1);
-        __syncthreads();
+        vstore(t + 1);
+        tile_barrier();
     };
     const int tfull = mrel / TR;                                        // tiles 0 .. tfull-1 end at or before the last row
     int t = 0;
@@ -1136,8 +1155,12 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
         hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 4>), grid, dim3(64 * 4), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
     }
-    if (rp == 0)
-        hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH>), grid, dim3(64), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+    static const int share_env = [] { const char *e = getenv("NLH_QRX_SHARE"); return e ? atoi(e) : 1; }();
+    if (rp == 0 && share_env && nwin >= 2 && nwin <= QRX_SHARE_MAXWIN)
+        hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH, true>), dim3((unsigned)nprob), dim3(64 * nwin), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff,
+                           tst, vst, j, cur, T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+    else if (rp == 0)
+        hipLaunchKernelGGL((k_qrx_pass<NP, FLUSH, false>), grid, dim3(64), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
 }
 

@@ -42,8 +42,13 @@ def test_bench_single_process():
     a = d["auto_policy"]                                       # the fast opt-in policy and its measured deviation
     assert a["value"] > 0 and a["problems_compared"] == 4 and 0.0 <= a["max_rel_dev_x"] < 1e-4
     assert d["fd_jacobian_mode_h"]["bound"] == "hbm" and d["fd_jacobian_mode_h"]["achieved"] > 0
-    rows = d["other_paths"]                                   # Newton, quasi-Newton, bounded LSQ, BFGS, polynomial
-    assert len(rows) == 5 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
+    rows = d["other_paths"]                    # Newton, quasi-Newton, batched Newton, bounded LSQ, BFGS, polynomial
+    assert len(rows) == 6 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
+    assert any("lock-step" in r["path"] for r in rows)
+    ac = c["all_cores"]                                        # pinned workers, problems generated before the clock
+    assert ac["value"] > 0 and ac["cores"] >= 1 and "cpu_model" in ac and ac["gpu_over_all_cores"] > 0
+    eb = d["roofline"]["event_bracketing"]                     # what the live HIP-event brackets of the timed region cost
+    assert eb["value_without_brackets"] > 0 and 0.0 <= eb["overhead_frac"] < 0.5
 
 
 def test_bench_under_torchrun_one_rank():
