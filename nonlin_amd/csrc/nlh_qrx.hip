@@ -507,6 +507,18 @@ qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int 
 // time and the fabric delivers it once per problem, not once per window (as separate workgroups the sibling waves
 // drift apart by more than the few microseconds a line survives in an L2 that streams 750 GB/s: the counters showed
 // 1.18x the algorithmic bytes read).
+// Built on this form, measured and dropped (all bit-identical; 2048 x 4096x256, ms per factorisation of the batch against
+// 510 for pivot and pass launches alternating): with a problem's pass in ONE workgroup, its pivot steps need no other
+// workgroup either, so they can run inside the pass kernels -- (1) one persistent workgroup per problem for all n steps:
+// 581 (every pass variant and the pivot step in one kernel: 256 registers with spills, two workgroups per CU; 627 at one
+// per CU without spills); (2) step j + 1's pivot step as the TAIL of step j's pass kernel: 523, the launches longer by the
+// whole pivot time -- workgroups that share HBM evenly finish their passes together, so their pivot steps still leave
+// HBM idle together; (3) the problems in two classes half a step apart (pivot step at the head of the launch for the odd
+// ones, at the tail for the even ones): 532; (4) the same with the 2048-element NORM2 chunk (35 KB of LDS): the merged
+// kernels need 184-256 registers, two waves per SIMD.  The reason is the same each time: at two waves per SIMD the
+// pass streams at the HBM rate only with EVERY resident wave streaming (forcing today's pass kernels to that occupancy
+// costs nothing: 508), so a wave slot that spends 10-15 % of its time in a pivot step is 10-15 % of the bandwidth gone;
+// hiding the pivot step inside the launch needs spare wave slots, i.e. pass and pivot step within ~168 registers.
 #define QRX_SHARE_MAXWIN 4
 template <int NP, bool FLUSH, bool SHARE>
 __global__ void __launch_bounds__(SHARE ? 64 * QRX_SHARE_MAXWIN : 64) __attribute__((amdgpu_waves_per_eu(1, (FLUSH && NP >= 4) ? 2 : 4)))
