@@ -41,6 +41,9 @@ extern "C" {
 #define NLH_TOLERANCE_TOO_SMALL_ERROR  208   /* (:27) */
 #define NLH_UNDEFINED_FUNCTION_ERROR   211   /* (:34) */
 #define NLH_UNDERDEFINED_PROBLEM_ERROR 212   /* (:37) */
+/* Size limits of this implementation (the reference has none); an entry point given a larger problem returns
+ * NLH_ARRAY_SIZE_ERROR and touches nothing: least squares (nlh_lm_solve, nlh_dq_lm_solve_batch, ...) n <= 3000;
+ * quasi-Newton and BFGS n <= 4096; polynomial fits npts <= 18000 (what is kept in LDS inside a workgroup). */
 /* library-level failures (not reference codes) */
 #define NLH_ERR_NO_DEVICE             -1
 #define NLH_ERR_HIP                   -2
