@@ -48,6 +48,17 @@ def test_no_cpu_fallback():
         nl.least_squares_solver().solve(obj, np.ones(2), np.zeros(2))
     with pytest.raises(nl.NonlinHipUnavailable):
         nl.newton_solver().solve(obj, np.ones(2), np.zeros(2))
+    from nonlin_amd.device import DeviceSet
+    with pytest.raises(nl.NonlinHipUnavailable):          # several GPUs behind the boundary: same rule
+        DeviceSet()
+    import ctypes as C
+    set_ptr = C.c_void_p()
+    assert _lib.load().nlh_device_set_create(C.byref(set_ptr), None, 0) == -1 and not set_ptr.value   # NLH_ERR_NO_DEVICE
+    x, g = np.array([3.0, 0.0]), np.zeros(2)             # the one entry point with no device work: host FD gradient
+    f = _lib.FCNNVAR(lambda ctx, n, xx: xx[0] * xx[0] + 2.0 * xx[1])
+    assert _lib.load().nlh_fd_gradient(2, f, _lib.GRADFCN(), None, x.ctypes.data_as(_lib.c_double_p), None,
+                                       g.ctypes.data_as(_lib.c_double_p)) == 0
+    assert abs(g[0] - 6.0) < 1e-6 and abs(g[1] - 2.0) < 1e-6 and x[0] == 3.0 and x[1] == 0.0
     from nonlin_amd.device import DeviceSolver
     with pytest.raises(nl.NonlinHipUnavailable):
         DeviceSolver(0)
