@@ -382,6 +382,16 @@ __device__ __forceinline__ double nlh_wave_shr1(double t)
     return __hiloint2double(hi, lo);
 }
 
+// Which wave of a workgroup runs a serial chain.  The waves of a workgroup sit on the SIMDs of a CU in order, so "wave 0"
+// of two workgroups that share a CU is the same SIMD: two chains at half speed each with three SIMDs idle (measured on
+// the 65536 x 512 problem: 21 us per 4096-add chain instead of 9.6).  Which workgroups share a CU is the dispatcher's business (ids
+// 8 apart -- the same XCD -- or 256 apart, typically); this picks different waves for ids 1, 8 and 256 apart.
+__device__ __forceinline__ int nlh_chain_wave(int nwaves)
+{
+    const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    return (int)((b + (b >> 3) + (b >> 8)) & (unsigned)(nwaves - 1));    // differs for ids 1, 8 and 256 apart
+}
+
 template <int EL, int BSZ, typename Get>
 __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *aux)
 {
@@ -389,6 +399,7 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
     static_assert(CAP % BSZ == 0 && EL % E == 0 && E % 2 == 0, "chunk must split evenly");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int nw = BSZ / 64;
+    const int cw = nlh_chain_wave(nw);                                   // the wave that runs the serial recurrence
     double *cs = cd, *dsv = cd + PADCAP, *wmax = aux, *carry = aux + 32;
     int *tflags = reinterpret_cast<int *>(aux + 40);
     __syncthreads();
@@ -446,7 +457,7 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
         }
         tflags[tid] = plain ? 1 : 0;
         __syncthreads();
-        if (wid == 0) {
+        if (wid == cw) {
             const int nl = (cl + EL - 1) / EL;                       // runs in use
             double d[EL];
             const double2 *mine = reinterpret_cast<const double2 *>(dsv + lane * (EL + 2));

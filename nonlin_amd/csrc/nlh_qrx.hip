@@ -988,6 +988,7 @@ k_qrx_pass_col(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, do
     const int p = blockIdx.y;
     if (st && st[p].stage != ST_NEED_QR) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cw = nlh_chain_wave(4);                                    // the wave that runs the ordered sum
     const int k = j + 1 + blockIdx.x;                                   // slot of this workgroup's column (n = the residual)
     const int ldp = n + 1, jb = j & ~7;
     const QrxStep step = stepall[p];
@@ -1039,7 +1040,7 @@ k_qrx_pass_col(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, do
 #pragma unroll
         for (int u = 0; u < E; u += 2) dst[u >> 1] = make_double2(w[u], w[u + 1]);
         __syncthreads();
-        if (wid == 0) {
+        if (wid == cw) {
             const int nl = (cl + EL - 1) / EL;
             double d[EL];
             const double2 *mine = reinterpret_cast<const double2 *>(buf + lane * (EL + 2));
@@ -1099,6 +1100,117 @@ k_qrx_pass_col(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, do
             for (int u = 0; u < 8; ++u)
                 if (i + u * 256 < m) Tp[qrx_at(i + u * 256, col, ld)] = a8[u] - temp * v8[u];
         }
+    }
+}
+
+// The same pass for columns LONGER than one 4096-row chunk (BASELINE config 5: 65536 rows), software-pipelined.  In
+// k_qrx_pass_col a chunk costs a memory latency for the column, the products, two LDS hand-overs, three barriers and then
+// the 4096-add chain: ~21 us, of which the chain -- the only part that is serial by definition -- is 9.4.  Here chunks are
+// 2048 rows (a sector per thread), the products of chunk c + 1 are formed and handed over while wave 0 adds chunk c (two
+// LDS buffers, ONE LDS-only barrier per chunk), and the column loads of chunk c + 2 are already in flight: a chunk costs
+// its chain plus wave 0's own share of the hand-over.  Same products, same order: bit-identical.
+#define QRX_COLL_EL 32
+__global__ void __launch_bounds__(256)
+k_qrx_pass_col_long(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, double *__restrict__ T,
+                    const double *__restrict__ Vall, double *__restrict__ tpall, const int32_t *__restrict__ srcall,
+                    double *__restrict__ rdall, double *__restrict__ waall, const QrxStep *__restrict__ stepall,
+                    double *__restrict__ Rall, double *__restrict__ qtfall, const LmState *__restrict__ st)
+{
+    constexpr int EL = QRX_COLL_EL, CAP = 64 * EL, E = CAP / 256;       // 2048 rows per chunk, 8 per thread: one sector
+    static_assert(E == 8, "a thread's share of a chunk is one 64-byte sector");
+    __shared__ __attribute__((aligned(16))) double buf[2][CAP + 128];
+    __shared__ double xch[2];
+    const int p = blockIdx.y;
+    if (st && st[p].stage != ST_NEED_QR) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cw = nlh_chain_wave(4);                                    // the wave that runs the ordered sum
+    const int k = j + 1 + blockIdx.x;
+    const int ldp = n + 1, jb = j & ~7;
+    const QrxStep step = stepall[p];
+    const bool refl = step.ajnorm != 0.0;
+    const double ajj = step.ajj;
+    const int col = srcall[(size_t)p * ldp + k];
+    double *Tp = T + (size_t)p * tst;
+    const double *vbank = Vall + (size_t)p * 2 * QRX_C * vst;
+    const int r0 = j & 7, len = m - jb;
+    const double *colp = Tp + qrx_at(jb, col, ld);
+    double rowj0 = 0.0, rk0 = 0.0, wa0 = 1.0;
+    if (tid == 0) {
+        rowj0 = Tp[qrx_at(j, col, ld)];
+        if (k < n) { rk0 = rdall[(size_t)p * n + k]; wa0 = waall[(size_t)p * n + k]; }
+    }
+    const size_t blk = (size_t)ld * 8;
+    const int nch = (len + CAP - 1) / CAP, i0 = tid * E;
+    double2 av[4], vv[4];
+    auto loadchunk = [&](int c) __attribute__((always_inline)) {
+        const int rb = c * CAP + i0;                                    // rel row of this thread's 8-row block
+        const bool in = rb < len;
+        const double2 *src = reinterpret_cast<const double2 *>(colp + (size_t)(rb >> 3) * blk);
+        const double2 *vs = reinterpret_cast<const double2 *>(vbank + jb + rb);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            av[h] = in ? src[h] : make_double2(0.0, 0.0);
+            vv[h] = in ? vs[h] : make_double2(0.0, 0.0);
+        }
+    };
+    loadchunk(0);
+    double s = 0.0;                                                     // the running sum lives in the chain wave
+    for (int c = 0; c < nch; ++c) {
+        const int base = c * CAP;
+        double2 w[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int ra = base + i0 + 2 * h, rbb = ra + 1;
+            w[h].x = (ra >= r0 && ra < len && jb + ra < m) ? vv[h].x * av[h].x : 0.0;
+            w[h].y = (rbb >= r0 && rbb < len && jb + rbb < m) ? vv[h].y * av[h].y : 0.0;
+        }
+        // buf[c & 1] was last read by the chain of chunk c - 2, which wave 0 finished before it joined the barrier of
+        // chunk c - 1
+        double2 *dst = reinterpret_cast<double2 *>(buf[c & 1] + i0 + 2 * (i0 / EL));
+#pragma unroll
+        for (int h = 0; h < 4; ++h) dst[h] = w[h];
+        if (c + 1 < nch) loadchunk(c + 1);                              // in flight during the barrier and the chain
+        qrx_lds_barrier();                                              // orders LDS traffic only: the loads stay in flight
+        if (wid == cw) {
+            const int cl = min(CAP, len - base), nl = (cl + EL - 1) / EL;
+            double d[EL];
+            const double2 *mine = reinterpret_cast<const double2 *>(buf[c & 1] + lane * (EL + 2));
+#pragma unroll
+            for (int u = 0; u < EL / 2; ++u) { const double2 v2 = mine[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
+            double t = s;
+#pragma unroll 1
+            for (int l = 0; l < nl; ++l) {
+                if (l > 0) t = nlh_wave_shr1(t);
+#pragma unroll
+                for (int u = 0; u < EL; ++u) t = t + d[u];             // :653, rows ascending (terms outside the rows: +0.0)
+            }
+            const int lo_ = __builtin_amdgcn_readlane(__double2loint(t), nl - 1);
+            const int hi_ = __builtin_amdgcn_readlane(__double2hiint(t), nl - 1);
+            s = __hiloint2double(hi_, lo_);
+        }
+    }
+    if (wid == cw && lane == 0) xch[0] = s;
+    __syncthreads();
+    s = xch[0];
+    const double temp = refl ? s / ajj : 0.0;                           // :654
+    if (tid == 0) {
+        const double tq1[1] = {0.0};
+        qrx_pass_tail<0, false>(p, j, k, col, m, n, ld, coff, 0, vst, s, rowj0, rk0, wa0, refl, ajj, tq1, Tp, vbank + jb, vbank + jb, tpall,
+                                rdall, waall, Rall, qtfall);
+    }
+    __syncthreads();
+    if (!refl) return;
+    for (int i = j + 1 + tid; i < m; i += 8 * 256) {                   // :655; eight rows per thread loaded before any is stored
+        double a8[8], v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = min(i + u * 256, m - 1);
+            a8[u] = Tp[qrx_at(row, col, ld)];
+            v8[u] = vbank[row];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i + u * 256 < m) Tp[qrx_at(i + u * 256, col, ld)] = a8[u] - temp * v8[u];
     }
 }
 
@@ -1241,6 +1353,11 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
                                    (const LmState *)st);
             te(0, stream);
             tb(1, stream);
+            if (m - (j & ~7) > 64 * QRX_COL_EL)                   // longer than one chunk: the pipelined form
+                hipLaunchKernelGGL(k_qrx_pass_col_long, dim3(n - j, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, j, T,
+                                   (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
+                                   (const LmState *)st);
+            else
             hipLaunchKernelGGL(k_qrx_pass_col, dim3(n - j, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, j, T,
                                (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
                                (const LmState *)st);
