@@ -382,10 +382,12 @@ __device__ __forceinline__ double nlh_wave_shr1(double t)
     return __hiloint2double(hi, lo);
 }
 
-// Which wave of a workgroup runs a serial chain.  The waves of a workgroup sit on the SIMDs of a CU in order, so "wave 0"
-// of two workgroups that share a CU is the same SIMD: two chains at half speed each with three SIMDs idle (measured on
-// the 65536 x 512 problem: 21 us per 4096-add chain instead of 9.6).  Which workgroups share a CU is the dispatcher's business (ids
-// 8 apart -- the same XCD -- or 256 apart, typically); this picks different waves for ids 1, 8 and 256 apart.
+// Which wave of a workgroup runs a serial chain: spread over the wave indices by workgroup id.  Measured since
+// (profiles/ubench/chain_waves.hip): the waves of a workgroup do NOT sit on the SIMDs in index order (HW_ID: wave 0 of
+// workgroups 0 and 256, which share a CU, ran on SIMDs 0 and 2), and two chains on one CU cost nothing either way
+// (2.32 ns per add with wave 0 in both, 2.30 spread, 2.23 alone) -- the choice is neutral; a dependent fp64 add issues
+// every ~1.9 ns whatever the EXEC mask (no skipping of idle 16-lane passes), so 2.2 ns per term is the floor of every
+// ordered sum in this library.
 __device__ __forceinline__ int nlh_chain_wave(int nwaves)
 {
     const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -494,6 +496,164 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
     }
     __syncthreads();
     const double r = carry[0] * sqrt(1.0 + carry[1]);
+    __syncthreads();
+    return r;
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the global loads in flight
+// (s_waitcnt vmcnt(0)) -- a full memory latency per round of a pipelined loop.
+__device__ __forceinline__ void nlh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// norm2_flang_block_lanes for vectors of MANY chunks (a 65536-row column is 16), software-pipelined, with a wave that
+// does nothing but the chain.  In the plain form a chunk costs a memory latency for its elements, the prefix maximum
+// with two barriers, the divisions, an LDS hand-over and then the 64 * EL-add chain -- 21 us at EL = 64, of which the
+// chain (the only part that is serial by definition) is 9.2.  The running MAXIMUM does not go through the chain, so
+// everything but the chain can run a chunk ahead: the workgroup has BSZ / 64 PREPARING waves plus one CHAIN wave
+// (blockDim.x = BSZ + 64); while the chain wave adds chunk c the others form the coefficients of chunk c + 1 (second
+// LDS buffer), the maxima of chunk c + 2 and have the elements of chunk c + 3 in flight; ONE LDS-only barrier per chunk.
+// (Measured with the chain wave also preparing its share: 4 us of divisions, shuffles and load issue per chunk in front
+// of every chain, 16.4 us per chunk instead of 12.)  Same coefficients, same order: bit-identical.
+// cd: 4 * (64 * EL + 128) doubles of LDS (two buffers), 16-byte aligned; aux: 8 doubles + 2 * BSZ ints;
+// wm: nchunks * (BSZ / 64) doubles (the caller bounds len accordingly).
+template <int EL, int BSZ, typename Get>
+__device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, double *aux, double *wm)
+{
+    constexpr int CAP = 64 * EL, PADCAP = CAP + 128, E = CAP / BSZ, TPR = EL / E, nw = BSZ / 64;
+    static_assert(CAP % BSZ == 0 && EL % E == 0 && E % 2 == 0, "chunk must split evenly");
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool chain = (wid == nw);                                  // (wave-uniform)
+    const int nch = (len + CAP - 1) / CAP, i0 = tid * E;
+    int *tflags = reinterpret_cast<int *>(aux + 8);
+    auto loadabs = [&](int c, double (&a)[E]) __attribute__((always_inline)) {
+        const int base = c * CAP, cl = min(CAP, len - base);
+#pragma unroll
+        for (int u = 0; u < E; ++u) a[u] = (i0 + u < cl) ? fabs(get(base + i0 + u)) : 0.0;
+    };
+    // the maximum of everything in this wave's part of chunk c that lies before this thread's elements; the wave's own
+    // maximum goes to wm
+    auto scanmax = [&](int c, const double (&a)[E]) __attribute__((always_inline)) {
+        double lm = 0.0;
+#pragma unroll
+        for (int u = 0; u < E; ++u) lm = fmax(lm, a[u]);
+        double sc = lm;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(sc, off, 64);
+            if (lane >= off) sc = fmax(sc, o);
+        }
+        double ex = __shfl_up(sc, 1, 64);
+        if (lane == 0) ex = 0.0;
+        if (lane == 63) wm[c * nw + wid] = sc;
+        return ex;
+    };
+    double a0[E], a1[E], ex0 = 0.0;
+    __syncthreads();
+    if (!chain) {
+        loadabs(0, a0);
+        if (nch > 1) loadabs(1, a1);
+        ex0 = scanmax(0, a0);
+    }
+    __syncthreads();
+    double mxrun = 0.0, s = 0.0;
+    // (s_setprio 3 for the chain wave: measured slower here, 268 against 253 us per 65536-row pivot step -- the preparing
+    // wave that shares its SIMD falls behind; it helps k_qrx_pass_col_long, whose preparing waves have less to do)
+    for (int c = 0; c < nch; ++c) {
+        const int cl = min(CAP, len - c * CAP);
+        double *cs = cd + (size_t)(c & 1) * 2 * PADCAP, *dsv = cs + PADCAP;
+        int *tf = tflags + (c & 1) * BSZ;
+        double mxc = mxrun;
+#pragma unroll
+        for (int w = 0; w < nw; ++w) mxc = fmax(mxc, wm[c * nw + w]);
+        if (!chain) {
+            double prev = fmax(mxrun, ex0);
+#pragma unroll
+            for (int w = 0; w < nw; ++w)
+                if (w < wid) prev = fmax(prev, wm[c * nw + w]);
+            bool plain = true;
+            // element i of the chunk lives at i + 2 * (i / EL), see norm2_flang_block_lanes
+            double2 *cdst = reinterpret_cast<double2 *>(cs + i0 + 2 * (i0 / EL));
+            double2 *ddst = reinterpret_cast<double2 *>(dsv + i0 + 2 * (i0 / EL));
+#pragma unroll
+            for (int u = 0; u < E; u += 2) {
+                double cc[2], dd[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double cf = 1.0, d = 0.0;
+                    const double av = a0[u + h];
+                    if (prev == 0.0) {
+                        // mx was zero: element becomes the maximum, s untouched
+                    } else if (av > prev) {
+                        const double t = prev / av, tsq = t * t;
+                        cf = tsq; d = tsq;
+                    } else if (av != 0.0) {
+                        const double t = av / prev;
+                        d = t * t;
+                    }
+                    plain = plain && (cf == 1.0);
+                    cc[h] = cf; dd[h] = d;
+                    prev = fmax(prev, av);
+                }
+                cdst[u >> 1] = make_double2(cc[0], cc[1]);
+                ddst[u >> 1] = make_double2(dd[0], dd[1]);
+            }
+            tf[tid] = plain ? 1 : 0;
+            // a chunk ahead: the maxima of chunk c + 1 (its elements arrived long ago), the loads of chunk c + 2
+            if (c + 1 < nch) {
+#pragma unroll
+                for (int u = 0; u < E; ++u) a0[u] = a1[u];
+                ex0 = scanmax(c + 1, a0);
+            }
+            if (c + 2 < nch) loadabs(c + 2, a1);
+        }
+        mxrun = mxc;
+        // Publishes buffer c & 1 and wm[c + 1].  The preparing waves wait here for the chain of chunk c - 1 to end: the
+        // buffer they fill next (c + 1) & 1 is the one that chain read.
+        nlh_lds_barrier();
+        if (chain) {
+            const int nl = (cl + EL - 1) / EL;                       // runs in use
+            double d[EL];
+            const double2 *mine = reinterpret_cast<const double2 *>(dsv + lane * (EL + 2));
+#pragma unroll
+            for (int u = 0; u < EL / 2; ++u) { const double2 v2 = mine[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
+            int pl = 1;
+#pragma unroll
+            for (int k = 0; k < TPR; ++k) pl &= tf[lane * TPR + k];
+            const unsigned long long mask = __ballot(pl != 0);
+            double t = s;
+            if (mask == ~0ull && nl == 64) {
+                // the usual chunk -- full, no new maximum in it: nothing in the loop but the shift and the adds (the mask
+                // test of the general loop below costs 25 ns a step, 1.6 us a chunk)
+#pragma unroll 1
+                for (int l = 0; l < 64; ++l) {
+                    if (l > 0) t = nlh_wave_shr1(t);
+#pragma unroll
+                    for (int u = 0; u < EL; ++u) t = t + d[u];
+                }
+            } else
+#pragma unroll 1
+            for (int l = 0; l < nl; ++l) {
+                if (l > 0) t = nlh_wave_shr1(t);
+                if ((mask >> l) & 1ull) {
+#pragma unroll
+                    for (int u = 0; u < EL; ++u) t = t + d[u];
+                } else {
+                    const double *cm = cs + lane * (EL + 2), *dm = dsv + lane * (EL + 2);   // (d[] stays in registers: no dynamic index)
+#pragma unroll 4
+                    for (int u = 0; u < EL; ++u) {
+                        const double cf = cm[u];
+                        if (cf != 1.0) t = t * cf;
+                        t = t + dm[u];
+                    }
+                }
+            }
+            const int lo = __builtin_amdgcn_readlane(__double2loint(t), nl - 1);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(t), nl - 1);
+            s = __hiloint2double(hi, lo);
+        }
+    }
+    if (chain && lane == 0) aux[0] = s;
+    __syncthreads();
+    const double r = mxrun * sqrt(1.0 + aux[0]);
     __syncthreads();
     return r;
 }

@@ -239,17 +239,24 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
 // Step j, part 1: pivot (:622-637), the pivot column with its pending updates -> reflector (:642-646).
 // The new reflector goes to slot np of the current bank, or to slot 0 of the other bank when this step's pass
 // flushes (np == QRX_C - 1).
-template <int QRX_NL>
-__global__ void __launch_bounds__(256)
+#define QRX_LONG_MAXCH 64                                        // chunks of 4096 rows the pipelined NORM2 keeps maxima for
+template <int QRX_NL, bool LONG = false>
+__global__ void __launch_bounds__(LONG ? 320 : 256)
 k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
 {
-    __shared__ __attribute__((aligned(16))) double cd[2 * (64 * QRX_NL + 128)];
-    __shared__ __attribute__((aligned(16))) double aux[40 + 128];
+    // LONG (the column is more than one NORM2 chunk): two coefficient buffers and the per-chunk maxima for the
+    // pipelined NORM2 -- 136 KB of LDS, one workgroup per CU, which is all a handful of long-column problems need
+    __shared__ __attribute__((aligned(16))) double cd[(LONG ? 4 : 2) * (64 * QRX_NL + 128)];
+    __shared__ __attribute__((aligned(16))) double aux[LONG ? 8 + 256 : 40 + 128];
+    __shared__ double wmx[LONG ? 4 * QRX_LONG_MAXCH : 1];
     __shared__ double red[64];
     const int p = p0 + blockIdx.x;
     if (st && st[p].stage != ST_NEED_QR) return;
     const int tid = threadIdx.x, BS = blockDim.x, ldp = n + 1;
+#ifdef QRX_DBG_CLK
+    long long clk[6]; clk[0] = wall_clock64();
+#endif
     int *redi = reinterpret_cast<int *>(red + 32);
     double *rdiag = w.rdiag + (size_t)p * n, *wa = w.wa + (size_t)p * n;
     int32_t *src = w.src + (size_t)p * ldp;
@@ -306,6 +313,9 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     }
     __syncthreads();
     const int srck = pubi[0];
+#ifdef QRX_DBG_CLK
+    clk[1] = wall_clock64();
+#endif
     double tk[QRX_C];
 #pragma unroll
     for (int q = 0; q < QRX_C; ++q) tk[q] = (q < QRX_C - 1 && q < np) ? pub[q] : 0.0;
@@ -345,7 +355,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     double *Tp = T + (size_t)p * tst;
     // The gathered column also goes to LDS (the region NORM2 later fills with its coefficients: it reads every element
     // before it writes any) when it fits one NORM2 chunk, so that the norm does not start with another trip to memory.
-    const bool staged = (m - j <= 64 * QRX_NL);
+    const bool staged = !LONG && (m - j <= 64 * QRX_NL);
     double *stage = cd;
     // ... and in that case every thread KEEPS its rows (at most 64 * QRX_NL / 256 of them) in registers for the scaling
     // below: the raw column then never goes to memory -- one write of the reflector instead of write, read, write.
@@ -385,6 +395,36 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
                 }
             }
         }
+    } else if (LONG && np <= 1 && !move0) {
+        // a long column with at most one update pending (k_qrx_pass_col_long's regime): a lane takes a PAIR of rows (16
+        // bytes), four adjacent lanes a sector of the row-blocked matrix -- a load instruction of the wave covers 16 whole
+        // sectors and 1 KB of the pending reflector, eight pairs per thread in flight.  (A sector per lane had every load
+        // instruction touch 64 lines for a quarter of each: 62 us for 65536 rows; the row-at-a-time loop below: 67 us.)
+        const int jb = j & ~7, npair = (m - jb + 1) >> 1;
+        const double *colp = Tp + qrx_at(jb, srck, ld);
+        const size_t blk = (size_t)ld * 8;
+        const double t0 = np ? tk[0] : 0.0;
+        constexpr int GU = 8;
+        for (int pb = tid; pb < npair; pb += GU * BS) {
+            double2 ax[GU], px[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int pr = min(pb + u * BS, npair - 1);             // pair pr: rel rows 2 pr, 2 pr + 1 of sector pr >> 2
+                ax[u] = *reinterpret_cast<const double2 *>(colp + (size_t)(pr >> 2) * blk + 2 * (pr & 3));
+                px[u] = np ? *reinterpret_cast<const double2 *>(Vc + jb + 2 * pr) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int pr = pb + u * BS, row = jb + 2 * pr;
+                if (pr >= npair) continue;
+                if (np) { ax[u].x = ax[u].x - t0 * px[u].x; ax[u].y = ax[u].y - t0 * px[u].y; }
+                if (row >= j && row + 1 < m) *reinterpret_cast<double2 *>(Vn + row) = ax[u];
+                else {
+                    if (row >= j && row < m) Vn[row] = ax[u].x;
+                    if (row + 1 >= j && row + 1 < m) Vn[row + 1] = ax[u].y;
+                }
+            }
+        }
     } else {
         for (int i0 = j + tid; i0 < m; i0 += 4 * BS) {
             double e[4];
@@ -395,9 +435,18 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
         }
     }
     __syncthreads();
-    const double ejj = staged ? stage[0] : Vn[j];                 // the diagonal entry before scaling (read before NORM2 reuses the region)
-    double ajnorm = staged ? norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return stage[i]; }, m - j, cd, aux)
-                           : norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return Vn[j + i]; }, m - j, cd, aux);   // :642
+    const double ejj = staged ? stage[0] : Vn[j];
+#ifdef QRX_DBG_CLK
+    clk[2] = wall_clock64();
+#endif
+                 // the diagonal entry before scaling (read before NORM2 reuses the region)
+    double ajnorm;                                                // :642
+    if constexpr (LONG) ajnorm = norm2_flang_block_lanes_pipe<QRX_NL, 256>([&](int i) { return Vn[j + i]; }, m - j, cd, aux, wmx);
+    else ajnorm = staged ? norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return stage[i]; }, m - j, cd, aux)
+                         : norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return Vn[j + i]; }, m - j, cd, aux);
+#ifdef QRX_DBG_CLK
+    clk[3] = wall_clock64();
+#endif
     double ajj = 0.0;
     if (staged) {
         // :645-646 from the registers (ajnorm == 0: the column is zero; the reflector slot still gets the column)
@@ -418,6 +467,42 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
                 }
             }
         }
+    } else if (LONG && ajnorm != 0.0) {
+        if (ejj < 0.0) ajnorm = -ajnorm;                         // :644
+        // :645-646 a sector at a time, four per thread in flight (thread 0 holds row j)
+        const int jb = j & ~7, nsec = (m - jb + 7) >> 3;
+        for (int sb = tid; sb < nsec; sb += 4 * BS) {
+            double2 tx[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 *sp = reinterpret_cast<const double2 *>(Vn + jb + (size_t)min(sb + q * BS, nsec - 1) * 8);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) tx[q][h] = sp[h];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sc = sb + q * BS, row = jb + sc * 8;
+                if (sc >= nsec) continue;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    tx[q][h].x = tx[q][h].x / ajnorm;
+                    tx[q][h].y = tx[q][h].y / ajnorm;
+                    if (row + 2 * h == j) { tx[q][h].x = tx[q][h].x + 1.0; ajj = tx[q][h].x; }
+                    if (row + 2 * h + 1 == j) { tx[q][h].y = tx[q][h].y + 1.0; ajj = tx[q][h].y; }
+                }
+                if (row >= j && row + 8 <= m) {
+                    double2 *dp = reinterpret_cast<double2 *>(Vn + row);
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) dp[h] = tx[q][h];
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        if (row + 2 * h >= j && row + 2 * h < m) Vn[row + 2 * h] = tx[q][h].x;
+                        if (row + 2 * h + 1 >= j && row + 2 * h + 1 < m) Vn[row + 2 * h + 1] = tx[q][h].y;
+                    }
+                }
+            }
+        }
     } else if (ajnorm != 0.0) {
         if (ejj < 0.0) ajnorm = -ajnorm;                         // :644
         // :645-646; eight rows per thread are loaded together before any is stored: the compiler must assume that the
@@ -434,6 +519,10 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
             }
         }
     }
+#ifdef QRX_DBG_CLK
+    clk[4] = wall_clock64();
+    if (tid == 0 && j == 100) printf("pivot j=100: head %lld gather %lld norm %lld scale %lld (x10 ns)\n", clk[1]-clk[0], clk[2]-clk[1], clk[3]-clk[2], clk[4]-clk[3]);
+#endif
     if (tid == 0) {                                              // thread 0 scaled row j
         QrxStep s;
         s.ajnorm = ajnorm; s.ajj = ajj; s.kmax = kmax; s.pad = 0;
@@ -446,7 +535,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
 // final (R(j,k) / qtf(j), :655 at i = j), norm down-date (:656-661) with the rare recomputation.
 template <int NP, bool FLUSH>
 __device__ __forceinline__ void
-qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int cur, size_t vst, double s, double rowj, double rk, double wak,
+qrx_pass_tail(int p, int j, int k, int col, int wcol, int m, int n, int ld, int cur, size_t vst, double s, double rowj, double rk, double wak,
               bool refl, double ajj, const double (&tq)[NP > 0 ? NP : 1], const double *__restrict__ Tp, const double *__restrict__ vc,
               const double *__restrict__ vo, double *__restrict__ tpall,
               double *__restrict__ rdall, double *__restrict__ waall, double *__restrict__ Rall, double *__restrict__ qtfall)
@@ -484,8 +573,8 @@ qrx_pass_tail(int p, int j, int k, int col, int m, int n, int ld, int coff, int 
                 double vr[NP + 1];
 #pragma unroll
                 for (int q2 = 0; q2 < NP; ++q2) vr[q2] = vc[(size_t)q2 * vst + rel];
-                // a flush has just rewritten the column (pending updates applied) at its slot's own position
-                const double e = FLUSH ? Tp[qrx_at(row, coff + k, ld)] : pending(Tp[qrx_at(row, col, ld)], vr);
+                // a flush has just rewritten the column (pending updates applied) at physical column wcol
+                const double e = FLUSH ? Tp[qrx_at(row, wcol, ld)] : pending(Tp[qrx_at(row, col, ld)], vr);
                 const double vn = FLUSH ? vo[rel] : vc[(size_t)NPI * vst + rel];
                 return e - temp * vn;
             }, m - j - 1);
@@ -738,7 +827,7 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
     for (; t < ntile; ++t) tile_guard(t);
 
     if (!act) return;
-    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq, Tp, vc, vo, tpall,
+    qrx_pass_tail<NP, FLUSH>(p, j, k, col, coff + k, m, n, ld, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq, Tp, vc, vo, tpall,
                              rdall, waall, Rall, qtfall);
 }
 
@@ -957,7 +1046,7 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
         }
     }
     if (!adder || !act) return;
-    qrx_pass_tail<NP, FLUSH>(p, j, k, col, m, n, ld, coff, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq, Tp, vc, vo, tpall,
+    qrx_pass_tail<NP, FLUSH>(p, j, k, col, coff + k, m, n, ld, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq, Tp, vc, vo, tpall,
                              rdall, waall, Rall, qtfall);
 }
 
@@ -1064,7 +1153,7 @@ k_qrx_pass_col(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, do
     // multiplier, row j of R / qtf, norm down-date (with its rare recomputation, which reads the column as it still is)
     if (tid == 0) {
         const double tq1[1] = {0.0};
-        qrx_pass_tail<0, false>(p, j, k, col, m, n, ld, coff, 0, vst, s, rowj0, rk0, wa0, refl, ajj, tq1, Tp, vbank + jb, vbank + jb, tpall,
+        qrx_pass_tail<0, false>(p, j, k, col, col, m, n, ld, 0, vst, s, rowj0, rk0, wa0, refl, ajj, tq1, Tp, vbank + jb, vbank + jb, tpall,
                                 rdall, waall, Rall, qtfall);
     }
     __syncthreads();
@@ -1103,27 +1192,33 @@ k_qrx_pass_col(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, do
     }
 }
 
-// The same pass for columns LONGER than one 4096-row chunk (BASELINE config 5: 65536 rows), software-pipelined.  In
-// k_qrx_pass_col a chunk costs a memory latency for the column, the products, two LDS hand-overs, three barriers and then
-// the 4096-add chain: ~21 us, of which the chain -- the only part that is serial by definition -- is 9.4.  Here chunks are
-// 2048 rows (a sector per thread), the products of chunk c + 1 are formed and handed over while wave 0 adds chunk c (two
-// LDS buffers, ONE LDS-only barrier per chunk), and the column loads of chunk c + 2 are already in flight: a chunk costs
-// its chain plus wave 0's own share of the hand-over.  Same products, same order: bit-identical.
-#define QRX_COLL_EL 32
+// A handful of problems with columns LONGER than one 4096-row chunk (BASELINE config 5: 65536 rows): a workgroup per
+// trailing column again, but the update of a 65536-row column cannot wait in registers for the multiplier, and as a
+// second sweep (read, update, write: every column's workgroup at the same moment) it cost as much again as the chain-
+// bound sweep that forms the dot product.  So the update stays ONE STEP BEHIND: the sweep of step j applies step j - 1's
+// update (multiplier and reflector are known), writes the column back and multiplies the fresh values with step j's
+// reflector -- one read and one write of the trailing matrix per step, spread over the whole chain-bound sweep.  That is
+// the deferred-update machinery of k_qrx_pass with a flush at every step and exactly one pending reflector (the pivot
+// kernel applies it to the column it gathers, k_qrx_finish to the residual), without the physical move.
+// The sweep is software-pipelined around a wave that does nothing but the chain: three PREPARING waves form the
+// products of chunk c + 1 and hand them over while the chain wave adds chunk c (two LDS buffers, ONE LDS-only barrier per
+// chunk), the loads of chunk c + 2 already in flight: a chunk costs its 4096-add chain plus the chain wave's LDS
+// reads (9.9 us; k_qrx_pass_col: 21).  Same values, same order: bit-identical.
+#define QRX_COLL_EL 64
+template <bool PEND>
 __global__ void __launch_bounds__(256)
-k_qrx_pass_col_long(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, double *__restrict__ T,
+k_qrx_pass_col_long(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, double *__restrict__ T,
                     const double *__restrict__ Vall, double *__restrict__ tpall, const int32_t *__restrict__ srcall,
                     double *__restrict__ rdall, double *__restrict__ waall, const QrxStep *__restrict__ stepall,
                     double *__restrict__ Rall, double *__restrict__ qtfall, const LmState *__restrict__ st)
 {
-    constexpr int EL = QRX_COLL_EL, CAP = 64 * EL, E = CAP / 256;       // 2048 rows per chunk, 8 per thread: one sector
-    static_assert(E == 8, "a thread's share of a chunk is one 64-byte sector");
+    constexpr int EL = QRX_COLL_EL, CAP = 64 * EL, NPREP = 192, NPAIR = CAP / 2, PPT = (NPAIR + NPREP - 1) / NPREP;   // 2048 row pairs, 11 per thread
     __shared__ __attribute__((aligned(16))) double buf[2][CAP + 128];
     __shared__ double xch[2];
     const int p = blockIdx.y;
     if (st && st[p].stage != ST_NEED_QR) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int cw = nlh_chain_wave(4);                                    // the wave that runs the ordered sum
+    const bool chain = (wid == NPREP / 64);                             // (wave-uniform)
     const int k = j + 1 + blockIdx.x;
     const int ldp = n + 1, jb = j & ~7;
     const QrxStep step = stepall[p];
@@ -1131,87 +1226,118 @@ k_qrx_pass_col_long(int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     const double ajj = step.ajj;
     const int col = srcall[(size_t)p * ldp + k];
     double *Tp = T + (size_t)p * tst;
-    const double *vbank = Vall + (size_t)p * 2 * QRX_C * vst;
+    const double *vc = Vall + ((size_t)p * 2 + cur) * QRX_C * vst + jb;                       // slot 0: the pending reflector (PEND) or the new one
+    const double *vnew = PEND ? Vall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst + jb : vc;   // step j's reflector
+    const double tq0 = PEND ? tpall[((size_t)p * 2 + cur) * QRX_C * ldp + k] : 0.0;           // step j - 1's multiplier for this column
     const int r0 = j & 7, len = m - jb;
-    const double *colp = Tp + qrx_at(jb, col, ld);
-    double rowj0 = 0.0, rk0 = 0.0, wa0 = 1.0;
-    if (tid == 0) {
-        rowj0 = Tp[qrx_at(j, col, ld)];
-        if (k < n) { rk0 = rdall[(size_t)p * n + k]; wa0 = waall[(size_t)p * n + k]; }
-    }
+    double *colp = Tp + qrx_at(jb, col, ld);
+    double rk0 = 0.0, wa0 = 1.0;
+    if (tid == 0 && k < n) { rk0 = rdall[(size_t)p * n + k]; wa0 = waall[(size_t)p * n + k]; }
+#ifdef QRX_DBG_CLK
+    const long long c0 = wall_clock64();
+#endif
     const size_t blk = (size_t)ld * 8;
-    const int nch = (len + CAP - 1) / CAP, i0 = tid * E;
-    double2 av[4], vv[4];
+    const int nch = (len + CAP - 1) / CAP;
+    // A lane takes a PAIR of rows (16 bytes), four adjacent lanes a sector of the row-blocked matrix: a load or store
+    // instruction of the wave covers 16 whole sectors of the column and 1 KB of each reflector.
+    double2 av[PPT], vn[PPT], vp[PEND ? PPT : 1];
     auto loadchunk = [&](int c) __attribute__((always_inline)) {
-        const int rb = c * CAP + i0;                                    // rel row of this thread's 8-row block
-        const bool in = rb < len;
-        const double2 *src = reinterpret_cast<const double2 *>(colp + (size_t)(rb >> 3) * blk);
-        const double2 *vs = reinterpret_cast<const double2 *>(vbank + jb + rb);
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            av[h] = in ? src[h] : make_double2(0.0, 0.0);
-            vv[h] = in ? vs[h] : make_double2(0.0, 0.0);
+        for (int u = 0; u < PPT; ++u) {
+            const int pr = tid + u * NPREP, rb = c * CAP + 2 * pr;      // rel row of the pair
+            const bool in = pr < NPAIR && rb < len;
+            av[u] = in ? *reinterpret_cast<const double2 *>(colp + (size_t)(rb >> 3) * blk + (rb & 7)) : make_double2(0.0, 0.0);
+            vn[u] = in ? *reinterpret_cast<const double2 *>(vnew + rb) : make_double2(0.0, 0.0);
+            if (PEND) vp[u] = in ? *reinterpret_cast<const double2 *>(vc + rb) : make_double2(0.0, 0.0);
         }
     };
-    loadchunk(0);
-    double s = 0.0;                                                     // the running sum lives in the chain wave
-    for (int c = 0; c < nch; ++c) {
-        const int base = c * CAP;
-        double2 w[4];
+    double s = 0.0, rowj = 0.0;                                         // the running sum lives in the chain wave, row j in thread 0
+    // (Two loops, not one with two branches: the registers of the chunk in flight and the chain wave's 64 terms would
+    // otherwise be live together -- 293 registers, one workgroup per CU instead of two.  Both sides pass the same barriers.)
+    if (!chain) {
+        loadchunk(0);
+        for (int c = 0; c < nch; ++c) {
+            const int base = c * CAP;
+            // buf[c & 1] was last read by the chain of chunk c - 2, which ended before the chain wave joined the barrier
+            // of chunk c - 1
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int ra = base + i0 + 2 * h, rbb = ra + 1;
-            w[h].x = (ra >= r0 && ra < len && jb + ra < m) ? vv[h].x * av[h].x : 0.0;
-            w[h].y = (rbb >= r0 && rbb < len && jb + rbb < m) ? vv[h].y * av[h].y : 0.0;
+            for (int u = 0; u < PPT; ++u) {
+                const int pr = tid + u * NPREP, rel = 2 * pr;
+                if (pr < NPAIR) {
+                    const int ra = base + rel, rbb = ra + 1;
+                    const bool la = ra >= r0 && jb + ra < m, lb = rbb >= r0 && jb + rbb < m;
+                    double2 e = av[u];
+                    if (PEND) {                                         // :655 of step j - 1, rows j and below
+                        if (la) e.x = e.x - tq0 * vp[u].x;
+                        if (lb) e.y = e.y - tq0 * vp[u].y;
+                    }
+                    if (ra == r0) rowj = e.x;                           // (rel row r0 = row j: chunk 0, one of threads 0 .. 3)
+                    if (rbb == r0) rowj = e.y;
+                    double2 w;
+                    w.x = la ? vn[u].x * e.x : 0.0;                     // :653
+                    w.y = lb ? vn[u].y * e.y : 0.0;
+                    *reinterpret_cast<double2 *>(buf[c & 1] + rel + 2 * (rel / EL)) = w;
+                    if (PEND) {
+                        double *wp = colp + (size_t)(ra >> 3) * blk + (ra & 7);
+                        if (la && lb) *reinterpret_cast<double2 *>(wp) = e;
+                        else {
+                            if (la) wp[0] = e.x;
+                            if (lb) wp[1] = e.y;
+                        }
+                    }
+                }
+            }
+            if (c + 1 < nch) loadchunk(c + 1);                          // in flight during the barrier and the chain
+            qrx_lds_barrier();                                          // orders LDS traffic only: the loads stay in flight
         }
-        // buf[c & 1] was last read by the chain of chunk c - 2, which wave 0 finished before it joined the barrier of
-        // chunk c - 1
-        double2 *dst = reinterpret_cast<double2 *>(buf[c & 1] + i0 + 2 * (i0 / EL));
-#pragma unroll
-        for (int h = 0; h < 4; ++h) dst[h] = w[h];
-        if (c + 1 < nch) loadchunk(c + 1);                              // in flight during the barrier and the chain
-        qrx_lds_barrier();                                              // orders LDS traffic only: the loads stay in flight
-        if (wid == cw) {
+    } else {
+        __builtin_amdgcn_s_setprio(3);                                   // the chain wave goes first on its SIMD
+        for (int c = 0; c < nch; ++c) {
+            const int base = c * CAP;
+            qrx_lds_barrier();
             const int cl = min(CAP, len - base), nl = (cl + EL - 1) / EL;
             double d[EL];
             const double2 *mine = reinterpret_cast<const double2 *>(buf[c & 1] + lane * (EL + 2));
 #pragma unroll
             for (int u = 0; u < EL / 2; ++u) { const double2 v2 = mine[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
             double t = s;
+            if (nl == 64) {
 #pragma unroll 1
-            for (int l = 0; l < nl; ++l) {
-                if (l > 0) t = nlh_wave_shr1(t);
+                for (int l = 0; l < 64; ++l) {
+                    if (l > 0) t = nlh_wave_shr1(t);
 #pragma unroll
-                for (int u = 0; u < EL; ++u) t = t + d[u];             // :653, rows ascending (terms outside the rows: +0.0)
+                    for (int u = 0; u < EL; ++u) t = t + d[u];         // :653, rows ascending (terms outside the rows: +0.0)
+                }
+            } else {
+#pragma unroll 1
+                for (int l = 0; l < nl; ++l) {
+                    if (l > 0) t = nlh_wave_shr1(t);
+#pragma unroll
+                    for (int u = 0; u < EL; ++u) t = t + d[u];
+                }
             }
             const int lo_ = __builtin_amdgcn_readlane(__double2loint(t), nl - 1);
             const int hi_ = __builtin_amdgcn_readlane(__double2hiint(t), nl - 1);
             s = __hiloint2double(hi_, lo_);
         }
     }
-    if (wid == cw && lane == 0) xch[0] = s;
-    __syncthreads();
+    if (chain && lane == 0) xch[0] = s;
+    if (tid == (r0 >> 1)) xch[1] = rowj;                                // (the thread that held row j's pair)
+    __syncthreads();                                                    // (also: the column as written above is visible to thread 0)
     s = xch[0];
-    const double temp = refl ? s / ajj : 0.0;                           // :654
+    rowj = xch[1];
+#ifdef QRX_DBG_CLK
+    const long long c1 = wall_clock64();
+#endif
     if (tid == 0) {
-        const double tq1[1] = {0.0};
-        qrx_pass_tail<0, false>(p, j, k, col, m, n, ld, coff, 0, vst, s, rowj0, rk0, wa0, refl, ajj, tq1, Tp, vbank + jb, vbank + jb, tpall,
-                                rdall, waall, Rall, qtfall);
+        const double tq1[1] = {tq0};
+        qrx_pass_tail<PEND ? 1 : 0, PEND>(p, j, k, col, col, m, n, ld, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq1, Tp, vc,
+                                           Vall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst + jb, tpall, rdall, waall, Rall, qtfall);
     }
-    __syncthreads();
-    if (!refl) return;
-    for (int i = j + 1 + tid; i < m; i += 8 * 256) {                   // :655; eight rows per thread loaded before any is stored
-        double a8[8], v8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int row = min(i + u * 256, m - 1);
-            a8[u] = Tp[qrx_at(row, col, ld)];
-            v8[u] = vbank[row];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i + u * 256 < m) Tp[qrx_at(i + u * 256, col, ld)] = a8[u] - temp * v8[u];
-    }
+#ifdef QRX_DBG_CLK
+    if (tid == 0 && (j == 100 || j == 400) && (blockIdx.x == 0 || blockIdx.x == 100))
+        printf("pass j=%d wg %d: sweep %lld tail %lld (x10 ns)\n", j, blockIdx.x, c1 - c0, wall_clock64() - c1);
+#endif
 }
 
 // After the last step: wa4 = Q^T f (:241-253; rows < n are the qtf entries, the rest carries the pending
@@ -1342,22 +1468,49 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     const long rp6_max = std::min(rp_max, rp6_env >= 0 ? rp6_env : (long)QRX_RP6_MAX_WG);
     static const int col_env = [] { const char *e = getenv("NLH_QRX_COL"); return e ? atoi(e) : -1; }();
     if (nact <= (col_env >= 0 ? col_env : QRX_COL_MAX_NACT)) {
+        auto pivot = [&](int j, int cur, int np, int pf) {
+            if (m <= 2048)
+                hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
+                                   (const LmState *)st);
+            else if (m - j > 64 * 64 && m - j <= 64 * 64 * QRX_LONG_MAXCH)
+                hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(320), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w,
+                                   R, v, (const LmState *)st);
+            else
+                hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
+                                   (const LmState *)st);
+        };
+        if (m > 64 * QRX_COL_EL) {
+            // columns longer than one chunk: a workgroup per trailing column with the update one step behind
+            // (k_qrx_pass_col_long) -- one pending reflector from step 1 on, a bank switch at every step, no physical move
+            int cur = 0;
+            for (int j = 0; j < n; ++j) {
+                tb(0, stream);
+                pivot(j, cur, j > 0 ? 1 : 0, j > 0 ? 1 : 0);
+                te(0, stream);
+                tb(1, stream);
+                if (j == 0)
+                    hipLaunchKernelGGL(k_qrx_pass_col_long<false>, dim3(n - j, nprob), dim3(256), 0, stream, m, n, ld, tst, vst, j, cur, T,
+                                       (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
+                                       (const LmState *)st);
+                else
+                    hipLaunchKernelGGL(k_qrx_pass_col_long<true>, dim3(n - j, nprob), dim3(256), 0, stream, m, n, ld, tst, vst, j, cur, T,
+                                       (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
+                                       (const LmState *)st);
+                te(1, stream);
+                if (j > 0) cur ^= 1;
+            }
+            tb(2, stream);
+            hipLaunchKernelGGL(k_qrx_finish, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, cur, 1, (const double *)T, w, R, v,
+                               wa4, scratch, x, st, factor, gtol);
+            te(2, stream);
+            return;
+        }
         // a handful of problems: a workgroup per trailing column, eager updates, never a pending one (k_qrx_pass_col)
         for (int j = 0; j < n; ++j) {
             tb(0, stream);
-            if (m <= 2048)
-                hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, 0, 0, 0, T, w, R, v,
-                                   (const LmState *)st);
-            else
-                hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, 0, 0, 0, T, w, R, v,
-                                   (const LmState *)st);
+            pivot(j, 0, 0, 0);
             te(0, stream);
             tb(1, stream);
-            if (m - (j & ~7) > 64 * QRX_COL_EL)                   // longer than one chunk: the pipelined form
-                hipLaunchKernelGGL(k_qrx_pass_col_long, dim3(n - j, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, j, T,
-                                   (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
-                                   (const LmState *)st);
-            else
             hipLaunchKernelGGL(k_qrx_pass_col, dim3(n - j, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, j, T,
                                (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
                                (const LmState *)st);
@@ -1389,6 +1542,9 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         // trips through memory than in the fused kernel) against 191 us for this kernel's four rounds.)
         if (m <= 2048)
             hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
+                               T, w, R, v, (const LmState *)st);
+        else if (m - j > 64 * 64 && m - j <= 64 * 64 * QRX_LONG_MAXCH)
+            hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(320), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
                                T, w, R, v, (const LmState *)st);
         else
             hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,

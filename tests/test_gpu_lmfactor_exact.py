@@ -99,6 +99,20 @@ def test_lmfactor_exact_bitwise_beyond_internal_limits(ds, oracle, kind, m, n):
     _check(ds, oracle, a, f)
 
 
+@pytest.mark.parametrize("kind", ["random", "graded_rows", "graded_rows_down", "duplicates", "zero_cols", "sparse"])
+@pytest.mark.parametrize("m,n,copies", [(9001, 24, 1), (12290, 17, 3), (4101, 30, 2), (8200, 12, 40)])
+def test_lmfactor_exact_bitwise_long_columns(ds, oracle, kind, m, n, copies):
+    """Columns of several NORM2 chunks.  A handful of problems: the workgroup-per-column sweep with the update one step
+    behind (k_qrx_pass_col_long: one pending reflector, a bank switch per step, chain wave + preparing waves) and the
+    pipelined NORM2 of the pivot kernel (graded rows: a new maximum in every run, the general recurrence in every chunk;
+    graded down: the maximum is the first element; m not a multiple of 8, m - n on both sides of 4096).  Forty problems:
+    the lane-per-column passes with up to nine pending reflectors under the long-column pivot kernel."""
+    rng = np.random.default_rng(11 + m + n)
+    a = _matrix(kind, m, n, rng)
+    f = rng.standard_normal(m)
+    _check(ds, oracle, a, f, copies=copies)
+
+
 @pytest.mark.parametrize("copies", [1, 40, 300, 1100])
 def test_lmfactor_exact_every_pass_form(ds, oracle, copies):
     """The same graded 520 x 70 matrix (two 64-column windows) in batches of 1 / 40 / 300 / 1100: 2 .. 2200 (problem, window)
