@@ -509,7 +509,7 @@ __device__ __forceinline__ void nlh_lds_barrier() { asm volatile("s_waitcnt lgkm
 // with two barriers, the divisions, an LDS hand-over and then the 64 * EL-add chain -- 21 us at EL = 64, of which the
 // chain (the only part that is serial by definition) is 9.2.  The running MAXIMUM does not go through the chain, so
 // everything but the chain can run a chunk ahead: the workgroup has BSZ / 64 PREPARING waves plus one CHAIN wave
-// (blockDim.x = BSZ + 64); while the chain wave adds chunk c the others form the coefficients of chunk c + 1 (second
+// (blockDim.x >= BSZ + 64; waves beyond those only pass the barriers); while the chain wave adds chunk c the others form the coefficients of chunk c + 1 (second
 // LDS buffer), the maxima of chunk c + 2 and have the elements of chunk c + 3 in flight; ONE LDS-only barrier per chunk.
 // (Measured with the chain wave also preparing its share: 4 us of divisions, shuffles and load issue per chunk in front
 // of every chain, 16.4 us per chunk instead of 12.)  Same coefficients, same order: bit-identical.
@@ -521,7 +521,7 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
     constexpr int CAP = 64 * EL, PADCAP = CAP + 128, E = CAP / BSZ, TPR = EL / E, nw = BSZ / 64;
     static_assert(CAP % BSZ == 0 && EL % E == 0 && E % 2 == 0, "chunk must split evenly");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const bool chain = (wid == nw);                                  // (wave-uniform)
+    const bool prep = wid < nw, chain = (wid == nw);                 // (wave-uniform; further waves only pass the barriers)
     const int nch = (len + CAP - 1) / CAP, i0 = tid * E;
     int *tflags = reinterpret_cast<int *>(aux + 8);
     auto loadabs = [&](int c, double (&a)[E]) __attribute__((always_inline)) {
@@ -548,7 +548,7 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
     };
     double a0[E], a1[E], ex0 = 0.0;
     __syncthreads();
-    if (!chain) {
+    if (prep) {
         loadabs(0, a0);
         if (nch > 1) loadabs(1, a1);
         ex0 = scanmax(0, a0);
@@ -564,7 +564,7 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
         double mxc = mxrun;
 #pragma unroll
         for (int w = 0; w < nw; ++w) mxc = fmax(mxc, wm[c * nw + w]);
-        if (!chain) {
+        if (prep) {
             double prev = fmax(mxrun, ex0);
 #pragma unroll
             for (int w = 0; w < nw; ++w)

@@ -239,17 +239,21 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
 // Step j, part 1: pivot (:622-637), the pivot column with its pending updates -> reflector (:642-646).
 // The new reflector goes to slot np of the current bank, or to slot 0 of the other bank when this step's pass
 // flushes (np == QRX_C - 1).
-#define QRX_LONG_MAXCH 64                                        // chunks of 4096 rows the pipelined NORM2 keeps maxima for
+#define QRX_LONG_EL 48                                           // the pipelined NORM2: chunks of 64 * 48 rows, three preparing waves
+#define QRX_LONG_THREADS 256                                     // (512 -- four more waves for the gather and the scaling -- measured slower: 250 against 241 us per 65536-row step)
+#define QRX_LONG_MAXCH 96                                        // chunks the pipelined NORM2 keeps maxima for
 template <int QRX_NL, bool LONG = false>
-__global__ void __launch_bounds__(LONG ? 320 : 256)
+__global__ void __launch_bounds__(LONG ? QRX_LONG_THREADS : 256)
 k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
 {
     // LONG (the column is more than one NORM2 chunk): two coefficient buffers and the per-chunk maxima for the
-    // pipelined NORM2 -- 136 KB of LDS, one workgroup per CU, which is all a handful of long-column problems need
-    __shared__ __attribute__((aligned(16))) double cd[(LONG ? 4 : 2) * (64 * QRX_NL + 128)];
+    // pipelined NORM2 -- three preparing waves and the chain wave, one wave per SIMD (with four preparing waves, 320
+    // threads, the chain wave shared its SIMD with one of them: 253 us per 65536-row step against 241), 105 KB of LDS,
+    // one workgroup per CU, which is all a handful of long-column problems need
+    __shared__ __attribute__((aligned(16))) double cd[LONG ? 4 * (64 * QRX_LONG_EL + 128) : 2 * (64 * QRX_NL + 128)];
     __shared__ __attribute__((aligned(16))) double aux[LONG ? 8 + 256 : 40 + 128];
-    __shared__ double wmx[LONG ? 4 * QRX_LONG_MAXCH : 1];
+    __shared__ double wmx[LONG ? 3 * QRX_LONG_MAXCH : 1];
     __shared__ double red[64];
     const int p = p0 + blockIdx.x;
     if (st && st[p].stage != ST_NEED_QR) return;
@@ -441,7 +445,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
 #endif
                  // the diagonal entry before scaling (read before NORM2 reuses the region)
     double ajnorm;                                                // :642
-    if constexpr (LONG) ajnorm = norm2_flang_block_lanes_pipe<QRX_NL, 256>([&](int i) { return Vn[j + i]; }, m - j, cd, aux, wmx);
+    if constexpr (LONG) ajnorm = norm2_flang_block_lanes_pipe<QRX_LONG_EL, 192>([&](int i) { return Vn[j + i]; }, m - j, cd, aux, wmx);
     else ajnorm = staged ? norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return stage[i]; }, m - j, cd, aux)
                          : norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return Vn[j + i]; }, m - j, cd, aux);
 #ifdef QRX_DBG_CLK
@@ -1472,8 +1476,8 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
             if (m <= 2048)
                 hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
                                    (const LmState *)st);
-            else if (m - j > 64 * 64 && m - j <= 64 * 64 * QRX_LONG_MAXCH)
-                hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(320), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w,
+            else if (m - j > 64 * 64 && m - j <= 64 * QRX_LONG_EL * QRX_LONG_MAXCH)
+                hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w,
                                    R, v, (const LmState *)st);
             else
                 hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
@@ -1543,8 +1547,8 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         if (m <= 2048)
             hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
                                T, w, R, v, (const LmState *)st);
-        else if (m - j > 64 * 64 && m - j <= 64 * 64 * QRX_LONG_MAXCH)
-            hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(320), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
+        else if (m - j > 64 * 64 && m - j <= 64 * QRX_LONG_EL * QRX_LONG_MAXCH)
+            hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
                                T, w, R, v, (const LmState *)st);
         else
             hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
