@@ -278,6 +278,22 @@ def other_paths(ds):
     rows.append({"path": "constrained_least_squares_solver (bounded dog-leg), FD Jacobian, 4096x256", "gpu_ms": 1e3 * tg,
                  "cpu_oracle_ms": 1e3 * tc, "iterations": ibs[0]["iter_count"],
                  "bitwise_equal": bool(np.array_equal(ro[1], xg[0][0].cpu().numpy()))})
+    # a BATCH of bounded problems: the lock-step device state machine (nlh_kernels_cls.h); CPU: the first 4 on one core
+    nb, m, n = 256, 2048, 128
+    A, b, xt, x0 = ds.generate(nb, m, n, seed0=12345, spread=0.2)
+    lo, up = np.full(n, -2.0), np.full(n, 2.0)
+
+    def run_cls_batch():
+        xg[0] = x0.clone()
+        return ds.cls_solve_batch(A, b, 0.5, xg[0], opts=ds.options(max_evals=500), lower=lo, upper=up)
+    (_, ibs, st), tg = timed(run_cls_batch)
+    nc = 4
+    ro, tc = cpu(lambda: [O.dq_cls_solve(np.asfortranarray(A[q].cpu().numpy().T), b[q].cpu().numpy(), 0.5, x0[q].cpu().numpy(),
+                                         opts=O.default_options(max_evals=500), lower=lo, upper=up) for q in range(nc)])
+    rows.append({"path": f"constrained_least_squares_solver, FD Jacobian, batch of {nb} x {m}x{n} (lock-step state machine)",
+                 "gpu_ms": 1e3 * tg, "cpu_oracle_ms": 1e3 * tc * nb / nc, "cpu_sample": f"{nc} problems, scaled to {nb}",
+                 "iterations": ibs[0]["iter_count"], "solves_per_s": nb / tg,
+                 "bitwise_equal": bool(all(np.array_equal(ro[q][1], xg[0][q].cpu().numpy()) for q in range(nc)))})
     m, n = 2048, 256
     A, b, xt, x0 = ds.generate(1, m, n, seed0=77, spread=0.1)
     Ah, bh, xh = np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), x0[0].cpu().numpy()

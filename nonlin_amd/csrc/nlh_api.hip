@@ -27,6 +27,7 @@
 #include "nlh_kernels_lm.h"
 #include "nlh_kernels_lu.h"
 #include "nlh_kernels_newton.h"
+#include "nlh_kernels_cls.h"
 #include "nlh_kernels_broyden.h"
 #include "nlh_kernels_bfgs.h"
 #include "nlh_kernels_exact.h"
@@ -1507,7 +1508,7 @@ static int cls_core(nlh_handle *h, const nlh_options *o, double delta0, double s
     }
     auto matvec = [&](const double *vec, double *out) -> int {  // out = J vec (dgemv 'N')
         HIPCHK(h, hipMemcpyAsync(dvec, vec, sizeof(double) * n, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_matvec_cm, dim3((m + 255) / 256, 1), dim3(256), sizeof(double) * n, s, m, n, dJ, dvec, dJv);
+        hipLaunchKernelGGL(k_matvec_cm, dim3((m + 255) / 256, 1), dim3(256), sizeof(double) * n, s, m, n, dJ, dvec, dJv, (const LmState *)nullptr, -1);
         HIPCHK(h, hipMemcpyAsync(out, dJv, sizeof(double) * m, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
         return 0;
@@ -1784,7 +1785,7 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
             // B = R^T R (:709), bdx = B dx (:712)
             hipLaunchKernelGGL(k_bf_rtr, dim3((n + 255) / 256, n), dim3(256), 0, s, n, dR, dB);
             HIPCHK(h, hipMemcpyAsync(dvec, dx.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_matvec_cm, dim3((n + 255) / 256, 1), dim3(256), sizeof(double) * n, s, n, n, dB, dvec, dout);
+            hipLaunchKernelGGL(k_matvec_cm, dim3((n + 255) / 256, 1), dim3(256), sizeof(double) * n, s, n, n, dB, dvec, dout, (const LmState *)nullptr, -1);
             HIPCHK(h, hipMemcpyAsync(bdx.data(), dout, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipStreamSynchronize(s));
             if (ydx > 1.0e-10 && iter > 1) {                    // :715-724
@@ -2180,6 +2181,122 @@ int nlh_cls_solve(nlh_handle *h, const nlh_options *o, double delta0, double ste
     return rc;
 }
 
+// constrained_least_squares_solver%solve for a batch of device-model problems: the lock-step state machine of
+// nlh_kernels_cls.h.  A round takes every problem that wants a Jacobian through J (forward differences, fused into the
+// panel kernel), the QR of J with the reflectors applied to f, the Gauss-Newton step, the gradient and the dog-leg (with
+// J g and J p where the step needs them) to its trial point, evaluates F there and runs the ratio test; problems inside
+// the projected backtracking get one more trial point evaluated.  One 8-byte read-back per round.
+static int cls_lockstep(nlh_handle *h, const nlh_options *o, double delta0, double stepscale0, const double *xl_in,
+                        const double *xu_in, int32_t nprob, int32_t m, int32_t n, const double *dA, const double *db,
+                        double gamma, double *dx, double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
+{
+    int rc;
+    const size_t mn = (size_t)m * n, np = (size_t)nprob;
+    if ((rc = ensure(h, h->J, sizeof(double) * mn * np))) return rc;
+    if ((rc = ensure(h, h->W2, sizeof(double) * mn * np))) return rc;
+    const size_t per = 5 * (size_t)m + 7 * (size_t)n + 2 * ((size_t)n + 1) + 8;
+    if ((rc = ensure(h, h->qnV, sizeof(double) * (per * np + 2 * (size_t)n)))) return rc;
+    if ((rc = ensure(h, h->state, sizeof(LmState) * np))) return rc;
+    if ((rc = ensure(h, h->misc, sizeof(ClState) * np + 64))) return rc;
+    if ((rc = ensure_pinned(h, sizeof(ClState) * np + 64 + sizeof(double) * 2 * (size_t)n))) return rc;
+    double *dJ = (double *)h->J.p, *dW = (double *)h->W2.p, *q = (double *)h->qnV.p;
+    double *dE = q; q += (size_t)m * np;                         // the QR's extra column, then u in its head
+    double *dJv = q; q += (size_t)m * np;                        // J g, later J p
+    double *dfnew = q; q += (size_t)m * np;
+    double *vbuf = q; q += 2 * (size_t)m * np;
+    double *dg = q; q += (size_t)n * np;
+    double *dsc = q; q += (size_t)n * np;
+    double *dpgn = q; q += (size_t)n * np;
+    double *dpsd = q; q += (size_t)n * np;
+    double *du = q; q += (size_t)n * np;
+    double *dp = q; q += (size_t)n * np;
+    double *dxnew = q; q += (size_t)n * np;
+    double *wbuf = q; q += 2 * ((size_t)n + 1) * np;
+    double *st2 = q; q += 8 * np;
+    double *dxl = q, *dxu = q + n;
+    LmState *st = (LmState *)h->state.p;
+    int32_t *dcounts = (int32_t *)h->misc.p;
+    ClState *cs = (ClState *)((char *)h->misc.p + 64);
+    int32_t *hcounts = (int32_t *)h->pinned;
+    ClState *hcs = (ClState *)((char *)h->pinned + 64);
+    double *hb = (double *)((char *)h->pinned + 64 + sizeof(ClState) * np);
+    hipStream_t s = h->stream;
+    for (int i = 0; i < n; ++i) {                                // :999-1009
+        hb[i] = xl_in ? xl_in[i] : -DBL_MAX;
+        hb[n + i] = xu_in ? xu_in[i] : DBL_MAX;
+    }
+    HIPCHK(h, hipMemcpyAsync(dxl, hb, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    ClOpts co;
+    co.ftol = o->ftol; co.xtol = o->xtol; co.gtol = o->gtol; co.delta0 = delta0; co.stepscale0 = stepscale0;
+    co.max_evals = o->max_evals; co.pad = 0;
+    const int pb = (nprob + 255) / 256;
+    const bool echo = o->print_status && nprob == 1;
+    const int bsn = std::min(1024, ((n + 63) / 64) * 64);
+
+    hipLaunchKernelGGL(k_cls_reset, dim3(pb), dim3(256), 0, s, nprob, delta0, st, cs);
+    hipLaunchKernelGGL(k_cls_limits, dim3((n + 255) / 256, nprob), dim3(256), 0, s, n, (const double *)dxl, (const double *)dxu, dx);   // :1023
+    launch_dq_residual(h, nprob, m, n, dA, db, gamma, dx, dfvec, nullptr, st, CL_START);
+    hipLaunchKernelGGL(k_cls_start, dim3(nprob), dim3(256), 0, s, m, n, (const double *)dx, (const double *)dfvec, st, cs);
+    int need_jac = nprob;                                        // upper bound until the first read-back
+    // a round is an iteration or one backtracking trial: every one of them costs its problem an evaluation
+    const long max_rounds = (long)o->max_evals + 16;
+    for (long round = 0; round < max_rounds; ++round) {
+        if (need_jac > 0) {
+            launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, dJ, st, CL_NEED_JAC, dfvec);     // :1038, fused FD column write
+            hipLaunchKernelGGL(k_cls_qr_prep, dim3((m + 255) / 256, nprob), dim3(256), 0, s, m, (const double *)dfvec, dE, (const LmState *)st);
+            {
+                dim3 grid((m + 31) / 32, (n + 31) / 32, nprob);
+                hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, m, n, (const double *)dJ, dW, n, (const LmState *)st, (int)CL_NEED_JAC);
+            }
+            hipLaunchKernelGGL(k_qn_col0, dim3((m + 255) / 256, nprob), dim3(256), 0, s, m, n, (const double *)dW, vbuf);
+            launch_house_steps(h, nprob, m, n, 1, dW, dE, vbuf, wbuf, st2, st, CL_NEED_JAC);
+            hipLaunchKernelGGL(k_qn_solve_upper, dim3(nprob), dim3(bsn), sizeof(double) * n, s, n, (const double *)dW, dE, mn, (size_t)m,
+                               (const LmState *)st, (int)CL_NEED_JAC);
+            hipLaunchKernelGGL(k_qn_colsdot, dim3((n + 15) / 16, nprob), dim3(256), 0, s, m, n, (const double *)dJ, (const double *)dfvec, dg, 1.0,
+                               (const LmState *)st, (int)CL_NEED_JAC);
+            hipLaunchKernelGGL(k_cls_dog1, dim3(nprob), dim3(256), 0, s, m, n, (const double *)dx, (const double *)dxl, (const double *)dxu,
+                               (const double *)dE, dsc, dpgn, dp, st, cs);
+            hipLaunchKernelGGL(k_matvec_cm, dim3((m + 255) / 256, nprob), dim3(256), sizeof(double) * n, s, m, n, (const double *)dJ,
+                               (const double *)dg, dJv, (const LmState *)st, (int)CL_DOG_SD);
+            hipLaunchKernelGGL(k_cls_dog2, dim3(nprob), dim3(256), 0, s, m, n, (const double *)dx, (const double *)dxl, (const double *)dxu,
+                               (const double *)dg, (const double *)dJv, (const double *)dsc, (const double *)dpgn, dpsd, du, dp, st, cs);
+            hipLaunchKernelGGL(k_matvec_cm, dim3((m + 255) / 256, nprob), dim3(256), sizeof(double) * n, s, m, n, (const double *)dJ,
+                               (const double *)dp, dJv, (const LmState *)st, (int)CL_PRED);
+            hipLaunchKernelGGL(k_cls_pred, dim3(nprob), dim3(256), 0, s, m, n, (const double *)dx, (const double *)dg, (const double *)dp,
+                               (const double *)dJv, (const double *)dsc, dxnew, st, cs);
+            launch_dq_residual(h, nprob, m, n, dA, db, gamma, dxnew, dfnew, nullptr, st, CL_TRIAL);
+            hipLaunchKernelGGL(k_cls_judge, dim3(nprob), dim3(256), 0, s, m, n, co, dx, dxnew, dfvec, (const double *)dfnew, (const double *)dg,
+                               (const double *)dp, (const double *)dxl, (const double *)dxu, st, cs);
+        }
+        // (a problem that has just entered the backtracking gets its first point evaluated in the same round)
+        launch_dq_residual(h, nprob, m, n, dA, db, gamma, dxnew, dfnew, nullptr, st, CL_BT);
+        hipLaunchKernelGGL(k_cls_bt, dim3(nprob), dim3(256), 0, s, m, n, co, dx, dxnew, dfvec, (const double *)dfnew, (const double *)dp,
+                           (const double *)dxl, (const double *)dxu, st, cs);
+        hipLaunchKernelGGL(k_cls_count, dim3(1), dim3(256), 0, s, nprob, (const LmState *)st, dcounts);
+        HIPCHK(h, hipMemcpyAsync(hcounts, dcounts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (echo) HIPCHK(h, hipMemcpyAsync(hcs, cs, sizeof(ClState), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (echo && need_jac > 0 && hcs[0].print_due) print_status(hcs[0].pr_iter, hcs[0].pr_neval, hcs[0].pr_njac, hcs[0].pr_xnorm, hcs[0].pr_fnorm);
+        need_jac = hcounts[0];
+        if (need_jac == 0 && hcounts[1] == 0) break;
+    }
+    HIPCHK(h, hipMemcpyAsync(hcs, cs, sizeof(ClState) * np, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    for (int p = 0; p < nprob; ++p) {
+        const ClState &c = hcs[p];
+        if (ib) {                                                // :1163-1170 (a non-finite start leaves them zero)
+            memset(&ib[p], 0, sizeof ib[p]);
+            if (!c.silent) {
+                ib[p].iter_count = c.iter; ib[p].fcn_count = c.neval; ib[p].jacobian_count = c.njac;
+                ib[p].converge_on_fcn = c.fcnvrg; ib[p].converge_on_chng = c.xcnvrg; ib[p].converge_on_zero_diff = c.gcnvrg;
+            }
+        }
+        if (status) status[p] = (c.silent || c.converged) ? 0 : NLH_CONVERGENCE_ERROR;      // :1173-1175
+    }
+    return 0;
+}
+
 int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, double stepscale0, const double *xl,
                            const double *xu, int32_t nprob, int32_t m, int32_t n, const double *dA, const double *db,
                            double gamma, double *dx, double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
@@ -2189,6 +2306,8 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
     if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;
     if (m > QN_MAX_ROWS) return NLH_ARRAY_SIZE_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
+    static const int cls_host = [] { const char *e = getenv("NLH_CLS_HOSTLOOP"); return e ? atoi(e) : 0; }();
+    if (!cls_host) return cls_lockstep(h, o, delta0, stepscale0, xl, xu, nprob, m, n, dA, db, gamma, dx, dfvec, ib, status);
     // one problem per call; run_problems deals the problems to worker threads with private handles
     auto solve_one = [&](nlh_handle *h, int p) -> int {
         int rc;

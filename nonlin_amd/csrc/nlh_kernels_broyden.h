@@ -418,10 +418,12 @@ k_qn_col0(int rows, int ncA, const double *__restrict__ Aall, double *__restrict
 
 // out_i = sum_j v_j J(i,j), J column-major m x n, j ascending from an accumulator of zero (DGEMV 'N').
 __global__ void __launch_bounds__(256)
-k_matvec_cm(int m, int n, const double *__restrict__ J, const double *__restrict__ v, double *__restrict__ out)
+k_matvec_cm(int m, int n, const double *__restrict__ J, const double *__restrict__ v, double *__restrict__ out,
+            const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double xs[];
     const int p = blockIdx.y;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     for (int k = threadIdx.x; k < n; k += 256) xs[k] = v[(size_t)p * n + k];
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;

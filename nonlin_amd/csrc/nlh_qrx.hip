@@ -1483,7 +1483,8 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
                 hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
                                    (const LmState *)st);
         };
-        if (m > 64 * QRX_COL_EL) {
+        static const int roll_env = [] { const char *e = getenv("NLH_QRX_ROLL_MIN"); return e ? atoi(e) : -1; }();
+        if (m > (roll_env >= 0 ? roll_env : 64 * QRX_COL_EL)) {
             // columns longer than one chunk: a workgroup per trailing column with the update one step behind
             // (k_qrx_pass_col_long) -- one pending reflector from step 1 on, a bank switch at every step, no physical move
             int cur = 0;

@@ -134,3 +134,33 @@ def test_dq_cls_batch_bitwise(ds, oracle, m, n, bounded):
         assert np.array_equal(fvec[p].cpu().numpy(), fo)
         if bounded:
             assert np.all(xo >= lower) and np.all(xo <= upper)
+
+
+@pytest.mark.parametrize("m,n,lo,hi,max_evals", [(256, 24, -0.3, 0.25, 500), (700, 96, -2.0, 2.0, 500), (384, 40, -0.05, 0.04, 500),
+                                                 (256, 24, None, None, 6)])
+def test_dq_cls_lockstep_batch_bitwise(ds, oracle, m, n, lo, hi, max_evals):
+    """The lock-step state machine (nlh_kernels_cls.h) on a batch whose problems take different numbers of iterations,
+    hit their bounds, leave the trust region (steepest-descent leg), go through the projected backtracking, run out of
+    evaluations, or start from a non-finite point: every problem bit-identical to its CPU solve, counts and status too."""
+    nprob = 20
+    gen = ds.generate
+    A, b, xt, x0 = gen(nprob, m, n, seed0=4242, spread=0.2)
+    x0 = x0 * torch.linspace(0.2, 3.0, nprob, dtype=torch.float64, device=x0.device)[:, None]
+    x0[7, 3] = float("nan")                                          # the reference returns silently (:1028-1031)
+    lower = None if lo is None else np.full(n, lo)
+    upper = None if hi is None else np.full(n, hi)
+    x = x0.clone()
+    fvec, ibs, status = ds.cls_solve_batch(A, b, 0.5, x, opts=ds.options(max_evals=max_evals), lower=lower, upper=upper)
+    iters = set()
+    for p in range(nprob):
+        Ah = np.asfortranarray(A[p].cpu().numpy().T)
+        rc, xo, fo, ibo, _ = oracle.dq_cls_solve(Ah, b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(),
+                                                 opts=oracle.default_options(max_evals=max_evals), lower=lower, upper=upper)
+        assert status[p] == rc, (p, status[p], rc)
+        for k in COUNT_KEYS:
+            assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
+        assert np.array_equal(x[p].cpu().numpy(), xo, equal_nan=True), p
+        if p != 7:
+            assert np.array_equal(fvec[p].cpu().numpy(), fo, equal_nan=True), p
+        iters.add((ibo["iter_count"], ibo["fcn_count"]))
+    assert len(iters) > 1                                            # the batch is not in step
