@@ -14,10 +14,12 @@
 // B <- R^T R (tri_mtx_mult(.true., 1, r, 0, b), :709): thread per entry (i <= j), sum over k ascending;
 // both triangles of the column-major B are written.
 __global__ void __launch_bounds__(256)
-k_bf_rtr(int n, const double *__restrict__ Rt, double *__restrict__ B)
+k_bf_rtr(int n, const double *__restrict__ Rt, double *__restrict__ B, const LmState *__restrict__ gst, int gwant)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, p = blockIdx.z;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     if (i > j || i >= n) return;
+    Rt += (size_t)p * n * n; B += (size_t)p * n * n;
     double t = 0.0;
     for (int k = 0; k <= i; ++k) t = t + Rt[(size_t)k * n + i] * Rt[(size_t)k * n + j];
     B[(size_t)j * n + i] = t;
@@ -27,10 +29,12 @@ k_bf_rtr(int n, const double *__restrict__ Rt, double *__restrict__ B)
 // x <- R^-T x (DTRSV 'U','T','N'), one workgroup: x_j loses R(i,j) x_i for i ascending, which is the dot form's
 // order of subtractions.  Dynamic LDS: n doubles.
 __global__ void __launch_bounds__(1024)
-k_bf_solve_upper_t(int n, const double *__restrict__ Rt, double *__restrict__ x)
+k_bf_solve_upper_t(int n, const double *__restrict__ Rt, double *__restrict__ x, const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double xs[];
-    const int tid = threadIdx.x, BS = blockDim.x;
+    const int tid = threadIdx.x, BS = blockDim.x, p = blockIdx.x;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
+    Rt += (size_t)p * n * n; x += (size_t)p * n;
     for (int i = tid; i < n; i += BS) xs[i] = x[i];
     __syncthreads();
     for (int i = 0; i < n; ++i) {
@@ -48,10 +52,12 @@ k_bf_solve_upper_t(int n, const double *__restrict__ Rt, double *__restrict__ x)
 // 0 .. c-1 and then generates rotation c.  u is consumed.  Dynamic LDS: 2n doubles.
 template <int NC>
 __global__ void __launch_bounds__(1024)
-k_bf_chol_update(int n, double *__restrict__ Rt, const double *__restrict__ u)
+k_bf_chol_update(int n, double *__restrict__ Rt, const double *__restrict__ u, const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double cs[];                 // c[n], s[n]
-    const int tid = threadIdx.x, BS = blockDim.x;
+    const int tid = threadIdx.x, BS = blockDim.x, p = blockIdx.x;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
+    Rt += (size_t)p * n * n; u += (size_t)p * n;
     double ui[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) { const int c = tid + q * BS; ui[q] = (c < n) ? u[c] : 0.0; }
@@ -84,9 +90,12 @@ k_bf_chol_update(int n, double *__restrict__ Rt, const double *__restrict__ u)
 
 // Downdate, first half (qrupdate DCH1DN): given v = R^-T u (k_bf_solve_upper_t), rho = sqrt(1 - ||v||^2) with
 // NORM2 as the flang runtime evaluates it, then the rotations from the bottom.  info = 1: not positive definite.
-__global__ void k_bf_downdate_rot(int n, double *__restrict__ v, double *__restrict__ c, int *__restrict__ info)
+__global__ void k_bf_downdate_rot(int n, double *__restrict__ v, double *__restrict__ c, int *__restrict__ info, const LmState *__restrict__ gst, int gwant)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int p = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
+    v += (size_t)p * n; c += (size_t)p * n; info += p;
     double mx = 0.0, s = 0.0;
     for (int i = 0; i < n; ++i) {
         const double a = fabs(v[i]);
@@ -110,9 +119,12 @@ __global__ void k_bf_downdate_rot(int n, double *__restrict__ v, double *__restr
 // Downdate, second half: thread per column i, rows i .. 0.
 __global__ void __launch_bounds__(256)
 k_bf_downdate_apply(int n, double *__restrict__ Rt, const double *__restrict__ c, const double *__restrict__ s,
-                    const int *__restrict__ info)
+                    const int *__restrict__ info, const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double cs[];
+    const int p = blockIdx.y;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
+    Rt += (size_t)p * n * n; c += (size_t)p * n; s += (size_t)p * n; info += p;
     if (*info) return;
     for (int k = threadIdx.x; k < n; k += 256) { cs[k] = c[k]; cs[n + k] = s[k]; }
     __syncthreads();
@@ -131,12 +143,14 @@ k_bf_downdate_apply(int n, double *__restrict__ Rt, const double *__restrict__ c
 // diagonal.  One workgroup, thread per column (NC per thread).  info = 1-based index of a non-positive pivot.
 template <int NC>
 __global__ void __launch_bounds__(1024)
-k_bf_chol_factor(int n, const double *__restrict__ B, double *__restrict__ Rt, int *__restrict__ info)
+k_bf_chol_factor(int n, const double *__restrict__ B, double *__restrict__ Rt, int *__restrict__ info, const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double colj[];               // n: column j of R above the diagonal
     __shared__ double ajj_sh;
     __shared__ int bad;
-    const int tid = threadIdx.x, BS = blockDim.x;
+    const int tid = threadIdx.x, BS = blockDim.x, p = blockIdx.x;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
+    B += (size_t)p * n * n; Rt += (size_t)p * n * n; info += p;
     if (tid == 0) bad = 0;
     for (size_t e = tid; e < (size_t)n * n; e += BS) {          // row-major copy of the symmetric B
         const int r = (int)(e / n), c = (int)(e % n);
@@ -188,8 +202,15 @@ k_bf_chol_factor(int n, const double *__restrict__ B, double *__restrict__ Rt, i
 
 // R <- temp * I (DLASET, :705)
 __global__ void __launch_bounds__(256)
-k_bf_scaled_identity(int n, double temp, double *__restrict__ Rt)
+k_bf_scaled_identity(int n, double temp, double *__restrict__ Rt, const double *__restrict__ tempall, size_t tstride,
+                     const int32_t *__restrict__ iterall, size_t istride, const LmState *__restrict__ gst, int gwant)
 {
+    // tempall: the problem's own factor at tempall[p * tstride]; iterall: only for problems in their first iteration
+    const int p = blockIdx.y;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
+    if (iterall && iterall[(size_t)p * istride] != 1) return;
+    if (tempall) temp = tempall[(size_t)p * tstride];
+    Rt += (size_t)p * n * n;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e < (size_t)n * n) Rt[e] = (e / n == e % n) ? temp : 0.0;
 }
@@ -198,10 +219,13 @@ k_bf_scaled_identity(int n, double temp, double *__restrict__ Rt)
 // n perturbed points), sum over i ascending; then g_j = (f_j - f0) / h_j (:240).  Thread per column.
 __global__ void __launch_bounds__(64)
 k_bf_fd_gradient(int m, int n, const double *__restrict__ P, const double *__restrict__ x, double f0,
-                 double *__restrict__ g)
+                 double *__restrict__ g, const double *__restrict__ f0all, size_t fstride, const LmState *__restrict__ gst, int gwant)
 {
     __shared__ double tile[64 * 65];
-    const int t = threadIdx.x, k0 = blockIdx.x * 64;
+    const int t = threadIdx.x, k0 = blockIdx.x * 64, p = blockIdx.y;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
+    if (f0all) f0 = f0all[(size_t)p * fstride];    // the problem's own objective value
+    P += (size_t)p * m * n; x += (size_t)p * n; g += (size_t)p * n;
     double acc = 0.0;
     for (int i0 = 0; i0 < m; i0 += 64) {
         const int i = i0 + t;

@@ -290,13 +290,16 @@ k_nt_trial(int n, NtOpts o, double *__restrict__ xall, const double *__restrict_
     const double *xold = xoldall + (size_t)p * n, *dir = dirall + (size_t)p * n, *grad = gradall + (size_t)p * n;
     const double *fv = fall + (size_t)p * n;
     NtState *s = ns + p;
+    // (every thread takes its copy of the search state before the first barrier: thread 0 rewrites it below, and a wave
+    // that is behind must not see the new values)
+    const NtState q = *s;
     const double f = 0.5 * nt_ordered_sum(n, [&](int i) { return fv[i] * fv[i]; }, buf, xch);
-    int neval = s->neval;
+    int neval = q.neval;
     if (o.use_line_search) {
-        const int lsn = s->ls_neval + 1, lsi = s->ls_iter + 1;
-        const double alam = s->alam, fold = s->fold, slope = s->slope;
+        const int lsn = q.ls_neval + 1, lsi = q.ls_iter + 1;
+        const double alam = q.alam, fold = q.fold, slope = q.slope;
         bool accept = false;
-        if (alam < s->alamin) {                                       // :275-287
+        if (alam < q.alamin) {                                        // :275-287
             const double sq = nt_ordered_sum(n, [&](int i) { const double d = x[i] - xold[i]; return d * d; }, buf, xch);
             if (sqrt(sq) == 0.0) {
                 if (tid == 0) { s->f = f; s->neval = neval + lsn; s->ls_neval = lsn; s->ls_iter = lsi; s->rc = 106; st[p].stage = NT_DONE; }
@@ -310,7 +313,7 @@ k_nt_trial(int n, NtOpts o, double *__restrict__ xall, const double *__restrict_
             accept = true;
         }
         if (!accept) {
-            const double tmplam = nlh_min_backtrack_search(lsi, fold, f, s->f1, alam, s->alam1, slope);
+            const double tmplam = nlh_min_backtrack_search(lsi, fold, f, q.f1, alam, q.alam1, slope);
             const double nalam = fmax(tmplam, o.ls_factor * alam);    // :300-302
             if (lsn >= o.ls_max_evals) {                              // :305-309: error stop
                 if (tid == 0) {
@@ -355,7 +358,7 @@ k_nt_trial(int n, NtOpts o, double *__restrict__ xall, const double *__restrict_
             s->rc = 207; st[p].stage = NT_DONE;                       // :604-608
         } else {
             s->print_due = 1;                                         // :611-613 / :398-400
-            const int restart = o.broyden ? (s->jcount >= o.jdelta ? 1 : 0) : 1;     // :368-391
+            const int restart = o.broyden ? (q.jcount >= o.jdelta ? 1 : 0) : 1;      // :368-391
             s->restart = restart;
             if (neval >= o.max_evals) { s->flag = 1; st[p].stage = NT_DONE; }   // :616-619 / :403-406
             else st[p].stage = restart ? NT_NEED_JAC : NT_UPDATE;

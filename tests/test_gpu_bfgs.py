@@ -106,3 +106,30 @@ def test_dq_bfgs_batch_bitwise(ds, oracle, m, n):
             assert ibs[p][k] == ibo[k], (k, ibs[p], ibo)
         assert np.array_equal(x[p].cpu().numpy(), xo)
         assert fout[p] == fo
+
+
+@pytest.mark.parametrize("m,n,opts", [(256, 24, dict(max_evals=300, gtol=1e-8, xtol=1e-12)),
+                                      (400, 48, dict(max_evals=40, gtol=1e-10, xtol=1e-14)),
+                                      (300, 37, dict(max_evals=300, gtol=1e-8, xtol=1e-12, use_line_search=0)),
+                                      (128, 16, dict(max_evals=300, gtol=1e-3, xtol=1e-12))])
+def test_dq_bfgs_lockstep_batch_bitwise(ds, oracle, m, n, opts):
+    """The lock-step state machine (nlh_kernels_bfgs_batch.h) on a batch whose problems take different numbers of
+    iterations and backtracking steps, converge on the gradient at different times (one at its start point), run out of
+    evaluations, or step without a line search: every problem bit-identical to its CPU solve, counts, status and
+    objective value too."""
+    nprob = 18
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=909, spread=0.15)
+    x0 = xt + (x0 - xt) * torch.linspace(0.0, 2.5, nprob, dtype=torch.float64, device=x0.device)[:, None]
+    x = x0.clone()
+    fout, ibs, status = ds.bfgs_solve_batch(A, b, 0.5, x, opts=ds.options(**opts))
+    seen = set()
+    for p in range(nprob):
+        Ah = np.asfortranarray(A[p].cpu().numpy().T)
+        rc, xo, fo, ibo, _ = oracle.dq_bfgs_solve(Ah, b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(), opts=oracle.default_options(**opts))
+        assert status[p] == rc, (p, status[p], rc, ibs[p], ibo)
+        for k in COUNT_KEYS:
+            assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
+        assert np.array_equal(x[p].cpu().numpy(), xo), p
+        assert fout[p] == fo, p
+        seen.add((ibo["iter_count"], ibo["fcn_count"]))
+    assert len(seen) > 1                                             # the batch is not in step
