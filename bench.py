@@ -306,6 +306,21 @@ def other_paths(ds):
     ro, tc = cpu(lambda: O.dq_bfgs_solve(Ah, bh, 0.5, xh, opts=O.default_options(**ob)))
     rows.append({"path": "bfgs (FD gradient, Cholesky rank-1 updates), 2048x256", "gpu_ms": 1e3 * tg, "cpu_oracle_ms": 1e3 * tc,
                  "iterations": ibs[0]["iter_count"], "bitwise_equal": bool(np.array_equal(ro[1], xg[0][0].cpu().numpy()))})
+    # a BATCH of BFGS problems: the lock-step device state machine (nlh_kernels_bfgs_batch.h); CPU: the first 4 on one core
+    nb, m, n = 256, 1024, 64
+    A, b, xt, x0 = ds.generate(nb, m, n, seed0=77, spread=0.1)
+
+    def run_bfgs_batch():
+        xg[0] = x0.clone()
+        return ds.bfgs_solve_batch(A, b, 0.5, xg[0], opts=ds.options(**ob))
+    (_, ibs, st), tg = timed(run_bfgs_batch)
+    nc = 4
+    ro, tc = cpu(lambda: [O.dq_bfgs_solve(np.asfortranarray(A[q].cpu().numpy().T), b[q].cpu().numpy(), 0.5, x0[q].cpu().numpy(),
+                                          opts=O.default_options(**ob)) for q in range(nc)])
+    rows.append({"path": f"bfgs (FD gradient, Cholesky rank-1 updates), batch of {nb} x {m}x{n} (lock-step state machine)",
+                 "gpu_ms": 1e3 * tg, "cpu_oracle_ms": 1e3 * tc * nb / nc, "cpu_sample": f"{nc} problems, scaled to {nb}",
+                 "iterations": ibs[0]["iter_count"], "solves_per_s": nb / tg,
+                 "bitwise_equal": bool(all(np.array_equal(ro[q][1], xg[0][q].cpu().numpy()) for q in range(nc)))})
     nfit, npts, order = 4096, 4096, 7
     g = torch.Generator(device=ds.device).manual_seed(1)
     px = torch.rand((nfit, npts), dtype=torch.float64, device=ds.device, generator=g) * 2 - 1

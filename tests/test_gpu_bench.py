@@ -42,9 +42,9 @@ def test_bench_single_process():
     a = d["auto_policy"]                                       # the fast opt-in policy and its measured deviation
     assert a["value"] > 0 and a["problems_compared"] == 4 and 0.0 <= a["max_rel_dev_x"] < 1e-4
     assert d["fd_jacobian_mode_h"]["bound"] == "hbm" and d["fd_jacobian_mode_h"]["achieved"] > 0
-    rows = d["other_paths"]        # Newton, quasi-Newton, batched Newton, bounded LSQ, batched bounded LSQ, BFGS, polynomial
-    assert len(rows) == 7 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
-    assert sum("lock-step" in r["path"] for r in rows) == 2
+    rows = d["other_paths"]        # Newton, quasi-Newton, bounded LSQ, BFGS, their three lock-step batches, polynomial
+    assert len(rows) == 8 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
+    assert sum("lock-step" in r["path"] for r in rows) == 3
     ac = c["all_cores"]                                        # pinned workers, problems generated before the clock
     assert ac["value"] > 0 and ac["cores"] >= 1 and "cpu_model" in ac and ac["gpu_over_all_cores"] > 0
     eb = d["roofline"]["event_bracketing"]                     # what the live HIP-event brackets of the timed region cost
