@@ -56,6 +56,38 @@ def test_exact_policy_soak_slice(ds, oracle):
         assert miss is None, dict(miss, case=case)
 
 
+def test_lockstep_cls_bfgs_soak_slice(ds, oracle):
+    """Thirty random batches (seed 1) of the lock-step bounded least-squares / BFGS soak (tests/soak_lockstep.py): random sizes,
+    batch sizes, bounds, budgets and tolerances; every problem of every batch must carry the oracle's bits, counts and
+    status.  (Two seeds x 30 batches = 719 problems ran clean when the state machines were written.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import soak_lockstep
+    total, misses = soak_lockstep.run(ds, oracle, 1, 30)
+    assert total > 200 and not misses, misses[:3]
+
+
+def test_exact_long_column_soak_slice(ds, oracle):
+    """Forty random matrices with columns of 4097 .. 26000 rows, 1 .. 69 columns, alone or in batches of up to 20 (the
+    workgroup-per-column sweep with the update one step behind and the pipelined NORM2 for a handful of problems, the
+    lane-per-column passes under the long-column pivot kernel for more), every adversarial kind of
+    test_gpu_lmfactor_exact.py: bit-identical to the oracle's lmfactor and Q^T f."""
+    import test_gpu_lmfactor_exact as T
+    rng = np.random.default_rng(1)
+    for case in range(40):
+        m = int(rng.integers(4097, 26000)); n = int(rng.integers(1, 70)); copies = int(rng.choice([1, 1, 2, 3, 8, 9, 20]))
+        if rng.random() < 0.2:
+            m = int(rng.integers(4097, 4200))
+        kind = T.KINDS[int(rng.integers(len(T.KINDS)))]
+        a = T._matrix(kind, m, n, rng)
+        f = rng.standard_normal(m)
+        try:
+            T._check(ds, oracle, a, f, copies=copies)
+        except AssertionError as e:
+            raise AssertionError(dict(case=case, kind=kind, m=m, n=n, copies=copies)) from e
+
+
 @pytest.mark.parametrize("m,n,base,copies,gen,sub_batches", [
     (319, 255, 3, 500, dict(sigma=0.0), 0),
     (319, 255, 3, 500, dict(sigma=0.0), 1),
