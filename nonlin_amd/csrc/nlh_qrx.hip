@@ -243,7 +243,9 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
 #define QRX_LONG_THREADS 256                                     // (512 -- four more waves for the gather and the scaling -- measured slower: 250 against 241 us per 65536-row step)
 #define QRX_LONG_MAXCH 96                                        // chunks the pipelined NORM2 keeps maxima for
 template <int QRX_NL, bool LONG = false>
-__global__ void __launch_bounds__(LONG ? QRX_LONG_THREADS : 256)
+// (QRX_NL = 32, m <= 2048: 133 registers would leave three workgroups per CU; held to 128 -- four dwords spilled -- a launch of
+// 1024 problems is one round instead of two: 1024 x 2048x128 solves 1.8 % faster)
+__global__ void __launch_bounds__(LONG ? QRX_LONG_THREADS : 256, QRX_NL == 32 ? 4 : 1)
 k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
 {
