@@ -248,6 +248,17 @@ int  nlh_dq_model_lm_solve(nlh_handle *h, const nlh_options *opts, const nlh_dq_
                            nlh_iteration_behavior *ib, int32_t *status);
 int  nlh_dq_model_newton_solve(nlh_handle *h, const nlh_options *opts, const nlh_dq_model *model, int32_t analytic,
                                double *x, double *fvec, nlh_iteration_behavior *ib, int32_t *status);
+/* The same for quasi_newton_solver%solve (src/nonlin_solve.f90:156-427; jdelta: iterations between fresh Jacobians),
+ * constrained_least_squares_solver%solve (src/nonlin_least_squares.f90:938-1176; xl / xu: n entries or NULL, one box for
+ * every problem) and bfgs%solve on 0.5 ||F(x)||^2 (src/nonlin_optimize.f90:557-770; fout [nprob]: the objective at the
+ * solution, fvec: F there).  Each runs the lock-step device state machine of its solver on every share of the model. */
+int  nlh_dq_model_quasi_newton_solve(nlh_handle *h, const nlh_options *opts, const nlh_dq_model *model, int32_t jdelta,
+                                     int32_t analytic, double *x, double *fvec, nlh_iteration_behavior *ib, int32_t *status);
+int  nlh_dq_model_cls_solve(nlh_handle *h, const nlh_options *opts, const nlh_dq_model *model, double delta0,
+                            double stepscale0, const double *xl, const double *xu, double *x, double *fvec,
+                            nlh_iteration_behavior *ib, int32_t *status);
+int  nlh_dq_model_bfgs_solve(nlh_handle *h, const nlh_options *opts, const nlh_dq_model *model, double *x, double *fvec,
+                             double *fout, nlh_iteration_behavior *ib, int32_t *status);
 
 
 /* Synthetic problem generator of SURVEY.md 8(d) (bench/test inputs, not part of the

@@ -117,6 +117,12 @@ SYMBOLS = {
                                         C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_dq_model_newton_solve": (C.c_int, [_H, C.POINTER(Options), C.c_void_p, C.c_int32, c_double_p, c_double_p,
                                             C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_dq_model_quasi_newton_solve": (C.c_int, [_H, C.POINTER(Options), C.c_void_p, C.c_int32, C.c_int32, c_double_p, c_double_p,
+                                                  C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_dq_model_cls_solve": (C.c_int, [_H, C.POINTER(Options), C.c_void_p, C.c_double, C.c_double, c_double_p, c_double_p,
+                                         c_double_p, c_double_p, C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_dq_model_bfgs_solve": (C.c_int, [_H, C.POINTER(Options), C.c_void_p, c_double_p, c_double_p, c_double_p,
+                                          C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_timing_enable": (None, [_H, C.c_int32]),
     "nlh_timing_reset": (None, [_H]),
     "nlh_timing_get": (C.c_int, [_H, C.c_int32, c_double_p, C.POINTER(C.c_int64)]),

@@ -2862,6 +2862,50 @@ int nlh_dq_model_newton_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_
                      });
 }
 
+// quasi_newton_solver%solve on every (square) problem of the model.
+int nlh_dq_model_quasi_newton_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_model *md, int32_t jdelta,
+                                    int32_t analytic, double *x, double *fvec, nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!md || !o) return NLH_INVALID_INPUT_ERROR;
+    if (md->m != md->n) return NLH_INVALID_INPUT_ERROR;         // src/nonlin_solve.f90:241
+    return model_run(h, md, x, true, fvec, ib, status,
+                     [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
+                         return nlh_dq_quasi_newton_solve_batch(ph, o, jdelta, pt.cnt, md->n, pt.dA, pt.db, md->gamma, analytic, pt.dx, pt.df, pib, pst);
+                     });
+}
+
+// constrained_least_squares_solver%solve on every problem of the model; xl / xu: n entries each (or NULL), the same box
+// for every problem.
+int nlh_dq_model_cls_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_model *md, double delta0, double stepscale0,
+                           const double *xl, const double *xu, double *x, double *fvec, nlh_iteration_behavior *ib,
+                           int32_t *status)
+{
+    if (!md || !o) return NLH_INVALID_INPUT_ERROR;
+    return model_run(h, md, x, true, fvec, ib, status,
+                     [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
+                         return nlh_dq_cls_solve_batch(ph, o, delta0, stepscale0, xl, xu, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma,
+                                                       pt.dx, pt.df, pib, pst);
+                     });
+}
+
+// bfgs%solve on 0.5 ||F(x)||^2 of every problem of the model (forward-difference gradient); fout [nprob]: the objective
+// at the solution, fvec [nprob][m]: F there.
+int nlh_dq_model_bfgs_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_model *md, double *x, double *fvec, double *fout,
+                            nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!md || !o) return NLH_INVALID_INPUT_ERROR;
+    return model_run(h, md, x, true, fvec, ib, status,
+                     [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
+                         std::vector<double> fo(pt.cnt, 0.0);
+                         const int rc = nlh_dq_bfgs_solve_batch(ph, o, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma, pt.dx, fo.data(), pib, pst);
+                         if (rc) return rc;
+                         if (fout)
+                             for (int i = 0; i < pt.cnt; ++i) fout[(size_t)pt.first + (size_t)i * pt.stride] = fo[i];
+                         launch_dq_residual(ph, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma, pt.dx, pt.df, nullptr, nullptr, -1);
+                         return 0;
+                     });
+}
+
 int nlh_dq_residual(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const double *dA, const double *db,
                     double gamma, const double *dx, double *df)
 {

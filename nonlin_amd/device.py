@@ -356,6 +356,38 @@ class HostModel:
     def newton_solve(self, x, analytic=True, opts=None):
         return self._solve(self.lib.nlh_dq_model_newton_solve, x, opts, 1 if analytic else 0)
 
+    def quasi_newton_solve(self, x, analytic=True, jdelta=5, opts=None):
+        """quasi_newton_solver%solve on every (square) problem; jdelta: iterations between fresh Jacobians."""
+        return self._solve(self.lib.nlh_dq_model_quasi_newton_solve, x, opts, int(jdelta), 1 if analytic else 0)
+
+    def cls_solve(self, x, lower=None, upper=None, delta=1.0, stepscale=1.0, opts=None):
+        """constrained_least_squares_solver%solve on every problem inside the box [lower, upper] (n entries each, or None)."""
+        import numpy as np
+        lo = None if lower is None else np.ascontiguousarray(lower, dtype=np.float64)
+        hi = None if upper is None else np.ascontiguousarray(upper, dtype=np.float64)
+        for v in (lo, hi):
+            if v is not None and v.shape != (self.n,):
+                raise ValueError("bounds must have n entries")
+        dp = lambda a: None if a is None else a.ctypes.data_as(_lib.c_double_p)
+        return self._solve(self.lib.nlh_dq_model_cls_solve, x, opts, float(delta), float(stepscale), dp(lo), dp(hi))
+
+    def bfgs_solve(self, x, opts=None):
+        """bfgs%solve on 0.5 ||F(x)||^2 of every problem: returns (x, F(x), objective values, behaviours, status codes)."""
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        f = np.empty((self.nprob, self.m))
+        fo = np.empty(self.nprob)
+        ib = (_lib.IterationBehavior * self.nprob)()
+        st = (C.c_int32 * self.nprob)()
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        hptr = None if isinstance(self.owner, DeviceSet) else self.owner.h.ptr
+        rc = self.lib.nlh_dq_model_bfgs_solve(hptr, C.byref(opts if opts is not None else _lib.default_options()), self._md,
+                                              dp(x), dp(f), dp(fo), ib, st)
+        self.owner.check(rc, "nlh_dq_model_bfgs_solve")
+        if rc != 0:
+            raise RuntimeError(f"nlh_dq_model_bfgs_solve: {rc}")
+        return x, f, fo, [ib[p].as_dict() for p in range(self.nprob)], [int(st[p]) for p in range(self.nprob)]
+
     def close(self):
         if getattr(self, "_md", None) is not None and self._md.value:
             self.lib.nlh_dq_model_destroy(self._md)

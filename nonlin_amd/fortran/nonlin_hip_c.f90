@@ -207,6 +207,42 @@ module nonlin_hip_c
             integer(c_int32_t), intent(out) :: status(*)
             integer(c_int) :: rc
         end function
+        function nlh_dq_model_quasi_newton_solve(h, opts, model, jdelta, analytic, x, fvec, ib, status) &
+                bind(C, name="nlh_dq_model_quasi_newton_solve") result(rc)
+            import :: c_ptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h, model
+            type(nlh_options), intent(in) :: opts
+            integer(c_int32_t), value :: jdelta, analytic
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fvec(*)
+            type(nlh_iteration_behavior), intent(out) :: ib(*)
+            integer(c_int32_t), intent(out) :: status(*)
+            integer(c_int) :: rc
+        end function
+        function nlh_dq_model_cls_solve(h, opts, model, delta0, stepscale0, xl, xu, x, fvec, ib, status) &
+                bind(C, name="nlh_dq_model_cls_solve") result(rc)
+            import :: c_ptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h, model
+            type(nlh_options), intent(in) :: opts
+            real(c_double), value :: delta0, stepscale0
+            real(c_double), intent(in) :: xl(*), xu(*)
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fvec(*)
+            type(nlh_iteration_behavior), intent(out) :: ib(*)
+            integer(c_int32_t), intent(out) :: status(*)
+            integer(c_int) :: rc
+        end function
+        function nlh_dq_model_bfgs_solve(h, opts, model, x, fvec, fout, ib, status) &
+                bind(C, name="nlh_dq_model_bfgs_solve") result(rc)
+            import :: c_ptr, c_int, c_int32_t, c_double, nlh_options, nlh_iteration_behavior
+            type(c_ptr), value :: h, model
+            type(nlh_options), intent(in) :: opts
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), intent(out) :: fvec(*), fout(*)
+            type(nlh_iteration_behavior), intent(out) :: ib(*)
+            integer(c_int32_t), intent(out) :: status(*)
+            integer(c_int) :: rc
+        end function
     end interface
 
     type(c_ptr), save, private :: default_handle = c_null_ptr

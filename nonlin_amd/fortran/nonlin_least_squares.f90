@@ -46,6 +46,7 @@ module nonlin_least_squares
         procedure, public :: get_step_scaling_factor => tr_dogleg_scale
         procedure, public :: set_step_scaling_factor => tr_put_dogleg_scale
         procedure, public :: solve => tr_solve_one
+        procedure, public :: solve_batch => tr_solve_many
     end type
 
 contains
@@ -275,5 +276,52 @@ contains
         fvec = fwork
         if (present(ib)) call behavior_import(ib, counters)
         if (rc /= 0) error stop rc      ! as at :1173-1175
+    end subroutine
+
+    !> Extension: constrained_least_squares_solver%solve (cls_solve, :938-1176) for every problem of a device model batch,
+    !> all of them inside this solver's box.  Arguments as least_squares_solver%solve_batch.
+    subroutine tr_solve_many(this, model, x, fvec, ib, status)
+        class(constrained_least_squares_solver), intent(inout) :: this
+        class(device_model_batch), intent(in) :: model
+        real(real64), intent(inout), dimension(:,:) :: x
+        real(real64), intent(out), dimension(:,:) :: fvec
+        type(iteration_behavior), intent(out), dimension(:), optional :: ib
+        integer(int32), intent(out), dimension(:), optional :: status
+
+        type(nlh_options) :: opts
+        type(nlh_iteration_behavior), allocatable :: counters(:)
+        integer(c_int32_t), allocatable :: outcome(:)
+        real(c_double), allocatable :: xwork(:,:), fwork(:,:), lo(:), hi(:)
+        integer(c_int) :: rc
+        integer(int32) :: m, n, count
+
+        if (.not.model%is_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR
+        m = model%get_equation_count()
+        n = model%get_variable_count()
+        count = model%get_problem_count()
+        if (n > m) error stop NL_UNDERDEFINED_PROBLEM_ERROR
+        if (any(shape(x) /= [n, count])) error stop 3
+        if (any(shape(fvec) /= [m, count])) error stop 4
+        lo = this%get_lower_limits()
+        if (size(lo) /= n) then
+            lo = spread(-huge(1.0d0), 1, n)
+            call this%set_lower_limits(lo)
+        end if
+        hi = this%get_upper_limits()
+        if (size(hi) /= n) then
+            hi = spread(huge(1.0d0), 1, n)
+            call this%set_upper_limits(hi)
+        end if
+        call this%export_options(opts)
+        opts%print_status = 0
+        allocate(counters(count), outcome(count), fwork(m, count))
+        allocate(xwork(n, count), source = x)
+        rc = nlh_dq_model_cls_solve(nlh_default_handle(), opts, model%c_handle(), this%radius0_, this%dogleg_scale_, lo, hi, &
+            xwork, fwork, counters, outcome)
+        if (rc /= 0) error stop rc
+        x = xwork
+        fvec = fwork
+        if (present(status)) status = outcome
+        if (present(ib)) call behavior_import(ib, counters)
     end subroutine
 end module

@@ -7,6 +7,7 @@ module nonlin_optimize
     use nonlin_linesearch
     use nonlin_error_handling
     use nonlin_multi_var
+    use nonlin_multi_eqn_mult_var, only : device_model_batch
     use nonlin_types
     use nonlin_hip_c
     use nonlin_shim_support
@@ -34,6 +35,7 @@ module nonlin_optimize
     type, extends(line_search_optimizer) :: bfgs
     contains
         procedure, public :: solve => bfgs_solve_one
+        procedure, public :: solve_batch => bfgs_solve_many
     end type
 
 contains
@@ -137,5 +139,45 @@ contains
             ib%converge_on_fcn = .false.            ! bfgs has no such test (reference :751-759)
         end if
         if (rc /= 0) error stop rc      ! as at :765-767
+    end subroutine
+
+    !> Extension: bfgs%solve (bfgs_solve, :557-770) on the objective 0.5 ||F(x)||^2 of every problem of a device model
+    !> batch (forward-difference gradient).  x(n, count) in / out, fout(count): the objective values, status(count): the
+    !> code each solve would have stopped with (0: converged).
+    subroutine bfgs_solve_many(this, model, x, fout, ib, status)
+        class(bfgs), intent(inout) :: this
+        class(device_model_batch), intent(in) :: model
+        real(real64), intent(inout), dimension(:,:) :: x
+        real(real64), intent(out), dimension(:), optional :: fout
+        type(iteration_behavior), intent(out), dimension(:), optional :: ib
+        integer(int32), intent(out), dimension(:), optional :: status
+
+        type(nlh_options) :: opts
+        type(nlh_iteration_behavior), allocatable :: counters(:)
+        integer(c_int32_t), allocatable :: outcome(:)
+        real(c_double), allocatable :: xwork(:,:), fwork(:,:), fmin(:)
+        integer(c_int) :: rc
+        integer(int32) :: m, n, count, k
+
+        if (.not.model%is_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR
+        m = model%get_equation_count()
+        n = model%get_variable_count()
+        count = model%get_problem_count()
+        if (any(shape(x) /= [n, count])) error stop NL_INVALID_INPUT_ERROR
+        call this%export_options(opts)
+        opts%print_status = 0
+        allocate(counters(count), outcome(count), fwork(m, count), fmin(count))
+        allocate(xwork(n, count), source = x)
+        rc = nlh_dq_model_bfgs_solve(nlh_default_handle(), opts, model%c_handle(), xwork, fwork, fmin, counters, outcome)
+        if (rc /= 0) error stop rc
+        x = xwork
+        if (present(fout)) fout = fmin
+        if (present(status)) status = outcome
+        if (present(ib)) then
+            call behavior_import(ib, counters)
+            do k = 1, count
+                ib(k)%converge_on_fcn = .false.
+            end do
+        end if
     end subroutine
 end module

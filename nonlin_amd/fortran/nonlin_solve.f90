@@ -40,6 +40,7 @@ module nonlin_solve
         integer(int32), private :: refresh_every_ = 5    ! iterations between fresh Jacobians (reference default, :51)
     contains
         procedure, public :: solve => broyden_solve_one
+        procedure, public :: solve_batch => broyden_solve_many
         procedure, public :: get_jacobian_interval => broyden_refresh
         procedure, public :: set_jacobian_interval => broyden_put_refresh
     end type
@@ -187,6 +188,41 @@ contains
     end subroutine
 
     ! ---- quasi_newton_solver -----------------------------------------------------------------------------------
+    !> Extension: quasi_newton_solver%solve (qns_solve, :156-427) for every (square) problem of a device model batch.
+    !> Arguments as least_squares_solver%solve_batch.
+    subroutine broyden_solve_many(this, model, x, fvec, ib, status)
+        class(quasi_newton_solver), intent(inout) :: this
+        class(device_model_batch), intent(in) :: model
+        real(real64), intent(inout), dimension(:,:) :: x
+        real(real64), intent(out), dimension(:,:) :: fvec
+        type(iteration_behavior), intent(out), dimension(:), optional :: ib
+        integer(int32), intent(out), dimension(:), optional :: status
+
+        type(nlh_options) :: opts
+        type(nlh_iteration_behavior), allocatable :: counters(:)
+        integer(c_int32_t), allocatable :: outcome(:)
+        real(c_double), allocatable :: xwork(:,:), fwork(:,:)
+        integer(c_int) :: rc
+        integer(int32) :: n, count
+
+        if (.not.model%is_defined()) error stop NL_UNDEFINED_FUNCTION_ERROR
+        n = model%get_variable_count()
+        count = model%get_problem_count()
+        if (model%get_equation_count() /= n) error stop NL_INVALID_INPUT_ERROR
+        if (any(shape(x) /= [n, count])) error stop 3
+        if (any(shape(fvec) /= [n, count])) error stop 4
+        call this%export_search_options(opts, quiet = .true.)
+        allocate(counters(count), outcome(count), fwork(n, count))
+        allocate(xwork(n, count), source = x)
+        rc = nlh_dq_model_quasi_newton_solve(nlh_default_handle(), opts, model%c_handle(), this%refresh_every_, &
+            merge(1_c_int32_t, 0_c_int32_t, model%uses_analytic_jacobian()), xwork, fwork, counters, outcome)
+        if (rc /= 0) error stop rc
+        x = xwork
+        fvec = fwork
+        if (present(status)) status = outcome
+        if (present(ib)) call behavior_import(ib, counters)
+    end subroutine
+
     subroutine broyden_solve_one(this, fcn, x, fvec, ib, args)
         class(quasi_newton_solver), intent(inout) :: this
         class(vecfcn_helper), intent(in), target :: fcn

@@ -1,5 +1,6 @@
 ! User-side program for the device-model extension of the drop-in layer (vecfcn_helper%set_device_model,
-! device_model_batch, least_squares_solver%solve_batch / newton_solver%solve_batch): reads problem data written by
+! device_model_batch, solve_batch of the least-squares, Newton, quasi-Newton, bounded least-squares and BFGS solvers):
+! reads problem data written by
 ! tests/test_gpu_fortran.py (stream binary: nprob, m, n (int32), gamma (real64), A(m,n,nprob), b(m,nprob), x0(n,nprob)),
 ! solves on the GPU through `use nonlin`, prints counts, flags and the bit patterns of x.
 program device_model_suite
@@ -15,6 +16,8 @@ program device_model_suite
     call run_lm(trim(path))
     call get_command_argument(2, path)
     call run_newton(trim(path))
+    call get_command_argument(1, path)
+    call run_box_and_bfgs(trim(path))
 
 contains
     subroutine load(path, nprob, m, n, gamma, a, b, x0)
@@ -117,6 +120,62 @@ contains
         call nt%solve_batch(batch, x, f, ibs, st)
         do k = 1, nprob
             call report("dm_newton_batch", ibs(k), st(k), x(:,k))
+        end do
+        call run_broyden_batch(batch, x0)
+        call batch%destroy()
+    end subroutine
+
+    ! quasi_newton_solver%solve_batch on the square problems of run_newton
+    subroutine run_broyden_batch(batch, x0)
+        type(device_model_batch), intent(in) :: batch
+        real(real64), intent(in) :: x0(:,:)
+        type(quasi_newton_solver) :: qn
+        real(real64), allocatable :: x(:,:), f(:,:)
+        type(iteration_behavior), allocatable :: ibs(:)
+        integer(int32), allocatable :: st(:)
+        integer(int32) :: k
+        call qn%set_max_fcn_evals(500)
+        allocate(x, source = x0)
+        allocate(f(size(x0, 1), size(x0, 2)), ibs(size(x0, 2)), st(size(x0, 2)))
+        call qn%solve_batch(batch, x, f, ibs, st)
+        do k = 1, size(x0, 2)
+            call report("dm_broyden_batch", ibs(k), st(k), x(:,k))
+        end do
+    end subroutine
+
+    ! constrained_least_squares_solver%solve_batch (box -0.3 .. 0.25) and bfgs%solve_batch on the problems of run_lm
+    subroutine run_box_and_bfgs(path)
+        character(len=*), intent(in) :: path
+        integer(int32) :: nprob, m, n, k
+        real(real64) :: gamma
+        real(real64), allocatable :: a(:,:,:), b(:,:), x0(:,:), x(:,:), f(:,:), fo(:), lo(:), hi(:)
+        type(device_model_batch) :: batch
+        type(constrained_least_squares_solver) :: tr
+        type(bfgs) :: qb
+        type(iteration_behavior), allocatable :: ibs(:)
+        integer(int32), allocatable :: st(:)
+
+        call load(path, nprob, m, n, gamma, a, b, x0)
+        call batch%create(NLH_MODEL_DENSE_QUADRATIC, a, b, gamma)
+        allocate(x(n, nprob), f(m, nprob), fo(nprob), ibs(nprob), st(nprob), lo(n), hi(n))
+        lo = -0.3d0
+        hi = 0.25d0
+        call tr%set_lower_limits(lo)
+        call tr%set_upper_limits(hi)
+        call tr%set_max_fcn_evals(500)
+        x = x0
+        call tr%solve_batch(batch, x, f, ibs, st)
+        do k = 1, nprob
+            call report("dm_cls_batch", ibs(k), st(k), x(:,k))
+        end do
+        call qb%set_max_fcn_evals(300)
+        call qb%set_tolerance(1.0d-8)
+        call qb%set_var_tolerance(1.0d-12)
+        x = x0
+        call qb%solve_batch(batch, x, fo, ibs, st)
+        do k = 1, nprob
+            ibs(k)%jacobian_count = ibs(k)%gradient_count      ! (report prints the third counter)
+            call report("dm_bfgs_batch", ibs(k), st(k), [x(:,k), fo(k)])
         end do
         call batch%destroy()
     end subroutine

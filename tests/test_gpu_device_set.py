@@ -63,3 +63,41 @@ def test_bad_device_id_is_refused():
     from nonlin_amd import _lib
     with pytest.raises(_lib.NonlinHipUnavailable):
         DeviceSet([torch.cuda.device_count() + 3])
+
+
+def test_model_level_quasi_newton_cls_bfgs_on_a_device_set(oracle):
+    """nlh_dq_model_quasi_newton_solve / _cls_solve / _bfgs_solve on a model dealt over two shares (device 0 twice): the
+    lock-step batches behind host arrays, every problem bit-identical to the CPU oracle."""
+    import numpy as np
+    from nonlin_amd.device import DeviceSet
+    from nonlin_amd import _lib
+    ds = DeviceSet([0, 0])
+    o = _lib.default_options(); o.max_evals = 500
+    gen = [oracle.dq_generate(900 + k, 40, 40, gamma=0.5, sigma=0.0, square_shift=True) for k in range(5)]
+    A = np.stack([np.ascontiguousarray(g[0].T) for g in gen]); b = np.stack([g[1] for g in gen]); x0 = np.stack([g[3] for g in gen])
+    md = ds.model(A, b, 0.5)
+    x, f, ibs, st = md.quasi_newton_solve(x0, analytic=True, opts=o)
+    for k, g in enumerate(gen):
+        rc, xo, fo, ibo, _ = oracle.dq_quasi_newton_solve(g[0], g[1], 0.5, g[3], analytic=True, opts=oracle.default_options(max_evals=500))
+        assert st[k] == rc and np.array_equal(x[k], xo) and np.array_equal(f[k], fo)
+        assert ibs[k]["iter_count"] == ibo["iter_count"] and ibs[k]["fcn_count"] == ibo["fcn_count"]
+    md.close()
+    gen = [oracle.dq_generate(950 + k, 200, 24, gamma=0.5) for k in range(5)]
+    A = np.stack([np.ascontiguousarray(g[0].T) for g in gen]); b = np.stack([g[1] for g in gen]); x0 = np.stack([g[3] for g in gen])
+    md = ds.model(A, b, 0.5)
+    lo, hi = np.full(24, -0.4), np.full(24, 0.3)
+    x, f, ibs, st = md.cls_solve(x0, lower=lo, upper=hi, opts=o)
+    for k, g in enumerate(gen):
+        rc, xo, fo, ibo, _ = oracle.dq_cls_solve(g[0], g[1], 0.5, g[3], opts=oracle.default_options(max_evals=500), lower=lo, upper=hi)
+        assert st[k] == rc and np.array_equal(x[k], xo) and np.array_equal(f[k], fo)
+        assert ibs[k]["iter_count"] == ibo["iter_count"] and ibs[k]["jacobian_count"] == ibo["jacobian_count"]
+    ob = dict(max_evals=300, gtol=1e-8, xtol=1e-12)
+    o2 = _lib.default_options(); o2.max_evals = 300; o2.gtol = 1e-8; o2.xtol = 1e-12
+    x, f, fo_, ibs, st = md.bfgs_solve(x0, opts=o2)
+    for k, g in enumerate(gen):
+        rc, xo, fo, ibo, _ = oracle.dq_bfgs_solve(g[0], g[1], 0.5, g[3], opts=oracle.default_options(**ob))
+        assert st[k] == rc and np.array_equal(x[k], xo) and fo_[k] == fo
+        assert np.array_equal(f[k], oracle.dq_residual(g[0], g[1], 0.5, xo))
+        assert ibs[k]["gradient_count"] == ibo["gradient_count"]
+    md.close()
+    ds.close()

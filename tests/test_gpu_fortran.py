@@ -220,3 +220,28 @@ def test_device_model_newton_through_fortran(dm_results, oracle):
     for k, (A, b, xt, x0) in enumerate(data):
         rc, xo, fo, ibo, _ = oracle.dq_newton_solve(A, b, gamma, x0, analytic=True, opts=oracle.default_options(max_evals=500))
         _cmp_dm(res["dm_newton_batch"][k], rc, xo, ibo)
+
+
+def test_device_model_other_solver_batches_through_fortran(dm_results, oracle):
+    """quasi_newton_solver%solve_batch, constrained_least_squares_solver%solve_batch (box -0.3 .. 0.25) and bfgs%solve_batch
+    (objective 0.5 ||F||^2, forward-difference gradient) on device model batches -- the lock-step state machines behind the
+    reference's solver types: every problem bit-identical to the CPU oracle."""
+    res, (gamma, lm_data), (gamma_n, nt_data) = dm_results
+    assert len(res["dm_broyden_batch"]) == len(nt_data)
+    for k, (A, b, xt, x0) in enumerate(nt_data):
+        rc, xo, fo, ibo, _ = oracle.dq_quasi_newton_solve(A, b, gamma_n, x0, analytic=True, opts=oracle.default_options(max_evals=500))
+        _cmp_dm(res["dm_broyden_batch"][k], rc, xo, ibo)
+    n = lm_data[0][0].shape[1]
+    lo, hi = np.full(n, -0.3), np.full(n, 0.25)
+    assert len(res["dm_cls_batch"]) == len(lm_data)
+    for k, (A, b, xt, x0) in enumerate(lm_data):
+        rc, xo, fo, ibo, _ = oracle.dq_cls_solve(A, b, gamma, x0, opts=oracle.default_options(max_evals=500), lower=lo, upper=hi)
+        _cmp_dm(res["dm_cls_batch"][k], rc, xo, ibo)
+    assert len(res["dm_bfgs_batch"]) == len(lm_data)
+    for k, (A, b, xt, x0) in enumerate(lm_data):
+        rc, xo, fo, ibo, _ = oracle.dq_bfgs_solve(A, b, gamma, x0, opts=oracle.default_options(max_evals=300, gtol=1e-8, xtol=1e-12))
+        r = res["dm_bfgs_batch"][k]
+        assert r["status"] == rc
+        assert r["counts"] == (ibo["iter_count"], ibo["fcn_count"], ibo["gradient_count"]), (r, ibo)
+        assert r["flags"] == ("F", "T" if ibo["converge_on_chng"] else "F", "T" if ibo["converge_on_zero_diff"] else "F")
+        assert np.array_equal(r["x"][:-1], xo) and r["x"][-1] == fo
