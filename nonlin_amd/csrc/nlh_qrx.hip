@@ -241,6 +241,12 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
 // flushes (np == QRX_C - 1).
 #define QRX_LONG_EL 48                                           // the pipelined NORM2: chunks of 64 * 48 rows, three preparing waves
 #define QRX_LONG_THREADS 256                                     // (512 -- four more waves for the gather and the scaling -- measured slower: 250 against 241 us per 65536-row step)
+#ifndef QRX_LONG_GU
+#define QRX_LONG_GU 8                                            // row pairs per thread in flight in the long-column gather
+#endif
+#ifndef QRX_LONG_SU
+#define QRX_LONG_SU 4                                            // sectors per thread in flight in the long-column scaling
+#endif
 #define QRX_LONG_MAXCH 96                                        // chunks the pipelined NORM2 keeps maxima for
 template <int QRX_NL, bool LONG = false>
 // (QRX_NL = 32, m <= 2048: 133 registers would leave three workgroups per CU; held to 128 -- four dwords spilled -- a launch of
@@ -410,7 +416,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
         const double *colp = Tp + qrx_at(jb, srck, ld);
         const size_t blk = (size_t)ld * 8;
         const double t0 = np ? tk[0] : 0.0;
-        constexpr int GU = 8;
+        constexpr int GU = QRX_LONG_GU;
         for (int pb = tid; pb < npair; pb += GU * BS) {
             double2 ax[GU], px[GU];
 #pragma unroll
@@ -477,16 +483,16 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
         if (ejj < 0.0) ajnorm = -ajnorm;                         // :644
         // :645-646 a sector at a time, four per thread in flight (thread 0 holds row j)
         const int jb = j & ~7, nsec = (m - jb + 7) >> 3;
-        for (int sb = tid; sb < nsec; sb += 4 * BS) {
-            double2 tx[4][4];
+        for (int sb = tid; sb < nsec; sb += QRX_LONG_SU * BS) {
+            double2 tx[QRX_LONG_SU][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < QRX_LONG_SU; ++q) {
                 const double2 *sp = reinterpret_cast<const double2 *>(Vn + jb + (size_t)min(sb + q * BS, nsec - 1) * 8);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) tx[q][h] = sp[h];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < QRX_LONG_SU; ++q) {
                 const int sc = sb + q * BS, row = jb + sc * 8;
                 if (sc >= nsec) continue;
 #pragma unroll
