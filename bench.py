@@ -655,7 +655,7 @@ def main():
                                       "note": "nlh_default_options (exact policy, sub_batches = auto: latency-bound stages of one "
                                               "sub-batch run under the streaming kernels of another)"}
             # latency of BASELINE config 2 taken literally: ONE problem (seed 12345), warm handle
-            v1, _, ib1, t1 = run_policy(ds.options(max_evals=max_evals), nrep=1, sel=slice(0, 1))
+            v1, _, ib1, t1 = run_policy(ds.options(max_evals=max_evals), nrep=3, sel=slice(0, 1))
             out["single_problem"] = {"ms": 1e3 * t1, "lm_iterations": ib1[0]["jacobian_count"], "lm_iterations_per_s": v1,
                                      "factor_policy": POLICY_NAMES[2]}
             # the fast non-parity policy: J^T J on the fp64 MFMA + Cholesky; deviation from the CPU path measured here
