@@ -373,7 +373,7 @@ __device__ double norm2_flang_block_wide(Get get, int len, double *cd, int cap, 
 // one-thread forms above spend most of their time on (7.6 ns per element).  A run that contains a new maximum
 // (c_i != 1, flagged by the threads that prepared it) takes the general s <- s*c + d form for that step only.
 // Bit-identical to norm2_flang_block.  BSZ = blockDim.x (64 .. 1024, a power of two), EL a multiple of BSZ / 64 (and of 2);
-// cd: 2 * (64 * EL + 128) doubles of LDS, 16-byte aligned; aux: 40 doubles + BSZ ints.
+// cd: 64 * EL + 128 doubles of LDS, 16-byte aligned; aux: 40 doubles + BSZ ints.
 __device__ __forceinline__ double nlh_wave_shr1(double t)
 {
     int lo = __double2loint(t), hi = __double2hiint(t);
@@ -402,7 +402,7 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int nw = BSZ / 64;
     const int cw = nlh_chain_wave(nw);                                   // the wave that runs the serial recurrence
-    double *cs = cd, *dsv = cd + PADCAP, *wmax = aux, *carry = aux + 32;
+    double *dsv = cd, *wmax = aux, *carry = aux + 32;
     int *tflags = reinterpret_cast<int *>(aux + 40);
     __syncthreads();
     if (tid == 0) { carry[0] = 0.0; carry[1] = 0.0; }
@@ -429,35 +429,35 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
         const double mx_in = carry[0];
         double prev = fmax(mx_in, ex);
         for (int w = 0; w < wid; ++w) prev = fmax(prev, wmax[w]);
-        bool plain = true;
+        // The scale factor of an element is 1 unless the element is a new maximum, and then it EQUALS its term (both
+        // (mx / a)^2): a bit per element says which, the terms alone go to LDS.
+        unsigned newmax = 0;
         // element i of the chunk lives at i + 2 * (i / EL): two doubles of padding behind every run, so that the 16-byte
         // reads of a run's owner fall on other banks than its neighbours'
-        double2 *cdst = reinterpret_cast<double2 *>(cs + i0 + 2 * (i0 / EL));
         double2 *ddst = reinterpret_cast<double2 *>(dsv + i0 + 2 * (i0 / EL));
 #pragma unroll
         for (int u = 0; u < E; u += 2) {
-            double cc[2], dd[2];
+            double dd[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                double c = 1.0, d = 0.0;
+                double d = 0.0;
                 const double av = a[u + h];
                 if (prev == 0.0) {
                     // mx was zero: element becomes the maximum, s untouched
                 } else if (av > prev) {
                     const double t = prev / av, tsq = t * t;
-                    c = tsq; d = tsq;
+                    d = tsq;
+                    if (tsq != 1.0) newmax |= 1u << (u + h);         // s <- s * tsq + tsq
                 } else if (av != 0.0) {
                     const double t = av / prev;
                     d = t * t;
                 }
-                plain = plain && (c == 1.0);
-                cc[h] = c; dd[h] = d;
+                dd[h] = d;
                 prev = fmax(prev, av);
             }
-            cdst[u >> 1] = make_double2(cc[0], cc[1]);
             ddst[u >> 1] = make_double2(dd[0], dd[1]);
         }
-        tflags[tid] = plain ? 1 : 0;
+        tflags[tid] = (int)newmax;
         __syncthreads();
         if (wid == cw) {
             const int nl = (cl + EL - 1) / EL;                       // runs in use
@@ -465,10 +465,10 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
             const double2 *mine = reinterpret_cast<const double2 *>(dsv + lane * (EL + 2));
 #pragma unroll
             for (int u = 0; u < EL / 2; ++u) { const double2 v2 = mine[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
-            int pl = 1;
+            unsigned long long nm = 0;                               // this lane's run: which elements are new maxima
 #pragma unroll
-            for (int k = 0; k < TPR; ++k) pl &= tflags[lane * TPR + k];
-            const unsigned long long mask = __ballot(pl != 0);
+            for (int k = 0; k < TPR; ++k) nm |= (unsigned long long)(unsigned)tflags[lane * TPR + k] << (k * E);
+            const unsigned long long mask = __ballot(nm == 0);       // runs without one
             double t = carry[1];
 #pragma unroll 1
             for (int l = 0; l < nl; ++l) {
@@ -477,12 +477,10 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
 #pragma unroll
                     for (int u = 0; u < EL; ++u) t = t + d[u];
                 } else {
-                    const double *cm = cs + lane * (EL + 2), *dm = dsv + lane * (EL + 2);   // (d[] stays in registers: no dynamic index)
-#pragma unroll 4
-                    for (int u = 0; u < EL; ++u) {
-                        const double c = cm[u];
-                        if (c != 1.0) t = t * c;
-                        t = t + dm[u];
+#pragma unroll
+                    for (int u = 0; u < EL; ++u) {                   // s <- s * c + d with c = d at a new maximum, 1 elsewhere
+                        t = t * (((nm >> u) & 1ull) ? d[u] : 1.0);
+                        t = t + d[u];
                     }
                 }
             }
@@ -513,7 +511,7 @@ __device__ __forceinline__ void nlh_lds_barrier() { asm volatile("s_waitcnt lgkm
 // LDS buffer), the maxima of chunk c + 2 and have the elements of chunk c + 3 in flight; ONE LDS-only barrier per chunk.
 // (Measured with the chain wave also preparing its share: 4 us of divisions, shuffles and load issue per chunk in front
 // of every chain, 16.4 us per chunk instead of 12.)  Same coefficients, same order: bit-identical.
-// cd: 4 * (64 * EL + 128) doubles of LDS (two buffers), 16-byte aligned; aux: 8 doubles + 2 * BSZ ints;
+// cd: 2 * (64 * EL + 128) doubles of LDS (two buffers of terms), 16-byte aligned; aux: 8 doubles + 2 * BSZ ints;
 // wm: nchunks * (BSZ / 64) doubles (the caller bounds len accordingly).
 template <int EL, int BSZ, typename Get>
 __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, double *aux, double *wm)
@@ -559,7 +557,7 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
     // wave that shares its SIMD falls behind; it helps k_qrx_pass_col_long, whose preparing waves have less to do)
     for (int c = 0; c < nch; ++c) {
         const int cl = min(CAP, len - c * CAP);
-        double *cs = cd + (size_t)(c & 1) * 2 * PADCAP, *dsv = cs + PADCAP;
+        double *dsv = cd + (size_t)(c & 1) * PADCAP;
         int *tf = tflags + (c & 1) * BSZ;
         double mxc = mxrun;
 #pragma unroll
@@ -569,34 +567,32 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
 #pragma unroll
             for (int w = 0; w < nw; ++w)
                 if (w < wid) prev = fmax(prev, wm[c * nw + w]);
-            bool plain = true;
+            unsigned newmax = 0;                                     // see norm2_flang_block_lanes: a bit per new maximum
             // element i of the chunk lives at i + 2 * (i / EL), see norm2_flang_block_lanes
-            double2 *cdst = reinterpret_cast<double2 *>(cs + i0 + 2 * (i0 / EL));
             double2 *ddst = reinterpret_cast<double2 *>(dsv + i0 + 2 * (i0 / EL));
 #pragma unroll
             for (int u = 0; u < E; u += 2) {
-                double cc[2], dd[2];
+                double dd[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    double cf = 1.0, d = 0.0;
+                    double d = 0.0;
                     const double av = a0[u + h];
                     if (prev == 0.0) {
                         // mx was zero: element becomes the maximum, s untouched
                     } else if (av > prev) {
                         const double t = prev / av, tsq = t * t;
-                        cf = tsq; d = tsq;
+                        d = tsq;
+                        if (tsq != 1.0) newmax |= 1u << (u + h);
                     } else if (av != 0.0) {
                         const double t = av / prev;
                         d = t * t;
                     }
-                    plain = plain && (cf == 1.0);
-                    cc[h] = cf; dd[h] = d;
+                    dd[h] = d;
                     prev = fmax(prev, av);
                 }
-                cdst[u >> 1] = make_double2(cc[0], cc[1]);
                 ddst[u >> 1] = make_double2(dd[0], dd[1]);
             }
-            tf[tid] = plain ? 1 : 0;
+            tf[tid] = (int)newmax;
             // a chunk ahead: the maxima of chunk c + 1 (its elements arrived long ago), the loads of chunk c + 2
             if (c + 1 < nch) {
 #pragma unroll
@@ -615,10 +611,10 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
             const double2 *mine = reinterpret_cast<const double2 *>(dsv + lane * (EL + 2));
 #pragma unroll
             for (int u = 0; u < EL / 2; ++u) { const double2 v2 = mine[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
-            int pl = 1;
+            unsigned long long nm = 0;
 #pragma unroll
-            for (int k = 0; k < TPR; ++k) pl &= tf[lane * TPR + k];
-            const unsigned long long mask = __ballot(pl != 0);
+            for (int k = 0; k < TPR; ++k) nm |= (unsigned long long)(unsigned)tf[lane * TPR + k] << (k * E);
+            const unsigned long long mask = __ballot(nm == 0);
             double t = s;
             if (mask == ~0ull && nl == 64) {
                 // the usual chunk -- full, no new maximum in it: nothing in the loop but the shift and the adds (the mask
@@ -637,12 +633,10 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
 #pragma unroll
                     for (int u = 0; u < EL; ++u) t = t + d[u];
                 } else {
-                    const double *cm = cs + lane * (EL + 2), *dm = dsv + lane * (EL + 2);   // (d[] stays in registers: no dynamic index)
-#pragma unroll 4
+#pragma unroll
                     for (int u = 0; u < EL; ++u) {
-                        const double cf = cm[u];
-                        if (cf != 1.0) t = t * cf;
-                        t = t + dm[u];
+                        t = t * (((nm >> u) & 1ull) ? d[u] : 1.0);
+                        t = t + d[u];
                     }
                 }
             }

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256)
 k_qrx_init_norms(int m, int n, int ld, int coff, size_t tst, const double *__restrict__ T, QrxWs w, LmVecs v,
                  const LmState *__restrict__ st)
 {
-    __shared__ __attribute__((aligned(16))) double cd[2 * (64 * 64 + 128)];
+    __shared__ __attribute__((aligned(16))) double cd[64 * 64 + 128];
     __shared__ __attribute__((aligned(16))) double aux[40 + 128];
     const int p = blockIdx.y, k = blockIdx.x;
     if (st && st[p].stage != ST_NEED_QR) return;
@@ -259,7 +259,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     // pipelined NORM2 -- three preparing waves and the chain wave, one wave per SIMD (with four preparing waves, 320
     // threads, the chain wave shared its SIMD with one of them: 253 us per 65536-row step against 241), 105 KB of LDS,
     // one workgroup per CU, which is all a handful of long-column problems need
-    __shared__ __attribute__((aligned(16))) double cd[LONG ? 4 * (64 * QRX_LONG_EL + 128) : 2 * (64 * QRX_NL + 128)];
+    __shared__ __attribute__((aligned(16))) double cd[LONG ? 2 * (64 * QRX_LONG_EL + 128) : (64 * QRX_NL + 128)];
     __shared__ __attribute__((aligned(16))) double aux[LONG ? 8 + 256 : 40 + 128];
     __shared__ double wmx[LONG ? 3 * QRX_LONG_MAXCH : 1];
     __shared__ double red[64];
