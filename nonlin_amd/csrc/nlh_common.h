@@ -555,6 +555,9 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
     double mxrun = 0.0, s = 0.0;
     // (s_setprio 3 for the chain wave: measured slower here, 268 against 253 us per 65536-row pivot step -- the preparing
     // wave that shares its SIMD falls behind; it helps k_qrx_pass_col_long, whose preparing waves have less to do)
+    // (The chain wave one chunk BEHIND the barrier -- chunk c's terms requested from LDS while chunk c - 1 is added out of
+    // a second register set -- was measured too: 264 against 237 us per step.  96 more live registers push part of the
+    // terms into AGPRs, and every add of the chain then waits for a move.)
     for (int c = 0; c < nch; ++c) {
         const int cl = min(CAP, len - c * CAP);
         double *dsv = cd + (size_t)(c & 1) * PADCAP;
