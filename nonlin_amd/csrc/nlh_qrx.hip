@@ -1217,6 +1217,7 @@ k_qrx_pass_col(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, do
 // chunk), the loads of chunk c + 2 already in flight: a chunk costs its 4096-add chain plus the chain wave's LDS
 // reads (9.9 us; k_qrx_pass_col: 21).  Same values, same order: bit-identical.
 #define QRX_COLL_EL 64
+#define QRX_ROLL_MIN_ROWS 2048              // a handful of problems with more rows than this take this form (NLH_QRX_ROLL_MIN)
 template <bool PEND>
 __global__ void __launch_bounds__(256)
 k_qrx_pass_col_long(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, double *__restrict__ T,
@@ -1492,9 +1493,11 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
                                    (const LmState *)st);
         };
         static const int roll_env = [] { const char *e = getenv("NLH_QRX_ROLL_MIN"); return e ? atoi(e) : -1; }();
-        if (m > (roll_env >= 0 ? roll_env : 64 * QRX_COL_EL)) {
-            // columns longer than one chunk: a workgroup per trailing column with the update one step behind
-            // (k_qrx_pass_col_long) -- one pending reflector from step 1 on, a bank switch at every step, no physical move
+        if (m > (roll_env >= 0 ? roll_env : QRX_ROLL_MIN_ROWS)) {
+            // long columns: a workgroup per trailing column with the update one step behind (k_qrx_pass_col_long) -- one
+            // pending reflector from step 1 on, a bank switch at every step, no physical move.  Needed for columns of more
+            // than one 4096-row chunk; from 2048 rows on it is also the faster form of the single-chunk sweep (one
+            // 4096x256 problem: 19.1 instead of 21.2 us per step; equal at 2048 rows).
             int cur = 0;
             for (int j = 0; j < n; ++j) {
                 tb(0, stream);

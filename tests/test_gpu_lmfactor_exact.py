@@ -100,12 +100,13 @@ def test_lmfactor_exact_bitwise_beyond_internal_limits(ds, oracle, kind, m, n):
 
 
 @pytest.mark.parametrize("kind", ["random", "graded_rows", "graded_rows_down", "duplicates", "zero_cols", "sparse"])
-@pytest.mark.parametrize("m,n,copies", [(9001, 24, 1), (12290, 17, 3), (4101, 30, 2), (8200, 12, 40)])
+@pytest.mark.parametrize("m,n,copies", [(9001, 24, 1), (12290, 17, 3), (4101, 30, 2), (8200, 12, 40), (2100, 33, 1), (4096, 70, 3)])
 def test_lmfactor_exact_bitwise_long_columns(ds, oracle, kind, m, n, copies):
     """Columns of several NORM2 chunks.  A handful of problems: the workgroup-per-column sweep with the update one step
     behind (k_qrx_pass_col_long: one pending reflector, a bank switch per step, chain wave + preparing waves) and the
     pipelined NORM2 of the pivot kernel (graded rows: a new maximum in every run, the general recurrence in every chunk;
-    graded down: the maximum is the first element; m not a multiple of 8, m - n on both sides of 4096).  Forty problems:
+    graded down: the maximum is the first element; m not a multiple of 8, m - n on both sides of 4096; single-chunk columns
+    of more than 2048 rows take the same sweep).  Forty problems:
     the lane-per-column passes with up to nine pending reflectors under the long-column pivot kernel."""
     rng = np.random.default_rng(11 + m + n)
     a = _matrix(kind, m, n, rng)
