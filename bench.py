@@ -523,7 +523,7 @@ def main():
             unit_bytes, units = qr_pass_bytes(m, n), "problem-factorisations"
             kname = "k_qrx_pass (trailing pass of a Householder step, exact lmfactor)"
             if B <= 8:      # a handful of problems: the workgroup-per-column forms, bound by the serial chain of the ordered sums, not by HBM
-                kname = ("k_qrx_pass_col_long" if m > 4096 else "k_qrx_pass_col") + " (trailing pass, workgroup per column: " \
+                kname = "k_qrx_pass_col (trailing pass, workgroup per column: " \
                         "latency-bound by its ordered sums -- the HBM fraction is quoted for completeness)"
         else:
             unit_bytes, units = fd_bytes(m, n), "problem-Jacobians"

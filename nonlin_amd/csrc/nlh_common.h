@@ -397,7 +397,7 @@ __device__ __forceinline__ int nlh_chain_wave(int nwaves)
 template <int EL, int BSZ, typename Get>
 __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *aux)
 {
-    constexpr int CAP = 64 * EL, PADCAP = CAP + 128, E = CAP / BSZ, TPR = EL / E;   // E elements per thread, TPR threads per run
+    constexpr int CAP = 64 * EL, E = CAP / BSZ, TPR = EL / E;   // E elements per thread, TPR threads per run
     static_assert(CAP % BSZ == 0 && EL % E == 0 && E % 2 == 0, "chunk must split evenly");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int nw = BSZ / 64;
@@ -554,7 +554,7 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
     __syncthreads();
     double mxrun = 0.0, s = 0.0;
     // (s_setprio 3 for the chain wave: measured slower here, 268 against 253 us per 65536-row pivot step -- the preparing
-    // wave that shares its SIMD falls behind; it helps k_qrx_pass_col_long, whose preparing waves have less to do)
+    // wave that shares its SIMD falls behind; it helps k_qrx_pass_col, whose preparing waves have less to do)
     // (The chain wave one chunk BEHIND the barrier -- chunk c's terms requested from LDS while chunk c - 1 is added out of
     // a second register set -- was measured too: 264 against 237 us per step.  96 more live registers push part of the
     // terms into AGPRs, and every add of the chain then waits for a move.)

@@ -408,7 +408,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
             }
         }
     } else if (LONG && np <= 1 && !move0) {
-        // a long column with at most one update pending (k_qrx_pass_col_long's regime): a lane takes a PAIR of rows (16
+        // a long column with at most one update pending (k_qrx_pass_col's regime): a lane takes a PAIR of rows (16
         // bytes), four adjacent lanes a sector of the row-blocked matrix -- a load instruction of the wave covers 16 whole
         // sectors and 1 KB of the pending reflector, eight pairs per thread in flight.  (A sector per lane had every load
         // instruction touch 64 lines for a quarter of each: 62 us for 65536 rows; the row-at-a-time loop below: 67 us.)
@@ -1062,171 +1062,45 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
                              rdall, waall, Rall, qtfall);
 }
 
-// The pass for a HANDFUL of problems (straggler rounds, one problem alone): a workgroup per trailing column instead of a
-// lane per column -- n - j workgroups per problem where the other forms have ceil((n - j) / 64), so a lone 4096 x 256
-// problem still puts 256 workgroups on the chip.  The products of a column with the reflector are formed by all 256
-// threads; their ordered sum (:652-653) runs down the lanes of one wave exactly as NORM2's recurrence does in the pivot
-// kernel (64 consecutive terms per lane in registers, the running sum handed on with a DPP wave shift): ~10 us per
-// 4096 rows, which is the whole pass.  The update is EAGER (a column is read, updated (:655) and written back in the
-// same step; a few problems' matrices are no load on HBM), so a factorisation run in this form never has pending
-// updates: the pivot kernel always finds np = 0 and the reflector in slot 0 of bank 0.  Same operations on the same
-// operands in the same order as the deferred forms: bit-identical.  A workgroup writes its own column, its own
-// entries of R / qtf / rdiag / wa and nothing else.
-#ifndef QRX_COL_MAX_NACT
-#define QRX_COL_MAX_NACT 8              // factorisations with at most this many problems to factor take this form (4096 x 256,
-                                        // ms per solve: 1 problem 58 instead of 100, 4: 75 / 103, 8: 96 / 105)
-#endif
-#define QRX_COL_EL 64                   // terms per lane of the ordered sum (chunks of 4096 rows)
-__global__ void __launch_bounds__(256)
-k_qrx_pass_col(int m, int n, int ld, int coff, size_t tst, size_t vst, int j, double *__restrict__ T,
-               const double *__restrict__ Vall, double *__restrict__ tpall, const int32_t *__restrict__ srcall,
-               double *__restrict__ rdall, double *__restrict__ waall, const QrxStep *__restrict__ stepall,
-               double *__restrict__ Rall, double *__restrict__ qtfall, const LmState *__restrict__ st)
-{
-    constexpr int EL = QRX_COL_EL, CAP = 64 * EL, E = CAP / 256;
-    __shared__ __attribute__((aligned(16))) double buf[CAP + 128];
-    __shared__ double xch[2];
-    const int p = blockIdx.y;
-    if (st && st[p].stage != ST_NEED_QR) return;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int cw = nlh_chain_wave(4);                                    // the wave that runs the ordered sum
-    const int k = j + 1 + blockIdx.x;                                   // slot of this workgroup's column (n = the residual)
-    const int ldp = n + 1, jb = j & ~7;
-    const QrxStep step = stepall[p];
-    const bool refl = step.ajnorm != 0.0;
-    const double ajj = step.ajj;
-    const int col = srcall[(size_t)p * ldp + k];
-    double *Tp = T + (size_t)p * tst;
-    const double *vbank = Vall + (size_t)p * 2 * QRX_C * vst;           // bank 0, slot 0: this step's reflector
-    // Rows are counted from the start of row j's 8-row block (rel row r = absolute row jb + r): a thread's 16 consecutive
-    // rows are then two whole 64-byte sectors of the row-blocked matrix (eight 16-byte loads); the rows above j enter the
-    // sum as +0.0 terms in front.
-    const int r0 = j & 7, len = m - jb;
-    const double *colp = Tp + qrx_at(jb, col, ld);                      // rel row r of this column at colp[(r >> 3) * ld * 8 + (r & 7)]
-    // what thread 0's tail will need, fetched now: row j of the column, the column's down-dated norm and its reference
-    double rowj0 = 0.0, rk0 = 0.0, wa0 = 1.0;
-    if (tid == 0) {
-        rowj0 = Tp[qrx_at(j, col, ld)];
-        if (k < n) { rk0 = rdall[(size_t)p * n + k]; wa0 = waall[(size_t)p * n + k]; }
-    }
-    const size_t blk = (size_t)ld * 8;
-    const bool one_chunk = len <= CAP;
-    // s = sum_i v_i a_i, rows ascending, one chunk of CAP rows at a time
-    double s = 0.0, a[E], vv[E];
-    for (int base = 0; base < len; base += CAP) {
-        const int cl = min(CAP, len - base);
-        const int i0 = tid * E;
-        double w[E];
-#pragma unroll
-        for (int b8 = 0; b8 < E / 8; ++b8) {
-            const int rb = base + i0 + b8 * 8;                          // rel row of an 8-row block
-            const bool in = rb < len;                                   // (len is a multiple of 8 rows of storage: padding rows exist)
-            const double2 *src = reinterpret_cast<const double2 *>(colp + (size_t)(rb >> 3) * blk);
-            const double2 *vs = reinterpret_cast<const double2 *>(vbank + jb + rb);
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const double2 av = in ? src[h] : make_double2(0.0, 0.0);
-                const double2 v2 = in ? vs[h] : make_double2(0.0, 0.0);
-                a[b8 * 8 + 2 * h] = av.x; a[b8 * 8 + 2 * h + 1] = av.y;
-                vv[b8 * 8 + 2 * h] = v2.x; vv[b8 * 8 + 2 * h + 1] = v2.y;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < E; ++u) {
-            const int rr = base + i0 + u;
-            w[u] = (rr >= r0 && rr < len && jb + rr < m) ? vv[u] * a[u] : 0.0;
-        }
-        __syncthreads();                                                // the previous chunk's terms have been consumed
-        double2 *dst = reinterpret_cast<double2 *>(buf + i0 + 2 * (i0 / EL));
-#pragma unroll
-        for (int u = 0; u < E; u += 2) dst[u >> 1] = make_double2(w[u], w[u + 1]);
-        __syncthreads();
-        if (wid == cw) {
-            const int nl = (cl + EL - 1) / EL;
-            double d[EL];
-            const double2 *mine = reinterpret_cast<const double2 *>(buf + lane * (EL + 2));
-#pragma unroll
-            for (int u = 0; u < EL / 2; ++u) { const double2 v2 = mine[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
-            double t = s;
-#pragma unroll 1
-            for (int l = 0; l < nl; ++l) {
-                if (l > 0) t = nlh_wave_shr1(t);
-#pragma unroll
-                for (int u = 0; u < EL; ++u) t = t + d[u];             // :653, rows ascending (terms outside the rows: +0.0)
-            }
-            const int lo_ = __builtin_amdgcn_readlane(__double2loint(t), nl - 1);
-            const int hi_ = __builtin_amdgcn_readlane(__double2hiint(t), nl - 1);
-            if (lane == 0) xch[0] = __hiloint2double(hi_, lo_);
-        }
-        __syncthreads();
-        s = xch[0];
-    }
-    const double temp = refl ? s / ajj : 0.0;                           // :654
-    // multiplier, row j of R / qtf, norm down-date (with its rare recomputation, which reads the column as it still is)
-    if (tid == 0) {
-        const double tq1[1] = {0.0};
-        qrx_pass_tail<0, false>(p, j, k, col, col, m, n, ld, 0, vst, s, rowj0, rk0, wa0, refl, ajj, tq1, Tp, vbank + jb, vbank + jb, tpall,
-                                rdall, waall, Rall, qtfall);
-    }
-    __syncthreads();
-    if (!refl) return;
-    // :655 for the rows below j.  One chunk (the usual case): the column and the reflector are still in registers.
-    if (one_chunk) {
-        const int i0 = tid * E;
-#pragma unroll
-        for (int b8 = 0; b8 < E / 8; ++b8) {
-            const int rb = i0 + b8 * 8;
-            if (rb < len && rb + 7 > r0) {                              // the block holds rows below j
-                double2 *dstc = reinterpret_cast<double2 *>(Tp + qrx_at(jb, col, ld) + (size_t)(rb >> 3) * blk);
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int ra = rb + 2 * h, rbb = ra + 1;
-                    double2 o;
-                    o.x = (ra > r0 && jb + ra < m) ? a[b8 * 8 + 2 * h] - temp * vv[b8 * 8 + 2 * h] : a[b8 * 8 + 2 * h];
-                    o.y = (rbb > r0 && jb + rbb < m) ? a[b8 * 8 + 2 * h + 1] - temp * vv[b8 * 8 + 2 * h + 1] : a[b8 * 8 + 2 * h + 1];
-                    dstc[h] = o;
-                }
-            }
-        }
-    } else {
-        for (int i = j + 1 + tid; i < m; i += 8 * 256) {               // eight rows per thread loaded before any is stored
-            double a8[8], v8[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int row = min(i + u * 256, m - 1);
-                a8[u] = Tp[qrx_at(row, col, ld)];
-                v8[u] = vbank[row];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i + u * 256 < m) Tp[qrx_at(i + u * 256, col, ld)] = a8[u] - temp * v8[u];
-        }
-    }
-}
-
-// A handful of problems with columns LONGER than one 4096-row chunk (BASELINE config 5: 65536 rows): a workgroup per
-// trailing column again, but the update of a 65536-row column cannot wait in registers for the multiplier, and as a
-// second sweep (read, update, write: every column's workgroup at the same moment) it cost as much again as the chain-
-// bound sweep that forms the dot product.  So the update stays ONE STEP BEHIND: the sweep of step j applies step j - 1's
+// The pass for a HANDFUL of problems (straggler rounds, one problem alone; factorisations of at most QRX_COL_MAX_NACT
+// problems): a workgroup per trailing column instead of a lane per column -- n - j workgroups per problem where the other
+// forms have ceil((n - j) / 64), so a lone 4096 x 256 problem still puts 256 workgroups on the chip.  The products of a
+// column with the reflector are formed by the preparing waves; their ordered sum (:652-653) runs down the lanes of one
+// wave exactly as NORM2's recurrence does in the pivot kernel (64 consecutive terms per lane in registers, the running
+// sum handed on with a DPP wave shift): ~9.4 us per 4096 rows.  A workgroup writes its own column, its own entries of
+// tp / R / qtf / rdiag / wa and nothing else.
+// The update of a column stays ONE STEP BEHIND.  A 65536-row column (BASELINE config 5) cannot wait in registers for its
+// multiplier, and as a second sweep (read, update, write: every column's workgroup at the same moment) the update cost
+// as much again as the chain-bound sweep that forms the dot product.  So the sweep of step j applies step j - 1's
 // update (multiplier and reflector are known), writes the column back and multiplies the fresh values with step j's
 // reflector -- one read and one write of the trailing matrix per step, spread over the whole chain-bound sweep.  That is
 // the deferred-update machinery of k_qrx_pass with a flush at every step and exactly one pending reflector (the pivot
-// kernel applies it to the column it gathers, k_qrx_finish to the residual), without the physical move.
+// kernel applies it to the column it gathers, k_qrx_finish to the residual), without the physical move.  The eager form
+// this replaced (update from the registers the products were formed from, in the same step) was equal at 1024 rows and
+// slower from 2048 on (11.6 / 21.2 us per step at 2048 / 4096 rows against 10.3 / 17.2).
 // The sweep is software-pipelined around a wave that does nothing but the chain: three PREPARING waves form the
 // products of chunk c + 1 and hand them over while the chain wave adds chunk c (two LDS buffers, ONE LDS-only barrier per
 // chunk), the loads of chunk c + 2 already in flight: a chunk costs its 4096-add chain plus the chain wave's LDS
-// reads (9.9 us; k_qrx_pass_col: 21).  Same values, same order: bit-identical.
-#define QRX_COLL_EL 64
-#define QRX_ROLL_MIN_ROWS 2048              // a handful of problems with more rows than this take this form (NLH_QRX_ROLL_MIN)
+// reads (9.9 us).  A column of one chunk gets ONE buffer, sized to the column: the start-up time of these latency-bound
+// launches grows with their LDS allocation (4096 rows: 19.1 us per step with 68 KB, 17.2 with 34).
+// Same values, same order as the deferred forms: bit-identical.
+#ifndef QRX_COL_MAX_NACT
+#define QRX_COL_MAX_NACT 8              // factorisations with at most this many problems to factor take this form (4096 x 256,
+                                        // ms per solve, first version: 1 problem 58 instead of 100, 4: 75 / 103, 8: 96 / 105)
+#endif
+#define QRX_COL_EL 64                   // terms per lane of the ordered sum (chunks of 4096 rows)
 template <bool PEND>
 __global__ void __launch_bounds__(256)
-k_qrx_pass_col_long(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, double *__restrict__ T,
+k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, double *__restrict__ T,
                     const double *__restrict__ Vall, double *__restrict__ tpall, const int32_t *__restrict__ srcall,
                     double *__restrict__ rdall, double *__restrict__ waall, const QrxStep *__restrict__ stepall,
                     double *__restrict__ Rall, double *__restrict__ qtfall, const LmState *__restrict__ st)
 {
-    constexpr int EL = QRX_COLL_EL, CAP = 64 * EL, NPREP = 192, NPAIR = CAP / 2, PPT = (NPAIR + NPREP - 1) / NPREP;   // 2048 row pairs, 11 per thread
-    __shared__ __attribute__((aligned(16))) double buf[2][CAP + 128];
+    constexpr int EL = QRX_COL_EL, CAP = 64 * EL, NPREP = 192, NPAIR = CAP / 2, PPT = (NPAIR + NPREP - 1) / NPREP;   // 2048 row pairs, 11 per thread
+    // dynamic LDS: two product buffers of CAP + 128 doubles -- one when the column is a single chunk (the kernel's start-up
+    // time grows with its LDS allocation)
+    extern __shared__ __attribute__((aligned(16))) double bufs[];
+    double *buf[2] = {bufs, bufs + ((m - (j & ~7)) > CAP ? CAP + 128 : 0)};
     __shared__ double xch[2];
     const int p = blockIdx.y;
     if (st && st[p].stage != ST_NEED_QR) return;
@@ -1481,6 +1355,18 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     const long rp6_max = std::min(rp_max, rp6_env >= 0 ? rp6_env : (long)QRX_RP6_MAX_WG);
     static const int col_env = [] { const char *e = getenv("NLH_QRX_COL"); return e ? atoi(e) : -1; }();
     if (nact <= (col_env >= 0 ? col_env : QRX_COL_MAX_NACT)) {
+        static const bool coll_attr = [] {        // more than 64 KB of dynamic LDS has to be asked for
+            const int lim = (int)(sizeof(double) * 2 * (64 * QRX_COL_EL + 128));
+            hipFuncSetAttribute((const void *)k_qrx_pass_col<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            hipFuncSetAttribute((const void *)k_qrx_pass_col<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            return true;
+        }();
+        (void)coll_attr;
+        // two product buffers for columns of several chunks, one sized to the column otherwise
+        auto coll_lds = [](int m_, int j_) {
+            const int len = m_ - (j_ & ~7);
+            return sizeof(double) * (size_t)(len > 64 * QRX_COL_EL ? 2 * (64 * QRX_COL_EL + 128) : ((len + 1) & ~1) + 2 * (len / QRX_COL_EL) + 4);
+        };
         auto pivot = [&](int j, int cur, int np, int pf) {
             if (m <= 2048)
                 hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
@@ -1492,12 +1378,9 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
                 hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
                                    (const LmState *)st);
         };
-        static const int roll_env = [] { const char *e = getenv("NLH_QRX_ROLL_MIN"); return e ? atoi(e) : -1; }();
-        if (m > (roll_env >= 0 ? roll_env : QRX_ROLL_MIN_ROWS)) {
-            // long columns: a workgroup per trailing column with the update one step behind (k_qrx_pass_col_long) -- one
-            // pending reflector from step 1 on, a bank switch at every step, no physical move.  Needed for columns of more
-            // than one 4096-row chunk; from 2048 rows on it is also the faster form of the single-chunk sweep (one
-            // 4096x256 problem: 19.1 instead of 21.2 us per step; equal at 2048 rows).
+        {
+            // a workgroup per trailing column, the update one step behind (k_qrx_pass_col): one pending reflector from
+            // step 1 on, a bank switch at every step, no physical move
             int cur = 0;
             for (int j = 0; j < n; ++j) {
                 tb(0, stream);
@@ -1505,11 +1388,11 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
                 te(0, stream);
                 tb(1, stream);
                 if (j == 0)
-                    hipLaunchKernelGGL(k_qrx_pass_col_long<false>, dim3(n - j, nprob), dim3(256), 0, stream, m, n, ld, tst, vst, j, cur, T,
+                    hipLaunchKernelGGL(k_qrx_pass_col<false>, dim3(n - j, nprob), dim3(256), coll_lds(m, j), stream, m, n, ld, tst, vst, j, cur, T,
                                        (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
                                        (const LmState *)st);
                 else
-                    hipLaunchKernelGGL(k_qrx_pass_col_long<true>, dim3(n - j, nprob), dim3(256), 0, stream, m, n, ld, tst, vst, j, cur, T,
+                    hipLaunchKernelGGL(k_qrx_pass_col<true>, dim3(n - j, nprob), dim3(256), coll_lds(m, j), stream, m, n, ld, tst, vst, j, cur, T,
                                        (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
                                        (const LmState *)st);
                 te(1, stream);
@@ -1521,22 +1404,6 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
             te(2, stream);
             return;
         }
-        // a handful of problems: a workgroup per trailing column, eager updates, never a pending one (k_qrx_pass_col)
-        for (int j = 0; j < n; ++j) {
-            tb(0, stream);
-            pivot(j, 0, 0, 0);
-            te(0, stream);
-            tb(1, stream);
-            hipLaunchKernelGGL(k_qrx_pass_col, dim3(n - j, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, j, T,
-                               (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
-                               (const LmState *)st);
-            te(1, stream);
-        }
-        tb(2, stream);
-        hipLaunchKernelGGL(k_qrx_finish, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, vst, 0, 0, (const double *)T, w, R, v,
-                           wa4, scratch, x, st, factor, gtol);
-        te(2, stream);
-        return;
     }
     bool prev_flushed = false;
     int cur = 0, np = 0, lo = 1;             // lo: first slot position that can still hold live data (step 0 moves physically)

@@ -103,7 +103,7 @@ def test_lmfactor_exact_bitwise_beyond_internal_limits(ds, oracle, kind, m, n):
 @pytest.mark.parametrize("m,n,copies", [(9001, 24, 1), (12290, 17, 3), (4101, 30, 2), (8200, 12, 40), (2100, 33, 1), (4096, 70, 3)])
 def test_lmfactor_exact_bitwise_long_columns(ds, oracle, kind, m, n, copies):
     """Columns of several NORM2 chunks.  A handful of problems: the workgroup-per-column sweep with the update one step
-    behind (k_qrx_pass_col_long: one pending reflector, a bank switch per step, chain wave + preparing waves) and the
+    behind (k_qrx_pass_col: one pending reflector, a bank switch per step, chain wave + preparing waves) and the
     pipelined NORM2 of the pivot kernel (graded rows: a new maximum in every run, the general recurrence in every chunk;
     graded down: the maximum is the first element; m not a multiple of 8, m - n on both sides of 4096; single-chunk columns
     of more than 2048 rows take the same sweep).  Forty problems:
