@@ -1081,8 +1081,9 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
 // The sweep is software-pipelined around a wave that does nothing but the chain: three PREPARING waves form the
 // products of chunk c + 1 and hand them over while the chain wave adds chunk c (two LDS buffers, ONE LDS-only barrier per
 // chunk), the loads of chunk c + 2 already in flight: a chunk costs its 4096-add chain plus the chain wave's LDS
-// reads (9.9 us).  A column of one chunk gets ONE buffer, sized to the column: the start-up time of these latency-bound
-// launches grows with their LDS allocation (4096 rows: 19.1 us per step with 68 KB, 17.2 with 34).
+// reads (9.9 us).  The buffers are dynamic LDS behind two pointers; a column of one chunk gets ONE buffer, sized to the
+// column (4096 rows: 17.2 us per step against 19.1 with a static buf[2][...] array -- the generated addressing, not the
+// allocation: padded back to 68 KB it stays at 17.3, and an empty launch costs the same at any LDS size, lds_launch.hip).
 // Same values, same order as the deferred forms: bit-identical.
 #ifndef QRX_COL_MAX_NACT
 #define QRX_COL_MAX_NACT 8              // factorisations with at most this many problems to factor take this form (4096 x 256,
@@ -1097,8 +1098,7 @@ k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, dou
                     double *__restrict__ Rall, double *__restrict__ qtfall, const LmState *__restrict__ st)
 {
     constexpr int EL = QRX_COL_EL, CAP = 64 * EL, NPREP = 192, NPAIR = CAP / 2, PPT = (NPAIR + NPREP - 1) / NPREP;   // 2048 row pairs, 11 per thread
-    // dynamic LDS: two product buffers of CAP + 128 doubles -- one when the column is a single chunk (the kernel's start-up
-    // time grows with its LDS allocation)
+    // dynamic LDS: two product buffers of CAP + 128 doubles -- one, sized to the column, when the column is a single chunk
     extern __shared__ __attribute__((aligned(16))) double bufs[];
     double *buf[2] = {bufs, bufs + ((m - (j & ~7)) > CAP ? CAP + 128 : 0)};
     __shared__ double xch[2];

@@ -26,10 +26,10 @@ run_cfg c2auto --batch 2048 --policy 0                  # the opt-in fast policy
 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/calib" -o r03 -- profiles/ubench/fetch_calib > "$OUT/calib.log" 2>&1
 # memory-system, barrier and serial-chain microbenchmarks quoted in DESIGN.md (store shapes, mixed read/write streams,
 # grid barriers, the ordered-sum chain)
-( cd profiles/ubench && for f in rw_stream w_stream grid_sync chain_waves; do hipcc -O3 --offload-arch=gfx950 -o $f $f.hip > /dev/null 2>&1; done
+( cd profiles/ubench && for f in rw_stream w_stream grid_sync chain_waves lds_launch; do hipcc -O3 --offload-arch=gfx950 -o $f $f.hip > /dev/null 2>&1; done
   { echo "== rw_stream 1024"; timeout 120 ./rw_stream 1024 0; echo "== w_stream 1024"; timeout 120 ./w_stream 1024;
     echo "== grid_sync"; timeout 60 ./grid_sync 257 256; timeout 60 ./grid_sync 64 256;
-    echo "== chain_waves"; timeout 60 ./chain_waves; } > "$OUT/r03_ubench.txt" 2>&1 )
+    echo "== chain_waves"; timeout 60 ./chain_waves; echo "== lds_launch"; timeout 60 ./lds_launch; } > "$OUT/r03_ubench.txt" 2>&1 )
 python3 profiles/summarize_r03.py "$OUT" > "$OUT/summarize.log" 2>&1
 tail -5 "$OUT/summarize.log"
 # keep only what is small enough to be merged back
