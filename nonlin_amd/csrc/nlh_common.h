@@ -394,7 +394,10 @@ __device__ __forceinline__ int nlh_chain_wave(int nwaves)
     return (int)((b + (b >> 3) + (b >> 8)) & (unsigned)(nwaves - 1));    // differs for ids 1, 8 and 256 apart
 }
 
-template <int EL, int BSZ, typename Get>
+// REGGEN: the general runs (those with a new maximum) also work out of the registers, unrolled over d[] -- ~95 more
+// registers (one workgroup of 256 per CU instead of two) and a kernel that is faster when it has the CU to itself (a lone
+// 4096-row pivot step: 25.7 instead of 28 us), marginally slower in a batch that fills every CU twice over.
+template <int EL, int BSZ, bool REGGEN = false, typename Get>
 __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *aux)
 {
     constexpr int CAP = 64 * EL, E = CAP / BSZ, TPR = EL / E;   // E elements per thread, TPR threads per run
@@ -476,11 +479,20 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
                 if ((mask >> l) & 1ull) {
 #pragma unroll
                     for (int u = 0; u < EL; ++u) t = t + d[u];
-                } else {
+                } else if (REGGEN) {
 #pragma unroll
                     for (int u = 0; u < EL; ++u) {                   // s <- s * c + d with c = d at a new maximum, 1 elsewhere
                         t = t * (((nm >> u) & 1ull) ? d[u] : 1.0);
                         t = t + d[u];
+                    }
+                } else {
+                    // the same with the terms once more from LDS (no dynamic index into d[])
+                    const double *dm = dsv + lane * (EL + 2);
+#pragma unroll 4
+                    for (int u = 0; u < EL; ++u) {
+                        const double dv = dm[u];
+                        if ((nm >> u) & 1ull) t = t * dv;
+                        t = t + dv;
                     }
                 }
             }

@@ -248,10 +248,10 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
 #define QRX_LONG_SU 4                                            // sectors per thread in flight in the long-column scaling
 #endif
 #define QRX_LONG_MAXCH 96                                        // chunks the pipelined NORM2 keeps maxima for
-template <int QRX_NL, bool LONG = false>
+template <int QRX_NL, bool LONG = false, bool FEW = false>       // FEW: a handful of problems (the workgroup has its CU to itself)
 // (QRX_NL = 32, m <= 2048: 133 registers would leave three workgroups per CU; held to 128 -- four dwords spilled -- a launch of
 // 1024 problems is one round instead of two: 1024 x 2048x128 solves 1.8 % faster)
-__global__ void __launch_bounds__(LONG ? QRX_LONG_THREADS : 256, QRX_NL == 32 ? 4 : 1)
+__global__ void __launch_bounds__(LONG ? QRX_LONG_THREADS : 256, (QRX_NL == 32 && !FEW) ? 4 : 1)
 k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
 {
@@ -454,8 +454,8 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
                  // the diagonal entry before scaling (read before NORM2 reuses the region)
     double ajnorm;                                                // :642
     if constexpr (LONG) ajnorm = norm2_flang_block_lanes_pipe<QRX_LONG_EL, 192>([&](int i) { return Vn[j + i]; }, m - j, cd, aux, wmx);
-    else ajnorm = staged ? norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return stage[i]; }, m - j, cd, aux)
-                         : norm2_flang_block_lanes<QRX_NL, 256>([&](int i) { return Vn[j + i]; }, m - j, cd, aux);
+    else ajnorm = staged ? norm2_flang_block_lanes<QRX_NL, 256, FEW>([&](int i) { return stage[i]; }, m - j, cd, aux)
+                         : norm2_flang_block_lanes<QRX_NL, 256, FEW>([&](int i) { return Vn[j + i]; }, m - j, cd, aux);
 #ifdef QRX_DBG_CLK
     clk[3] = wall_clock64();
 #endif
@@ -1369,13 +1369,13 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         };
         auto pivot = [&](int j, int cur, int np, int pf) {
             if (m <= 2048)
-                hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
+                hipLaunchKernelGGL((k_qrx_pivot<32, false, true>), dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
                                    (const LmState *)st);
             else if (m - j > 64 * 64 && m - j <= 64 * QRX_LONG_EL * QRX_LONG_MAXCH)
                 hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w,
                                    R, v, (const LmState *)st);
             else
-                hipLaunchKernelGGL(k_qrx_pivot<64>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
+                hipLaunchKernelGGL((k_qrx_pivot<64, false, true>), dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
                                    (const LmState *)st);
         };
         {
