@@ -1062,8 +1062,8 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
                              rdall, waall, Rall, qtfall);
 }
 
-// The pass for a HANDFUL of problems (straggler rounds, one problem alone; factorisations of at most QRX_COL_MAX_NACT
-// problems): a workgroup per trailing column instead of a lane per column -- n - j workgroups per problem where the other
+// The pass for a HANDFUL of problems (straggler rounds, one problem alone; factorisations of at most QRX_COL_MAX_WG
+// (problem, column) pairs): a workgroup per trailing column instead of a lane per column -- n - j workgroups per problem where the other
 // forms have ceil((n - j) / 64), so a lone 4096 x 256 problem still puts 256 workgroups on the chip.  The products of a
 // column with the reflector are formed by the preparing waves; their ordered sum (:652-653) runs down the lanes of one
 // wave exactly as NORM2's recurrence does in the pivot kernel (64 consecutive terms per lane in registers, the running
@@ -1085,9 +1085,10 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
 // column (4096 rows: 17.2 us per step against 19.1 with a static buf[2][...] array -- the generated addressing, not the
 // allocation: padded back to 68 KB it stays at 17.3, and an empty launch costs the same at any LDS size, lds_launch.hip).
 // Same values, same order as the deferred forms: bit-identical.
-#ifndef QRX_COL_MAX_NACT
-#define QRX_COL_MAX_NACT 8              // factorisations with at most this many problems to factor take this form (4096 x 256,
-                                        // ms per solve, first version: 1 problem 58 instead of 100, 4: 75 / 103, 8: 96 / 105)
+#ifndef QRX_COL_MAX_WG
+#define QRX_COL_MAX_WG 3072             // factorisations of at most this many (problem, column) pairs take this form.  ms per
+                                        // solve, this form / the lane-per-column forms: 4096 x 256: 4 problems 59 / 102, 8: 78 / 104,
+                                        // 12: 99 / 109, 16: 118 / 110; 2048 x 128: 8: 19 / 30, 16: 26 / 32, 24: 31 / 33, 32: 37 / 33
 #endif
 #define QRX_COL_EL 64                   // terms per lane of the ordered sum (chunks of 4096 rows)
 template <bool PEND>
@@ -1336,7 +1337,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         hipLaunchKernelGGL(k_qrx_transpose, dim3(gx, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, J, T, (const LmState *)st);
     }
     if (nact <= 0 || nact > nprob) nact = nprob;
-    if (nact <= QRX_COL_MAX_NACT) {                              // a handful of problems: a workgroup per column for the norms
+    if ((long)nact * n <= QRX_COL_MAX_WG) {                      // a handful of problems: a workgroup per column for the norms
         hipLaunchKernelGGL(k_qrx_init<false>, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
         hipLaunchKernelGGL(k_qrx_init_norms, dim3(n, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, (const double *)T, w, v,
                            (const LmState *)st);
@@ -1354,7 +1355,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     static const long rp6_env = [] { const char *e = getenv("NLH_QRX_RP6"); return e ? atol(e) : -1L; }();
     const long rp6_max = std::min(rp_max, rp6_env >= 0 ? rp6_env : (long)QRX_RP6_MAX_WG);
     static const int col_env = [] { const char *e = getenv("NLH_QRX_COL"); return e ? atoi(e) : -1; }();
-    if (nact <= (col_env >= 0 ? col_env : QRX_COL_MAX_NACT)) {
+    if (col_env >= 0 ? nact <= col_env : (long)nact * n <= QRX_COL_MAX_WG) {
         static const bool coll_attr = [] {        // more than 64 KB of dynamic LDS has to be asked for
             const int lim = (int)(sizeof(double) * 2 * (64 * QRX_COL_EL + 128));
             hipFuncSetAttribute((const void *)k_qrx_pass_col<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
