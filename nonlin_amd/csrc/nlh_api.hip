@@ -205,6 +205,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     h->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
     // allow the single-workgroup kernels their full dynamic LDS (n-vectors live there)
     const int lds_max = 160 * 1024 - 2048;
+    qrx_init_device();
     hipFuncSetAttribute((const void *)k_gram_tri<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_gram_tri<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);

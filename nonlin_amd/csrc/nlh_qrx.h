@@ -16,6 +16,7 @@ struct QrxTimer {
 };
 
 // Row stride of the row-major working matrix (n columns + the residual, padded to 64 bytes).
+void qrx_init_device();          // once per device a handle is created on (kernel attributes)
 int qrx_ld(int n);
 // Doubles between the working matrices of two consecutive problems.
 size_t qrx_matrix_stride(int m, int n);

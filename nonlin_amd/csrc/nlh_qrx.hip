@@ -1320,6 +1320,15 @@ static void dispatch_pass(int np, bool flush, int rp, hipStream_t stream, int p0
     }
 }
 
+// Per device (called when a handle is created on it): the column sweep of long columns asks for more than 64 KB of
+// dynamic LDS (two product buffers), which has to be allowed on every device the kernel is launched on.
+void qrx_init_device()
+{
+    const int lim = (int)(sizeof(double) * 2 * (64 * QRX_COL_EL + 128));
+    hipFuncSetAttribute((const void *)k_qrx_pass_col<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    hipFuncSetAttribute((const void *)k_qrx_pass_col<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+}
+
 void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, double *T, const double *fvec,
                 double *R, LmVecs v, double *wa4, double *scratch, const double *x, LmState *st, double factor,
                 double gtol, void *ws, const QrxTimer *tm, int nact)
@@ -1356,13 +1365,6 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     const long rp6_max = std::min(rp_max, rp6_env >= 0 ? rp6_env : (long)QRX_RP6_MAX_WG);
     static const int col_env = [] { const char *e = getenv("NLH_QRX_COL"); return e ? atoi(e) : -1; }();
     if (col_env >= 0 ? nact <= col_env : (long)nact * n <= QRX_COL_MAX_WG) {
-        static const bool coll_attr = [] {        // more than 64 KB of dynamic LDS has to be asked for
-            const int lim = (int)(sizeof(double) * 2 * (64 * QRX_COL_EL + 128));
-            hipFuncSetAttribute((const void *)k_qrx_pass_col<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            hipFuncSetAttribute((const void *)k_qrx_pass_col<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            return true;
-        }();
-        (void)coll_attr;
         // two product buffers for columns of several chunks, one sized to the column otherwise
         auto coll_lds = [](int m_, int j_) {
             const int len = m_ - (j_ & ~7);
