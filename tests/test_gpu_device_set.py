@@ -101,3 +101,18 @@ def test_model_level_quasi_newton_cls_bfgs_on_a_device_set(oracle):
         assert ibs[k]["gradient_count"] == ibo["gradient_count"]
     md.close()
     ds.close()
+
+
+def test_long_columns_on_a_device_set(ds):
+    """Columns of more than one 4096-row chunk on every share of a device set: the column sweep's two LDS product buffers
+    (more than 64 KB of dynamic LDS) have to be allowed on each device a handle is created on."""
+    from nonlin_amd.device import DeviceSet
+    nprob, m, n = 3, 9000, 10
+    A, b, x0 = _host_problem(ds, nprob, m, n)
+    ref = ds.model(A, b, 0.5)
+    xr, fr, ibr, sr = ref.lm_solve(x0, ds.options(max_evals=200))
+    dset = DeviceSet(None)                                  # every visible device
+    model = dset.model(A, b, 0.5)
+    x, f, ib, st = model.lm_solve(x0, ds.options(max_evals=200))
+    assert np.array_equal(x, xr) and np.array_equal(f, fr) and st == sr
+    model.close(); ref.close(); dset.close()
