@@ -856,7 +856,9 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
 #define QRX_RP6_MAX_WG 256              // ... and of at most this many, with six waves (five producers) instead of four
 #endif
 #ifndef QRX_RP_MAX_WG
-#define QRX_RP_MAX_WG 1024              // launches of at most this many (problem, window) pairs take the row-parallel pass
+#define QRX_RP_MAX_WG 512               // launches of at most this many (problem, window) pairs take the row-parallel pass
+                                        // (re-swept at the end of round 3, ms per solve at 0 / 512 / 1024: 256 x 4096x256 431 / 410 / 428,
+                                        // 1024 x 2048x128 196 / 196 / 200, 1024 x 1024x64 47.6 / 47.2 / 50.5, 64 x 4096x256 289 / 192 / 192)
 #endif
 #define QRX_RP_G 16                     // rows per producer and round (two 8-row blocks)
 #define QRX_RP_D 4                      // rounds per producer tile = row groups in flight per producer
