@@ -853,7 +853,8 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
 // works one round behind the producers.  Same arithmetic on the same operands in the same order: bit-identical to
 // k_qrx_pass.
 #ifndef QRX_RP6_MAX_WG
-#define QRX_RP6_MAX_WG 256              // ... and of at most this many, with six waves (five producers) instead of four
+#define QRX_RP6_MAX_WG 128              // ... and of at most this many, with six waves (five producers) instead of four
+                                        // (256 until the end of round 3; 64 x 4096x256 = 256 pairs: 181 ms per solve with four waves, 190 with six)
 #endif
 #ifndef QRX_RP_MAX_WG
 #define QRX_RP_MAX_WG 512               // launches of at most this many (problem, window) pairs take the row-parallel pass
