@@ -266,7 +266,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     const int p = p0 + blockIdx.x;
     if (st && st[p].stage != ST_NEED_QR) return;
     const int tid = threadIdx.x, BS = blockDim.x, ldp = n + 1;
-#ifdef QRX_DBG_CLK
+#ifdef QRX_DBG_CLK      // -DQRX_DBG_CLK: in-kernel phase clocks (100 MHz), printed for step 100 -- where DESIGN.md's phase figures come from
     long long clk[6]; clk[0] = wall_clock64();
 #endif
     int *redi = reinterpret_cast<int *>(red + 32);
