@@ -151,6 +151,12 @@ def load():
         raise NonlinHipUnavailable(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C nonlin_amd/csrc` (there is no CPU fallback)")
+    # PyTorch ships its own HIP runtime.  Two runtimes in one process coexist only if torch's is loaded first (the other way
+    # round torch.cuda reports no device, or this library does): import torch before the library whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)       # AttributeError if the ABI and this table drift
