@@ -1,5 +1,5 @@
-"""Random-size soak of the lock-step bounded least-squares and BFGS batches (nlh_kernels_cls.h, nlh_kernels_bfgs_batch.h)
-against the CPU oracle: every problem of every batch must carry the oracle's bits, counts and status.  Test
+"""Random-size soak of the lock-step bounded least-squares, BFGS, Newton and quasi-Newton batches (nlh_kernels_cls.h,
+nlh_kernels_bfgs_batch.h, nlh_kernels_newton.h) against the CPU oracle: every problem of every batch must carry the oracle's bits, counts and status.  Test
 infrastructure (run from tests/test_gpu_random_parity.py, or stand-alone on a GPU box:
 python tests/soak_lockstep.py SEED NCASES)."""
 import os
@@ -21,7 +21,25 @@ def run(ds, O, seed, ncase, verbose=False):
         spread = float(rng.choice([0.0, 0.05, 0.2])); s0 = int(rng.integers(1, 10**6))
         A, b, xt, x0 = ds.generate(nb, m, n, seed0=s0, spread=spread)
         x0 = x0 * torch.tensor(rng.uniform(0.3, 2.5, nb), dtype=torch.float64, device=x0.device)[:, None]
-        if case % 2 == 0:
+        if case % 4 >= 2:                                            # square systems: Newton (case % 4 == 2) / quasi-Newton (3)
+            m = n
+            A, b, xt, x0 = ds.generate(nb, n, n, seed0=s0, sigma=0.0, square_shift=True, spread=spread)
+            x0 = xt + (x0 - xt) * torch.tensor(rng.uniform(0.2, 1.5, nb), dtype=torch.float64, device=x0.device)[:, None]
+            an = bool(rng.integers(2)); me = int(rng.choice([8, 60, 500])); ls = int(rng.choice([1, 1, 0]))
+            oo = dict(max_evals=me, use_line_search=ls)
+            x = x0.clone()
+            if case % 4 == 2:
+                fv, ibs, st = ds.newton_solve_batch(A, b, 0.5, x, analytic=an, opts=ds.options(**oo))
+                ref = lambda p: O.dq_newton_solve(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(),
+                                                  analytic=an, opts=O.default_options(**oo))
+                name = "newton"
+            else:
+                jd = int(rng.choice([1, 3, 5]))
+                fv, ibs, st = ds.quasi_newton_solve_batch(A, b, 0.5, x, analytic=an, opts=ds.options(**oo), jdelta=jd)
+                ref = lambda p: O.dq_quasi_newton_solve(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(),
+                                                        analytic=an, opts=O.default_options(**oo), jdelta=jd)
+                name = "quasi-newton"
+        elif case % 2 == 0:
             w = float(rng.choice([0.02, 0.3, 2.0, 50.0])); lo, hi = np.full(n, -w), np.full(n, 0.8 * w)
             me = int(rng.choice([5, 60, 500]))
             x = x0.clone()

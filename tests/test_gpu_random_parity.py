@@ -56,15 +56,16 @@ def test_exact_policy_soak_slice(ds, oracle):
         assert miss is None, dict(miss, case=case)
 
 
-def test_lockstep_cls_bfgs_soak_slice(ds, oracle):
-    """Thirty random batches (seed 1) of the lock-step bounded least-squares / BFGS soak (tests/soak_lockstep.py): random sizes,
-    batch sizes, bounds, budgets and tolerances; every problem of every batch must carry the oracle's bits, counts and
-    status.  (Two seeds x 30 batches = 719 problems ran clean when the state machines were written.)"""
+def test_lockstep_soak_slice(ds, oracle):
+    """Forty random batches (seed 1) of the lock-step soak (tests/soak_lockstep.py: bounded least squares, BFGS, Newton,
+    quasi-Newton in turn): random sizes, batch sizes, bounds, budgets, tolerances, analytic / FD Jacobians, refresh
+    intervals; every problem of every batch must carry the oracle's bits, counts and status.  (Several seeds, ~3000
+    problems, ran clean during round 3.)"""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import soak_lockstep
-    total, misses = soak_lockstep.run(ds, oracle, 1, 30)
+    total, misses = soak_lockstep.run(ds, oracle, 1, 40)
     assert total > 200 and not misses, misses[:3]
 
 
