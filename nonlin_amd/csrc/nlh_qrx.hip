@@ -479,6 +479,11 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
                 }
             }
         }
+    } else if (LONG && (flush & 4) && ajnorm != 0.0) {
+        // the scaling of the rows below j is left to k_qrx_scale_long, which spreads it over the chip (on this one
+        // workgroup the 65536 divisions of a long column take 24 us); row j and the step record are settled here
+        if (ejj < 0.0) ajnorm = -ajnorm;                         // :644
+        if (tid == 0) { ajj = ejj / ajnorm + 1.0; Vn[j] = ajj; } // :645-646 at i = j
     } else if (LONG && ajnorm != 0.0) {
         if (ejj < 0.0) ajnorm = -ajnorm;                         // :644
         // :645-646 a sector at a time, four per thread in flight (thread 0 holds row j)
@@ -541,6 +546,33 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
         w.step[p] = s;
         rdiag[j] = -ajnorm;                                      // :665
     }
+}
+
+// :645-646 for the rows below j of a long pivot column (k_qrx_pivot with flush bit 2 left them unscaled): a launch of its
+// own so that every CU takes a share of the divisions.  Vn as in k_qrx_pivot; each thread a pair of rows per load, four in flight.
+__global__ void __launch_bounds__(256)
+k_qrx_scale_long(int m, size_t vst, int j, int cur, int np, int flush, QrxWs w, const LmState *__restrict__ st)
+{
+    const int p = blockIdx.y;
+    if (st && st[p].stage != ST_NEED_QR) return;
+    const double ajnorm = w.step[p].ajnorm;
+    if (ajnorm == 0.0) return;                                   // (the column is zero: nothing to scale)
+    double *__restrict__ Vn = (flush & 1) ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
+                                    : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
+    const int first = (j + 2) & ~1;                              // first even row above j (row j + 1 alone when j is even)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && first == j + 2 && j + 1 < m) Vn[j + 1] = Vn[j + 1] / ajnorm;
+    const int npair = (m - first) >> 1;
+    const int pb = (blockIdx.x * 256 + threadIdx.x) * 4;
+    double2 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = (pb + u < npair) ? *reinterpret_cast<const double2 *>(Vn + first + 2 * (pb + u)) : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (pb + u < npair) {
+            t[u].x = t[u].x / ajnorm; t[u].y = t[u].y / ajnorm;
+            *reinterpret_cast<double2 *>(Vn + first + 2 * (pb + u)) = t[u];
+        }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ((m - first) & 1)) Vn[m - 1] = Vn[m - 1] / ajnorm;     // odd last row
 }
 
 // The end of a trailing column's pass, given its dot product s with the reflector: multiplier (:654), row j becomes
@@ -1377,10 +1409,13 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
             if (m <= 2048)
                 hipLaunchKernelGGL((k_qrx_pivot<32, false, true>), dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
                                    (const LmState *)st);
-            else if (m - j > 64 * 64 && m - j <= 64 * QRX_LONG_EL * QRX_LONG_MAXCH)
-                hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w,
+            else if (m - j > 64 * 64 && m - j <= 64 * QRX_LONG_EL * QRX_LONG_MAXCH) {
+                // long column: the scaling of the reflector as a launch of its own over the whole chip (flush bit 2)
+                hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf | 4, T, w,
                                    R, v, (const LmState *)st);
-            else
+                hipLaunchKernelGGL(k_qrx_scale_long, dim3((unsigned)(((m - j) / 2 + 1023) / 1024 + 1), nprob), dim3(256), 0, stream, m, vst, j, cur, np, pf,
+                                   w, (const LmState *)st);
+            } else
                 hipLaunchKernelGGL((k_qrx_pivot<64, false, true>), dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
                                    (const LmState *)st);
         };
