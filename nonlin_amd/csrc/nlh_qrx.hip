@@ -76,7 +76,7 @@
 
 typedef unsigned int qrx_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int qrx_u32x4 __attribute__((ext_vector_type(4)));
-struct QrxStep { double ajnorm, ajj; int32_t kmax, pad; };
+struct QrxStep { double ajnorm, ajj; int32_t kmax, srck; double t0; };   // srck, t0: pivot column and its pending multiplier (split long-column step)
 
 // Physical column of slot k (k = 0 .. n, n = the residual) is k + qrx_coff(n): the row ENDS on a 64-column boundary, so
 // that the trailing slots j+1 .. n of any step fill whole 64-column windows counted from the end: every wave-level load
@@ -358,6 +358,16 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
         slotof[srck] = -1;                                       // the pivot column is consumed
     }
     const bool move0 = (j == 0 && kmax != 0);                   // see above: slot 0's column takes the pivot column's place
+    if (LONG && (flush & 8)) {
+        // split long-column step, part 1 of 3: the search and the bookkeeping only; the gather (k_qrx_gather_long, the
+        // whole chip) and NORM2 (k_qrx_norm_long) follow as launches of their own
+        if (tid == 0) {
+            QrxStep s;
+            s.ajnorm = 0.0; s.ajj = 0.0; s.kmax = kmax; s.srck = srck; s.t0 = np ? tk[0] : 0.0;
+            w.step[p] = s;
+        }
+        return;
+    }
     const int src0 = coff;                                       // physical column of slot 0 at step 0
     // The pivot column with its pending updates applied, oldest first.  Consecutive threads take consecutive rows (eight
     // of them share a sector of the row-blocked matrix); four rows per thread are loaded together before any is stored.
@@ -542,9 +552,75 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
 #endif
     if (tid == 0) {                                              // thread 0 scaled row j
         QrxStep s;
-        s.ajnorm = ajnorm; s.ajj = ajj; s.kmax = kmax; s.pad = 0;
+        s.ajnorm = ajnorm; s.ajj = ajj; s.kmax = kmax; s.srck = srck; s.t0 = 0.0;
         w.step[p] = s;
         rdiag[j] = -ajnorm;                                      // :665
+    }
+}
+
+// Split long-column step, part 2 of 3: the pivot column with its (at most one) pending update applied, for the whole
+// chip -- on the pivot kernel's one workgroup the 1.5 MB of a 65536-row gather took 29 us.  A lane takes a pair of rows.
+__global__ void __launch_bounds__(256)
+k_qrx_gather_long(int m, int ld, size_t tst, size_t vst, int j, int cur, int np, int flush, const double *__restrict__ T, QrxWs w,
+                  const LmState *__restrict__ st)
+{
+    const int p = blockIdx.y;
+    if (st && st[p].stage != ST_NEED_QR) return;
+    const QrxStep step = w.step[p];
+    const double *Tp = T + (size_t)p * tst;
+    const double *__restrict__ Vc = w.V + ((size_t)p * 2 + cur) * QRX_C * vst;
+    double *__restrict__ Vn = (flush & 1) ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
+                                    : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
+    const int jb = j & ~7, npair = (m - jb + 1) >> 1;
+    const double *colp = Tp + qrx_at(jb, step.srck, ld);
+    const size_t blk = (size_t)ld * 8;
+    const double t0 = step.t0;
+    const int pb = (blockIdx.x * 256 + threadIdx.x) * 4;
+    double2 ax[4], px[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int pr = min(pb + u, npair - 1);                   // pair pr: rel rows 2 pr, 2 pr + 1 of sector pr >> 2
+        ax[u] = *reinterpret_cast<const double2 *>(colp + (size_t)(pr >> 2) * blk + 2 * (pr & 3));
+        px[u] = np ? *reinterpret_cast<const double2 *>(Vc + jb + 2 * pr) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int pr = pb + u, row = jb + 2 * pr;
+        if (pr >= npair) continue;
+        if (np) { ax[u].x = ax[u].x - t0 * px[u].x; ax[u].y = ax[u].y - t0 * px[u].y; }
+        if (row >= j && row + 1 < m) *reinterpret_cast<double2 *>(Vn + row) = ax[u];
+        else {
+            if (row >= j && row < m) Vn[row] = ax[u].x;
+            if (row + 1 >= j && row + 1 < m) Vn[row + 1] = ax[u].y;
+        }
+    }
+}
+
+// Split long-column step, part 3 of 3: NORM2 of the gathered column (pipelined: three preparing waves, a chain wave),
+// the sign, row j of the reflector and the step record; the rows below j are scaled by k_qrx_scale_long.
+__global__ void __launch_bounds__(QRX_LONG_THREADS)
+k_qrx_norm_long(int m, int n, size_t vst, int j, int cur, int np, int flush, QrxWs w, const LmState *__restrict__ st)
+{
+    __shared__ __attribute__((aligned(16))) double cd[2 * (64 * QRX_LONG_EL + 128)];
+    __shared__ __attribute__((aligned(16))) double aux[8 + 256];
+    __shared__ double wmx[3 * QRX_LONG_MAXCH];
+    const int p = blockIdx.x;
+    if (st && st[p].stage != ST_NEED_QR) return;
+    double *__restrict__ Vn = (flush & 1) ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
+                                    : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
+    const double ejj = Vn[j];                                     // the diagonal entry before scaling
+    double ajnorm = norm2_flang_block_lanes_pipe<QRX_LONG_EL, 192>([&](int i) { return Vn[j + i]; }, m - j, cd, aux, wmx);   // :642
+    if (threadIdx.x == 0) {
+        QrxStep s = w.step[p];
+        double ajj = 0.0;
+        if (ajnorm != 0.0) {
+            if (ejj < 0.0) ajnorm = -ajnorm;                      // :644
+            ajj = ejj / ajnorm + 1.0;                             // :645-646 at i = j
+            Vn[j] = ajj;
+        }
+        s.ajnorm = ajnorm; s.ajj = ajj;
+        w.step[p] = s;
+        w.rdiag[(size_t)p * n + j] = -ajnorm;                     // :665
     }
 }
 
@@ -1410,7 +1486,16 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
                 hipLaunchKernelGGL((k_qrx_pivot<32, false, true>), dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf, T, w, R, v,
                                    (const LmState *)st);
             else if (m - j > 64 * 64 && m - j <= 64 * QRX_LONG_EL * QRX_LONG_MAXCH) {
-                // long column: the scaling of the reflector as a launch of its own over the whole chip (flush bit 2)
+                // long column: the scaling of the reflector as a launch of its own over the whole chip (flush bit 2), and
+                // from step 1 on (no physical interchange, at most one update pending) the gather too: search and
+                // bookkeeping (flush bit 3), gather, NORM2 as three launches -- 218 -> ~200 us per 65536-row step
+                if (j >= 1 && np <= 1) {
+                    hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np,
+                                       pf | 4 | 8, T, w, R, v, (const LmState *)st);
+                    hipLaunchKernelGGL(k_qrx_gather_long, dim3((unsigned)(((m - (j & ~7)) / 2 + 1023) / 1024 + 1), nprob), dim3(256), 0, stream, m, ld, tst, vst,
+                                       j, cur, np, pf, (const double *)T, w, (const LmState *)st);
+                    hipLaunchKernelGGL(k_qrx_norm_long, dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, m, n, vst, j, cur, np, pf, w, (const LmState *)st);
+                } else
                 hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf | 4, T, w,
                                    R, v, (const LmState *)st);
                 hipLaunchKernelGGL(k_qrx_scale_long, dim3((unsigned)(((m - j) / 2 + 1023) / 1024 + 1), nprob), dim3(256), 0, stream, m, vst, j, cur, np, pf,
