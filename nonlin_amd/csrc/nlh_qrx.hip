@@ -240,6 +240,8 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
 // The new reflector goes to slot np of the current bank, or to slot 0 of the other bank when this step's pass
 // flushes (np == QRX_C - 1).
 #define QRX_LONG_EL 48                                           // the pipelined NORM2: chunks of 64 * 48 rows, three preparing waves
+                                                                 // (chunks of 4096 rows with four preparing waves, 320 threads, also as the
+                                                                 // stand-alone k_qrx_norm_long: 199 against 195 ms per 65536 x 512 factorisation)
 #define QRX_LONG_THREADS 256                                     // (512 -- four more waves for the gather and the scaling -- measured slower: 250 against 241 us per 65536-row step)
 #ifndef QRX_LONG_GU
 #define QRX_LONG_GU 8                                            // row pairs per thread in flight in the long-column gather
