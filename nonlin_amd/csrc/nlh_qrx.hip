@@ -249,11 +249,14 @@ k_qrx_init(int m, int n, int ld, int coff, size_t tst, double *__restrict__ T, c
 #ifndef QRX_LONG_SU
 #define QRX_LONG_SU 4                                            // sectors per thread in flight in the long-column scaling
 #endif
+#ifndef QRX_PIV64_WG
+#define QRX_PIV64_WG 1                                           // workgroups per CU the batch instance of the 4096-row pivot kernel is compiled for
+#endif
 #define QRX_LONG_MAXCH 96                                        // chunks the pipelined NORM2 keeps maxima for
 template <int QRX_NL, bool LONG = false, bool FEW = false>       // FEW: a handful of problems (the workgroup has its CU to itself)
 // (QRX_NL = 32, m <= 2048: 133 registers would leave three workgroups per CU; held to 128 -- four dwords spilled -- a launch of
 // 1024 problems is one round instead of two: 1024 x 2048x128 solves 1.8 % faster)
-__global__ void __launch_bounds__(LONG ? QRX_LONG_THREADS : 256, (QRX_NL == 32 && !FEW) ? 4 : 1)
+__global__ void __launch_bounds__(LONG ? QRX_LONG_THREADS : 256, (QRX_NL == 32 && !FEW) ? 4 : (QRX_NL == 64 && !FEW && !LONG) ? QRX_PIV64_WG : 1)
 k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, int np, int flush, double *__restrict__ T, QrxWs w,
             double *__restrict__ Rall, LmVecs v, const LmState *__restrict__ st)
 {
@@ -1175,6 +1178,224 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
                              rdall, waall, Rall, qtfall);
 }
 
+// The row-parallel pass, WIDE form, for the mid regime (tens to a few hundred problems: the straggler rounds of a big
+// batch, every per-rank share of a sharded batch): a launch of at most a few hundred (problem, window) pairs gives every
+// workgroup a CU (or half of one) to itself, and there k_qrx_pass_rp is bound by that CU's LDS pipe -- every producer
+// reads its reflector entries back as BROADCAST ds_reads, (NP + 1) / 2 sixteen-byte reads per row that each occupy the
+// pipe like a full 1 KB read, on top of the 1 KB written and 1 KB read per row pair for the products themselves:
+// 18-28 LDS cycles per row, 35-55 us per 4096-row step, whatever the number of producers.  Here the reflector entries
+// never go through LDS: lane l of a producer fetches the entries of ONE row of the producer's next eight row groups
+// (one coalesced load per slot and tile, as before) and a row's entries are pulled out of those registers with
+// v_readlane (constant lane index: the loops are unrolled) into scalar registers, which the multiplies take as scalar
+// operands.  The VALU has room for that once the work is spread over W - 1 = 7 or 15 producers (a wave's instruction
+// stream no longer bounds anything), and the LDS pipe is left with the products alone: 8 cycles per row.
+// Same arithmetic on the same operands in the same order: bit-identical to k_qrx_pass.
+#ifndef QRX_RPW16_MAX_WG
+#define QRX_RPW16_MAX_WG 256            // launches of at most this many (problem, window) pairs: sixteen waves per workgroup
+#endif                                  // (120 KB of LDS: one workgroup per CU), a flush every 4th step
+#ifndef QRX_RPW8_MAX_WG
+#define QRX_RPW8_MAX_WG 512             // ... and of at most this many: eight waves (56 KB: two per CU)
+#endif
+#ifndef QRX_FEW_MAX
+#define QRX_FEW_MAX 256                 // batches of at most this many active problems take the pivot kernel's FEW instance
+#endif
+#define QRX_RPW_G 8                     // rows per producer and round: one 64-byte sector per lane
+#define QRX_RPW_AH 4                    // row groups in flight per producer
+__device__ __forceinline__ double qrx_readlane_f64(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+template <int NP, bool FLUSH, int W>
+__global__ void __launch_bounds__(64 * W)
+k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
+               double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
+               int32_t *__restrict__ srcall, int32_t *__restrict__ slotall, double *__restrict__ rdall,
+               double *__restrict__ waall, const QrxStep *__restrict__ stepall, double *__restrict__ Rall,
+               double *__restrict__ qtfall, const LmState *__restrict__ st)
+{
+    constexpr int NPR = W - 1, G = QRX_RPW_G, AH = QRX_RPW_AH, D = 64 / G, RR = NPR * G;
+    static_assert(D % AH == 0 && G == 8, "a tile is 64 / G rounds, a row group one sector per lane");
+    constexpr int NPI = NP < QRX_C ? NP : 0;
+    extern __shared__ __attribute__((aligned(16))) double pbw[];         // [2][RR / 2][64][2]: the products of a round, row pairs
+    const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
+    const int pl = grp * 8 + (r_ & 7), win = r_ >> 3;
+    if (pl >= nprob) return;
+    const int p = p0 + pl;
+    if (st && st[p].stage != ST_NEED_QR) return;
+    const int lane = threadIdx.x & 63, ldp = n + 1;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool adder = (wv == 0);
+    const int pw = adder ? 0 : wv - 1;
+    const QrxStep step = stepall[p];
+    const bool refl = step.ajnorm != 0.0;
+    const double ajj = step.ajj;
+    int32_t *slotp = slotall + (size_t)p * ld;
+    double *tpc = tpall + ((size_t)p * 2 + cur) * QRX_C * ldp;
+    double *Tp = T + (size_t)p * tst;
+    const int jb = j & ~7, r0 = j & 7, mrel = m - jb;
+    const double *vc = Vall + ((size_t)p * 2 + cur) * QRX_C * vst + jb;
+    const double *vo = Vall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst + jb;
+    const int col = ld - 64 * (win + 1) + lane;
+    const int kslot = (col >= coff + lo) ? slotp[col] : -1;
+    const bool act = kslot > j;
+    const int k = act ? kslot : n;
+    double tq[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) tq[q] = tpc[(size_t)q * ldp + k];
+    const double rk0 = (adder && act && k < n) ? rdall[(size_t)p * n + k] : 0.0;
+    const double wa0 = (adder && act && k < n) ? waall[(size_t)p * n + k] : 1.0;
+    double rowj = 0.0;
+    if (adder) {                                                        // row j with its pending updates (becomes final in the tail)
+        double e = Tp[qrx_at(j, col, ld)];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) e = e - tq[q] * vc[(size_t)q * vst + r0];
+        rowj = e;
+    }
+    const int nblk = (mrel + 7) >> 3;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(Tp + (size_t)(jb >> 3) * ld * 8, 0, (int)((size_t)nblk * ld * 64), 0x00020000);
+    const unsigned so = act ? (unsigned)col * 64u : 0x80000000u;
+    const unsigned ko = act ? (unsigned)(coff + k) * 64u : 0x80000000u;
+    const unsigned ldb = (unsigned)ld * 64u;
+    const int nround = (mrel + RR - 1) / RR;                            // producers: rounds 0 .. nround-1, adder: 1 .. nround
+    const int ntile = (nround + 1 + D - 1) / D;
+    double *pb0 = pbw, *pb1 = pbw + (size_t)(RR / 2) * 128;
+
+    if (adder) {
+        // ------------------------------------------------------------------------------------------------------------
+        // the ordered sum (:652-653): the products of round t - 1 while the producers form those of round t; a producer's
+        // eight rows at a time, the reads of the next two producers' rows in flight
+        double s = 0.0;
+        auto consume = [&](const double *half) __attribute__((always_inline)) {
+            const double2 *src2 = reinterpret_cast<const double2 *>(half) + lane;      // pair pr at src2[pr * 64]
+            double2 w3[3][4];
+            auto rd = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) w3[c % 3][h] = src2[(size_t)(c * 4 + h) * 64];
+            };
+            rd(0);
+            if (NPR > 1) rd(1);
+#pragma unroll
+            for (int c = 0; c < NPR; ++c) {
+                if (c + 2 < NPR) rd(c + 2);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    s = s + w3[c % 3][h].x;                             // :653, rows ascending
+                    s = s + w3[c % 3][h].y;
+                }
+            }
+        };
+        auto consume_edge = [&](const double *half, int rbase) __attribute__((always_inline)) {    // the round of row j, the last round
+            const double2 *src2 = reinterpret_cast<const double2 *>(half) + lane;
+#pragma unroll 1
+            for (int pr = 0; pr < RR / 2; ++pr) {
+                const double2 ww = src2[(size_t)pr * 64];
+                const int row = rbase + 2 * pr;
+                if (row >= r0 && row < mrel) s = s + ww.x;              // uniform
+                if (row + 1 >= r0 && row + 1 < mrel) s = s + ww.y;
+            }
+        };
+        qrx_lds_barrier();
+#pragma unroll 1
+        for (int t = 0; t < ntile * D; ++t) {
+            if (t >= 1 && t <= nround) {
+                const int rbase = (t - 1) * RR;
+                const double *half = ((t - 1) & 1) ? pb1 : pb0;
+                if (rbase >= r0 && rbase + RR <= mrel) consume(half);
+                else consume_edge(half, rbase);
+            }
+            qrx_lds_barrier();
+        }
+        if (!act) return;
+        qrx_pass_tail<NP, FLUSH>(p, j, k, col, coff + k, m, n, ld, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq, Tp, vc, vo, tpall,
+                                 rdall, waall, Rall, qtfall);
+        return;
+    }
+    // producer side ---------------------------------------------------------------------------------------------------
+    // reflector tile kt of producer pw: the D row groups it handles in rounds kt*D .. kt*D + D-1; lane l holds the entries
+    // of group l / G, row l % G (clamped to the last row: entries past it are never used)
+    double sv[NP + 1], svn[NP + 1];
+    auto vfetch = [&](int kt, double (&dst)[NP + 1]) __attribute__((always_inline)) {
+        const int row = min((kt * D + (lane >> 3)) * RR + pw * G + (lane & 7), mrel - 1);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dst[q] = vc[(size_t)q * vst + row];
+        dst[NP] = FLUSH ? vo[row] : vc[(size_t)NPI * vst + row];
+    };
+    double a[AH][G];
+    auto load = [&](double (&buf)[G], int t) __attribute__((always_inline)) {                          // the producer's group of round t
+        const unsigned boff = (unsigned)((t * RR + pw * G) >> 3) * ldb;
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+            const qrx_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + 16u * q2, boff, QRX_AUX_LOAD);
+            buf[2 * q2] = __hiloint2double((int)w.y, (int)w.x);
+            buf[2 * q2 + 1] = __hiloint2double((int)w.w, (int)w.z);
+        }
+    };
+    auto produce = [&](const double (&buf)[G], int t, int i) __attribute__((always_inline)) {         // i = t % D: compile-time
+        const int rbase = t * RR + pw * G;
+        double *dst = ((t & 1) ? pb1 : pb0) + ((size_t)(pw * (G / 2)) * 64 + lane) * 2;
+        double est[8];
+#pragma unroll
+        for (int u = 0; u < G; u += 2) {
+            double e0 = buf[u], e1 = buf[u + 1];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const double p0_ = tq[q] * qrx_readlane_f64(sv[q], i * G + u), p1_ = tq[q] * qrx_readlane_f64(sv[q], i * G + u + 1);
+                e0 = e0 - p0_;
+                e1 = e1 - p1_;
+            }
+            double2 ww;                                                 // rows outside the live range: garbage the adder skips
+            ww.x = qrx_readlane_f64(sv[NP], i * G + u) * e0;
+            ww.y = qrx_readlane_f64(sv[NP], i * G + u + 1) * e1;
+            *reinterpret_cast<double2 *>(dst + (size_t)(u >> 1) * 128) = ww;
+            if (FLUSH) { est[u] = e0; est[u + 1] = e1; }
+        }
+        if (FLUSH) {
+            const unsigned boff = (unsigned)(rbase >> 3) * ldb;
+            if (rbase >= r0 && rbase + 8 <= mrel) {                      // uniform: a whole 64-byte sector per lane
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) {
+                    qrx_u32x4 w;
+                    w.x = (unsigned)__double2loint(est[2 * q2]); w.y = (unsigned)__double2hiint(est[2 * q2]);
+                    w.z = (unsigned)__double2loint(est[2 * q2 + 1]); w.w = (unsigned)__double2hiint(est[2 * q2 + 1]);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, ko + 16u * q2, boff, QRX_AUX_STORE);
+                }
+            } else {                                                    // the block of row j, the last block: row by row
+#pragma unroll
+                for (int q2 = 0; q2 < 8; ++q2) {
+                    qrx_u32x2 w;
+                    w.x = (unsigned)__double2loint(est[q2]); w.y = (unsigned)__double2hiint(est[q2]);
+                    if (rbase + q2 >= r0 && rbase + q2 < mrel)
+                        __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, ko + 8u * q2, boff, QRX_AUX_STORE);
+                }
+            }
+        }
+    };
+    vfetch(0, sv);
+#pragma unroll
+    for (int i = 0; i < AH - 1; ++i) load(a[i], i);
+    qrx_lds_barrier();
+#pragma unroll 1
+    for (int kt = 0; kt < ntile; ++kt) {
+        vfetch(kt + 1, svn);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const int t = kt * D + i;
+            // (the scheduler fences keep a round's arithmetic behind the round's loads: the products depend on nothing but
+            // registers, and left alone the compiler hoists the arithmetic of every group in flight to the head of the tile
+            // -- a full drain of the load pipeline per tile)
+            load(a[(i + AH - 1) % AH], t + AH - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            produce(a[i % AH], t, i);
+            qrx_lds_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q <= NP; ++q) sv[q] = svn[q];
+    }
+}
+
 // The pass for a HANDFUL of problems (straggler rounds, one problem alone; factorisations of at most QRX_COL_MAX_WG
 // (problem, column) pairs): a workgroup per trailing column instead of a lane per column -- n - j workgroups per problem where the other
 // forms have ceil((n - j) / 64), so a lone 4096 x 256 problem still puts 256 workgroups on the chip.  The products of a
@@ -1389,6 +1610,8 @@ k_qrx_finish(int m, int n, int ld, int coff, size_t tst, size_t vst, int cur, in
     }
 }
 
+static constexpr size_t qrx_rpw_lds(int W) { return (size_t)(W - 1) * QRX_RPW_G * 1024; }   // two buffers of (W - 1) * 8 rows x 64 lanes x 8 bytes
+
 template <int NP, bool FLUSH>
 static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
                         double *R, double *qtf, const LmState *st)
@@ -1398,7 +1621,16 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     const int nwin = (n + 1 - lo + 63) / 64;                            // live physical columns coff + lo .. coff + n
     const dim3 grid((unsigned)(((nprob + 7) / 8) * 8 * nwin));
     if constexpr (NP >= 8) rp = 0;
+    if constexpr (NP >= 4) { if (rp == 16) rp = 8; }
     if constexpr (NP < 8) {
+    if constexpr (NP < 4) {
+    if (rp == 16)
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16>), grid, dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+    }
+    if (rp == 8)
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 8>), grid, dim3(64 * 8), qrx_rpw_lds(8), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
     if (rp == 6)
         hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 6>), grid, dim3(64 * 6), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
@@ -1435,11 +1667,22 @@ static void dispatch_pass(int np, bool flush, int rp, hipStream_t stream, int p0
 
 // Per device (called when a handle is created on it): the column sweep of long columns asks for more than 64 KB of
 // dynamic LDS (two product buffers), which has to be allowed on every device the kernel is launched on.
+template <int NP>
+static void qrx_rpw_attr()
+{
+    const int lim = (int)qrx_rpw_lds(16);
+    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    if constexpr (qrx_can_flush(NP))
+        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    if constexpr (NP < 3) qrx_rpw_attr<NP + 1>();
+}
+
 void qrx_init_device()
 {
     const int lim = (int)(sizeof(double) * 2 * (64 * QRX_COL_EL + 128));
     hipFuncSetAttribute((const void *)k_qrx_pass_col<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     hipFuncSetAttribute((const void *)k_qrx_pass_col<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    qrx_rpw_attr<0>();                                           // the sixteen-wave row-parallel pass: 120 KB
 }
 
 void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, double *T, const double *fvec,
@@ -1476,6 +1719,9 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     const long rp_max = rp_env >= 0 ? rp_env : QRX_RP_MAX_WG;
     static const long rp6_env = [] { const char *e = getenv("NLH_QRX_RP6"); return e ? atol(e) : -1L; }();
     const long rp6_max = std::min(rp_max, rp6_env >= 0 ? rp6_env : (long)QRX_RP6_MAX_WG);
+    static const long rpw16_env = [] { const char *e = getenv("NLH_QRX_RPW16"); return e ? atol(e) : -1L; }();
+    static const long rpw8_env = [] { const char *e = getenv("NLH_QRX_RPW8"); return e ? atol(e) : -1L; }();
+    const long rpw16_max = rpw16_env >= 0 ? rpw16_env : (long)QRX_RPW16_MAX_WG, rpw8_max = rpw8_env >= 0 ? rpw8_env : (long)QRX_RPW8_MAX_WG;
     static const int col_env = [] { const char *e = getenv("NLH_QRX_COL"); return e ? atoi(e) : -1; }();
     if (col_env >= 0 ? nact <= col_env : (long)nact * n <= QRX_COL_MAX_WG) {
         // two product buffers for columns of several chunks, one sized to the column otherwise
@@ -1533,15 +1779,20 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
             return;
         }
     }
+    // the pivot kernel's instance for a handful of problems (NORM2's general runs out of registers, at most two workgroups
+    // per CU) also serves every launch whose workgroups are all resident at once anyway
+    static const int few_env = [] { const char *e = getenv("NLH_QRX_FEW"); return e ? atoi(e) : -1; }();
+    const int few_max = few_env >= 0 ? few_env : QRX_FEW_MAX;
     bool prev_flushed = false;
     int cur = 0, np = 0, lo = 1;             // lo: first slot position that can still hold live data (step 0 moves physically)
     for (int j = 0; j < n; ++j) {
         const int nwin = (n + 1 - lo + 63) / 64;
         const long nwg = (long)nact * nwin;
-        const int rp = nwg <= rp6_max ? 6 : nwg <= rp_max ? 4 : 0;        // waves per workgroup of the row-parallel pass, 0: one wave
+        // waves per workgroup of the row-parallel pass (16 / 8: the wide form, reflector entries by v_readlane), 0: one wave
+        const int rp = nwg <= rpw16_max ? 16 : nwg <= rpw8_max ? 8 : nwg <= rp6_max ? 6 : nwg <= rp_max ? 4 : 0;
         // a launch that leaves most of the chip idle is bound by the instruction stream of its few waves, not by HBM:
         // flush every 3rd step there (at most 3 pending updates per row instead of 7; lone problem: 111 -> 103 ms)
-        const int period = forced_period ? forced_period : (rp == 6 ? 4 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
+        const int period = forced_period ? forced_period : ((rp == 6 || rp == 16) ? 4 : (rp == 4 || rp == 8) ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
         const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
         const int pf = (flush ? 1 : 0) | (prev_flushed ? 2 : 0);
@@ -1551,8 +1802,14 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         // sectors and np reflector vectors, ~210 KB per problem) + norm 88 us (46 us loading and preparing coefficients
         // with a lane per 64-element run, 24 us the chains -- two per SIMD --, 24 us scaling: the column makes three more
         // trips through memory than in the fused kernel) against 191 us for this kernel's four rounds.)
-        if (m <= 2048)
+        if (m <= 2048 && nact <= few_max)
+            hipLaunchKernelGGL((k_qrx_pivot<32, false, true>), dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
+                               T, w, R, v, (const LmState *)st);
+        else if (m <= 2048)
             hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
+                               T, w, R, v, (const LmState *)st);
+        else if (m - j <= 64 * 64 && nact <= few_max)
+            hipLaunchKernelGGL((k_qrx_pivot<64, false, true>), dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
                                T, w, R, v, (const LmState *)st);
         else if (m - j > 64 * 64 && m - j <= 64 * QRX_LONG_EL * QRX_LONG_MAXCH)
             hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,

@@ -266,6 +266,15 @@ void nlo_lmsolve(int32_t n, double *r, int32_t ldr, const int32_t *ipvt,
  *   deviation A (:531): norm2 over all m entries of wa2 (caller's wa4)
  *   deviation B (:552): the whole wa1 vector is updated, not only rows j+1..n
  * ------------------------------------------------------------------------- */
+/* Test-only switch (tests/test_oracle.py, tests/golden/make_minpack_vectors.py): 1 restores MINPACK's own two lines --
+ * the norm over n entries at :531 and the update of rows j+1..n at :552 -- so that everything else in lmpar / lmsolve /
+ * the reject path of lss_solve can be checked against MINPACK itself (scipy's lmder).  0 (default) = the reference.
+ * g_lmpar_loops counts how often the iteration :522-563 was entered (the fixtures must reach it). */
+static int g_lmpar_minpack = 0;
+static long g_lmpar_loops = 0;
+void nlo_set_lmpar_minpack(int on) { g_lmpar_minpack = on; }
+long nlo_lmpar_loop_entries(int reset) { long v = g_lmpar_loops; if (reset) g_lmpar_loops = 0; return v; }
+
 void nlo_lmpar(int32_t m, int32_t n, double *r, int32_t ldr, const int32_t *ipvt,
                const double *diag, const double *qtb, double delta, double *par,
                double *x, double *sdiag, double *wa1, double *wa2)
@@ -324,6 +333,7 @@ void nlo_lmpar(int32_t m, int32_t n, double *r, int32_t ldr, const int32_t *ipvt
     *par = dmin(*par, paru);
     if (*par == 0.0) *par = gnorm / dxnorm;
 
+    g_lmpar_loops += 1;
     for (;;) {                                               /* :522-563 */
         iter = iter + 1;
         if (*par == 0.0) *par = dmax(dwarf, p001 * paru);
@@ -331,7 +341,7 @@ void nlo_lmpar(int32_t m, int32_t n, double *r, int32_t ldr, const int32_t *ipvt
         for (int32_t i = 0; i < n; ++i) wa1[i] = temp * diag[i];
         nlo_lmsolve(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2);
         for (int32_t i = 0; i < n; ++i) wa2[i] = diag[i] * x[i];
-        dxnorm = nlo_norm2(m, wa2);                          /* :531 deviation A */
+        dxnorm = nlo_norm2(g_lmpar_minpack ? n : m, wa2);    /* :531 deviation A (MINPACK: n) */
         temp = fp;
         fp = dxnorm - delta;
 #ifdef NLO_TRACE
@@ -350,7 +360,7 @@ void nlo_lmpar(int32_t m, int32_t n, double *r, int32_t ldr, const int32_t *ipvt
             wa1[j] = wa1[j] / sdiag[j];
             temp = wa1[j];
             if (n < j + 2) continue;
-            for (int32_t i = 0; i < n; ++i)                  /* :552 deviation B */
+            for (int32_t i = g_lmpar_minpack ? j + 1 : 0; i < n; ++i)   /* :552 deviation B (MINPACK: rows j+1..n) */
                 wa1[i] = wa1[i] - A_(r, ldr, i, j) * temp;
         }
         temp = nlo_norm2(n, wa1);

@@ -94,6 +94,9 @@ double nlo_norm2(int32_t n, const double *x);
  * reference as built here), 1 = sqrt(sequential sum of squares).  Mode 1 exists only to show
  * how far "the reference" moves between Fortran processors (tests/test_oracle.py). */
 void nlo_set_norm2_mode(int mode);
+/* test-only: 1 = MINPACK's lmpar lines at :531 / :552 instead of the reference's (see nonlin_oracle.c); loop-entry counter */
+void nlo_set_lmpar_minpack(int on);
+long nlo_lmpar_loop_entries(int reset);
 double nlo_dot(int32_t n, const double *x, const double *y);
 
 /* vfh_jac_fcn (src/nonlin_multi_eqn_mult_var.f90:198-277).  fv may be NULL. */

@@ -64,6 +64,10 @@ def lib():
         L.nlo_default_options.argtypes = [C.POINTER(Options)]
         L.nlo_set_norm2_mode.argtypes = [C.c_int]
         L.nlo_set_norm2_mode.restype = None
+        L.nlo_set_lmpar_minpack.argtypes = [C.c_int]
+        L.nlo_set_lmpar_minpack.restype = None
+        L.nlo_lmpar_loop_entries.argtypes = [C.c_int]
+        L.nlo_lmpar_loop_entries.restype = C.c_long
         L.nlo_norm2.restype = C.c_double
         L.nlo_norm2.argtypes = [C.c_int32, dp]
         L.nlo_fd_jacobian.argtypes = [VECFCN, JACFCN, C.c_void_p, C.c_int32, C.c_int32, dp, dp, dp]
@@ -133,6 +137,16 @@ def _ip(a):
 def set_norm2_mode(mode):
     """0 = flang algorithm (default), 1 = sqrt(sum of squares)."""
     lib().nlo_set_norm2_mode(int(mode))
+
+
+def set_lmpar_minpack(on):
+    """Test-only: 1 = MINPACK's own lines at src/nonlin_least_squares.f90:531 / :552 (norm over n, rows j+1..n)."""
+    lib().nlo_set_lmpar_minpack(int(bool(on)))
+
+
+def lmpar_loop_entries(reset=False):
+    """How often lmpar's iteration (:522-563) has been entered since the last reset."""
+    return int(lib().nlo_lmpar_loop_entries(int(bool(reset))))
 
 
 def norm2(x):
