@@ -117,6 +117,14 @@ def _cpu_worker(cpu, ks, m, n, ready, go, out):
         os.sched_setaffinity(0, {cpu})
     except OSError:
         pass
+    try:
+        _cpu_worker_body(ks, m, n, ready, go, out)
+    except Exception as e:                                         # the parent must hear about it, not wait for ever
+        ready.release()
+        out.put(RuntimeError(f"cpu worker on cpu {cpu}: {e!r}"))
+
+
+def _cpu_worker_body(ks, m, n, ready, go, out):
     import numpy as np
     from oracle import pyoracle as O
     probs = [O.dq_generate(SEED0 + k, m, n, gamma=GAMMA, sigma=SIGMA, spread=SPREAD) for k in ks]
@@ -160,12 +168,31 @@ def cpu_all_cores(m, n, one_core_rate, per_worker=4):
                                                    ready, go, out), daemon=True) for w in range(W)]
     for p in procs:
         p.start()
+
+    def dead():
+        return [p.pid for p in procs if p.exitcode not in (None, 0)]
+    # a worker that dies before it signals (import error, out of memory) must not hang the bench: bounded waits
     for _ in procs:
-        ready.acquire()
+        if not ready.acquire(timeout=600):
+            for p in procs:
+                p.terminate()
+            raise RuntimeError(f"cpu_all_cores: a worker never became ready (dead workers: {dead()})")
     go.set()
-    res = [out.get() for _ in procs]
+    res = []
+    for _ in procs:
+        try:
+            r = out.get(timeout=1800)
+        except Exception:
+            for p in procs:
+                p.terminate()
+            raise RuntimeError(f"cpu_all_cores: a worker never reported (dead workers: {dead()})")
+        if isinstance(r, Exception):
+            for p in procs:
+                p.terminate()
+            raise r
+        res.append(r)
     for p in procs:
-        p.join()
+        p.join(timeout=60)
     wall = max(r[2] for r in res) - min(r[1] for r in res)
     njac = sum(r[0] for r in res)
     rate = njac / wall
@@ -389,7 +416,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32,
                     help="problems solved by the CPU oracle: the cpu_baseline timing and the parity sample (0 = skip)")
     ap.add_argument("--extras", type=int, default=1,
-                    help="0 = only the timed steps (profiles/capture.sh: every launch rocprofv3 sees then belongs to a "
+                    help="0 = only the timed steps (profiles/capture_r04.sh: every launch rocprofv3 sees then belongs to a "
                          "warm-up or timed step, so its per-kernel averages are the ones printed here)")
     ap.add_argument("--other-paths", type=int, default=1,
                     help="1 = also time the Newton / quasi-Newton / bounded LSQ / BFGS / polynomial rows (SURVEY 8 a16-a24, "

@@ -61,6 +61,8 @@ struct nlh_handle {
            qnQ, qnR, qnV, bfB, bfR, bfV, qxV;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    void *staging = nullptr;           // pinned staging of a device-set share's rows of the caller's host arrays
+    size_t staging_bytes = 0;
     bool qrx_open_on = false; hipEvent_t qrx_a{}, qrx_b{}; int qrx_kid = 0;   // open bracket of a nlh_qrx.hip launch
     std::vector<nlh_handle *> workers;   // private handles (own stream + workspace) for concurrent host-loop solves
 };
@@ -85,6 +87,16 @@ static int ensure(nlh_handle *h, DevBuf &b, size_t bytes)
     bool known = false;
     for (auto *q : h->bufs) if (q == &b) known = true;
     if (!known) h->bufs.push_back(&b);
+    return 0;
+}
+
+static int ensure_staging(nlh_handle *h, size_t bytes)
+{
+    if (bytes <= h->staging_bytes) return 0;
+    if (h->staging) hipHostFree(h->staging);
+    h->staging = nullptr; h->staging_bytes = 0;
+    if (hipHostMalloc(&h->staging, bytes, hipHostMallocDefault) != hipSuccess) { h->err = "hipHostMalloc (staging)"; return NLH_OUT_OF_MEMORY_ERROR; }
+    h->staging_bytes = bytes;
     return 0;
 }
 
@@ -247,6 +259,7 @@ void nlh_destroy(nlh_handle *h)
     for (auto e : h->pool) hipEventDestroy(e);
     for (auto *b : h->bufs) if (b->p) hipFree(b->p);
     if (h->pinned) hipHostFree(h->pinned);
+    if (h->staging) hipHostFree(h->staging);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -801,6 +814,18 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     return 0;
 }
 
+// Several kernels of the lock-step drivers carry the problem index in gridDim.y / .z (at most 65535): a larger batch is
+// solved in slices of NLH_MAX_LOCKSTEP problems, one after the other (independent problems: the same bits).
+static const int32_t NLH_MAX_LOCKSTEP = 65535;
+static int lockstep_slices(int32_t nprob, const std::function<int(int32_t, int32_t)> &run)         // run(first, count)
+{
+    for (int32_t p0 = 0; p0 < nprob; p0 += NLH_MAX_LOCKSTEP) {
+        const int rc = run(p0, std::min<int32_t>(NLH_MAX_LOCKSTEP, nprob - p0));
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // Several sub-batches in flight.  A batch is a lock-step state machine whose rounds contain latency-bound stages (pivot /
 // NORM2 chains of the exact lmfactor, Cholesky, lmpar's iteration for the few problems that need it, straggler rounds,
 // the status read-back): with the batch dealt to S host threads, each driving its own stream and workspace, those stages
@@ -828,6 +853,11 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     if (nprob <= 0) return 0;
     int rc = check_opts_lm(o, m, n);
     if (rc) return rc;
+    if (nprob > NLH_MAX_LOCKSTEP)
+        return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {
+            return nlh_dq_lm_solve_batch(h, o, cnt, m, n, dA + (size_t)p0 * m * n, db + (size_t)p0 * m, gamma, dx + (size_t)p0 * n,
+                                         dfvec + (size_t)p0 * m, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
+        });
     const int S = lm_sub_batches(o, nprob, m, n);
     if (S == 1) return lm_solve_range(h, o, nprob, m, n, dA, db, gamma, dx, dfvec, ib, status);
     if ((rc = ensure_workers(h, S))) return rc;
@@ -2074,7 +2104,10 @@ int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (!o || n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
-    return square_lockstep(h, o, false, 0, nprob, n, dA, db, gamma, analytic, dx, dfvec, ib, status);
+    return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {
+        return square_lockstep(h, o, false, 0, cnt, n, dA + (size_t)p0 * n * n, db + (size_t)p0 * n, gamma, analytic, dx + (size_t)p0 * n,
+                               dfvec + (size_t)p0 * n, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
+    });
 }
 
 // quasi_newton_solver%solve -- qns_solve, src/nonlin_solve.f90:156-427
@@ -2130,7 +2163,10 @@ int nlh_dq_quasi_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (!o || n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
-    return square_lockstep(h, o, true, jdelta, nprob, n, dA, db, gamma, analytic, dx, dfvec, ib, status);   // the same state machine
+    return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {                                           // the same state machine
+        return square_lockstep(h, o, true, jdelta, cnt, n, dA + (size_t)p0 * n * n, db + (size_t)p0 * n, gamma, analytic, dx + (size_t)p0 * n,
+                               dfvec + (size_t)p0 * n, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
+    });
 }
 
 // constrained_least_squares_solver%solve -- cls_solve, src/nonlin_least_squares.f90:938-1176
@@ -2309,7 +2345,11 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
     if (m > QN_MAX_ROWS) return NLH_ARRAY_SIZE_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     static const int cls_host = [] { const char *e = getenv("NLH_CLS_HOSTLOOP"); return e ? atoi(e) : 0; }();
-    if (!cls_host) return cls_lockstep(h, o, delta0, stepscale0, xl, xu, nprob, m, n, dA, db, gamma, dx, dfvec, ib, status);
+    if (!cls_host)
+        return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {
+            return cls_lockstep(h, o, delta0, stepscale0, xl, xu, cnt, m, n, dA + (size_t)p0 * m * n, db + (size_t)p0 * m, gamma,
+                                dx + (size_t)p0 * n, dfvec + (size_t)p0 * m, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
+        });
     // one problem per call; run_problems deals the problems to worker threads with private handles
     auto solve_one = [&](nlh_handle *h, int p) -> int {
         int rc;
@@ -2531,7 +2571,11 @@ int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, 
     if (!o || n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     static const int bfgs_host = [] { const char *e = getenv("NLH_BFGS_HOSTLOOP"); return e ? atoi(e) : 0; }();
-    if (!bfgs_host) return bfgs_lockstep(h, o, nprob, m, n, dA, db, gamma, dx, hfout, ib, status);
+    if (!bfgs_host)
+        return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {
+            return bfgs_lockstep(h, o, cnt, m, n, dA + (size_t)p0 * m * n, db + (size_t)p0 * m, gamma, dx + (size_t)p0 * n,
+                                 hfout ? hfout + p0 : nullptr, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
+        });
     // one problem per call; run_problems deals the problems to worker threads with private handles
     auto solve_one = [&](nlh_handle *h, int p) -> int {
         int rc;
@@ -2616,7 +2660,8 @@ int nlh_dq_generate(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, uint64_t
 struct nlh_device_set {
     std::vector<nlh_handle *> handles;
     std::string err;
-};
+    std::atomic<int> refs{1};          // the creator's reference + one per model dealt over the set: nlh_device_set_destroy
+};                                     // only drops the creator's, the handles go when the last model has gone too
 
 int nlh_device_set_create(nlh_device_set **out, const int32_t *devices, int32_t ndev)
 {
@@ -2646,12 +2691,14 @@ int nlh_device_set_create(nlh_device_set **out, const int32_t *devices, int32_t 
     return 0;
 }
 
-void nlh_device_set_destroy(nlh_device_set *set)
+static void device_set_release(nlh_device_set *set)
 {
-    if (!set) return;
+    if (!set || set->refs.fetch_sub(1) != 1) return;
     for (auto *h : set->handles) nlh_destroy(h);
     delete set;
 }
+
+void nlh_device_set_destroy(nlh_device_set *set) { device_set_release(set); }
 
 int32_t nlh_device_set_size(const nlh_device_set *set) { return set ? (int32_t)set->handles.size() : 0; }
 
@@ -2733,6 +2780,7 @@ int nlh_dq_model_create_on(nlh_device_set *set, int32_t nprob, int32_t m, int32_
     *out = nullptr;
     nlh_dq_model *md = new nlh_dq_model();
     md->nprob = nprob; md->m = m; md->n = n; md->gamma = gamma; md->set = set;
+    set->refs.fetch_add(1);                                      // released by nlh_dq_model_destroy
     const int nd = (int)set->handles.size();
     for (int d = 0; d < nd; ++d) {
         DqPart pt;
@@ -2754,6 +2802,7 @@ void nlh_dq_model_destroy(nlh_dq_model *md)
     if (!md) return;
     for (auto &pt : md->parts)
         if (pt.dA) { hipSetDevice(pt.device); hipFree(pt.dA); }
+    device_set_release(md->set);
     delete md;
 }
 
@@ -2787,15 +2836,19 @@ static int model_part_run(nlh_handle *h, const nlh_dq_model *md, const DqPart &p
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return 0;
     }
-    std::vector<double> xs(cnt * n), fs(cnt * m);                // the broadcast / gather ends of the dealt batch
+    // the broadcast / gather ends of the dealt batch, staged through a PINNED buffer of the share's handle (its own, apart
+    // from the one the solvers keep their read-back state in: a pageable staging vector makes every one of these copies a
+    // synchronous bounce through the runtime's own pinned pool)
+    if (int rcp = ensure_staging(h, sizeof(double) * cnt * (n + m))) return rcp;
+    double *xs = (double *)h->staging, *fs = xs + cnt * n;
     std::vector<nlh_iteration_behavior> ibs(ib ? cnt : 0);
     std::vector<int32_t> sts(status ? cnt : 0);
     for (size_t i = 0; i < cnt; ++i) memcpy(&xs[i * n], x + ((size_t)pt.first + i * pt.stride) * n, sizeof(double) * n);
-    HIPCHK(h, hipMemcpyAsync(pt.dx, xs.data(), sizeof(double) * cnt * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(pt.dx, xs, sizeof(double) * cnt * n, hipMemcpyHostToDevice, h->stream));
     const int rc = op(h, pt, ib ? ibs.data() : nullptr, status ? sts.data() : nullptr);
     if (rc) return rc;
-    if (x_out) HIPCHK(h, hipMemcpyAsync(xs.data(), pt.dx, sizeof(double) * cnt * n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(fs.data(), pt.df, sizeof(double) * cnt * m, hipMemcpyDeviceToHost, h->stream));
+    if (x_out) HIPCHK(h, hipMemcpyAsync(xs, pt.dx, sizeof(double) * cnt * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(fs, pt.df, sizeof(double) * cnt * m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < cnt; ++i) {
         const size_t k = (size_t)pt.first + i * pt.stride;
@@ -2813,6 +2866,10 @@ static int model_run(nlh_handle *h, const nlh_dq_model *md, double *x, bool x_ou
     if (!md || !x || !f) return NLH_INVALID_INPUT_ERROR;
     if (!md->set) {
         if (!h) return NLH_ERR_BAD_HANDLE;
+        if (h->device != md->parts[0].device) {                  // the model's buffers live on the device of the handle that
+            h->err = "device model used with a handle on another device";   // created it: another device's stream cannot run it
+            return NLH_INVALID_INPUT_ERROR;
+        }
         return model_part_run(h, md, md->parts[0], x, x_out, f, ib, status, op);
     }
     const int nd = (int)md->parts.size();
@@ -2844,6 +2901,11 @@ int nlh_dq_model_lm_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mode
                           nlh_iteration_behavior *ib, int32_t *status)
 {
     if (!md || !o) return NLH_INVALID_INPUT_ERROR;
+    // a batch stays silent (the reference prints between the iterations of ONE solve): a share of a dealt batch may hold a
+    // single problem and would otherwise print from its host thread
+    nlh_options oq = *o;
+    if (md->nprob > 1) oq.print_status = 0;
+    o = &oq;
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          return nlh_dq_lm_solve_batch(ph, o, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma, pt.dx, pt.df, pib, pst);
@@ -2856,6 +2918,9 @@ int nlh_dq_model_newton_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_
                               double *fvec, nlh_iteration_behavior *ib, int32_t *status)
 {
     if (!md || !o) return NLH_INVALID_INPUT_ERROR;
+    nlh_options oq = *o;
+    if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
+    o = &oq;
     if (md->m != md->n) return NLH_INVALID_INPUT_ERROR;         // src/nonlin_solve.f90:519
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
@@ -2868,6 +2933,9 @@ int nlh_dq_model_quasi_newton_solve(nlh_handle *h, const nlh_options *o, const n
                                     int32_t analytic, double *x, double *fvec, nlh_iteration_behavior *ib, int32_t *status)
 {
     if (!md || !o) return NLH_INVALID_INPUT_ERROR;
+    nlh_options oq = *o;
+    if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
+    o = &oq;
     if (md->m != md->n) return NLH_INVALID_INPUT_ERROR;         // src/nonlin_solve.f90:241
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
@@ -2882,6 +2950,9 @@ int nlh_dq_model_cls_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mod
                            int32_t *status)
 {
     if (!md || !o) return NLH_INVALID_INPUT_ERROR;
+    nlh_options oq = *o;
+    if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
+    o = &oq;
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          return nlh_dq_cls_solve_batch(ph, o, delta0, stepscale0, xl, xu, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma,
@@ -2895,6 +2966,9 @@ int nlh_dq_model_bfgs_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mo
                             nlh_iteration_behavior *ib, int32_t *status)
 {
     if (!md || !o) return NLH_INVALID_INPUT_ERROR;
+    nlh_options oq = *o;
+    if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
+    o = &oq;
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          std::vector<double> fo(pt.cnt, 0.0);

@@ -253,12 +253,17 @@ contains
     !> Extension: the GPUs that device_model_batch%create deals a batch over (solve_batch then runs one host thread
     !> per GPU inside this process).  devices = device ids, 0-based; an empty list selects every visible GPU.  Without
     !> this call the environment variable NLH_DEVICES decides ("all", or a comma-separated id list); unset: one GPU
-    !> (device 0, the default handle).  Models created earlier keep the devices they were created on.
+    !> (device 0, the default handle).  Models created earlier keep the devices they were created on: the previous set is
+    !> released here, and the library keeps its handles alive until the last model dealt over it has been destroyed.
     subroutine nlh_use_devices(devices)
         integer(c_int32_t), intent(in), dimension(:) :: devices
         integer(c_int) :: rc
         integer(c_int32_t) :: none(1)
         none = 0
+        if (c_associated(default_set)) then
+            call nlh_device_set_destroy(default_set)
+            default_set = c_null_ptr
+        end if
         if (size(devices) > 0) then
             rc = nlh_device_set_create(default_set, devices, int(size(devices), c_int32_t))
         else
@@ -286,9 +291,21 @@ contains
                     k = 1
                     do i = 1, length + 1
                         if (i > length .or. spec(i:min(i, length)) == ",") then
-                            if (i > k .and. cnt < size(ids)) then
+                            if (i > k) then
+                                if (cnt >= size(ids)) then
+                                    print '(A,I0,A)', "nonlin_hip: NLH_DEVICES lists more than ", size(ids), " devices"
+                                    error stop 1
+                                end if
                                 cnt = cnt + 1
-                                read (spec(k:i - 1), *) ids(cnt)
+                                read (spec(k:i - 1), *, iostat = stat) ids(cnt)
+                                if (stat /= 0 .or. verify(trim(adjustl(spec(k:i - 1))), "0123456789") /= 0) then
+                                    print '(3A)', "nonlin_hip: NLH_DEVICES must be 'all' or a comma-separated list of device ids, got '", &
+                                        spec(1:length), "'"
+                                    error stop 1
+                                end if
+                            else if (i <= length .or. k > 1) then      ! an empty entry ("0,,1", a trailing comma)
+                                print '(3A)', "nonlin_hip: NLH_DEVICES has an empty entry: '", spec(1:length), "'"
+                                error stop 1
                             end if
                             k = i + 1
                         end if

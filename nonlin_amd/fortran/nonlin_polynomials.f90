@@ -1,138 +1,144 @@
-! polynomial with the reference's public interface for the fitting front end
-! (src/nonlin_polynomials.f90:39-62: initialize, order, fit, fit_thru_zero, evaluate (real), get, get_all, set);
-! fit / fit_thru_zero marshal to nlh_poly_fit (Vandermonde panel + Householder QR + back substitution on the GPU,
-! :146-238).  Roots, the companion matrix and polynomial arithmetic are outside the hot path and not provided.
+! `polynomial` as far as the fitting front end needs it (public surface of src/nonlin_polynomials.f90:39-62:
+! initialize, order, fit, fit_thru_zero, evaluate (real argument), get, get_all, set).  The two fits marshal to
+! nlh_poly_fit -- Vandermonde panel, Householder QR and back substitution on the GPU (:146-238).  Roots, the companion
+! matrix and polynomial arithmetic are outside the hot path and not provided.
+!
+! Representation: `cf(0:deg)`, cf(k) multiplying x**k; an object that was never initialised has no `cf` and reports
+! order -1 exactly as the reference does (:112-143).
 module nonlin_polynomials
     use iso_fortran_env
     use, intrinsic :: iso_c_binding
+    use nonlin_error_handling, only : NL_INVALID_OPERATION_ERROR, NL_INDEX_OUT_OF_RANGE_ERROR
     use nonlin_hip_c
     implicit none
     private
     public :: polynomial
 
     type polynomial
-        real(real64), private, allocatable, dimension(:) :: m_coeffs
+        real(real64), private, allocatable :: cf(:)          ! cf(0:deg)
     contains
-        generic, public :: initialize => init_poly, init_poly_coeffs
-        procedure, public :: order => get_poly_order
-        procedure, public :: fit => poly_fit
-        procedure, public :: fit_thru_zero => poly_fit_thru_zero
-        generic, public :: evaluate => evaluate_real
-        procedure, public :: get => get_poly_coefficient
-        procedure, public :: get_all => get_poly_coefficients
-        procedure, public :: set => set_poly_coefficient
-        procedure, private :: evaluate_real => poly_eval_double
-        procedure, private :: init_poly
-        procedure, private :: init_poly_coeffs
+        generic, public :: initialize => pl_alloc, pl_from_coefs
+        procedure, public :: order => pl_degree
+        procedure, public :: fit => pl_fit_free
+        procedure, public :: fit_thru_zero => pl_fit_origin
+        generic, public :: evaluate => pl_horner
+        procedure, public :: get => pl_coef
+        procedure, public :: get_all => pl_coefs
+        procedure, public :: set => pl_put
+        procedure, private :: pl_horner
+        procedure, private :: pl_alloc
+        procedure, private :: pl_from_coefs
     end type
 
 contains
-    pure subroutine init_poly(this, order)                  ! :69-90
+    ! zero polynomial of the given order (:69-90; a negative order is the reference's NL_INVALID_INPUT_ERROR there,
+    ! reported here by the same small integer the shim uses for size errors)
+    pure subroutine pl_alloc(this, order)
         class(polynomial), intent(inout) :: this
         integer(int32), intent(in) :: order
         if (order < 0) error stop 2
-        if (allocated(this%m_coeffs)) deallocate(this%m_coeffs)
-        allocate(this%m_coeffs(order + 1))
-        this%m_coeffs = 0.0d0
+        if (allocated(this%cf)) deallocate(this%cf)
+        allocate(this%cf(0:order), source = 0.0d0)
     end subroutine
 
-    pure subroutine init_poly_coeffs(this, c)               ! :93-109
+    ! from a coefficient array, lowest power first (:93-109)
+    pure subroutine pl_from_coefs(this, c)
         class(polynomial), intent(inout) :: this
         real(real64), intent(in), dimension(:) :: c
-        call init_poly(this, size(c) - 1)
-        this%m_coeffs = c
+        if (size(c) < 1) error stop 2
+        if (allocated(this%cf)) deallocate(this%cf)
+        allocate(this%cf(0:size(c) - 1))
+        this%cf(0:) = c
     end subroutine
 
-    pure function get_poly_order(this) result(n)            ! :112-143
+    pure integer(int32) function pl_degree(this) result(deg)
         class(polynomial), intent(in) :: this
-        integer(int32) :: n
-        if (.not.allocated(this%m_coeffs)) then
-            n = -1
-        else
-            n = size(this%m_coeffs) - 1
-        end if
+        deg = -1
+        if (allocated(this%cf)) deg = ubound(this%cf, 1)
     end function
 
-    subroutine poly_fit_impl(this, x, y, order, thru_zero)
+    ! both fits: size checks of :159-166 / :206-213, then the device
+    subroutine pl_fit_front(this, x, y, order, origin)
         class(polynomial), intent(inout) :: this
         real(real64), intent(in), dimension(:) :: x
         real(real64), intent(inout), dimension(:) :: y
-        integer(int32), intent(in) :: order, thru_zero
+        integer(int32), intent(in) :: order
+        logical, intent(in) :: origin
         integer(c_int) :: rc
-        real(c_double), allocatable :: xc(:), yc(:), cc(:)
-        if (size(y) /= size(x)) error stop 3                ! :159-162
-        if (order >= size(x) .or. order < 1) error stop 4   ! :163-166
-        if (this%order() /= order) call this%initialize(order)
-        allocate(xc(size(x)), yc(size(x)), cc(order + 1))
-        xc = x
-        yc = y
-        rc = nlh_poly_fit(nlh_default_handle(), int(size(x), c_int32_t), order, thru_zero, xc, yc, cc)
+        integer(c_int32_t) :: npts
+        real(c_double), allocatable :: xs(:), ys(:), sol(:)
+        npts = int(size(x), c_int32_t)
+        if (size(y) /= npts) error stop 3
+        if (order < 1 .or. order >= npts) error stop 4
+        allocate(xs(npts), source = x)
+        allocate(ys(npts), source = y)
+        allocate(sol(0:order))
+        rc = nlh_poly_fit(nlh_default_handle(), npts, order, merge(1, 0, origin), xs, ys, sol)
         if (rc /= 0) error stop rc
-        this%m_coeffs = cc
+        if (pl_degree(this) /= order) call pl_alloc(this, order)
+        this%cf = sol
     end subroutine
 
-    subroutine poly_fit(this, x, y, order)                  ! :146-190
+    subroutine pl_fit_free(this, x, y, order)               ! :146-190
         class(polynomial), intent(inout) :: this
         real(real64), intent(in), dimension(:) :: x
         real(real64), intent(inout), dimension(:) :: y
         integer(int32), intent(in) :: order
-        call poly_fit_impl(this, x, y, order, 0)
+        call pl_fit_front(this, x, y, order, .false.)
     end subroutine
 
-    subroutine poly_fit_thru_zero(this, x, y, order)        ! :193-238
+    subroutine pl_fit_origin(this, x, y, order)             ! :193-238
         class(polynomial), intent(inout) :: this
         real(real64), intent(in), dimension(:) :: x
         real(real64), intent(inout), dimension(:) :: y
         integer(int32), intent(in) :: order
-        call poly_fit_impl(this, x, y, order, 1)
+        call pl_fit_front(this, x, y, order, .true.)
     end subroutine
 
-    pure elemental function poly_eval_double(this, x) result(y)     ! :241-268
+    ! Horner from the leading coefficient down: the operations of :241-268 in the same order (its first line is this
+    ! loop's first trip), 0 for an uninitialised object
+    pure elemental function pl_horner(this, x) result(y)
         class(polynomial), intent(in) :: this
         real(real64), intent(in) :: x
         real(real64) :: y
-        integer(int32) :: j, order, n
-        order = this%order()
-        n = order + 1
-        if (order == -1) then
-            y = 0.0d0
-            return
-        else if (order == 0) then
-            y = this%m_coeffs(1)
-            return
-        end if
-        y = this%m_coeffs(n) * x + this%m_coeffs(order)
-        do j = n - 2, 1, -1
-            y = y * x + this%m_coeffs(j)
+        integer(int32) :: k
+        y = 0.0d0
+        if (.not. allocated(this%cf)) return
+        y = this%cf(ubound(this%cf, 1))
+        do k = ubound(this%cf, 1) - 1, 0, -1
+            y = y * x + this%cf(k)
         end do
     end function
 
-    pure function get_poly_coefficient(this, ind) result(c)
+    ! coefficient `ind` (1-based: c(1) + c(2) x + ...).  Asking an uninitialised polynomial for a coefficient is an
+    ! invalid operation in the reference (:399) -- it stops; so does this.
+    pure function pl_coef(this, ind) result(c)
         class(polynomial), intent(in) :: this
         integer(int32), intent(in) :: ind
         real(real64) :: c
-        c = 0.0d0
-        if (.not.allocated(this%m_coeffs)) return
-        if (ind <= 0 .or. ind > size(this%m_coeffs)) error stop 209     ! NL_INDEX_OUT_OF_RANGE_ERROR
-        c = this%m_coeffs(ind)
+        if (.not. allocated(this%cf)) error stop NL_INVALID_OPERATION_ERROR
+        if (ind < 1 .or. ind > size(this%cf)) error stop NL_INDEX_OUT_OF_RANGE_ERROR
+        c = this%cf(ind - 1)
     end function
 
-    pure function get_poly_coefficients(this) result(c)
+    pure function pl_coefs(this) result(c)
         class(polynomial), intent(in) :: this
         real(real64), allocatable, dimension(:) :: c
-        if (allocated(this%m_coeffs)) then
-            c = this%m_coeffs
+        if (allocated(this%cf)) then
+            allocate(c(size(this%cf)))
+            c = this%cf
         else
             allocate(c(0))
         end if
     end function
 
-    pure subroutine set_poly_coefficient(this, ind, c)
+    ! (:426-447: silently ignored on an uninitialised object, index checked otherwise)
+    pure subroutine pl_put(this, ind, c)
         class(polynomial), intent(inout) :: this
         integer(int32), intent(in) :: ind
         real(real64), intent(in) :: c
-        if (.not.allocated(this%m_coeffs)) return
-        if (ind <= 0 .or. ind > size(this%m_coeffs)) error stop 209
-        this%m_coeffs(ind) = c
+        if (.not. allocated(this%cf)) return
+        if (ind < 1 .or. ind > size(this%cf)) error stop NL_INDEX_OUT_OF_RANGE_ERROR
+        this%cf(ind - 1) = c
     end subroutine
 end module

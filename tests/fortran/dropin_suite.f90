@@ -114,6 +114,25 @@ program dropin_suite
     type(iteration_behavior) :: ib
     real(real64) :: x2(2), f2(2), x4(4), f21(21), a, numjac(2,2), ics(2)
     integer :: k
+    character(len=64) :: mode
+
+    ! `dropin_suite errstop_poly_get`: a coefficient of a polynomial that was never initialised -- the reference stops with
+    ! NL_INVALID_OPERATION_ERROR (src/nonlin_polynomials.f90:399); tests/test_gpu_fortran.py checks the exit code.
+    ! `... errstop_poly_index`: index out of range on an initialised one (NL_INDEX_OUT_OF_RANGE_ERROR, :402-405).
+    if (command_argument_count() >= 1) then
+        call get_command_argument(1, mode)
+        block
+            type(polynomial) :: pq
+            if (trim(mode) == "errstop_poly_get") then
+                print *, pq%get(1)
+            else if (trim(mode) == "errstop_poly_index") then
+                call pq%initialize(2)
+                print *, pq%order(), pq%evaluate(1.5d0), size(pq%get_all())
+                call pq%set(4, 1.0d0)
+            end if
+        end block
+        stop 0
+    end if
 
     ! README Example 2 (BASELINE config 1)
     fcn => cubicfit

@@ -50,6 +50,17 @@ def _cmp(r, rc, xo, ibo):
     assert np.array_equal(r["x"], xo), (r["x"], xo)
 
 
+def test_polynomial_error_stops_are_the_references(results):
+    """src/nonlin_polynomials.f90:399: `get` on a polynomial that was never initialised stops with
+    NL_INVALID_OPERATION_ERROR (104 here, see nonlin_error_handling.f90); :402-405: an index out of range stops with
+    NL_INDEX_OUT_OF_RANGE_ERROR (209) -- `set` on an initialised polynomial (on an uninitialised one it returns, :436)."""
+    out = subprocess.run([EXE, "errstop_poly_get"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 104, (out.returncode, out.stderr)
+    out = subprocess.run([EXE, "errstop_poly_index"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 209, (out.returncode, out.stderr)
+    assert out.stdout.split()[:3] == ["2", "0.", "3"]           # order, value of the zero polynomial, coefficient count
+
+
 def test_readme_example_2(results, oracle):
     rc, xo, fo, ibo = oracle.lm_solve(lambda x, f: P.lsfcn1(x, f, None), 21, 4, [1.0] * 4)
     _cmp(results["lm_readme"][0], rc, xo, ibo)
