@@ -361,6 +361,113 @@ def other_paths(ds):
     return rows
 
 
+def mode_h_rows(ds):
+    """The literal drop-in case (BASELINE config 2 as a user of the reference would run it): ONE problem solved
+    through nlh_lm_solve with a COMPILED HOST CALLBACK (tests/host_callback/dq_callback.c, plain C) -- the solver's linear
+    algebra on the GPU, the user's function on the host, called n + 1 times per Jacobian in the reference's order.  Against
+    it: the CPU oracle driving the same callback on one host core.  x must be the same bits."""
+    import ctypes as C
+    import numpy as np
+    from nonlin_amd import _lib
+    from oracle import pyoracle as O
+    so = os.path.join(ROOT, "tests", "host_callback", "libdq_callback.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.dirname(so), "-s"])
+    cb = C.CDLL(so)
+
+    class Ctx(C.Structure):
+        _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("A", C.POINTER(C.c_double)), ("b", C.POINTER(C.c_double)),
+                    ("gamma", C.c_double), ("ncalls", C.c_int64), ("u", C.POINTER(C.c_double))]
+    dp = C.POINTER(C.c_double)
+    rows = []
+    for m, n in ((4096, 256), (512, 64)):
+        A, b, xt, x0 = O.dq_generate(SEED0, m, n, gamma=GAMMA, sigma=SIGMA, spread=SPREAD)
+        u = np.zeros(m)
+        ctx = Ctx(m, n, A.ctypes.data_as(dp), b.ctypes.data_as(dp), GAMMA, 0, u.ctypes.data_as(dp))
+        fcn_g = C.cast(cb.dq_user_fcn, _lib.VECFCN)
+        nojac_g = C.cast(None, _lib.JACFCN)
+        og = _lib.default_options()
+        og.max_evals = 500
+
+        def gpu():
+            x = x0.copy()
+            f = np.zeros(m)
+            ib = _lib.IterationBehavior()
+            ctx.ncalls = 0
+            rc = ds.lib.nlh_lm_solve(ds.h.ptr, C.byref(og), m, n, fcn_g, nojac_g, C.byref(ctx), x.ctypes.data_as(dp),
+                                     f.ctypes.data_as(dp), C.byref(ib))
+            return rc, x, ib.as_dict(), int(ctx.ncalls)
+        gpu()                                                     # warm: workspaces, pinned buffers
+        t0 = time.perf_counter()
+        rc_g, xg, ibg, calls_g = gpu()
+        tg = time.perf_counter() - t0
+        # the callbacks alone (what no solver can take off the host): the same number of calls, timed
+        xs = x0.copy()
+        f = np.zeros(m)
+        t0 = time.perf_counter()
+        for _ in range(calls_g):
+            cb.dq_user_fcn(C.byref(ctx), n, xs.ctypes.data_as(dp), m, f.ctypes.data_as(dp))
+        tcb = time.perf_counter() - t0
+        # the CPU path: the oracle with the same compiled callback
+        L = O.lib()
+        oo = O.default_options(max_evals=500)
+        xo = x0.copy()
+        fo = np.zeros(m)
+        ibo = O.IterationBehavior()
+        ctx.ncalls = 0
+        t0 = time.perf_counter()
+        rc_o = L.nlo_lm_solve(C.byref(oo), C.cast(cb.dq_user_fcn, O.VECFCN), C.cast(None, O.JACFCN), C.byref(ctx), m, n,
+                              xo.ctypes.data_as(dp), fo.ctypes.data_as(dp), C.byref(ibo))
+        tc = time.perf_counter() - t0
+        rows.append({"path": f"least_squares_solver through nlh_lm_solve, compiled host callback (mode H), one {m}x{n} problem, FD Jacobian",
+                     "gpu_ms": 1e3 * tg, "cpu_oracle_ms": 1e3 * tc, "host_callback_ms_inside_gpu_ms": 1e3 * tcb,
+                     "callbacks": calls_g, "lm_iterations": ibg["jacobian_count"], "status": [int(rc_g), int(rc_o)],
+                     "bitwise_equal": bool(np.array_equal(xg, xo)),
+                     "counts_equal": bool(all(ibg[k] == ibo.as_dict()[k] for k in ("iter_count", "fcn_count", "jacobian_count"))),
+                     "note": "host-to-host, PCIe included (panel of n perturbed residuals up, nothing but x-sized vectors down); "
+                             "the n + 1 host callbacks per Jacobian are serial by the reference's contract (args may be mutated) "
+                             "and bound both columns: the drop-in wins what the factorisation costs on the host"})
+    return rows
+
+
+def predicted_scaling(ds, m=2048, n=128):
+    """What ONE GPU can say about the 1/2/4/8-GPU curves before an 8-GPU node measures them: the batch sizes each rank of
+    BASELINE config 4 (1024 problems of 2048x128) and of north_star's strong-scaling workload (8192 problems) gets at
+    1 / 2 / 4 / 8 GPUs, each solved here as rank 0's own share (problems 0, N, 2N, ...: seeds 12345 + i*N), exact policy,
+    library defaults.  Independent problems, no data-path collective: a rank does nothing else, so the N-GPU step time is
+    the slowest rank's solve plus the RCCL gather of x and fvec (tens of MB)."""
+    import torch
+    out = {"m": m, "n": n, "policy": POLICY_NAMES[2], "options": "nlh_default_options (sub-batches automatic)",
+           "note": "predicted speed-up at N GPUs = time(total) / time(total / N) on this GPU; measured here, not on N GPUs"}
+    for total, key in ((1024, "config4_1024_problems"), (8192, "strong_8192_problems")):
+        rows = []
+        t1 = None
+        for N in (1, 2, 4, 8):
+            nb = total // N
+            A, b, xt, x0 = ds.generate(nb, m, n, seed0=SEED0, gamma=GAMMA, sigma=SIGMA, spread=SPREAD, seed_stride=N)
+            o = ds.options(max_evals=500)
+            x = x0.clone()
+            ds.lm_solve_batch(A, b, GAMMA, x, o)
+            ts = []
+            for _ in range(3 if nb <= 2048 else 2):
+                x.copy_(x0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, ibs, st = ds.lm_solve_batch(A, b, GAMMA, x, o)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            t = min(ts)
+            nj = sum(i["jacobian_count"] for i in ibs)
+            if N == 1:
+                t1 = t
+            rows.append({"gpus": N, "problems_per_rank": nb, "solve_ms": 1e3 * t, "lm_iterations_per_s_per_rank": nj / t,
+                         "predicted_speedup": t1 / t, "predicted_efficiency": t1 / t / N})
+            del A, b, xt, x0, x
+            torch.cuda.empty_cache()
+        out[key] = rows
+    return out
+
+
 def fd_mode_h_roofline(ds, m=65536, n=512, reps=5):
     """The stand-alone FD column kernel (what the host-callback path runs: J(:,j) = (P(:,j) - f0)/h_j over a panel of
     perturbed residuals) at BASELINE config 5's size, HIP events on the launch stream."""
@@ -597,6 +704,11 @@ def main():
                 "parallelism": f"independent problems, block-cyclic over {world} rank(s)"
                                + ("; x and fvec all-gathered over RCCL inside every timed step" if world > 1 else ""),
                 "gather_check": gather_ok,
+                "timed_region": "host call to host return of nlh_dq_lm_solve_batch per step (SURVEY 8(d)'s solve wall time) with "
+                                "A, b, x0 resident in HBM and x, fvec LEFT in HBM: the device-to-host copy of the results "
+                                f"({8e-6 * B * (m + n):.0f} MB per step, about 0.1 % of a step over PCIe) is not in the timed region; "
+                                "per-problem counts and status come back in every step",
+
                 "accepted_steps_per_s": naccept_all / elapsed,
                 "non_converged": int(bad_all),
                 "iters_first_problem": [int(v) for v in allrows[0, :3].tolist()],
@@ -702,8 +814,11 @@ def main():
             v1a, _, ib1a, t1a = run_policy(ds.options(max_evals=max_evals, factor_policy=0), nrep=1, sel=slice(0, 1))
             out["auto_policy"]["single_problem_ms"] = 1e3 * t1a
             out["fd_jacobian_mode_h"] = fd_mode_h_roofline(ds)
+            del A, b, xt, x0, x                                    # the batch's 70 GB go before the scaling sweep allocates its own
+            torch.cuda.empty_cache()
+            out["predicted_scaling"] = predicted_scaling(ds)
         if world == 1 and args.other_paths:
-            out["other_paths"] = other_paths(ds)
+            out["other_paths"] = other_paths(ds) + mode_h_rows(ds)
         if cpu is not None:
             cpu["gpu_over_one_core"] = out["value"] / cpu["value"]
             if isinstance(cpu.get("all_cores"), dict) and "value" in cpu["all_cores"]:

@@ -965,10 +965,6 @@ k_qrx_pass(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, 
 // that is serial by definition (a dependent fp64 add with register operands issues every ~2 ns: profiles/ubench/dp_issue.hip).  One barrier per round of (W-1) x 16 rows; the adder
 // works one round behind the producers.  Same arithmetic on the same operands in the same order: bit-identical to
 // k_qrx_pass.
-#ifndef QRX_RP6_MAX_WG
-#define QRX_RP6_MAX_WG 128              // ... and of at most this many, with six waves (five producers) instead of four
-                                        // (256 until the end of round 3; 64 x 4096x256 = 256 pairs: 181 ms per solve with four waves, 190 with six)
-#endif
 #ifndef QRX_RP_MAX_WG
 #define QRX_RP_MAX_WG 512               // launches of at most this many (problem, window) pairs take the row-parallel pass
                                         // (re-swept at the end of round 3, ms per solve at 0 / 512 / 1024: 256 x 4096x256 431 / 410 / 428,
@@ -1178,27 +1174,33 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
                              rdall, waall, Rall, qtfall);
 }
 
-// The row-parallel pass, WIDE form, for the mid regime (tens to a few hundred problems: the straggler rounds of a big
-// batch, every per-rank share of a sharded batch): a launch of at most a few hundred (problem, window) pairs gives every
-// workgroup a CU (or half of one) to itself, and there k_qrx_pass_rp is bound by that CU's LDS pipe -- every producer
-// reads its reflector entries back as BROADCAST ds_reads, (NP + 1) / 2 sixteen-byte reads per row that each occupy the
-// pipe like a full 1 KB read, on top of the 1 KB written and 1 KB read per row pair for the products themselves:
-// 18-28 LDS cycles per row, 35-55 us per 4096-row step, whatever the number of producers.  Here the reflector entries
-// never go through LDS: lane l of a producer fetches the entries of ONE row of the producer's next eight row groups
-// (one coalesced load per slot and tile, as before) and a row's entries are pulled out of those registers with
-// v_readlane (constant lane index: the loops are unrolled) into scalar registers, which the multiplies take as scalar
-// operands.  The VALU has room for that once the work is spread over W - 1 = 7 or 15 producers (a wave's instruction
-// stream no longer bounds anything), and the LDS pipe is left with the products alone: 8 cycles per row.
+// The row-parallel pass, WIDE form: launches of at most QRX_RPW16_MAX_WG (problem, window) pairs -- the straggler rounds of
+// a big batch, small per-rank shares of a sharded batch.  There every workgroup has a CU to itself and k_qrx_pass_rp is
+// bound by that CU: its producers read their reflector entries back as BROADCAST ds_reads ((NP + 1) / 2 sixteen-byte
+// reads per row that each occupy the LDS pipe like a full 1 KB read) and a lone wave per SIMD pays every instruction's
+// latency itself.  Here: sixteen waves per workgroup -- wave 0 the adder, twelve producers, and the three waves that
+// share the adder's SIMD retire at once (the chain of dependent adds wants a SIMD to itself; roles are dealt from the
+// hardware's SIMD id at run time) --, the reflector entries of a producer's eight rows arrive by SCALAR loads (one
+// s_load_dwordx16 per slot and round, requested a barrier ahead) and are scalar operands of the multiplies: no LDS
+// traffic and no VALU work for them; the adder's LDS reads are issued by hand three producers' rows ahead of its adds.
 // Same arithmetic on the same operands in the same order: bit-identical to k_qrx_pass.
+// Measured on the way (in-kernel clocks, 32 x 4096x256, us per pass of ~4000 rows): reflector entries through v_readlane
+// out of a register tile instead of scalar loads -- 2 (NP + 1) more VALU instructions per row -- had the twelve producers
+// at 26 us of produce time against 8 us now; the compiler's own schedule of the adder ("twelve reads, wait for all,
+// twenty-four adds") 30 us of consume against 26; a branch around the flush's stores made the compiler's wait counts
+// assume the path without stores.  What bounds the form from 32 problems of 4096 x 256 on is HBM again: a pass reads
+// 268 MB (45 us = 5.9 TB/s, profiles/ubench/tcp_pattern.hip: a CU alone pulls 20 bytes per clock in the lane-per-column
+// access shape and 39 with whole sectors per lane quad, 256 CUs together 9.7 / 11.3 = the HBM rate) and a flushing pass
+// reads and writes it (118 us) -- which is why the form ends at 128 pairs: beyond, the four-wave form's longer flush
+// period (8 instead of 4 steps; this form keeps at most three pending reflectors in scalar registers) is worth more than
+// its faster passes (ms per solve, this form up to 128 / 256 / 384 pairs: 64 x 4096x256 172 / 184 / 184, 128 x 4096x256
+// 232 / 240 / 253, 192 x 2048x128 60 / 58 / 66; eight-wave workgroups for 257-512 pairs: 128 x 4096x256 257, dropped).
 #ifndef QRX_RPW16_MAX_WG
-#define QRX_RPW16_MAX_WG 256            // launches of at most this many (problem, window) pairs: sixteen waves per workgroup
-#endif                                  // (120 KB of LDS: one workgroup per CU), a flush every 4th step
-#ifndef QRX_RPW8_MAX_WG
-#define QRX_RPW8_MAX_WG 512             // ... and of at most this many: eight waves (56 KB: two per CU)
+#define QRX_RPW16_MAX_WG 128            // launches of at most this many (problem, window) pairs take the wide form
 #endif
 #ifndef QRX_FEW_MAX
 #define QRX_FEW_MAX 256                 // batches of at most this many active problems take the pivot kernel's FEW instance
-#endif
+#endif                                  // (32 x 4096x256: 111 instead of 122 ms per solve)
 #define QRX_RPW_G 8                     // rows per producer and round: one 64-byte sector per lane
 #define QRX_RPW_AH 4                    // row groups in flight per producer
 __device__ __forceinline__ double qrx_readlane_f64(double x, int l)
@@ -1214,8 +1216,14 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
                double *__restrict__ waall, const QrxStep *__restrict__ stepall, double *__restrict__ Rall,
                double *__restrict__ qtfall, const LmState *__restrict__ st)
 {
-    constexpr int NPR = W - 1, G = QRX_RPW_G, AH = QRX_RPW_AH, D = 64 / G, RR = NPR * G;
-    static_assert(D % AH == 0 && G == 8, "a tile is 64 / G rounds, a row group one sector per lane");
+    // The adder's chain of dependent adds wants a SIMD to itself (an add every ~4.6 cycles is 87 % of the SIMD's fp64 issue
+    // rate; sharing it round-robin with four producers stretched every add to ~20 cycles: 50 us per 4096-row pass whatever
+    // NP).  The W waves of the workgroup land W / 4 on each SIMD; the waves that share wave 0's SIMD retire at once and the
+    // other 3 W / 4 are the producers.  (Which waves those are is read from the hardware id at run time; if the placement
+    // is ever uneven, waves of the adder's SIMD fill in, or surplus ones retire: always exactly NPR producers.)
+    constexpr int NPR = 3 * W / 4, G = QRX_RPW_G, AH = QRX_RPW_AH, D = AH, RR = NPR * G;                 // D: rounds per trip of the outer loops
+    static_assert(G == 8, "a row group is one sector per lane");
+    __shared__ int simd_of[W];
     constexpr int NPI = NP < QRX_C ? NP : 0;
     extern __shared__ __attribute__((aligned(16))) double pbw[];         // [2][RR / 2][64][2]: the products of a round, row pairs
     const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
@@ -1226,7 +1234,29 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
     const int lane = threadIdx.x & 63, ldp = n + 1;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool adder = (wv == 0);
-    const int pw = adder ? 0 : wv - 1;
+#ifdef QRX_DBG_CLK
+    const long long ckk = wall_clock64();
+#endif
+    // roles: HW_REG_HW_ID bits 5:4 = the SIMD this wave runs on
+    if (lane == 0) simd_of[wv] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
+    __syncthreads();
+    int pw = 0;
+    {
+        const int as = simd_of[0];
+        int other = 0, same = 0, mine_other = 0, mine_same = 0;          // waves 1 .. W-1 off / on the adder's SIMD, and how many before this one
+#pragma unroll
+        for (int w2 = 1; w2 < W; ++w2) {
+            const bool o = simd_of[w2] != as;
+            if (w2 < wv) { mine_other += o ? 1 : 0; mine_same += o ? 0 : 1; }
+            other += o ? 1 : 0; same += o ? 0 : 1;
+        }
+        if (!adder) {
+            const bool o = simd_of[wv] != as;
+            pw = o ? mine_other : other + mine_same;                     // off-SIMD waves first, then fill-ins
+            if (pw >= NPR) return;                                       // shares the adder's SIMD (or surplus): retire
+        }
+    }
+    if (adder) __builtin_amdgcn_s_setprio(3);
     const QrxStep step = stepall[p];
     const bool refl = step.ajnorm != 0.0;
     const double ajj = step.ajj;
@@ -1267,24 +1297,45 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
         // the ordered sum (:652-653): the products of round t - 1 while the producers form those of round t; a producer's
         // eight rows at a time, the reads of the next two producers' rows in flight
         double s = 0.0;
+        // The reads are issued by hand, three producers' rows (12 reads: the counter holds 15) ahead of the adds, and waited
+        // for chunk by chunk (LDS returns in order).  Left to the compiler the round became "twelve reads, wait for all of
+        // them, twenty-four adds": the LDS latency in full once per 24 rows, 16-20 cycles per row instead of the chain's 4.6.
+        typedef double qrx_v2d __attribute__((ext_vector_type(2)));
         auto consume = [&](const double *half) __attribute__((always_inline)) {
-            const double2 *src2 = reinterpret_cast<const double2 *>(half) + lane;      // pair pr at src2[pr * 64]
-            double2 w3[3][4];
-            auto rd = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-                for (int h = 0; h < 4; ++h) w3[c % 3][h] = src2[(size_t)(c * 4 + h) * 64];
-            };
-            rd(0);
-            if (NPR > 1) rd(1);
+            const unsigned addr = (unsigned)(size_t)(half + 2 * lane);                 // pair pr at addr + pr * 1024 bytes
+            qrx_v2d w4[4][4];
+#define QRX_RD4(c)                                                                                                  \
+            asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"                       \
+                         "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                           \
+                         : "=&v"(w4[(c) & 3][0]), "=&v"(w4[(c) & 3][1]), "=&v"(w4[(c) & 3][2]), "=&v"(w4[(c) & 3][3])  \
+                         : "v"(addr), "n"((c) * 4096), "n"((c) * 4096 + 1024), "n"((c) * 4096 + 2048), "n"((c) * 4096 + 3072) : "memory")
+#define QRX_WAIT4(c, N)                                                                                             \
+            asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(w4[(c) & 3][0]), "+v"(w4[(c) & 3][1]), "+v"(w4[(c) & 3][2]), "+v"(w4[(c) & 3][3]))
+            static_assert(NPR >= 3 && NPR * 4096 <= 65536, "three chunks in flight; immediate offsets of the reads");
+            QRX_RD4(0); QRX_RD4(1); QRX_RD4(2);
 #pragma unroll
             for (int c = 0; c < NPR; ++c) {
-                if (c + 2 < NPR) rd(c + 2);
+                // chunk c complete (at most two younger chunks outstanding), then the chunk three ahead is requested
+                if (c + 2 < NPR) { QRX_WAIT4(c, 8); }
+                else if (c + 1 < NPR) { QRX_WAIT4(c, 4); }
+                else { QRX_WAIT4(c, 0); }
+                if (c + 3 < NPR) {
+                    switch ((c + 3) % 16) {                               // (the chunk index must be a literal for the immediates)
+#define QRX_CASE(k) case k: QRX_RD4(k); break;
+                    QRX_CASE(3) QRX_CASE(4) QRX_CASE(5) QRX_CASE(6) QRX_CASE(7) QRX_CASE(8) QRX_CASE(9) QRX_CASE(10) QRX_CASE(11)
+                    QRX_CASE(12) QRX_CASE(13) QRX_CASE(14) QRX_CASE(15)
+#undef QRX_CASE
+                    default: break;
+                    }
+                }
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    s = s + w3[c % 3][h].x;                             // :653, rows ascending
-                    s = s + w3[c % 3][h].y;
+                    s = s + w4[c & 3][h].x;                             // :653, rows ascending
+                    s = s + w4[c & 3][h].y;
                 }
             }
+#undef QRX_RD4
+#undef QRX_WAIT4
         };
         auto consume_edge = [&](const double *half, int rbase) __attribute__((always_inline)) {    // the round of row j, the last round
             const double2 *src2 = reinterpret_cast<const double2 *>(half) + lane;
@@ -1296,32 +1347,68 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
                 if (row + 1 >= r0 && row + 1 < mrel) s = s + ww.y;
             }
         };
+#ifdef QRX_DBG_CLK
+        long long ck0 = wall_clock64(), cwork = 0, cwait = 0;
+#endif
         qrx_lds_barrier();
+#ifdef QRX_DBG_CLK
+        long long ck1 = wall_clock64();
+#endif
 #pragma unroll 1
         for (int t = 0; t < ntile * D; ++t) {
+#ifdef QRX_DBG_CLK
+            const long long ca = wall_clock64();
+#endif
             if (t >= 1 && t <= nround) {
                 const int rbase = (t - 1) * RR;
                 const double *half = ((t - 1) & 1) ? pb1 : pb0;
                 if (rbase >= r0 && rbase + RR <= mrel) consume(half);
                 else consume_edge(half, rbase);
             }
+#ifdef QRX_DBG_CLK
+            const long long cb = wall_clock64();
+#endif
             qrx_lds_barrier();
+#ifdef QRX_DBG_CLK
+            cwork += cb - ca; cwait += wall_clock64() - cb;
+#endif
         }
+#ifdef QRX_DBG_CLK
+        if (lane == 0 && j >= 99 && j <= 101 && blockIdx.x < 1)
+            printf("rpw adder wg %d j=100 W=%d NP=%d: head %lld first-barrier %lld consume %lld barrier-wait %lld rounds %d (x10 ns) simd %d\n",
+                   blockIdx.x, W, NP, ck0 - ckk, ck1 - ck0, cwork, cwait, nround, simd_of[0]);
+#endif
         if (!act) return;
         qrx_pass_tail<NP, FLUSH>(p, j, k, col, coff + k, m, n, ld, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq, Tp, vc, vo, tpall,
                                  rdall, waall, Rall, qtfall);
         return;
     }
     // producer side ---------------------------------------------------------------------------------------------------
-    // reflector tile kt of producer pw: the D row groups it handles in rounds kt*D .. kt*D + D-1; lane l holds the entries
-    // of group l / G, row l % G (clamped to the last row: entries past it are never used)
-    double sv[NP + 1], svn[NP + 1];
-    auto vfetch = [&](int kt, double (&dst)[NP + 1]) __attribute__((always_inline)) {
-        const int row = min((kt * D + (lane >> 3)) * RR + pw * G + (lane & 7), mrel - 1);
+    // The reflector entries of a producer's eight rows of a round are wave-uniform: one scalar load of 64 bytes per slot
+    // (s_load_dwordx16 into sixteen SGPRs), requested at the end of the round before -- the barrier in between covers its
+    // latency -- and taken by the multiplies as scalar operands: no LDS traffic, no VALU work for them.  (With v_readlane out
+    // of a register tile instead, 2 (NP + 1) extra VALU instructions per row made the producers the bottleneck: twelve
+    // producers x 34 cycles per row on three SIMDs against the ~8 cycles per row the LDS pipe needs for the products.)
+    typedef int qrx_i16 __attribute__((ext_vector_type(16)));
+    qrx_i16 sq[NP + 1];
+    auto sfetch = [&](int t) __attribute__((always_inline)) {            // rounds past the last one re-read the last (never used)
+        const int row = min(t, nround - 1) * RR + pw * G;               // a multiple of 8: 64-byte aligned
 #pragma unroll
-        for (int q = 0; q < NP; ++q) dst[q] = vc[(size_t)q * vst + row];
-        dst[NP] = FLUSH ? vo[row] : vc[(size_t)NPI * vst + row];
+        for (int q = 0; q <= NP; ++q) {
+            const double *src = (q < NP) ? vc + (size_t)q * vst + row : (FLUSH ? vo + row : vc + (size_t)NPI * vst + row);
+            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(sq[q]) : "s"(src) : "memory");
+        }
     };
+    auto swait = [&]() __attribute__((always_inline)) {
+        if constexpr (NP == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]));
+        if constexpr (NP == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]));
+        if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]), "+s"(sq[2]));
+        if constexpr (NP == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]), "+s"(sq[2]), "+s"(sq[3]));
+        if constexpr (NP == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]), "+s"(sq[2]), "+s"(sq[3]), "+s"(sq[4]));
+        if constexpr (NP == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]), "+s"(sq[2]), "+s"(sq[3]), "+s"(sq[4]), "+s"(sq[5]));
+        static_assert(NP <= 5, "sixteen SGPRs per slot");
+    };
+    auto sval = [&](int q, int u) __attribute__((always_inline)) { return __hiloint2double(sq[q][2 * u + 1], sq[q][2 * u]); };
     double a[AH][G];
     auto load = [&](double (&buf)[G], int t) __attribute__((always_inline)) {                          // the producer's group of round t
         const unsigned boff = (unsigned)((t * RR + pw * G) >> 3) * ldb;
@@ -1332,7 +1419,7 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
             buf[2 * q2 + 1] = __hiloint2double((int)w.w, (int)w.z);
         }
     };
-    auto produce = [&](const double (&buf)[G], int t, int i) __attribute__((always_inline)) {         // i = t % D: compile-time
+    auto produce = [&](const double (&buf)[G], int t) __attribute__((always_inline)) {
         const int rbase = t * RR + pw * G;
         double *dst = ((t & 1) ? pb1 : pb0) + ((size_t)(pw * (G / 2)) * 64 + lane) * 2;
         double est[8];
@@ -1341,59 +1428,78 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
             double e0 = buf[u], e1 = buf[u + 1];
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const double p0_ = tq[q] * qrx_readlane_f64(sv[q], i * G + u), p1_ = tq[q] * qrx_readlane_f64(sv[q], i * G + u + 1);
+                const double p0_ = tq[q] * sval(q, u), p1_ = tq[q] * sval(q, u + 1);
                 e0 = e0 - p0_;
                 e1 = e1 - p1_;
             }
             double2 ww;                                                 // rows outside the live range: garbage the adder skips
-            ww.x = qrx_readlane_f64(sv[NP], i * G + u) * e0;
-            ww.y = qrx_readlane_f64(sv[NP], i * G + u + 1) * e1;
+            ww.x = sval(NP, u) * e0;
+            ww.y = sval(NP, u + 1) * e1;
             *reinterpret_cast<double2 *>(dst + (size_t)(u >> 1) * 128) = ww;
             if (FLUSH) { est[u] = e0; est[u + 1] = e1; }
         }
         if (FLUSH) {
+            // The whole sector, unconditionally.  Rows of the block above row j are dead (final rows of R live in their own
+            // array), rows past m are the padding of the problem's last block, blocks past the matrix are dropped by the
+            // buffer's range check, idle lanes are parked out of range.  A branch around these stores makes the compiler's
+            // wait counts assume the path WITHOUT stores (stores count in vmcnt on this part and retire in issue order), so
+            // that every wait for a load group also waited for the stores of the rounds before: a store acknowledgement
+            // per round, 117 instead of 45 us per 4096-row flushing pass.
             const unsigned boff = (unsigned)(rbase >> 3) * ldb;
-            if (rbase >= r0 && rbase + 8 <= mrel) {                      // uniform: a whole 64-byte sector per lane
 #pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2) {
-                    qrx_u32x4 w;
-                    w.x = (unsigned)__double2loint(est[2 * q2]); w.y = (unsigned)__double2hiint(est[2 * q2]);
-                    w.z = (unsigned)__double2loint(est[2 * q2 + 1]); w.w = (unsigned)__double2hiint(est[2 * q2 + 1]);
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, ko + 16u * q2, boff, QRX_AUX_STORE);
-                }
-            } else {                                                    // the block of row j, the last block: row by row
-#pragma unroll
-                for (int q2 = 0; q2 < 8; ++q2) {
-                    qrx_u32x2 w;
-                    w.x = (unsigned)__double2loint(est[q2]); w.y = (unsigned)__double2hiint(est[q2]);
-                    if (rbase + q2 >= r0 && rbase + q2 < mrel)
-                        __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, ko + 8u * q2, boff, QRX_AUX_STORE);
-                }
+            for (int q2 = 0; q2 < 4; ++q2) {
+                qrx_u32x4 w;
+                w.x = (unsigned)__double2loint(est[2 * q2]); w.y = (unsigned)__double2hiint(est[2 * q2]);
+                w.z = (unsigned)__double2loint(est[2 * q2 + 1]); w.w = (unsigned)__double2hiint(est[2 * q2 + 1]);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, ko + 16u * q2, boff, QRX_AUX_STORE);
             }
         }
     };
-    vfetch(0, sv);
+    sfetch(0);
 #pragma unroll
     for (int i = 0; i < AH - 1; ++i) load(a[i], i);
+#ifdef QRX_DBG_CLK
+    long long pk0 = wall_clock64(), pwork = 0, pwait = 0, psm = 0;
+#endif
     qrx_lds_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int kt = 0; kt < ntile; ++kt) {
-        vfetch(kt + 1, svn);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             const int t = kt * D + i;
+#ifdef QRX_DBG_CLK
+            const long long pa = wall_clock64();
+#endif
             // (the scheduler fences keep a round's arithmetic behind the round's loads: the products depend on nothing but
-            // registers, and left alone the compiler hoists the arithmetic of every group in flight to the head of the tile
-            // -- a full drain of the load pipeline per tile)
+            // registers, and left alone the compiler hoists the arithmetic of every group in flight to the head of the
+            // unrolled rounds -- a full drain of the load pipeline each time)
             load(a[(i + AH - 1) % AH], t + AH - 1);
+            swait();
             __builtin_amdgcn_sched_barrier(0);
-            produce(a[i % AH], t, i);
+            produce(a[i % AH], t);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef QRX_DBG_CLK
+            const long long pbs = wall_clock64();
+#endif
+            sfetch(t + 1);                                              // after the last use of this round's entries
+#ifdef QRX_DBG_CLK
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long long pbk = wall_clock64();
+            psm += pbk - pbs;
+#endif
             qrx_lds_barrier();
+#ifdef QRX_DBG_CLK
+            pwork += pbk - pa; pwait += wall_clock64() - pbk;
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int q = 0; q <= NP; ++q) sv[q] = svn[q];
     }
+#ifdef QRX_DBG_CLK
+    if (lane == 0 && j >= 99 && j <= 101 && blockIdx.x < 1 && (pw == 0 || pw == NPR - 1))
+        printf("rpw producer %d wg %d j=100: head %lld produce+smem %lld (smem+lds drain %lld) barrier-wait %lld (x10 ns) simd %d\n", pw, blockIdx.x, pk0 - ckk, pwork, psm, pwait,
+               simd_of[wv]);
+#endif
 }
 
 // The pass for a HANDFUL of problems (straggler rounds, one problem alone; factorisations of at most QRX_COL_MAX_WG
@@ -1610,7 +1716,7 @@ k_qrx_finish(int m, int n, int ld, int coff, size_t tst, size_t vst, int cur, in
     }
 }
 
-static constexpr size_t qrx_rpw_lds(int W) { return (size_t)(W - 1) * QRX_RPW_G * 1024; }   // two buffers of (W - 1) * 8 rows x 64 lanes x 8 bytes
+static constexpr size_t qrx_rpw_lds(int W) { return (size_t)(3 * W / 4) * QRX_RPW_G * 1024; }   // two buffers of 3 W / 4 * 8 rows x 64 lanes x 8 bytes
 
 template <int NP, bool FLUSH>
 static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
@@ -1621,20 +1727,16 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     const int nwin = (n + 1 - lo + 63) / 64;                            // live physical columns coff + lo .. coff + n
     const dim3 grid((unsigned)(((nprob + 7) / 8) * 8 * nwin));
     if constexpr (NP >= 8) rp = 0;
-    if constexpr (NP >= 4) { if (rp == 16) rp = 8; }
+    // the wide row-parallel form keeps its reflector entries in scalar registers (sixteen per slot): at most three pending
+    // updates; a launch that inherits more from the form before it takes the four-wave form until the next flush
+    if constexpr (NP >= 4) { if (rp == 16) rp = 4; }
     if constexpr (NP < 8) {
     if constexpr (NP < 4) {
     if (rp == 16)
         hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16>), grid, dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
     }
-    if (rp == 8)
-        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 8>), grid, dim3(64 * 8), qrx_rpw_lds(8), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
-                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
-    if (rp == 6)
-        hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 6>), grid, dim3(64 * 6), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
-                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
-    else if (rp == 4)
+    if (rp == 4)
         hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 4>), grid, dim3(64 * 4), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
     }
@@ -1717,11 +1819,8 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     static const int forced_period = [] { const char *e = getenv("NLH_QRX_PERIOD"); return e ? atoi(e) : 0; }();
     static const long rp_env = [] { const char *e = getenv("NLH_QRX_RP"); return e ? atol(e) : -1L; }();
     const long rp_max = rp_env >= 0 ? rp_env : QRX_RP_MAX_WG;
-    static const long rp6_env = [] { const char *e = getenv("NLH_QRX_RP6"); return e ? atol(e) : -1L; }();
-    const long rp6_max = std::min(rp_max, rp6_env >= 0 ? rp6_env : (long)QRX_RP6_MAX_WG);
     static const long rpw16_env = [] { const char *e = getenv("NLH_QRX_RPW16"); return e ? atol(e) : -1L; }();
-    static const long rpw8_env = [] { const char *e = getenv("NLH_QRX_RPW8"); return e ? atol(e) : -1L; }();
-    const long rpw16_max = rpw16_env >= 0 ? rpw16_env : (long)QRX_RPW16_MAX_WG, rpw8_max = rpw8_env >= 0 ? rpw8_env : (long)QRX_RPW8_MAX_WG;
+    const long rpw16_max = std::min(rp_max, rpw16_env >= 0 ? rpw16_env : (long)QRX_RPW16_MAX_WG);
     static const int col_env = [] { const char *e = getenv("NLH_QRX_COL"); return e ? atoi(e) : -1; }();
     if (col_env >= 0 ? nact <= col_env : (long)nact * n <= QRX_COL_MAX_WG) {
         // two product buffers for columns of several chunks, one sized to the column otherwise
@@ -1788,11 +1887,11 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     for (int j = 0; j < n; ++j) {
         const int nwin = (n + 1 - lo + 63) / 64;
         const long nwg = (long)nact * nwin;
-        // waves per workgroup of the row-parallel pass (16 / 8: the wide form, reflector entries by v_readlane), 0: one wave
-        const int rp = nwg <= rpw16_max ? 16 : nwg <= rpw8_max ? 8 : nwg <= rp6_max ? 6 : nwg <= rp_max ? 4 : 0;
-        // a launch that leaves most of the chip idle is bound by the instruction stream of its few waves, not by HBM:
-        // flush every 3rd step there (at most 3 pending updates per row instead of 7; lone problem: 111 -> 103 ms)
-        const int period = forced_period ? forced_period : ((rp == 6 || rp == 16) ? 4 : (rp == 4 || rp == 8) ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
+        // waves per workgroup of the row-parallel pass (16: the wide form, k_qrx_pass_rpw), 0: one wave per window
+        const int rp = nwg <= rpw16_max ? 16 : nwg <= rp_max ? 4 : 0;
+        // the wide form keeps at most three pending reflectors (scalar registers): a flush every 4th step; the four-wave
+        // form every 8th; full launches every QRX_C-th
+        const int period = forced_period ? forced_period : (rp == 16 ? 4 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
         const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
         const int pf = (flush ? 1 : 0) | (prev_flushed ? 2 : 0);

@@ -18,16 +18,20 @@ def main():
     import torch
     from nonlin_amd.device import DeviceSolver
     check = "--check" in sys.argv
+    sub = 1                                                        # --sub=N: sub-batches in flight (0 = the library's automatic choice)
+    for a in sys.argv[1:]:
+        if a.startswith("--sub="):
+            sub = int(a.split("=")[1])
     specs = [a for a in sys.argv[1:] if not a.startswith("--")]
     ds = DeviceSolver(0)
     tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("NLH_QRX"))
-    print(f"# {tag or 'defaults'}", flush=True)
+    print(f"# {tag or 'defaults'} sub_batches={sub}", flush=True)
     for spec in specs:
         shape, _, counts = spec.partition(":")
         m, n = (int(v) for v in shape.split("x"))
         for nb in (int(c) for c in counts.split(",")):
             A, b, xt, x0 = ds.generate(nb, m, n, seed0=12345)
-            opts = ds.options(max_evals=500, sub_batches=1)
+            opts = ds.options(max_evals=500, sub_batches=sub)
             x = x0.clone()
             ds.lm_solve_batch(A, b, 0.5, x, opts)
             torch.cuda.synchronize()

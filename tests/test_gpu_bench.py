@@ -42,9 +42,17 @@ def test_bench_single_process():
     a = d["auto_policy"]                                       # the fast opt-in policy and its measured deviation
     assert a["value"] > 0 and a["problems_compared"] == 4 and 0.0 <= a["max_rel_dev_x"] < 1e-4
     assert d["fd_jacobian_mode_h"]["bound"] == "hbm" and d["fd_jacobian_mode_h"]["achieved"] > 0
-    rows = d["other_paths"]        # Newton, quasi-Newton, bounded LSQ, BFGS, their three lock-step batches, polynomial
-    assert len(rows) == 8 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
+    rows = d["other_paths"]        # Newton, quasi-Newton, bounded LSQ, BFGS, their three lock-step batches, polynomial,
+    #                                and the two mode-H rows (nlh_lm_solve with a compiled host callback)
+    assert len(rows) == 10 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
     assert sum("lock-step" in r["path"] for r in rows) == 3
+    mh = [r for r in rows if "mode H" in r["path"]]
+    assert len(mh) == 2 and all(r["counts_equal"] and r["callbacks"] > 0 and r["status"] == [0, 0] for r in mh)
+    ps = d["predicted_scaling"]    # per-rank batch sizes of config 4 / the 8192-problem run at 1, 2, 4, 8 GPUs, timed on this one
+    for key, total in (("config4_1024_problems", 1024), ("strong_8192_problems", 8192)):
+        assert [r["gpus"] for r in ps[key]] == [1, 2, 4, 8]
+        assert all(r["problems_per_rank"] * r["gpus"] == total and r["solve_ms"] > 0 for r in ps[key])
+    assert "timed_region" in d["config"]
     ac = c["all_cores"]                                        # pinned workers, problems generated before the clock
     assert ac["value"] > 0 and ac["cores"] >= 1 and "cpu_model" in ac and ac["gpu_over_all_cores"] > 0
     eb = d["roofline"]["event_bracketing"]                     # what the live HIP-event brackets of the timed region cost

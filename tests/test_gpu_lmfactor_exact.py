@@ -4,7 +4,7 @@ on matrices built to reach the corners the random LM problems rarely visit: grad
 every NORM2 run), graded and permuted columns (non-trivial pivoting), duplicate columns (ties: lowest index wins), zero
 and dependent columns (zero reflectors), exact zeros, sizes on both sides of the kernels' internal limits (more than 256
 candidate columns, columns longer than one NORM2 chunk), and the same matrix in batches that select each of the three
-forms of the trailing pass (six-wave and four-wave row-parallel, one wave per window)."""
+forms of the trailing pass (the wide sixteen-wave and the four-wave row-parallel form, one wave per window)."""
 import numpy as np
 import pytest
 import torch
@@ -117,7 +117,7 @@ def test_lmfactor_exact_bitwise_long_columns(ds, oracle, kind, m, n, copies):
 @pytest.mark.parametrize("copies", [1, 40, 60, 200, 300, 1100])
 def test_lmfactor_exact_every_pass_form(ds, oracle, copies):
     """The same graded 520 x 70 matrix (two 64-column windows) in batches of 1 / 40 (<= 3072 (problem, column) pairs: the
-    workgroup-per-column sweep), 60 (120 (problem, window) pairs: six-wave row-parallel; at most 128), 200 (400: four-wave; at most 512), 300 and 1100
+    workgroup-per-column sweep), 60 (120 (problem, window) pairs: the wide row-parallel form, sixteen waves; at most 128), 200 (400: four-wave; at most 512), 300 and 1100
     (one wave per window, separate and as the waves of one workgroup); all the same bits."""
     rng = np.random.default_rng(99)
     a = _matrix("graded_rows", 520, 70, rng)
