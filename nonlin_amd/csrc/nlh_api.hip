@@ -61,6 +61,7 @@ struct nlh_handle {
            qnQ, qnR, qnV, bfB, bfR, bfV, qxV;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    DevBuf cholmc;                     // side buffer of the multi-CU Cholesky (solved panels, bad-pivot flags)
     void *staging = nullptr;           // pinned staging of a device-set share's rows of the caller's host arrays
     size_t staging_bytes = 0;
     bool qrx_open_on = false; hipEvent_t qrx_a{}, qrx_b{}; int qrx_kid = 0;   // open bracket of a nlh_qrx.hip launch
@@ -222,6 +223,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_gram_tri<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_nopiv<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_chol_mc_step<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -625,7 +627,26 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
     {   // fast path: blocked Cholesky in natural order, G -> R
         Timed t(h, NLH_K_CHOL);
         size_t sh = sizeof(double) * ((size_t)NB * n + NB * NB + n + NB + 64);
-        if (sh <= 150 * 1024) {
+        // a handful of problems (BASELINE config 5's one 65536 x 512 problem): a launch per panel step over many CUs
+        // instead of one workgroup per problem; same bits (nlh_kernels_factor.h)
+        const char *mc_e = getenv("NLH_CHOL_MC");                   // (read per call: tests switch between the two forms)
+        const int mc_max = mc_e ? atoi(mc_e) : 8;
+        const int na = nact < 0 ? nprob : nact;
+        if (sh <= 150 * 1024 && n >= 192 && na <= mc_max) {
+            int rc2;
+            if ((rc2 = ensure(h, h->cholmc, sizeof(double) * (size_t)nprob * 2 * (NB * n + NB * NB + NB) + sizeof(int32_t) * (size_t)nprob + 64))) return rc2;
+            double *side = (double *)h->cholmc.p;
+            double *fact = side + (size_t)nprob * 2 * NB * n;
+            int32_t *bad = (int32_t *)(fact + (size_t)nprob * 2 * (NB * NB + NB));
+            hipLaunchKernelGGL(k_chol_mc_begin<NB>, dim3(64, nprob), dim3(256), 0, h->stream, n, (const double *)w.G, (const double *)w.g, w.R, w.v,
+                               fact, bad, (const LmState *)w.st, o->ne_pivot_tol);
+            const size_t shm = sizeof(double) * ((size_t)NB * n + 2 * (NB * NB + 2 * NB));
+            for (int jb = 0; jb < n; jb += NB)
+                hipLaunchKernelGGL(k_chol_mc_step<NB>, dim3(CHOLMC_NWG + 2, nprob), dim3(512), shm, h->stream, n, jb, w.R, w.v, side, fact, bad,
+                                   (const LmState *)w.st, o->ne_pivot_tol);
+            hipLaunchKernelGGL(k_chol_mc_end<NB>, dim3(nprob), dim3(ft), sizeof(double) * (size_t)n, h->stream, n, w.R, w.v, (const double *)side, (const int32_t *)bad, dx,
+                               w.st, o->factor, o->gtol);
+        } else if (sh <= 150 * 1024) {
             // more problems than CUs: 512-thread workgroups, two of which fit a CU (128 VGPRs each), so that the
             // latency-bound phases of one factorisation overlap the MFMA phase of the other
             const int ct = (ft == 1024 && (nact < 0 ? nprob : nact) > 256) ? 512 : ft;

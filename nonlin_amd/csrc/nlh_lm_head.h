@@ -15,8 +15,9 @@ template <bool EXACT>
 __device__ void lm_head(int n, const double *R, int ldr, const int32_t *ipvt,
                         const double *acnorm, const double *qtf, const double *x,
                         double *diag, double *diag_prev, LmState *s, double factor,
-                        double gtol, int ready_stage, double *red, double *scratch)
-{
+                        double gtol, int ready_stage, double *red, double *scratch, double *qs = nullptr)
+{   // qs: optional n doubles of LDS for the quotients qtf(i) / fnorm of the gradient test (each thread otherwise divides
+    // again for every term of its sum: n^2 / 2 divisions; the same quotients either way, hence the same bits)
     const int tid = threadIdx.x, BS = blockDim.x;
     const int iter = s->iter;
     if (iter == 1) {                                            // :229-238
@@ -38,7 +39,17 @@ __device__ void lm_head(int n, const double *R, int ldr, const int32_t *ipvt,
     }
     const double fnorm = s->fnorm;
     double gn = 0.0;                                            // :256-267
-    if (fnorm != 0.0) {
+    if (fnorm != 0.0 && qs) {
+        for (int i = tid; i < n; i += BS) qs[i] = qtf[i] / fnorm;
+        __syncthreads();
+        for (int j = tid; j < n; j += BS) {
+            const int l = ipvt[j];
+            if (acnorm[l] == 0.0) continue;
+            double sm = 0.0;
+            for (int i = 0; i <= j; ++i) sm = sm + R[(size_t)j * ldr + i] * qs[i];
+            gn = fmax(gn, fabs(sm / acnorm[l]));
+        }
+    } else if (fnorm != 0.0) {
         for (int j = tid; j < n; j += BS) {
             const int l = ipvt[j];
             if (acnorm[l] == 0.0) continue;

@@ -1,0 +1,56 @@
+"""The multi-CU blocked Cholesky of the opt-in normal-equations policy (k_chol_mc_begin / _step / _end: a launch per panel
+step over many CUs, for a handful of problems -- BASELINE config 5) against the one-workgroup-per-problem kernel it
+stands in for (k_chol_nopiv): the same operations in the same order, so an LM solve under NLH_FACTOR_AUTO must produce the
+same bits either way (NLH_CHOL_MC = largest number of active problems that takes the multi-CU form; 0 = never)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("nb,m,n", [(1, 3000, 512), (3, 2048, 256), (2, 1500, 200), (1, 4100, 500), (1, 2000, 700)])
+def test_multi_cu_cholesky_same_bits_as_single_workgroup(ds, nb, m, n):
+    A, b, xt, x0 = ds.generate(nb, m, n, seed0=4242)
+    res = {}
+    old = os.environ.get("NLH_CHOL_MC")
+    try:
+        for mc in ("0", "8"):
+            os.environ["NLH_CHOL_MC"] = mc
+            x = x0.clone()
+            fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=500, factor_policy=0))
+            torch.cuda.synchronize()
+            res[mc] = (x.cpu().numpy().copy(), fvec.cpu().numpy().copy(), [tuple(sorted(i.items())) for i in ibs], list(status))
+    finally:
+        if old is None:
+            os.environ.pop("NLH_CHOL_MC", None)
+        else:
+            os.environ["NLH_CHOL_MC"] = old
+    assert res["0"][3] == res["8"][3] == [0] * nb
+    assert res["0"][2] == res["8"][2]
+    assert np.array_equal(res["0"][0], res["8"][0]) and np.array_equal(res["0"][1], res["8"][1])
+
+
+def test_multi_cu_cholesky_hands_over_on_a_bad_pivot(ds):
+    """Duplicated columns: J^T J is singular, the natural-order Cholesky meets a non-positive pivot and hands over to the
+    pivoted kernel / QR (ST_NEED_PCHOL) -- same decision, same result in both forms."""
+    A, b, xt, x0 = ds.generate(1, 1024, 256, seed0=99)
+    A[:, 200:, :] = A[:, :56, :]
+    res = {}
+    old = os.environ.get("NLH_CHOL_MC")
+    try:
+        for mc in ("0", "8"):
+            os.environ["NLH_CHOL_MC"] = mc
+            x = x0.clone()
+            fvec, ibs, status = ds.lm_solve_batch(A, b, 0.5, x, ds.options(max_evals=60, factor_policy=0))
+            torch.cuda.synchronize()
+            res[mc] = (x.cpu().numpy().copy(), [tuple(sorted(i.items())) for i in ibs], list(status))
+    finally:
+        if old is None:
+            os.environ.pop("NLH_CHOL_MC", None)
+        else:
+            os.environ["NLH_CHOL_MC"] = old
+    assert res["0"][1] == res["8"][1] and res["0"][2] == res["8"][2]
+    assert np.array_equal(res["0"][0], res["8"][0])
