@@ -221,6 +221,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     qrx_init_device();
     hipFuncSetAttribute((const void *)k_gram_tri<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_gram_tri<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_gram_512, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_nopiv<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_chol_mc_step<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -473,6 +474,8 @@ static int gram_splits(int m)
     return s < 1 ? 1 : s;
 }
 
+static bool gram512_on() { const char *e = getenv("NLH_GRAM512"); return !e || atoi(e) != 0; }   // (0: k_gram_mfma for 256 < n <= 512, for comparison)
+
 static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, const double *f,
                        double *G, double *g, const LmState *st, int want)
 {
@@ -504,6 +507,12 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
                                    g ? f : (const double *)nullptr, gp, st, want, ns, direct ? G : (double *)nullptr,
                                    direct ? g : (double *)nullptr);
             if (direct) return 0;          // one split: G and g are final, nothing to reduce
+        } else if (n > 256 && n <= 512 && gram512_on()) {
+            // four workgroups per item: the two diagonal 256-column blocks and the two halves of the square between them
+            const long groups = (items + 7) / 8;
+            const size_t sh = sizeof(double) * (size_t)(384 * GRAM_LD + GRAM_KT + 1024);
+            hipLaunchKernelGGL(k_gram_512, dim3((unsigned)(groups * 32)), dim3(512), sh, h->stream, m, n, rps, J, Gp,
+                               g ? f : (const double *)nullptr, gp, st, want, ns, nprob);
         } else {
             const long groups = (items + 7) / 8;
             hipLaunchKernelGGL(k_gram_mfma, dim3((unsigned)(groups * 8 * nblk)), dim3(256), 0, h->stream, m, n, rps, J, Gp,

@@ -203,8 +203,11 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
 // NT = tile rows of the triangle: 16 (n <= 256, 8 waves) or 8 (n <= 128, 4 waves, same scheme at half the size).
 template <int W, int NT>
 __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, int kend, int m, int n,
-                                              const double *Jp, const double *fp, double *Gp, double *gout, double *gscr, bool direct)
-{
+                                              const double *Jp, const double *fp, double *Gp, double *gout, double *gscr, bool direct,
+                                              int ldg = 0)
+{   // n: columns of THIS panel (Jp points at its first column); ldg: leading dimension of G when the panel is a diagonal
+    // block of a wider matrix (Gp then points at the block's (0, 0) entry), 0: n
+    if (ldg == 0) ldg = n;
     constexpr int NL = NT - W, NS = W + 1, RL = NT - 1 - W, RS = W;  // long / short tile row of this wave
     constexpr int NTH = 32 * NT, TN = 16 * NT, HALF = NTH / 2;       // threads, columns, columns again
     const int tid = threadIdx.x, lane = tid & 63;
@@ -280,8 +283,8 @@ __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, 
         for (int r = 0; r < 4; ++r) {
             const int gr = RL * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
             if (gr < n && gcol < n) {
-                if (!direct) Gp[(size_t)gcol * n + gr] = accL[c][r];
-                else if (gr >= gcol) { Gp[(size_t)gcol * n + gr] = accL[c][r]; Gp[(size_t)gr * n + gcol] = accL[c][r]; }
+                if (!direct) Gp[(size_t)gcol * ldg + gr] = accL[c][r];
+                else if (gr >= gcol) { Gp[(size_t)gcol * ldg + gr] = accL[c][r]; Gp[(size_t)gr * ldg + gcol] = accL[c][r]; }
             }
         }
 #pragma unroll
@@ -290,8 +293,8 @@ __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, 
         for (int r = 0; r < 4; ++r) {
             const int gr = RS * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
             if (gr < n && gcol < n) {
-                if (!direct) Gp[(size_t)gcol * n + gr] = accS[c][r];
-                else if (gr >= gcol) { Gp[(size_t)gcol * n + gr] = accS[c][r]; Gp[(size_t)gr * n + gcol] = accS[c][r]; }
+                if (!direct) Gp[(size_t)gcol * ldg + gr] = accS[c][r];
+                else if (gr >= gcol) { Gp[(size_t)gcol * ldg + gr] = accS[c][r]; Gp[(size_t)gr * ldg + gcol] = accS[c][r]; }
             }
         }
 }
@@ -338,7 +341,147 @@ k_gram_tri(int m, int n, int rows_per_split, const double *__restrict__ J, doubl
     }
 }
 
-// Sum the K-split partials in split order and mirror the lower triangle.
+// ---------------------------------------------------------------------------------------------
+// 256 < n <= 512 (BASELINE config 5: 65536 x 512).  The lower triangle of G no longer fits one CU's registers (528 tiles
+// of 16 x 16), so a (problem, K-split) item is FOUR workgroups of about equal work, each staging only the columns it
+// needs: unit 0 / 1 = the diagonal 256-column blocks (gram_tri_wave on columns 0..255 / 256..n-1: 136 tiles), unit 2 / 3 =
+// the upper / lower half of the off-diagonal square G(256.., 0..255) (128 tiles each: a 32-row tile of columns 0..255 and
+// of 128 columns of the second panel in LDS, 104 KB; eight waves, a wave two tile rows x eight tile columns: 2 + 8
+// operand reads for 16 MFMAs per k-step, 128 MFMAs between barriers).  J is staged 3 times per item where k_gram_mfma's
+// 64 x 64 blocks stage it 9 times, and a barrier pair covers 128-136 MFMAs per wave instead of 32.
+// Same accumulation order (rows ascending inside a split, splits summed by k_gram_reduce), same slabs: bitwise the same
+// G and g as k_gram_mfma.
+template <int W>      // wave index
+__device__ __forceinline__ void gram_sq_wave(double *tB, double *tA, int kbeg, int kend, int m, int nA, const double *JpB,
+                                             const double *JpA, double *Gp, int ldg)
+{
+    // B side: panel 0, 256 columns (tile columns 0..15); A side: this unit's 128 columns of panel 1 (8 tile rows, nA valid)
+    constexpr int RP = W >> 1, CH = W & 1;                           // tile rows 2 RP, 2 RP + 1; tile columns 8 CH .. 8 CH + 7
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int lr = tid % GRAM_KT, lc0 = tid / GRAM_KT;                // loader: row lr, columns lc0 + 16 cc
+    constexpr int LSTEP = 512 / GRAM_KT, NLB = 256 / LSTEP, NLA = 128 / LSTEP;
+    v4d acc[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[a][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int lrow = (lane & 15) * GRAM_LD + (lane >> 4);
+    const unsigned baddr = (unsigned)(size_t)(tB + CH * 8 * 16 * GRAM_LD + lrow);
+    const unsigned aaddr0 = (unsigned)(size_t)(tA + (2 * RP) * 16 * GRAM_LD + lrow);
+    const unsigned aaddr1 = (unsigned)(size_t)(tA + (2 * RP + 1) * 16 * GRAM_LD + lrow);
+    double rb[NLB], ra[NLA];
+    auto load_tile = [&](int k0) {
+        const int row = k0 + lr;
+        const bool rok = row < kend;
+#pragma unroll
+        for (int cc = 0; cc < NLB; ++cc) rb[cc] = rok ? JpB[(size_t)(lc0 + LSTEP * cc) * m + row] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NLA; ++cc) {
+            const int col = lc0 + LSTEP * cc;
+            ra[cc] = (rok && col < nA) ? JpA[(size_t)col * m + row] : 0.0;
+        }
+    };
+    if (kbeg < kend) load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GRAM_KT) {
+#pragma unroll
+        for (int cc = 0; cc < NLB; ++cc) tB[(lc0 + LSTEP * cc) * GRAM_LD + lr] = rb[cc];
+#pragma unroll
+        for (int cc = 0; cc < NLA; ++cc) tA[(lc0 + LSTEP * cc) * GRAM_LD + lr] = ra[cc];
+        __syncthreads();
+        if (k0 + GRAM_KT < kend) load_tile(k0 + GRAM_KT);
+#pragma unroll
+        for (int ks = 0; ks < GRAM_KT / 4; ++ks) {
+            double a0, a1, b[8];
+            asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4"
+                         : "=&v"(a0), "=&v"(a1) : "v"(aaddr0), "v"(aaddr1), "n"(ks * 32) : "memory");
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(b[c]) : "v"(baddr), "n"(c * 16 * GRAM_LD * 8 + ks * 32) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
+#pragma unroll
+            for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(b[c]));
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[c], acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[c], acc[1][c], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // f64 16x16x4 C/D map: col = lane & 15 (B side: column of panel 0), row = (lane >> 4) + 4 * reg (A side: row of G)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = (2 * RP + a) * 16 + (lane >> 4) + 4 * r, gcol = (CH * 8 + c) * 16 + (lane & 15);
+                if (gr < nA) Gp[(size_t)gcol * ldg + gr] = acc[a][c][r];
+            }
+}
+
+__global__ void __launch_bounds__(512)
+k_gram_512(int m, int n, int rows_per_split, const double *__restrict__ J, double *__restrict__ Gpart,
+           const double *__restrict__ f, double *__restrict__ gpart, const LmState *__restrict__ st, int want_stage,
+           int nsplit, int nprob)
+{
+    extern __shared__ double gsm[];
+    // the four units of an item on the same XCD (workgroup ids that agree modulo 8: one L2 serves their reads of J)
+    const long L = blockIdx.x;
+    const long grp = L / 32;
+    const int within = (int)(L % 32);
+    const long item = grp * 8 + (within & 7);
+    const int unit = within >> 3;
+    if (item >= (long)nsplit * nprob) return;
+    const int p = (int)(item / nsplit), split = (int)(item % nsplit);
+    if (st && st[p].stage != want_stage) return;
+    const int kbeg = split * rows_per_split, kend = min(m, kbeg + rows_per_split);
+    const double *Jp = J + (size_t)p * m * n;
+    double *Gp = Gpart + ((size_t)p * nsplit + split) * (size_t)n * n;
+    double *gout = gpart + ((size_t)p * nsplit + split) * n;
+    const int wv = threadIdx.x >> 6;
+    if (unit < 2) {
+        double *tA = gsm;                                   // 256 * GRAM_LD
+        double *fs = tA + 256 * GRAM_LD;                    // GRAM_KT
+        double *gscr = fs + GRAM_KT;                        // 1024
+        const int c0 = unit * 256, nc = min(256, n - c0);
+        const double *fp = f ? f + (size_t)p * m : nullptr;
+        const double *Jc = Jp + (size_t)c0 * m;
+        double *Gc = Gp + (size_t)c0 * n + c0;
+        switch (wv) {
+        case 0: gram_tri_wave<0, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
+        case 1: gram_tri_wave<1, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
+        case 2: gram_tri_wave<2, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
+        case 3: gram_tri_wave<3, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
+        case 4: gram_tri_wave<4, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
+        case 5: gram_tri_wave<5, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
+        case 6: gram_tri_wave<6, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
+        default: gram_tri_wave<7, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
+        }
+    } else {
+        double *tB = gsm;                                   // 256 * GRAM_LD: panel 0
+        double *tA = tB + 256 * GRAM_LD;                    // 128 * GRAM_LD: this unit's half of panel 1
+        const int r0 = 256 + (unit - 2) * 128, nA = max(0, min(128, n - r0));
+        if (nA == 0) return;                                // (uniform)
+        const double *JA = Jp + (size_t)r0 * m;
+        double *Gs = Gp + r0;                               // G(r0 + gr, gcol)
+        switch (wv) {
+        case 0: gram_sq_wave<0>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
+        case 1: gram_sq_wave<1>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
+        case 2: gram_sq_wave<2>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
+        case 3: gram_sq_wave<3>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
+        case 4: gram_sq_wave<4>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
+        case 5: gram_sq_wave<5>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
+        case 6: gram_sq_wave<6>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
+        default: gram_sq_wave<7>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
+        }
+    }
+}
+
+// Sum the K-split partials in split order and mirror the lower triangle.  A thread per entry of the LOWER triangle (a
+// wave: 64 consecutive rows of one column, contiguous in every slab); it writes G(r, c) and G(c, r).  The partials of
+// eight splits are requested together and added in split order (a thread per entry of the full matrix with one load in
+// flight read every slab entry twice, one dependent load after the other: 90 us for 64 slabs of 512 x 512).
 __global__ void __launch_bounds__(256)
 k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__restrict__ G,
               const double *__restrict__ gpart, double *__restrict__ g,
@@ -355,12 +498,20 @@ k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__res
     }
     if (e >= nn) return;
     const int r = (int)(e % n), c = (int)(e / n);
-    const bool lower = r >= c;                     // the slabs hold every entry with row >= column (16 x 16 tile granularity)
-    const size_t src = lower ? ((size_t)c * n + r) : ((size_t)r * n + c);
-    const double *gp = Gpart + (size_t)p * nsplit * nn + src;
+    if (r < c) return;                             // the slabs hold every entry with row >= column (16 x 16 tile granularity)
+    const double *gp = Gpart + (size_t)p * nsplit * nn + e;
     double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s = s + gp[(size_t)k * nn];
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gp[(size_t)(k + u) * nn];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = s + v[u];
+    }
+    for (; k < nsplit; ++k) s = s + gp[(size_t)k * nn];
     G[(size_t)p * nn + e] = s;
+    if (r != c) G[(size_t)p * nn + (size_t)r * n + c] = s;
 }
 
 // g = J^T f: one wave per column, lanes stride the rows (coalesced), shuffle reduction.

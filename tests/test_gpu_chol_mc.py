@@ -54,3 +54,31 @@ def test_multi_cu_cholesky_hands_over_on_a_bad_pivot(ds):
             os.environ["NLH_CHOL_MC"] = old
     assert res["0"][1] == res["8"][1] and res["0"][2] == res["8"][2]
     assert np.array_equal(res["0"][0], res["8"][0])
+
+
+@pytest.mark.parametrize("nb,m,n", [(1, 5000, 512), (2, 1000, 300), (1, 3100, 257), (2, 2048, 384), (1, 700, 400), (3, 1500, 511)])
+def test_gram_512_same_bits_as_block_kernel(ds, nb, m, n):
+    """k_gram_512 (256 < n <= 512: the two diagonal 256-column blocks and the two halves of the square between them as
+    four workgroups per (problem, K-split)) against k_gram_mfma (64 x 64 blocks): the same accumulation order, hence
+    the same bits of G and g; and both against a float64 reference."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    J = torch.randn((nb, n, m), dtype=torch.float64, generator=g).cuda()
+    f = torch.randn((nb, m), dtype=torch.float64, generator=g).cuda()
+    old = os.environ.get("NLH_GRAM512")
+    try:
+        os.environ["NLH_GRAM512"] = "0"
+        G0, g0 = ds.gram(J, f)
+        os.environ["NLH_GRAM512"] = "1"
+        G1, g1 = ds.gram(J, f)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop("NLH_GRAM512", None)
+        else:
+            os.environ["NLH_GRAM512"] = old
+    assert torch.equal(G0, G1) and torch.equal(g0, g1)
+    Gref = torch.matmul(J, J.transpose(1, 2))
+    gref = torch.matmul(J, f.unsqueeze(-1)).squeeze(-1)
+    assert float((G1 - Gref).abs().max()) <= 1e-13 * float(Gref.abs().max()) * np.sqrt(m)
+    assert float((g1 - gref).abs().max()) <= 1e-13 * float(gref.abs().max()) * np.sqrt(m)
+    assert torch.equal(G1, G1.transpose(1, 2))
