@@ -231,7 +231,7 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_panel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    hipFuncSetAttribute((const void *)k_qn_house_dot, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_house_dot<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_dot2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_fused<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_house_fused<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -1276,7 +1276,7 @@ static int newton_core(nlh_handle *h, const nlh_options *o, int n, NewtonEval &e
 // every O(n^2)/O(n^3) operation in the kernels of nlh_kernels_broyden.h.
 // ===========================================================================
 static const int QN_MAX_N = 4096;      // k_qn_retri: 4 columns per thread at most
-static const int QN_MAX_ROWS = 18000;  // k_qn_house_dot keeps the reflector (rows doubles) in LDS
+static const int QN_LDS_ROWS = 18000;  // up to here k_qn_house_dot keeps the reflector (rows doubles) in LDS; beyond: in global memory
 
 // B (column-major) -> Q, R: Householder QR with Q formed (qr_factor(b, q = q, r = r), :289)
 // Householder steps on the row-major work array [A | E] (rows x ncA | rows x ncE); vbuf slot 0 must hold column 0 of A.
@@ -1310,9 +1310,12 @@ static void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int 
         if (wide)
             hipLaunchKernelGGL(k_qn_house_dot2, dim3((nc + QN_DOT2_CG - 1) / QN_DOT2_CG, nprob), dim3(256), sh2, s,
                                rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant);
-        else
-            hipLaunchKernelGGL(k_qn_house_dot, dim3((nc + QN_DOT_BS - 1) / QN_DOT_BS, nprob), dim3(QN_DOT_BS),
+        else if (rows <= QN_LDS_ROWS)
+            hipLaunchKernelGGL(k_qn_house_dot<false>, dim3((nc + QN_DOT_BS - 1) / QN_DOT_BS, nprob), dim3(QN_DOT_BS),
                                sizeof(double) * rows, s, rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant);
+        else                                                // the reflector does not fit LDS: it stays in global memory
+            hipLaunchKernelGGL(k_qn_house_dot<true>, dim3((nc + QN_DOT_BS - 1) / QN_DOT_BS, nprob), dim3(QN_DOT_BS),
+                               0, s, rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant);
         hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - j + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
                            rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, nc, 4, 0, gst, gwant);
     }
@@ -2209,7 +2212,6 @@ int nlh_cls_solve(nlh_handle *h, const nlh_options *o, double delta0, double ste
     if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :988
     if (!o || n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
     if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;           // :989
-    if (m > QN_MAX_ROWS) return NLH_ARRAY_SIZE_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     const size_t mn = (size_t)m * n;
@@ -2372,7 +2374,6 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (!o || n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
     if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;
-    if (m > QN_MAX_ROWS) return NLH_ARRAY_SIZE_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     static const int cls_host = [] { const char *e = getenv("NLH_CLS_HOSTLOOP"); return e ? atoi(e) : 0; }();
     if (!cls_host)
@@ -3271,7 +3272,6 @@ int nlh_poly_fit_batch(nlh_handle *h, int32_t nprob, int32_t npts, int32_t order
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (nprob < 1) return 0;
     if (order >= npts || order < 1) return 4;                   // :163-166
-    if (npts > QN_MAX_ROWS) return NLH_ARRAY_SIZE_ERROR;        // the reflector is staged in LDS
     HIPCHK(h, hipSetDevice(h->device));
     const int ncols = thru_zero ? order : order + 1;
     int rc;

@@ -54,36 +54,45 @@ k_qn_qr_init(int n, const double *__restrict__ Rt, double *__restrict__ Q, doubl
 // General shape: `rows` rows, A has ncA columns (row-major, ld ncA), E has ncE columns (row-major, ld ncE).
 // Broyden: rows = ncA = ncE = n (E = Q^T accumulator).  Constrained least squares: rows = m, ncA = n,
 // ncE = 1 (E = the right-hand side f, which becomes Q^T f).
+// GV = true: more rows than LDS holds (rows > 18000: the reflector would not fit) -- the reflector stays in global memory
+// and is scaled where it is used: (v_i * scal) * T(i,k) is the stored-then-multiplied value's two roundings exactly, so
+// the same bits as the LDS form at any size.  What the reference has no limit for (a 65536-row constrained least-squares
+// problem, a polynomial fit through 10^5 points) then works, at the price of L2 instead of LDS reads in the chains.
+template <bool GV>
 __global__ void __launch_bounds__(QN_DOT_BS)
 k_qn_house_dot(int rows, int ncA, int ncE, int j, const double *__restrict__ Aall, const double *__restrict__ Eall,
                const double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st,
         const LmState *__restrict__ gst, int gwant)
 {
-    extern __shared__ double vs[];                 // rows: reflector, rows j+1 .. rows-1
+    extern __shared__ double vs_lds[];             // rows: reflector, rows j+1 .. rows-1 (GV: unused)
     __shared__ double sq_sh;
     const int p = blockIdx.y, tid = threadIdx.x;
     if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     const double *A = Aall + (size_t)p * rows * ncA, *E = Eall + (size_t)p * rows * ncE;
     const double *vcur = vbuf + ((size_t)p * 2 + (j & 1)) * rows;
-    for (int i0 = j + 1 + tid; i0 < rows; i0 += 8 * QN_DOT_BS) {      // 8 loads in flight per thread
-        double t[8];
+    double *vs = vs_lds;
+    if (!GV) {
+        for (int i0 = j + 1 + tid; i0 < rows; i0 += 8 * QN_DOT_BS) {      // 8 loads in flight per thread
+            double t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * QN_DOT_BS; t[u] = (i < rows) ? vcur[i] : 0.0; }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QN_DOT_BS; t[u] = (i < rows) ? vcur[i] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * QN_DOT_BS; if (i < rows) vs[i] = t[u]; }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QN_DOT_BS; if (i < rows) vs[i] = t[u]; }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0) {                                // one ordered sum; LDS reads batched 16 at a time
+    const double *vr = GV ? vcur : vs;             // the unscaled reflector, wherever it is
+    if (tid == 0) {                                // one ordered sum; reads batched 16 at a time
         double s = 0.0;
         int i = j + 1;
         for (; i + 16 <= rows; i += 16) {
             double t[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = vs[i + u];
+            for (int u = 0; u < 16; ++u) t[u] = vr[i + u];
 #pragma unroll
             for (int u = 0; u < 16; ++u) s = s + t[u] * t[u];
         }
-        for (; i < rows; ++i) s = s + vs[i] * vs[i];
+        for (; i < rows; ++i) s = s + vr[i] * vr[i];
         sq_sh = s;
     }
     __syncthreads();
@@ -97,20 +106,25 @@ k_qn_house_dot(int rows, int ncA, int ncE, int j, const double *__restrict__ Aal
     const double tau = (beta - alpha) / beta;
     const double scal = 1.0 / (alpha - beta);
     if (blockIdx.x == 0 && tid == 0) { st[(size_t)p * 4] = tau; st[(size_t)p * 4 + 1] = scal; st[(size_t)p * 4 + 2] = beta; }
-    for (int i = j + 1 + tid; i < rows; i += QN_DOT_BS) vs[i] = vs[i] * scal;
-    __syncthreads();
+    if (!GV) {
+        for (int i = j + 1 + tid; i < rows; i += QN_DOT_BS) vs[i] = vs[i] * scal;
+        __syncthreads();
+    }
     const int k = blockIdx.x * QN_DOT_BS + tid;
     if (k >= ncA + ncE || (k < ncA && k <= j)) return;
     const double *T = (k < ncA) ? A + k : E + (k - ncA);
     const size_t ld = (k < ncA) ? ncA : ncE;
     double w = T[(size_t)j * ld];
     for (int i = j + 1; i < rows; i += QN_U) {     // the chain is serial in i; the loads are not
-        double t[QN_U];
+        double t[QN_U], vv[QN_U];
 #pragma unroll
-        for (int u = 0; u < QN_U; ++u) t[u] = (i + u < rows) ? T[(size_t)(i + u) * ld] : 0.0;
+        for (int u = 0; u < QN_U; ++u) {
+            t[u] = (i + u < rows) ? T[(size_t)(i + u) * ld] : 0.0;
+            vv[u] = (i + u < rows) ? (GV ? vcur[i + u] * scal : vs[i + u]) : 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < QN_U; ++u)
-            if (i + u < rows) w = w + vs[i + u] * t[u];
+            if (i + u < rows) w = w + vv[u] * t[u];
     }
     wbuf[(size_t)p * (ncA + ncE) + k] = tau * w;
 }

@@ -112,7 +112,7 @@ def test_active_bound(oracle):
         assert x[0] <= 4.5 and np.array_equal(x, xo)
 
 
-@pytest.mark.parametrize("m,n,bounded", [(64, 8, False), (512, 64, False), (512, 64, True), (300, 37, True)])
+@pytest.mark.parametrize("m,n,bounded", [(64, 8, False), (512, 64, False), (512, 64, True), (300, 37, True), (20000, 12, True)])
 def test_dq_cls_batch_bitwise(ds, oracle, m, n, bounded):
     """Device-model problems (FD Jacobian fused into the panel kernel): bitwise equal to the CPU path."""
     nprob = 2

@@ -38,9 +38,12 @@ def test_fit_thru_zero_and_errors(oracle):
     assert e.value.code == 3
 
 
-@pytest.mark.parametrize("npts,order,thru_zero", [(21, 3, False), (500, 7, False), (64, 5, True), (4096, 12, False)])
+@pytest.mark.parametrize("npts,order,thru_zero", [(21, 3, False), (500, 7, False), (64, 5, True), (4096, 12, False),
+                                                  (9000, 6, False), (17000, 5, False), (18001, 4, False), (70000, 5, True)])
 def test_poly_fit_batch_bitwise(ds, oracle, npts, order, thru_zero):
-    nprob = 5
+    """Every form of the Householder steps: fused (npts <= 4096), workgroup-wide tiles (<= 8192), reflector in LDS (<= 18000)
+    and -- what the reference has no limit for -- reflector in global memory beyond that."""
+    nprob = 5 if npts <= 4096 else 2
     rng = np.random.default_rng(npts + order)
     xs = np.sort(rng.uniform(-1.0, 1.0, size=(nprob, npts)), axis=1)
     ys = np.cos(3.0 * xs) + 0.01 * rng.standard_normal((nprob, npts))
