@@ -1563,6 +1563,7 @@ k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, dou
     if (tid == 0 && k < n) { rk0 = rdall[(size_t)p * n + k]; wa0 = waall[(size_t)p * n + k]; }
 #ifdef QRX_DBG_CLK
     const long long c0 = wall_clock64();
+    long long cw = 0, cr = 0, cc = 0;                                   // chain wave: barrier waits, LDS reads, the chains
 #endif
     const size_t blk = (size_t)ld * 8;
     const int nch = (len + CAP - 1) / CAP;
@@ -1622,12 +1623,23 @@ k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, dou
         __builtin_amdgcn_s_setprio(3);                                   // the chain wave goes first on its SIMD
         for (int c = 0; c < nch; ++c) {
             const int base = c * CAP;
+#ifdef QRX_DBG_CLK
+            const long long q0 = wall_clock64();
+#endif
             qrx_lds_barrier();
+#ifdef QRX_DBG_CLK
+            const long long q1 = wall_clock64();
+#endif
             const int cl = min(CAP, len - base), nl = (cl + EL - 1) / EL;
             double d[EL];
             const double2 *mine = reinterpret_cast<const double2 *>(buf[c & 1] + lane * (EL + 2));
 #pragma unroll
             for (int u = 0; u < EL / 2; ++u) { const double2 v2 = mine[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
+#ifdef QRX_DBG_CLK
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long long q2 = wall_clock64();
+            cw += q1 - q0; cr += q2 - q1;
+#endif
             double t = s;
             if (nl == 64) {
 #pragma unroll 1
@@ -1647,6 +1659,9 @@ k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, dou
             const int lo_ = __builtin_amdgcn_readlane(__double2loint(t), nl - 1);
             const int hi_ = __builtin_amdgcn_readlane(__double2hiint(t), nl - 1);
             s = __hiloint2double(hi_, lo_);
+#ifdef QRX_DBG_CLK
+            cc += wall_clock64() - q2;
+#endif
         }
     }
     if (chain && lane == 0) xch[0] = s;
@@ -1665,6 +1680,8 @@ k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, dou
 #ifdef QRX_DBG_CLK
     if (tid == 0 && (j == 100 || j == 400) && (blockIdx.x == 0 || blockIdx.x == 100))
         printf("pass j=%d wg %d: sweep %lld tail %lld (x10 ns)\n", j, blockIdx.x, c1 - c0, wall_clock64() - c1);
+    if (chain && lane == 0 && (j == 100 || j == 400) && (blockIdx.x == 0 || blockIdx.x == 100))
+        printf("pass_col chain wave j=%d wg %d: %d chunks, barrier wait %lld, lds read %lld, chain %lld (x10 ns)\n", j, blockIdx.x, nch, cw, cr, cc);
 #endif
 }
 
