@@ -13,7 +13,7 @@
 
 // B <- R^T R (tri_mtx_mult(.true., 1, r, 0, b), :709): thread per entry (i <= j), sum over k ascending;
 // both triangles of the column-major B are written.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bf_rtr(int n, const double *__restrict__ Rt, double *__restrict__ B, const LmState *__restrict__ gst, int gwant)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, p = blockIdx.z;
@@ -28,7 +28,7 @@ k_bf_rtr(int n, const double *__restrict__ Rt, double *__restrict__ B, const LmS
 
 // x <- R^-T x (DTRSV 'U','T','N'), one workgroup: x_j loses R(i,j) x_i for i ascending, which is the dot form's
 // order of subtractions.  Dynamic LDS: n doubles.
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_bf_solve_upper_t(int n, const double *__restrict__ Rt, double *__restrict__ x, const LmState *__restrict__ gst, int gwant)
 {
     extern __shared__ double xs[];
@@ -90,7 +90,7 @@ k_bf_chol_update(int n, double *__restrict__ Rt, const double *__restrict__ u, c
 
 // Downdate, first half (qrupdate DCH1DN): given v = R^-T u (k_bf_solve_upper_t), rho = sqrt(1 - ||v||^2) with
 // NORM2 as the flang runtime evaluates it, then the rotations from the bottom.  info = 1: not positive definite.
-__global__ void k_bf_downdate_rot(int n, double *__restrict__ v, double *__restrict__ c, int *__restrict__ info, const LmState *__restrict__ gst, int gwant)
+static __global__ void k_bf_downdate_rot(int n, double *__restrict__ v, double *__restrict__ c, int *__restrict__ info, const LmState *__restrict__ gst, int gwant)
 {
     const int p = blockIdx.x;
     if (threadIdx.x != 0) return;
@@ -117,7 +117,7 @@ __global__ void k_bf_downdate_rot(int n, double *__restrict__ v, double *__restr
 }
 
 // Downdate, second half: thread per column i, rows i .. 0.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bf_downdate_apply(int n, double *__restrict__ Rt, const double *__restrict__ c, const double *__restrict__ s,
                     const int *__restrict__ info, const LmState *__restrict__ gst, int gwant)
 {
@@ -201,7 +201,7 @@ k_bf_chol_factor(int n, const double *__restrict__ B, double *__restrict__ Rt, i
 }
 
 // R <- temp * I (DLASET, :705)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bf_scaled_identity(int n, double temp, double *__restrict__ Rt, const double *__restrict__ tempall, size_t tstride,
                      const int32_t *__restrict__ iterall, size_t istride, const LmState *__restrict__ gst, int gwant)
 {
@@ -217,7 +217,7 @@ k_bf_scaled_identity(int n, double temp, double *__restrict__ Rt, const double *
 
 // f_j = 0.5 * sum_i P(i,j)^2 for every column of the residual panel (objective of the device model at the
 // n perturbed points), sum over i ascending; then g_j = (f_j - f0) / h_j (:240).  Thread per column.
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 k_bf_fd_gradient(int m, int n, const double *__restrict__ P, const double *__restrict__ x, double f0,
                  double *__restrict__ g, const double *__restrict__ f0all, size_t fstride, const LmState *__restrict__ gst, int gwant)
 {

@@ -43,7 +43,7 @@ struct BfOpts {
     int32_t rc_divergent, rc_convergence, rc_invalid_op, pad0, pad1;      // the C ABI's codes for the three error stops
 };
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bfl_reset(int nprob, LmState *__restrict__ st, BfState *__restrict__ bs, int32_t *__restrict__ info)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,7 +60,7 @@ k_bfl_reset(int nprob, LmState *__restrict__ st, BfState *__restrict__ bs, int32
 }
 
 // :633 after F(x0): f = 0.5 F.F
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bfl_start(int m, const double *__restrict__ fall, LmState *__restrict__ st, BfState *__restrict__ bs)
 {
     __shared__ __attribute__((aligned(16))) double buf[NT_CHUNK];
@@ -108,7 +108,7 @@ __device__ void bfl_search_begin(int n, const BfOpts &o, const double *x, const 
 
 // After the gradient: the start-up (:639-656) the first time, afterwards the tests and the secant pair (:681-706).
 // dxs: the step just taken (x - xold), y: g - gold.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bfl_after_grad(int n, BfOpts o, const double *__restrict__ xall, const double *__restrict__ gall, const double *__restrict__ goldall,
                  double *__restrict__ dxall, double *__restrict__ yall, double *__restrict__ xnewall, LmState *__restrict__ st,
                  BfState *__restrict__ bs)
@@ -157,7 +157,7 @@ k_bfl_after_grad(int n, BfOpts o, const double *__restrict__ xall, const double 
 }
 
 // Given B dx: the rank-one pair u = y / sqrt(y.dx), v = B dx / sqrt(dx.B dx) (:716-720), or a refactorisation (:724).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bfl_split(int n, const double *__restrict__ dxall, const double *__restrict__ bdxall, const double *__restrict__ yall,
             double *__restrict__ uall, double *__restrict__ vall, LmState *__restrict__ st, BfState *__restrict__ bs)
 {
@@ -178,7 +178,7 @@ k_bfl_split(int n, const double *__restrict__ dxall, const double *__restrict__ 
 }
 
 // right-hand side of the direction solve (:727)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bfl_neg(int n, const double *__restrict__ gall, double *__restrict__ wall, const LmState *__restrict__ st)
 {
     const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
@@ -187,7 +187,7 @@ k_bfl_neg(int n, const double *__restrict__ gall, double *__restrict__ wall, con
 }
 
 // The end of an iteration (:728-743) and the head of the next one (:650, :659-669).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bfl_dir_done(int n, BfOpts o, const double *__restrict__ xall, const double *__restrict__ gall, double *__restrict__ dxall,
                const double *__restrict__ wall, double *__restrict__ xnewall, const int32_t *__restrict__ info,
                LmState *__restrict__ st, BfState *__restrict__ bs)
@@ -220,7 +220,7 @@ k_bfl_dir_done(int n, BfOpts o, const double *__restrict__ xall, const double *_
 }
 
 // After F(xnew): one turn of ls_search_miso's loop (:402-468), or the plain step; an accepted point becomes x (:672-678).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bfl_trial(int m, int n, BfOpts o, double *__restrict__ xall, double *__restrict__ xnewall, double *__restrict__ dxall,
             const double *__restrict__ gall, double *__restrict__ goldall, const double *__restrict__ fall,
             LmState *__restrict__ st, BfState *__restrict__ bs)
@@ -280,7 +280,7 @@ k_bfl_trial(int m, int n, BfOpts o, double *__restrict__ xall, double *__restric
     if (tid == 0) { s->fp = f; s->neval += add; st[p].stage = BF_GRAD; }
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bfl_count(int nprob, const LmState *__restrict__ st, int32_t *__restrict__ counts)
 {
     __shared__ int c[2];

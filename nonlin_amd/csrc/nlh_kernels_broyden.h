@@ -28,7 +28,7 @@ __device__ __forceinline__ void givens_dev(double f, double g, double &c, double
 }
 
 // Q <- I, and the first reflector's column: vbuf[i] = A(i,0).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_qr_init(int n, const double *__restrict__ Rt, double *__restrict__ Q, double *__restrict__ vbuf,
         const LmState *__restrict__ gst, int gwant)
 {
@@ -138,7 +138,7 @@ k_qn_house_dot(int rows, int ncA, int ncE, int j, const double *__restrict__ Aal
 #define QN_DOT2_MAXROWS 8192
 #define QN_DOT2_CG 16
 #define QN_DOT2_TR 256
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_house_dot2(int rows, int ncA, int ncE, int j, const double *__restrict__ Aall, const double *__restrict__ Eall,
                 const double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st,
         const LmState *__restrict__ gst, int gwant)
@@ -372,7 +372,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
 // Second half: T(j,k) -= w_k, T(i,k) -= v_i w_k (elementwise, one thread per column and QN_RC rows),
 // column j becomes (beta, 0, ..., 0), and the updated column j+1 is copied to the other vbuf slot.
 #define QN_RC 16
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_house_apply(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
                  double *__restrict__ vbuf, const double *__restrict__ wbuf, const double *__restrict__ st,
                  int wps /* w doubles per problem */, int sps /* st doubles per problem */,
@@ -420,7 +420,7 @@ k_qn_house_apply(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
 }
 
 // vbuf slot 0 <- column 0 of the row-major A (the first reflector's column).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_col0(int rows, int ncA, const double *__restrict__ Aall, double *__restrict__ vbuf)
 {
     const int p = blockIdx.y;
@@ -431,7 +431,7 @@ k_qn_col0(int rows, int ncA, const double *__restrict__ Aall, double *__restrict
 }
 
 // out_i = sum_j v_j J(i,j), J column-major m x n, j ascending from an accumulator of zero (DGEMV 'N').
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_matvec_cm(int m, int n, const double *__restrict__ J, const double *__restrict__ v, double *__restrict__ out,
             const LmState *__restrict__ gst, int gwant)
 {
@@ -457,7 +457,7 @@ k_matvec_cm(int m, int n, const double *__restrict__ J, const double *__restrict
 }
 
 // s = (df - B dx) / x2   (:301-302): thread per row, sum over columns ascending.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_resid(int n, const double *__restrict__ B, const double *__restrict__ dx, const double *__restrict__ df,
            double x2, const double *__restrict__ x2all /* per problem, or NULL: x2 */, double *__restrict__ s,
         const LmState *__restrict__ gst, int gwant)
@@ -484,7 +484,7 @@ k_qn_resid(int n, const double *__restrict__ B, const double *__restrict__ dx, c
 }
 
 // B += s dx^T  (rank1_update, :306)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_rank1(int n, double *__restrict__ B, const double *__restrict__ s, const double *__restrict__ dx,
         const LmState *__restrict__ gst, int gwant)
 {
@@ -500,7 +500,7 @@ k_qn_rank1(int n, double *__restrict__ B, const double *__restrict__ s, const do
 // 16 columns per workgroup; a tile of 256 rows x 16 columns is fetched by all 256 threads (coalesced along the
 // rows), the products go to LDS and one thread per column adds them in row order; the loads of the next tile are
 // in flight during the sums.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_colsdot(int m, int n, const double *__restrict__ M, const double *__restrict__ f, double *__restrict__ out,
              double sign,
         const LmState *__restrict__ gst, int gwant)
@@ -547,7 +547,7 @@ k_qn_colsdot(int m, int n, const double *__restrict__ M, const double *__restric
 }
 
 // DQRTV1: rotations folding w into w(0), generated from the bottom (one thread per problem).
-__global__ void k_qn_fold(int n, double *__restrict__ w, double *__restrict__ c, double *__restrict__ s,
+static __global__ void k_qn_fold(int n, double *__restrict__ w, double *__restrict__ c, double *__restrict__ s,
         const LmState *__restrict__ gst, int gwant)
 {
     const int p = blockIdx.x;
@@ -565,7 +565,7 @@ __global__ void k_qn_fold(int n, double *__restrict__ w, double *__restrict__ c,
 }
 
 // DQROT: rotations on adjacent columns of Q, thread per row.  backward: pairs n-2 .. 0, else 0 .. n-2.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_rot_q(int n, double *__restrict__ Q, const double *__restrict__ c, const double *__restrict__ s, int backward,
         const LmState *__restrict__ gst, int gwant)
 {
@@ -599,7 +599,7 @@ k_qn_rot_q(int n, double *__restrict__ Q, const double *__restrict__ c, const do
 }
 
 // DQRQH + the first-row update: R -> upper Hessenberg, then R(0,:) += w0 v^T.  Thread per column.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_hess_r(int n, double *__restrict__ Rt, const double *__restrict__ c, const double *__restrict__ s,
             const double *__restrict__ w, const double *__restrict__ v,
         const LmState *__restrict__ gst, int gwant)
@@ -687,7 +687,7 @@ k_qn_retri(int n, double *__restrict__ Rt, double *__restrict__ c, double *__res
 }
 
 // x <- R^-1 x, column oriented (DTRSV 'U','N','N'); R row-major.  Dynamic LDS: n doubles.
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall, size_t stride_r, size_t stride_x,
         const LmState *__restrict__ gst, int gwant)
 {
@@ -713,7 +713,7 @@ k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall
 
 // Vandermonde panel of polynomial%fit (src/nonlin_polynomials.f90:177-184, :222-225), row-major npts x ncols:
 // column c = column c-1 * x, one thread per point (the products chain along the row).  Also copies y to rhs.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_vandermonde(int npts, int ncols, int thru_zero, const double *__restrict__ x, const double *__restrict__ y,
               double *__restrict__ A, double *__restrict__ rhs)
 {
@@ -728,4 +728,22 @@ k_vandermonde(int npts, int ncols, int thru_zero, const double *__restrict__ x, 
     else { row[0] = 1.0; a = xj; if (ncols > 1) row[1] = a; c = 2; }
     for (; c < ncols; ++c) { a = a * xj; row[c] = a; }
     rhs[(size_t)p * npts + j] = y[(size_t)p * npts + j];
+}
+
+
+// Dynamic-LDS limits of this header's kernels, for the copies of the translation unit that includes it (called once per
+// device from that unit's init function).
+static void broyden_kernel_attrs(int lds_max)
+{
+    hipFuncSetAttribute((const void *)k_qn_house_dot<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_house_dot2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_house_fused<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_house_fused<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_matvec_cm, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_rot_q, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_hess_r, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_retri<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_retri<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_solve_upper, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_resid, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
 }

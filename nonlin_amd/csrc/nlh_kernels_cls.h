@@ -108,7 +108,7 @@ __device__ void cl_finish_iter(int m, int n, const ClOpts &o, const double *x, c
     sg->stage = next;
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_reset(int nprob, double delta0, LmState *__restrict__ st, ClState *__restrict__ cs)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,7 +125,7 @@ k_cls_reset(int nprob, double delta0, LmState *__restrict__ st, ClState *__restr
 }
 
 // x <- the box (:1023): every problem
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_limits(int n, const double *__restrict__ xl, const double *__restrict__ xu, double *__restrict__ xall)
 {
     const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
@@ -133,7 +133,7 @@ k_cls_limits(int n, const double *__restrict__ xl, const double *__restrict__ xu
 }
 
 // :1024-1031 after F(x0)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_start(int m, int n, const double *__restrict__ xall, const double *__restrict__ fall, LmState *__restrict__ st,
             ClState *__restrict__ cs)
 {
@@ -154,7 +154,7 @@ k_cls_start(int m, int n, const double *__restrict__ xall, const double *__restr
 }
 
 // the residual joins the working array of the QR as its extra column (:1047, :1334)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_qr_prep(int m, const double *__restrict__ fall, double *__restrict__ Eall, const LmState *__restrict__ st)
 {
     const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
@@ -164,7 +164,7 @@ k_cls_qr_prep(int m, const double *__restrict__ fall, double *__restrict__ Eall,
 
 // After the QR (u = R^-1 (Q^T f)(1:n) in the head of E, g = J^T f): coleman_li_scaling (:1222-1260), the Gauss-Newton
 // step and its scaled length (:1336-1338); inside the region it is the step.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_dog1(int m, int n, const double *__restrict__ xall, const double *__restrict__ xl, const double *__restrict__ xu,
            const double *__restrict__ Eall, double *__restrict__ scall, double *__restrict__ pgnall, double *__restrict__ pall,
            LmState *__restrict__ st, ClState *__restrict__ cs)
@@ -207,7 +207,7 @@ k_cls_dog1(int m, int n, const double *__restrict__ xall, const double *__restri
 }
 
 // The steepest-descent leg (:1340-1390), given J g.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_dog2(int m, int n, const double *__restrict__ xall, const double *__restrict__ xl, const double *__restrict__ xu,
            const double *__restrict__ gall, const double *__restrict__ Jgall, const double *__restrict__ scall,
            const double *__restrict__ pgnall, double *__restrict__ psdall, double *__restrict__ uall, double *__restrict__ pall,
@@ -264,7 +264,7 @@ k_cls_dog2(int m, int n, const double *__restrict__ xall, const double *__restri
 }
 
 // Given J p: predicted reduction (:1398-1403), scaled step length and gradient norm (:1055-1057), the trial point.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_pred(int m, int n, const double *__restrict__ xall, const double *__restrict__ gall, const double *__restrict__ pall,
            const double *__restrict__ Jpall, const double *__restrict__ scall, double *__restrict__ xnewall,
            LmState *__restrict__ st, ClState *__restrict__ cs)
@@ -288,7 +288,7 @@ k_cls_pred(int m, int n, const double *__restrict__ xall, const double *__restri
 }
 
 // After F(x + p): actual reduction, ratio, trust-region radius, acceptance or the start of the backtracking (:1060-1123).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_judge(int m, int n, ClOpts o, double *__restrict__ xall, double *__restrict__ xnewall, double *__restrict__ fall,
             const double *__restrict__ fnewall, const double *__restrict__ gall, const double *__restrict__ pall,
             const double *__restrict__ xl, const double *__restrict__ xu, LmState *__restrict__ st, ClState *__restrict__ cs)
@@ -333,7 +333,7 @@ k_cls_judge(int m, int n, ClOpts o, double *__restrict__ xall, double *__restric
 }
 
 // After F at a backtracking point (:1101-1118).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_bt(int m, int n, ClOpts o, double *__restrict__ xall, double *__restrict__ xnewall, double *__restrict__ fall,
          const double *__restrict__ fnewall, const double *__restrict__ pall, const double *__restrict__ xl,
          const double *__restrict__ xu, LmState *__restrict__ st, ClState *__restrict__ cs)
@@ -370,7 +370,7 @@ k_cls_bt(int m, int n, ClOpts o, double *__restrict__ xall, double *__restrict__
     cl_finish_iter(m, n, o, x, fv, st + p, s, red);
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cls_count(int nprob, const LmState *__restrict__ st, int32_t *__restrict__ counts)
 {
     __shared__ int c[2];

@@ -7,7 +7,7 @@
 
 // Column-major m-by-n  ->  row-major m-by-n with row stride ld, 32x32 tiles through LDS (the Householder kernels of
 // the quasi-Newton and bounded least-squares paths work on row-major copies).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_transpose(int m, int n, const double *__restrict__ J, double *__restrict__ Jt, int ld,
             const LmState *__restrict__ st, int want_stage)
 {
@@ -30,7 +30,7 @@ k_transpose(int m, int n, const double *__restrict__ J, double *__restrict__ Jt,
 }
 
 // fnorm = NORM2(fvec) in reference order for every problem (:213), counters reset.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_lm_init_exact(int m, const double *__restrict__ fvec, LmState *__restrict__ st, int first_stage)
 {
     __shared__ double scratch[3 * NLH_NCH + 8];

@@ -27,7 +27,7 @@
 // Dynamic LDS: (3n + 64) doubles.
 // standalone != 0: only factor (stage-level entry point nlh_chol_factor).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_chol_factor(int n, double *__restrict__ Gall, const double *__restrict__ Gsrc_all,
               const double *__restrict__ gall,
               LmVecs v, const double *__restrict__ xall, LmState *__restrict__ st,
@@ -749,7 +749,7 @@ k_chol_mc_end(int n, double *__restrict__ Rall, LmVecs v, const double *__restri
 // Dynamic LDS: (3n + 64) doubles + 64 ints.
 // Rout: n-by-n (ld n) receives R (upper, diagonal = rdiag) for lmpar.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_qr_factor(int m, int n, double *__restrict__ Jall, const double *__restrict__ fall,
             double *__restrict__ Rall, LmVecs v, double *__restrict__ wa4all,
             double *__restrict__ scratch_all /* [nprob][m], used when inner_pass > 0 */,

@@ -28,7 +28,7 @@ __device__ __forceinline__ void gram_block_index(int idx, int &bi, int &bj)
     bj = idx - r * (r + 1) / 2;
 }
 
-__global__ void __launch_bounds__(256, 3)
+static __global__ void __launch_bounds__(256, 3)
 k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
             double *__restrict__ Gpart /* [nprob][nsplit][n*n] */,
             const double *__restrict__ f /* [nprob][m] or null */,
@@ -420,7 +420,7 @@ __device__ __forceinline__ void gram_sq_wave(double *tB, double *tA, int kbeg, i
             }
 }
 
-__global__ void __launch_bounds__(512)
+static __global__ void __launch_bounds__(512)
 k_gram_512(int m, int n, int rows_per_split, const double *__restrict__ J, double *__restrict__ Gpart,
            const double *__restrict__ f, double *__restrict__ gpart, const LmState *__restrict__ st, int want_stage,
            int nsplit, int nprob)
@@ -482,7 +482,7 @@ k_gram_512(int m, int n, int rows_per_split, const double *__restrict__ J, doubl
 // wave: 64 consecutive rows of one column, contiguous in every slab); it writes G(r, c) and G(c, r).  The partials of
 // eight splits are requested together and added in split order (a thread per entry of the full matrix with one load in
 // flight read every slab entry twice, one dependent load after the other: 90 us for 64 slabs of 512 x 512).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__restrict__ G,
               const double *__restrict__ gpart, double *__restrict__ g,
               const LmState *__restrict__ st, int want_stage)
@@ -515,7 +515,7 @@ k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__res
 }
 
 // g = J^T f: one wave per column, lanes stride the rows (coalesced), shuffle reduction.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_jtf(int m, int n, const double *__restrict__ J, const double *__restrict__ f,
       double *__restrict__ g, const LmState *__restrict__ st, int want_stage)
 {
@@ -542,7 +542,7 @@ k_jtf(int m, int n, const double *__restrict__ J, const double *__restrict__ f,
 // grad(i) = dot(jac(:,i), fvec) in the reference's order (src/nonlin_solve.f90:565-567): one thread per column,
 // rows ascending, separate multiply and add.  The Newton line search feeds dot(grad, dir) into the backtracking
 // formula, so a reordered sum changes the accepted step in its last bits.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_jtf_exact(int m, int n, const double *__restrict__ Jall, const double *__restrict__ fall, double *__restrict__ gall,
             const LmState *__restrict__ st, int want)
 {

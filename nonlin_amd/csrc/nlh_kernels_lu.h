@@ -7,7 +7,7 @@
 #pragma once
 #include "nlh_common.h"
 
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_lu_factor(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
             const LmState *__restrict__ st, int want)
 {
@@ -57,7 +57,7 @@ k_lu_factor(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, in
 }
 
 // Solve LU x = b in place (dynamic LDS: n doubles).
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ ipvt_all,
            double *__restrict__ ball, const LmState *__restrict__ st, int want)
 {
@@ -155,7 +155,7 @@ k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ 
 // ---------------------------------------------------------------------------
 #define LU_NB 32
 
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_lu_panel(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
            int jb, int nb, const LmState *__restrict__ st, int want)
 {
@@ -269,7 +269,7 @@ __device__ __forceinline__ void lu_wave_first_max(double v, int idx, double &vma
     imin = __builtin_amdgcn_readlane(c, 63);
 }
 
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
                int jb, int nb, const LmState *__restrict__ st, int want)
 {
@@ -357,7 +357,7 @@ k_lu_panel_lds(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
 // panel -- the column's part of the block row: u(j,k) final after the updates of the earlier panel columns (unit lower
 // triangular solve, j ascending).  One launch for both: these kernels are launch-latency-bound (n = 1024: 64 panels x
 // three launches of 5 - 12 us each were a third of the factorisation).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_lu_swap_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipvt_all, int jb, int nb,
                const LmState *__restrict__ st, int want)
 {
@@ -403,7 +403,7 @@ k_lu_swap_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipv
 
 // Trailing update A22 -= L21 U12 on 64x64 tiles; each thread owns a 4x4 register tile and
 // subtracts the nb products in j order (separate multiply and subtract).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__restrict__ st, int want)
 {
     __shared__ double Ls[LU_NB * 64];              // Ls[j*64 + r]

@@ -122,7 +122,7 @@ __device__ double nt_block_max(int n, Term term, double *red)
     return r;
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_nt_reset(int nprob, LmState *__restrict__ st, NtState *__restrict__ ns)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -138,7 +138,7 @@ k_nt_reset(int nprob, LmState *__restrict__ st, NtState *__restrict__ ns)
 }
 
 // :538-553 after F(x0): f = 0.5 F.F, the start-point convergence test, stpmax
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_nt_start(int n, NtOpts o, const double *__restrict__ xall, const double *__restrict__ fall, LmState *__restrict__ st,
            NtState *__restrict__ ns)
 {
@@ -166,7 +166,7 @@ k_nt_start(int n, NtOpts o, const double *__restrict__ xall, const double *__res
 }
 
 // rhs = -F(x) (:577), elementwise
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_nt_rhs(int n, const double *__restrict__ fall, double *__restrict__ rall, const LmState *__restrict__ st)
 {
     const int p = blockIdx.y;
@@ -176,7 +176,7 @@ k_nt_rhs(int n, const double *__restrict__ fall, double *__restrict__ rall, cons
 }
 
 // quasi-Newton, an update iteration's head (:294-296): df = F(x) - F(xold), dx = x - xold, x2 = dx.dx (ordered)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_qn_prep(int n, const double *__restrict__ xall, const double *__restrict__ xoldall, const double *__restrict__ fall,
           const double *__restrict__ fvoldall, double *__restrict__ ddxall, double *__restrict__ ddfall,
           double *__restrict__ x2all, const LmState *__restrict__ st)
@@ -193,7 +193,7 @@ k_qn_prep(int n, const double *__restrict__ xall, const double *__restrict__ xol
     if (tid == 0) x2all[p] = x2;
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_nt_advance(int nprob, LmState *__restrict__ st, int from, int to)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +202,7 @@ k_nt_advance(int nprob, LmState *__restrict__ st, int from, int to)
 
 // :573-589 after the LU solve (quasi-Newton: :316-351 after grad = B^T F and step = -R^-1 Q^T F): xold, fold, the
 // step-length guards, the set-up of ls_search_mimo (:249-265) and the first trial point
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_nt_step_begin(int n, NtOpts o, int want, double *__restrict__ xall, double *__restrict__ xoldall, double *__restrict__ dirall,
                 const double *__restrict__ gradall, const double *__restrict__ fall, double *__restrict__ fvoldall,
                 LmState *__restrict__ st, NtState *__restrict__ ns)
@@ -276,7 +276,7 @@ k_nt_step_begin(int n, NtOpts o, int want, double *__restrict__ xall, double *__
 
 // F(x) at the trial point is in fvec: one turn of ls_search_mimo's loop (:266-310); on acceptance test_convergence and the
 // end of the outer iteration (:599-619)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_nt_trial(int n, NtOpts o, double *__restrict__ xall, const double *__restrict__ xoldall, const double *__restrict__ dirall,
            const double *__restrict__ gradall, const double *__restrict__ fall, LmState *__restrict__ st,
            NtState *__restrict__ ns)
@@ -366,7 +366,7 @@ k_nt_trial(int n, NtOpts o, double *__restrict__ xall, const double *__restrict_
     }
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_nt_count(int nprob, const LmState *__restrict__ st, int32_t *__restrict__ counts)
 {
     __shared__ int c[3];

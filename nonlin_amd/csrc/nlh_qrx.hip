@@ -41,7 +41,7 @@
 // column with its pending updates, NORM2 -- a serial chain of m - j adds --, scaling -> reflector) and
 // k_qrx_pass (lane per trailing column; k_qrx_pass_rp, the row-parallel form, when the launch cannot fill the chip:
 // a few problems still iterating, one problem alone, the last narrow steps).  The driver keeps several sub-batches in flight on private streams
-// (nlh_api.hip, lm_sub_batches) so that one sub-batch's pivot kernels run under another's passes.
+// (nlh_lm.hip, lm_sub_batches) so that one sub-batch's pivot kernels run under another's passes.
 #include "nlh_qrx.h"
 #include "nlh_common.h"
 #include <type_traits>
@@ -1832,7 +1832,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     // (Measured and dropped: the two halves of the batch on two streams, half B's pivot kernel under half A's pass, with
     // events keeping the passes from overlapping each other -- 1035 ms instead of 999 ms per 512 x 4096x256 solve; the
     // cross-stream event waits cost more than the pivot latency they hide.  Sub-batches on host threads, which need no
-    // cross-stream ordering, do hide it: nlh_api.hip, lm_sub_batches.)
+    // cross-stream ordering, do hide it: nlh_lm.hip, lm_sub_batches.)
     static const int forced_period = [] { const char *e = getenv("NLH_QRX_PERIOD"); return e ? atoi(e) : 0; }();
     static const long rp_env = [] { const char *e = getenv("NLH_QRX_RP"); return e ? atol(e) : -1L; }();
     const long rp_max = rp_env >= 0 ? rp_env : QRX_RP_MAX_WG;
