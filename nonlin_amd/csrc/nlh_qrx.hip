@@ -1198,6 +1198,9 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
 #ifndef QRX_RPW16_MAX_WG
 #define QRX_RPW16_MAX_WG 128            // launches of at most this many (problem, window) pairs take the wide form
 #endif
+#ifndef QRX_PIV32_MAXM
+#define QRX_PIV32_MAXM 2048
+#endif
 #ifndef QRX_FEW_MAX
 #define QRX_FEW_MAX 256                 // batches of at most this many active problems take the pivot kernel's FEW instance
 #endif                                  // (32 x 4096x256: 111 instead of 122 ms per solve)
@@ -1899,6 +1902,15 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     // per CU) also serves every launch whose workgroups are all resident at once anyway
     static const int few_env = [] { const char *e = getenv("NLH_QRX_FEW"); return e ? atoi(e) : -1; }();
     const int few_max = few_env >= 0 ? few_env : QRX_FEW_MAX;
+    // rows up to which a BATCH takes the pivot kernel's 32-terms-per-lane instance (128 registers, four workgroups per CU;
+    // a column of more than 2048 rows then goes through its reflector slot in memory and two NORM2 chunks).  Measured at
+    // 2048 x 4096x256 with the instance for 4096 rows too: 3,458 / 3,428 against 3,458 / 3,500 LM it/s (same box, alternating
+    // runs): no gain, the default stays 2048.  (Also built and measured: an
+    // instance whose threads gather whole 64-byte sectors -- sixteen consecutive elements each, the column in registers
+    // from the gather to the scaling, two NORM2 chunks out of registers -- at three / four workgroups per CU: 96 / 268
+    // bytes of spills, 1.4 / 4.4 % SLOWER than the 64-term instance.)
+    static const int piv32_env = [] { const char *e = getenv("NLH_QRX_PIV32_MAXM"); return e ? atoi(e) : -1; }();
+    const int piv32_maxm = std::max(2048, piv32_env >= 0 ? piv32_env : QRX_PIV32_MAXM);
     bool prev_flushed = false;
     int cur = 0, np = 0, lo = 1;             // lo: first slot position that can still hold live data (step 0 moves physically)
     for (int j = 0; j < n; ++j) {
@@ -1921,7 +1933,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         if (m <= 2048 && nact <= few_max)
             hipLaunchKernelGGL((k_qrx_pivot<32, false, true>), dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
                                T, w, R, v, (const LmState *)st);
-        else if (m <= 2048)
+        else if (m <= piv32_maxm && (m <= 2048 || nact > few_max))
             hipLaunchKernelGGL(k_qrx_pivot<32>, dim3(nprob), dim3(256), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf,
                                T, w, R, v, (const LmState *)st);
         else if (m - j <= 64 * 64 && nact <= few_max)
