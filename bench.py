@@ -667,7 +667,7 @@ def main():
         # applied) committed under profiles/: bytes moved per algorithmic byte, scaled to this run's average launch.
         traffic, traffic_src = None, None
         try:
-            pmc_file = next(f for f in ("r03_pmc_summary.json", "r02_pmc_summary.json")
+            pmc_file = next(f for f in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             prof = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             if (prof["m"], prof["n"], prof.get("policy")) == (m, n, args.policy):
@@ -761,7 +761,7 @@ def main():
             ]
             if kernel_ms["gram"] > 0:
                 gram_flops = (m * n * (n + 1) + 2 * m * n) * njac         # symmetric half + J^T f
-                kr.insert(0, {"kernel": "k_gram_tri / k_gram_mfma", "bound": "mfma",
+                kr.insert(0, {"kernel": "k_gram_tri / k_gram_512 / k_gram_mfma (whichever serves this n)", "bound": "mfma",
                               "achieved": gram_flops / max(kernel_ms["gram"] * 1e-3, 1e-30) / 1e12, "peak": 78.6,
                               "unit": "TFLOP/s", "frac": gram_flops / max(kernel_ms["gram"] * 1e-3, 1e-30) / 1e12 / 78.6})
             out["kernel_rooflines"] = kr
