@@ -51,7 +51,7 @@ struct nlh_handle {
     std::vector<DevBuf *> bufs;       // every workspace buffer, for destroy
     // named workspace buffers (grown on demand, reused across calls)
     DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2, R,
-           qnQ, qnR, qnV, bfB, bfR, bfV, qxV;
+           qnQ, qnR, qnV, bfB, bfR, bfV, qxV, lumv;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     DevBuf cholmc;                     // side buffer of the multi-CU Cholesky (solved panels, bad-pivot flags)

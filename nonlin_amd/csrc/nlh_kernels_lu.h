@@ -416,8 +416,12 @@ k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__res
     const int tid = threadIdx.x;
     for (int e = tid; e < nb * 64; e += 256) {
         const int j = e >> 6, q = e & 63;
-        Ls[e] = (r0 + q < n) ? a[(size_t)(jb + j) * n + r0 + q] : 0.0;     // L21(r, j), contiguous in r
-        Us[e] = (c0 + q < n) ? a[(size_t)(c0 + q) * n + jb + j] : 0.0;     // U12(j, c)
+        // (loads unconditional with clamped indices: a load under a condition is waited for before the next is issued)
+        double lv = a[(size_t)(jb + j) * n + (r0 + q < n ? r0 + q : n - 1)];     // L21(r, j), contiguous in r
+        double uv = a[(size_t)(c0 + q < n ? c0 + q : n - 1) * n + jb + j];       // U12(j, c)
+        asm volatile("" : "+v"(lv), "+v"(uv));
+        Ls[e] = (r0 + q < n) ? lv : 0.0;
+        Us[e] = (c0 + q < n) ? uv : 0.0;
     }
     __syncthreads();
     const int tr = (tid & 15) * 4, tc = (tid >> 4) * 4;
@@ -427,7 +431,7 @@ k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__res
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = r0 + tr + rr, c = c0 + tc + cc;
-            acc[cc][rr] = (r < n && c < n) ? a[(size_t)c * n + r] : 0.0;
+            acc[cc][rr] = a[(size_t)(c < n ? c : n - 1) * n + (r < n ? r : n - 1)];
         }
     for (int j = 0; j < nb; ++j) {
         double l[4], u[4];
@@ -445,4 +449,315 @@ k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__res
             const int r = r0 + tr + rr, c = c0 + tc + cc;
             if (r < n && c < n) a[(size_t)c * n + r] = acc[cc][rr];
         }
+}
+
+// ---------------------------------------------------------------------------
+// Round 4: the panel with SEVERAL ROWS PER THREAD, implicit interchanges and ONE barrier per column.
+//
+// k_lu_panel_lds runs sixteen waves for 1024 rows, and what a column step costs there is the instruction stream of the
+// reductions, executed by four waves on every SIMD, and two barriers.  Here thread t holds RPT rows (row q*T + t of the
+// panel in slot q) of an NB-column panel, so a 1024-row panel is four waves -- one per SIMD.
+//
+// * Interchanges are not performed: every row carries its current POSITION (pos[q]: what LAPACK's sequence of
+//   interchanges would have made its row index); rows at positions < c are finished, the pivot search runs over the
+//   rows at positions >= c and takes the first maximum in POSITION order (so ipvt is the sequence the unblocked loop
+//   finds, ties included), the winner takes position c and the row that was there takes the winner's.  Rows go back
+//   to memory at their final positions, and the panel leaves a MOVE LIST (which row ends where) so that the columns
+//   outside the panel are permuted with all loads in flight at once instead of nb dependent exchanges.
+// * The maximum of |a| is an unsigned maximum of its bit pattern, high word then low word: 32-bit DPP steps.
+// * Every wave's winner publishes its whole row and the reciprocal of its entry BEFORE the barrier (the reciprocal is
+//   formed by every lane for its own candidate in the shadow of the reduction: the same IEEE division whoever performs
+//   it); after the barrier every thread picks the winning wave from the per-wave results and reads that row.
+// * Column c + 1 is updated first and its candidates go out while the other columns are updated.
+//
+// Per element the operations are those of the unblocked loop in the same order: multiplier = a * (1 / pivot), then
+// a(i,k) = a(i,k) - l(i) * u(k) for the pivots in ascending order -- with a separate multiply and subtract the factors
+// are bit-identical to k_lu_panel_lds / the CPU restatement (FAST = false); FAST = true contracts them into one FMA.
+// NaN handling as in k_lu_panel_lds: a NaN on the diagonal is taken, a NaN below it never.
+// ---------------------------------------------------------------------------
+#define LU_PIN(x) asm volatile("" : "+v"(x))
+#define LU_MV_STRIDE 128   // ints per problem: [i < 32] source row of the row that ends at panel position i; [32] number of
+                           // displaced rows; [33 + 2e], [34 + 2e] destination and source of displaced row e (panel-relative)
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t lu_dpp_umax_step(uint32_t v)
+{
+    // bound_ctrl: lanes without a source (and rows outside the mask) read 0 -- neutral for an unsigned maximum
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t lu_wave_umax(uint32_t v)
+{
+    v = lu_dpp_umax_step<0x111, 0xf>(v);
+    v = lu_dpp_umax_step<0x112, 0xf>(v);
+    v = lu_dpp_umax_step<0x114, 0xf>(v);
+    v = lu_dpp_umax_step<0x118, 0xf>(v);
+    v = lu_dpp_umax_step<0x142, 0xa>(v);
+    v = lu_dpp_umax_step<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int lu_wave_min(int c)
+{
+    c = lu_row16_min(c);
+    c = lu_dpp_min_step<0x142, 0xa, 0xf>(c);
+    c = lu_dpp_min_step<0x143, 0xc, 0xf>(c);
+    return __builtin_amdgcn_readlane(c, 63);
+}
+
+// dynamic LDS of k_lu_panel_reg: the finished multipliers, column by column, indexed by the row's slot
+static inline size_t lu_panel_reg_lds(int rpt, int nbw, int threads) { return sizeof(double) * (size_t)nbw * rpt * threads; }
+
+template <int RPT, int NB, int TMAX, bool FAST>
+static __global__ void __launch_bounds__(TMAX)
+k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
+               int32_t *__restrict__ mv_all, int jb, int nb, const LmState *__restrict__ st, int want)
+{
+    constexpr int NWMAX = TMAX / 64;
+    constexpr int WS = NB + 2;                                   // doubles per published row: the window, then 1 / its entry
+    __shared__ __attribute__((aligned(16))) uint32_t red_hi[2][NWMAX];
+    __shared__ __attribute__((aligned(16))) uint32_t red_lo[2][NWMAX];
+    __shared__ __attribute__((aligned(16))) int red_p[2][NWMAX];
+    __shared__ __attribute__((aligned(16))) double wrow[2][NWMAX][WS];
+    __shared__ __attribute__((aligned(16))) double ubuf[NB][NB]; // ubuf[c][j]: u(c, c + j)
+    __shared__ int piv_s[NB], src_s[NB];                         // pivot position and slot row of step c
+    __shared__ int zero_s;                                       // first step with a zero pivot + 1
+    __shared__ int mvcnt;
+    extern __shared__ __attribute__((aligned(16))) double lbuf[];            // lbuf[c * RT + slot row]: multiplier of column c
+    const int p = blockIdx.x, t = threadIdx.x, T = blockDim.x, lane = t & 63, wid = t >> 6, RT = RPT * T;
+    if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
+    const int rows = n - jb;
+    double *a = Aall + (size_t)p * n * n + (size_t)jb * n + jb;  // a[k * n + r]: panel column k, panel row r
+    int32_t *ipvt = ipvt_all + (size_t)p * n + jb;
+    int32_t *mv = mv_all ? mv_all + (size_t)p * LU_MV_STRIDE : nullptr;
+    // The window: w[q][j] is column c + j of the row in slot q at step c.  The step loop is NOT unrolled and has (almost)
+    // no branches: a branch into code that has never run costs 200 cycles, 40 when warm (profiles/ubench/icache_branch.hip),
+    // and the unrolled, branchy form of this kernel took 2 us a column.  Finished rows keep being "updated": their
+    // windows are never read again, so no predicate is needed.
+    double w[RPT][NB];
+    int pos[RPT];
+#ifdef LU_DBG_CLK       // -DLU_DBG_CLK: in-kernel phase clocks (100 MHz) of the first panel, printed by thread 0
+    long long clk[8]; clk[0] = wall_clock64();
+#endif
+    // loads are unconditional (clamped indices) and all issued before any is used: the compiler puts a load under a
+    // condition back under it, and a load in a conditional block is waited for before the next one is issued
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = q * T + t;
+        pos[q] = r < rows ? r : -1;
+        const int rc = r < rows ? r : rows - 1;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) w[q][k] = a[(size_t)(k < nb ? k : nb - 1) * n + rc];
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = q * T + t;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            LU_PIN(w[q][k]);
+            w[q][k] = (r < rows && k < nb) ? w[q][k] : 0.0;
+        }
+    }
+    if (t < 2 * NWMAX) {                                         // waves that do not exist never win
+        (&red_hi[0][0])[t] = 0u; (&red_lo[0][0])[t] = 0u; (&red_p[0][0])[t] = 0x7fffffff;
+    }
+    if (t == 0) { mvcnt = 0; zero_s = 0; }
+    __syncthreads();
+    // this lane's candidate of the column being searched: key = bits of |a|, position, reciprocal of the signed entry
+    int lp = 0x7fffffff;
+    bool winner = false;
+    double wlrc = 1.0;
+    auto search = [&](int cc) {
+        const int par = cc & 1;
+        uint32_t lhi = 0, llo = 0;
+        lp = 0x7fffffff;
+        double lx = 1.0;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const double x = w[q][0];
+            const bool nan = x != x, alive = pos[q] >= cc, dia = pos[q] == cc;
+            uint32_t hi = (uint32_t)__double2hiint(x) & 0x7fffffffu, lo = (uint32_t)__double2loint(x);
+            hi = nan ? 0x7ff00000u : hi; lo = nan ? 0u : lo;     // a NaN on the diagonal is taken, as the ordered search does
+            const bool valid = alive & (!nan | dia);
+            const bool take = valid & ((hi > lhi) | ((hi == lhi) & ((lo > llo) | ((lo == llo) & (pos[q] < lp)))));
+            lhi = take ? hi : lhi; llo = take ? lo : llo; lp = take ? pos[q] : lp; lx = take ? x : lx;
+        }
+        wlrc = 1.0 / lx;
+        const bool have = lp != 0x7fffffff;
+        const uint32_t mhi = lu_wave_umax(have ? lhi : 0u);
+        const uint32_t mlo = lu_wave_umax((have & (lhi == mhi)) ? llo : 0u);
+        const int cp = (have & (lhi == mhi) & (llo == mlo)) ? lp : 0x7fffffff;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cp != 0x7fffffff);
+        int wp;
+        if (__builtin_expect(__builtin_popcountll(m) == 1, 1)) wp = __builtin_amdgcn_readlane(cp, __builtin_ctzll(m));
+        else wp = lu_wave_min(cp);
+        winner = (cp == wp) & (cp != 0x7fffffff);
+        if (lane == 0) { red_hi[par][wid] = mhi; red_lo[par][wid] = mlo; red_p[par][wid] = wp; }
+    };
+    // ... and, once the step's updates are complete, this wave's winner publishes its window and reciprocal
+    auto publish = [&](int cc) {
+        double *wr = &wrow[cc & 1][wid][0];
+        if (winner) {
+#pragma unroll
+            for (int q = 0; q < RPT; ++q)
+                if (pos[q] == lp) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) wr[k] = w[q][k];
+                }
+            wr[NB] = wlrc;
+        }
+    };
+#ifdef LU_DBG_CLK
+    clk[1] = wall_clock64();
+#endif
+    search(0);
+    publish(0);
+#ifdef LU_DBG_CLK
+    clk[2] = wall_clock64();
+#endif
+#pragma unroll 1
+    for (int c = 0; c < nb; ++c) {
+        const int par = c & 1;
+#ifdef LU_DBG_CLK
+        if (c == 4) clk[3] = wall_clock64();
+        if (c == 12) clk[4] = wall_clock64();
+#endif
+        nlh_lds_barrier();                         // LDS only: nothing in the loop goes to global memory
+        // the winning wave: largest key, smallest position among equals
+        uint32_t bhi = red_hi[par][0], blo = red_lo[par][0];
+        int ppos = red_p[par][0], ws = 0;
+#pragma unroll
+        for (int v = 1; v < NWMAX; ++v) {
+            const uint32_t oh = red_hi[par][v], ol = red_lo[par][v];
+            const int op = red_p[par][v];
+            const bool take = (oh > bhi) | ((oh == bhi) & ((ol > blo) | ((ol == blo) & (op < ppos))));
+            bhi = take ? oh : bhi; blo = take ? ol : blo; ppos = take ? op : ppos; ws = take ? v : ws;
+        }
+        const double *pr = &wrow[par][ws][0];
+        double u[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) u[j] = pr[j];
+        const double rcp = pr[NB];
+        const bool nz = u[0] != 0.0;
+        int myslot = 0;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) myslot = pos[q] == ppos ? q * T + t : myslot;
+        if (lp == ppos) { piv_s[c] = ppos; src_s[c] = myslot; }  // the owner
+        if (t < NB) ubuf[c][t] = pr[t];
+        if (!nz && t == 0 && zero_s == 0) zero_s = c + 1;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const bool own = pos[q] == ppos, dia = pos[q] == c;
+            pos[q] = own ? c : (dia ? ppos : pos[q]);
+        }
+        // multipliers, then column c + 1 first: its candidates go out while the other columns are updated
+        double l[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            l[q] = nz ? w[q][0] * rcp : w[q][0];   // zero pivot: no scaling; the update still runs
+            lbuf[(size_t)c * RT + q * T + t] = l[q];
+            w[q][0] = FAST ? __builtin_fma(-l[q], u[1], w[q][1]) : w[q][1] - l[q] * u[1];
+        }
+        if (c + 1 < nb) search(c + 1);
+#pragma unroll
+        for (int j = 2; j < NB; ++j) {
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) w[q][j - 1] = FAST ? __builtin_fma(-l[q], u[j], w[q][j]) : w[q][j] - l[q] * u[j];
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) w[q][NB - 1] = 0.0;
+        if (c + 1 < nb) publish(c + 1);
+    }
+#ifdef LU_DBG_CLK
+    clk[5] = wall_clock64();
+#endif
+    __syncthreads();
+    // rows to their final places: multipliers left of the row's pivot step, its U part from there on
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+        if (pos[q] >= 0) {
+            const int fin = pos[q], cp = fin < nb ? fin : nb, slot = q * T + t;
+            for (int k = 0; k < cp; ++k) a[(size_t)k * n + fin] = lbuf[(size_t)k * RT + slot];
+            for (int k = cp; k < nb; ++k) a[(size_t)k * n + fin] = ubuf[cp][k - cp];
+            if (mv && fin >= nb && fin != slot) {                // displaced below the panel's block row
+                const int e = atomicAdd(&mvcnt, 1);
+                mv[33 + 2 * e] = fin;
+                mv[34 + 2 * e] = slot;
+            }
+        }
+    if (t < nb) {
+        ipvt[t] = jb + piv_s[t];
+        if (mv) mv[t] = src_s[t];
+    }
+    if (t == 0 && zero_s != 0 && info && info[p] == 0) info[p] = jb + zero_s;
+    if (mv) {
+        __syncthreads();
+        if (t == 0) mv[32] = mvcnt;
+    }
+#ifdef LU_DBG_CLK
+    clk[6] = wall_clock64();
+    if (t == 0 && p == 0 && (jb == 0 || jb == 512 || jb == 768))
+        printf("k_lu_panel_reg<%d,%d> jb %d rows %d: load %lld, first search %lld, steps 0-3 %lld (x10 ns), steps 4-11 %lld, rest %lld, output %lld\n", RPT, NB, jb,
+               rows, (clk[1] - clk[0]), (clk[2] - clk[1]), (clk[3] - clk[2]), (clk[4] - clk[3]), (clk[5] - clk[4]), (clk[6] - clk[5]));
+#endif
+}
+
+// The columns outside panel [jb, jb + nb) after k_lu_panel_reg: the panel's row moves (all sources loaded before any
+// destination is stored: one trip to memory each way instead of nb dependent exchanges), then -- right of the panel --
+// the column's part of the block row (unit lower triangular solve, j ascending; separate multiply and subtract unless
+// FAST).  A thread per column.
+template <int TR, bool FAST>
+static __global__ void __launch_bounds__(256)
+k_lu_move_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ mv_all, int jb, int nb,
+               const LmState *__restrict__ st, int want)
+{
+    __shared__ double L11[TR * TR + TR];           // L11[i + j*TR], i > j used (+ TR: the shifting window reads past the end)
+    __shared__ int32_t mv[LU_MV_STRIDE];
+    const int p = blockIdx.y;
+    if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
+    double *a = Aall + (size_t)p * n * n;
+    for (int e = threadIdx.x; e < TR * TR + TR; e += blockDim.x) {
+        const int i = e % TR, j = e / TR;
+        double v = a[(size_t)(jb + (j < nb ? j : nb - 1)) * n + jb + (i < nb ? i : nb - 1)];     // (unconditional, clamped)
+        LU_PIN(v);
+        L11[e] = (i < nb && j < nb) ? v : 0.0;
+    }
+    if (threadIdx.x < LU_MV_STRIDE) mv[threadIdx.x] = mv_all[(size_t)p * LU_MV_STRIDE + threadIdx.x];
+    __syncthreads();
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n - nb) return;
+    if (k >= jb) k += nb;                          // skip the panel's own columns
+    double *ck = a + (size_t)k * n + jb;
+    const int cnt2 = mv[32];
+    // every source before any destination; the loads are unconditional (index 0 for unused entries): a load under a
+    // condition is waited for before the next one is issued
+    double u[TR], d[TR];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) u[i] = ck[i < nb ? mv[i] : 0];
+#pragma unroll
+    for (int e = 0; e < TR; ++e) d[e] = ck[e < cnt2 ? mv[34 + 2 * e] : 0];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) { LU_PIN(u[i]); LU_PIN(d[i]); }
+#pragma unroll
+    for (int e = 0; e < TR; ++e)
+        if (e < cnt2) ck[mv[33 + 2 * e]] = d[e];
+    if (k < jb + nb) {                             // left of the panel: the moves only
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+            if (i < nb && mv[i] != i) ck[i] = u[i];
+        return;
+    }
+    // right of the panel: the block row.  u(j) is final when step j begins; the window u[0 ..] holds rows j, j + 1, ...
+    // (a rolled loop: TR - 1 multiply / subtract pairs a step, the code stays in the instruction cache)
+#pragma unroll 1
+    for (int j = 0; j < nb; ++j) {
+        const double uj = u[0];
+        ck[j] = uj;
+        const double *lj = L11 + j * TR + j;       // lj[i]: l(j + i, j); beyond the panel it reads zeros or the next column (rows >= nb: unused)
+#pragma unroll
+        for (int i = 1; i < TR; ++i) {
+            const double li = lj[i];
+            u[i - 1] = FAST ? __builtin_fma(-li, uj, u[i]) : u[i] - li * uj;
+        }
+        u[TR - 1] = 0.0;
+    }
 }

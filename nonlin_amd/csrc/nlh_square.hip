@@ -10,11 +10,41 @@
 #include "nlh_kernels_broyden.h"
 #include "nlh_kernels_exact.h"
 
+template <bool FAST> static void lu_panel_reg_attrs(int lds_max);
+
 void nlh_square_init_device(int lds_max)
 {
     hipFuncSetAttribute((const void *)k_lu_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lu_panel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     broyden_kernel_attrs(lds_max);
+    lu_panel_reg_attrs<false>(lds_max);
+}
+
+// The register panel with several rows per thread (k_lu_panel_reg): instance by the number of panel rows.
+template <bool FAST>
+static int launch_lu_panel_reg(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipvt, int32_t *dinfo, int jb,
+                               const LmState *st, int want, int wide)
+{
+    const int rows = n - jb;
+    auto go = [&](auto kern, int rpt, int pw) {
+        const int nb = std::min(pw, rows);
+        const int T = std::max(64, (((rows + rpt - 1) / rpt) + 63) & ~63);
+        hipLaunchKernelGGL(kern, dim3(nprob), dim3(T), lu_panel_reg_lds(rpt, pw, T), h->stream, n, dA, dipvt, dinfo, (int32_t *)h->lumv.p,
+                           jb, nb, st, want);
+        return nb;
+    };
+    if (rows <= 256) return go(k_lu_panel_reg<1, 32, 256, FAST>, 1, 32);
+    if (rows <= 512) return go(k_lu_panel_reg<2, 32, 256, FAST>, 2, 32);
+    if (rows <= 1024) return wide ? go(k_lu_panel_reg<2, 16, 512, FAST>, 2, 16) : go(k_lu_panel_reg<4, 16, 256, FAST>, 4, 16);
+    return 0;
+}
+template <bool FAST>
+static void lu_panel_reg_attrs(int lds_max)
+{
+    hipFuncSetAttribute((const void *)k_lu_panel_reg<1, 32, 256, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lu_panel_reg<2, 32, 256, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lu_panel_reg<2, 16, 512, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lu_panel_reg<4, 16, 256, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
 }
 
 // lu_factor: unblocked single-workgroup kernel for small n, blocked multi-kernel path otherwise.
@@ -27,20 +57,38 @@ void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipv
         return;
     }
     if (dinfo) hipMemsetAsync(dinfo, 0, sizeof(int32_t) * (size_t)nprob, h->stream);
-    // panels of 16 columns factored in registers (thread per row) while n - jb <= 1024 rows, 32-column panels in global memory before
+    static const int panel_env = [] { const char *e = getenv("NLH_LU_PANEL"); return e ? atoi(e) : 1; }();
+    int panel_mode = panel_env;
+    if (panel_mode >= 1 && ensure(h, h->lumv, sizeof(int32_t) * LU_MV_STRIDE * (size_t)nprob)) panel_mode = 0;   // (no memory for the move lists)
+    // panels factored in registers while they have at most 2048 rows (several rows per thread, implicit interchanges),
+    // 32-column panels in global memory before
     for (int jb = 0; jb < n;) {
-        const bool lds = (n - jb) <= LU_PROWS;
-        const int pw = lds ? LU_PNB : LU_NB;
-        const int nb = (n - jb < pw) ? (n - jb) : pw;
-        if (lds)
-            // one thread per panel row: waves without rows would still run the step's instruction stream and barriers
-            hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(std::min(1024, (n - jb + 63) & ~63)), 0, h->stream, n, dA, dipvt, dinfo, jb, nb,
-                               st, want);
-        else
-            hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb, st, want);
-        if (n - nb > 0)
-            hipLaunchKernelGGL(k_lu_swap_trsm, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
-                               (const int32_t *)dipvt, jb, nb, st, want);
+        int nb = 0;
+        if (panel_mode >= 1) nb = launch_lu_panel_reg<false>(h, nprob, n, dA, dipvt, dinfo, jb, st, want, panel_mode >= 2);
+        const bool reg = nb != 0;
+        if (nb == 0) {
+            const bool lds = panel_mode == 0 && (n - jb) <= LU_PROWS;
+            const int pw = lds ? LU_PNB : LU_NB;
+            nb = (n - jb < pw) ? (n - jb) : pw;
+            if (lds)
+                // one thread per panel row: waves without rows would still run the step's instruction stream and barriers
+                hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(std::min(1024, (n - jb + 63) & ~63)), 0, h->stream, n, dA, dipvt, dinfo, jb, nb,
+                                   st, want);
+            else
+                hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb, st, want);
+        }
+        if (n - nb > 0) {
+            if (reg)
+                if (nb <= 16)
+                    hipLaunchKernelGGL((k_lu_move_trsm<16, false>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
+                                       (const int32_t *)h->lumv.p, jb, nb, st, want);
+                else
+                    hipLaunchKernelGGL((k_lu_move_trsm<32, false>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
+                                       (const int32_t *)h->lumv.p, jb, nb, st, want);
+            else
+                hipLaunchKernelGGL(k_lu_swap_trsm, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
+                                   (const int32_t *)dipvt, jb, nb, st, want);
+        }
         const int nt = n - jb - nb;
         if (nt > 0) {
             hipLaunchKernelGGL(k_lu_gemm, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, h->stream, n, dA, jb, nb, st, want);

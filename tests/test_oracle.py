@@ -14,6 +14,7 @@ import pytest
 import problems_ref as P
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
 _G = json.load(open(os.path.join(HERE, "golden", "reference_known_answers.json")))
 GOLD = _G["reference_held"]
 RECORDED = _G["recorded_not_reference_held"]          # regression values, NOT golden vectors (see the module docstring)
@@ -429,3 +430,93 @@ def test_readme_example_1_quasi_newton_counts(oracle):
     assert (ib["iter_count"], ib["fcn_count"], ib["jacobian_count"]) == (11, 15, 1)          # README.md:95-97
     assert "%.5f, %.5f" % (x[0], x[1]) == "5.00000, 3.00000"                                  # README.md:93
     assert ("%.2e" % f[0], "%.2e" % f[1]) == ("3.23e-12", "7.05e-12")                         # 0.323E-11, 0.705E-11 (:94)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The un-vendored `linalg` pieces against LAPACK itself (tests/golden/lapack_vectors.npz, written by
+# tests/golden/make_lapack_vectors.py from scipy's LAPACK in the build container).  LAPACK's blocked routines do not fix the
+# order of their sums, so the pin is: pivot sequence EXACT, factors and solutions within a few ulp of the matrix norm.
+# ---------------------------------------------------------------------------------------------------------------------
+def _lapack_vectors():
+    return np.load(os.path.join(GOLDEN, "lapack_vectors.npz"))
+
+
+def _lu_names():
+    return [str(s) for s in _lapack_vectors()["lu_names"]]
+
+
+@pytest.mark.parametrize("name", _lu_names())
+def test_lu_factor_follows_lapack_dgetrf(oracle, name):
+    """lu_factor / solve_lu (call sites src/nonlin_solve.f90:570,577; linalg -> DGETRF / DGETRS): same interchanges at
+    every step, same `info` for an exactly zero pivot column, L and U within 64 ulp of the growth-scaled matrix norm."""
+    import ctypes as C
+    g = _lapack_vectors()
+    a = np.array(g[f"lu_{name}_a"], order="F")
+    n = a.shape[0]
+    lu = a.copy(order="F")
+    ipvt = np.zeros(n, dtype=np.int32)
+    info = oracle.lib().nlo_lu_factor(n, lu.ctypes.data_as(C.POINTER(C.c_double)), n, ipvt.ctypes.data_as(C.POINTER(C.c_int32)))
+    ref, piv, rinfo = g[f"lu_{name}_lu"], g[f"lu_{name}_piv"], int(g[f"lu_{name}_info"])
+    assert info == rinfo
+    if name == "singular12":                       # equal columns: the pivot of the dependent column is rounding noise; pivots agree before it
+        k = 9
+        assert np.array_equal(ipvt[:k], piv[:k])
+        scale = np.abs(ref).max()
+        assert np.abs(lu[:k, :] - ref[:k, :]).max() <= 64 * np.finfo(float).eps * scale    # rows below k are permuted by the later (noise) pivots
+        return
+    assert np.array_equal(ipvt, piv)
+    scale = np.abs(ref).max(axis=0, keepdims=True).clip(min=np.abs(a).max() * 1e-300)
+    assert (np.abs(lu - ref) / np.maximum(scale, np.abs(a).max(axis=0, keepdims=True))).max() <= 64 * np.finfo(float).eps
+    if rinfo == 0:
+        b = np.array(g[f"lu_{name}_b"])
+        oracle.lib().nlo_lu_solve(n, lu.ctypes.data_as(C.POINTER(C.c_double)), n, ipvt.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  b.ctypes.data_as(C.POINTER(C.c_double)))
+        x = g[f"lu_{name}_x"]
+        cond = np.linalg.cond(a)
+        assert np.abs(b - x).max() <= 16 * np.finfo(float).eps * cond * np.abs(x).max()
+
+
+@pytest.mark.parametrize("name", [str(s) for s in _lapack_vectors()["qr_names"]])
+def test_qr_with_q_follows_lapack_and_the_rank1_update_an_independent_one(oracle, name):
+    """qr_factor with Q formed (src/nonlin_solve.f90:286; DGEQRF + DORGQR: same Householder sign convention, so Q and R
+    agree entry for entry), then qr_rank1_update (:303) against scipy.linalg.qr_update -- an independent Givens
+    implementation: rows of R / columns of Q may differ in sign, nothing else."""
+    g = _lapack_vectors()
+    a = g[f"qr_{name}_a"]
+    n = a.shape[0]
+    eps = np.finfo(float).eps
+    q, r = oracle.qr_factor_full(a)
+    assert np.abs(q - g[f"qr_{name}_q"]).max() <= 32 * n * eps
+    assert np.abs(r - g[f"qr_{name}_r"]).max() <= 32 * n * eps * np.abs(a).max()
+    q1, r1 = oracle.qr_rank1_update(q, r, g[f"qr_{name}_u"], g[f"qr_{name}_v"])
+    rq1, rr1 = g[f"qr_{name}_q1"], g[f"qr_{name}_r1"]
+    sgn = np.sign(np.diag(r1)) * np.sign(np.diag(rr1))           # align the free signs
+    tol = 256 * n * eps * max(1.0, np.abs(rr1).max())
+    assert np.abs(r1 * sgn[:, None] - rr1).max() <= tol
+    assert np.abs(q1 * sgn[None, :] - rq1).max() <= 256 * n * eps
+
+
+@pytest.mark.parametrize("name", [str(s) for s in _lapack_vectors()["tall_names"]])
+def test_tall_qr_with_rhs_follows_lapack(oracle, name):
+    """qr_factor + the reflectors applied to the residual (src/nonlin_least_squares.f90:1061; polynomial fit through
+    linalg's solve_least_squares): DGEQRF's R and DORMQR's Q^T f."""
+    g = _lapack_vectors()
+    a, f = g[f"tall_{name}_a"], g[f"tall_{name}_f"]
+    m, n = a.shape
+    eps = np.finfo(float).eps
+    rfull, qtf = oracle.qr_factor_rhs(a, f)
+    assert np.abs(np.triu(rfull[:n, :]) - g[f"tall_{name}_r"]).max() <= 32 * m * eps * np.abs(a).max()
+    assert np.abs(qtf - g[f"tall_{name}_qtf"]).max() <= 32 * m * eps * np.abs(f).max()
+
+
+@pytest.mark.parametrize("name", [str(s) for s in _lapack_vectors()["chol_names"]])
+def test_cholesky_follows_lapack_dpotrf(oracle, name):
+    g = _lapack_vectors()
+    b = g[f"chol_{name}_b"]
+    n = b.shape[0]
+    eps = np.finfo(float).eps
+    rc, r = oracle.chol_factor_upper(b)
+    assert rc == 0
+    assert np.abs(r - g[f"chol_{name}_r"]).max() <= 32 * n * eps * np.sqrt(np.abs(b).max()) * np.linalg.cond(b) ** 0.5
+    x = oracle.solve_cholesky_upper(r, g[f"chol_{name}_rhs"])
+    assert np.abs(x - g[f"chol_{name}_x"]).max() <= 64 * n * eps * np.linalg.cond(b) * np.abs(g[f"chol_{name}_x"]).max()
