@@ -6,6 +6,7 @@
 // exact pivot search).  One workgroup per problem; a wave owns a trailing column per step.
 #pragma once
 #include "nlh_common.h"
+#define LU_PIN(x) asm volatile("" : "+v"(x))      // keeps a load where it was written (the compiler moves loads back under conditions)
 
 static __global__ void __launch_bounds__(1024)
 k_lu_factor(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
@@ -56,92 +57,178 @@ k_lu_factor(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, in
     if (tid == 0 && info) info[p] = inf;
 }
 
-// Solve LU x = b in place (dynamic LDS: n doubles).
+// Solve LU x = b in place (dynamic LDS: lu_solve_lds(n)).
+//
+// Round 4: BLOCKED substitution.  The straightforward form is 2 n barrier-separated steps of a sixteen-wave workgroup
+// (n = 1024: 0.85 ms, 0.4 us a step) after one thread has walked the n interchanges.  Here
+//  * every element of b traces its own way through the interchanges (position i is touched by step j only if j == i or
+//    ipvt(j) == i, and an element that has been moved into position j < current step is final): all rows in parallel;
+//  * columns are taken LUS_W at a time: ONE wave solves the LUS_W x LUS_W triangle of the block out of LDS -- the solved
+//    entry of step j goes to the other lanes with a v_readlane, no barrier --, then every thread applies the block's
+//    LUS_W solved entries to its own row outside the block, its column entries prefetched before the triangle was solved.
+// Every element of b still receives b(i) = b(i) - x(j) * a(i,j) for j ascending (L) / descending (U), skipped where the
+// sequential loop skips (an exactly zero b(j)), and x(j) = b(j) / u(j,j) is the same IEEE division: the same bits.
+#define LUS_W 16
+static inline size_t lu_solve_lds(int n) { return sizeof(double) * ((size_t)n + 2 * LUS_W * LUS_W) + sizeof(int32_t) * ((size_t)n + 8 + 4); }
+
 static __global__ void __launch_bounds__(1024)
 k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ ipvt_all,
            double *__restrict__ ball, const LmState *__restrict__ st, int want)
 {
+    constexpr int W = LUS_W;
     extern __shared__ double bs[];
-    const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    double *tri = bs + n;                                         // two buffers of tri[j * W + l] = a(jb + l, jb + j)
+    int32_t *ips = reinterpret_cast<int32_t *>(tri + 2 * W * W);
+    int32_t *flag = ips + n + 8;                                  // which of the block's back-substitution steps ran
+    const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6;
     if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
     const double *a = LUall + (size_t)p * n * n;
     const int32_t *ipvt = ipvt_all + (size_t)p * n;
     double *b = ball + (size_t)p * n;
-    for (int i = tid; i < n; i += BS) bs[i] = b[i];
-    __syncthreads();
-    if (tid == 0)
-        for (int j = 0; j < n; ++j) {
-            const int q = ipvt[j];
-            if (q != j) { const double t = bs[j]; bs[j] = bs[q]; bs[q] = t; }
+    // The loads of block k + 1 (this thread's row entries of its columns, its element of the triangle) are issued
+    // before block k is worked on, and the barriers in between wait for LDS only: the memory latency is paid once.
+    // All loads are unconditional with clamped indices (a load under a condition is waited for where it stands).
+    // Blocks are numbered along the whole sweep: 0 .. nblk - 1 the forward substitution (columns k * W ...), nblk ..
+    // 2 nblk - 1 the back substitution (columns (2 nblk - 1 - k) * W ...).  The loads of block k + 1 (this thread's row
+    // entries of its columns, its element of the triangle) are issued before block k is worked on, and the barriers in
+    // between wait for LDS only.  (Two blocks ahead: no faster -- a block costs its instruction chains, 2 - 3 us, not
+    // the memory latency.)  All loads are unconditional with clamped indices, uniform column base + 32-bit row offset.
+    const int nblk = (n + W - 1) / W;
+    double pf[W], pf1[W], t1 = 0.0;
+    auto issue = [&](int k) {
+        const int kk = k < 2 * nblk ? k : 2 * nblk - 1;
+        const bool fwd = kk < nblk;
+        const int jb = (fwd ? kk : 2 * nblk - 1 - kk) * W;
+        const int row = fwd ? jb + W + tid : tid;                 // this thread's first row outside the block
+        const int w = n - jb < W ? n - jb : W;
+        const unsigned rc = row < n ? row : n - 1;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const double *col = a + (size_t)(jb + (j < w ? j : w - 1)) * n;      // (uniform)
+            pf1[j] = col[rc];
         }
+        const unsigned e = tid < W * W ? tid : 0, j = e / W, l = e % W;
+        t1 = a[(size_t)(jb + (j < (unsigned)w ? j : w - 1)) * n + jb + (l < (unsigned)w ? l : w - 1)];
+    };
+    auto land = [&](int buf) {                                    // the issued loads arrive: triangle to LDS, row entries to pf
+        LU_PIN(t1);
+        if (tid < W * W) tri[buf * W * W + tid] = t1;
+#pragma unroll
+        for (int j = 0; j < W; ++j) { LU_PIN(pf1[j]); pf[j] = pf1[j]; }
+    };
+#ifdef LU_DBG_CLK
+    long long sc[6]; sc[0] = wall_clock64();
+#endif
+    issue(0);
+    for (int i = tid; i < n + 8; i += BS) ips[i] = i < n ? ipvt[i] : -1;
     __syncthreads();
-    // Each thread owns row tid (+ BS, ...).  Its entries of the next LUS_PF columns are fetched while the current
-    // LUS_PF steps run, so a step costs a barrier and an LDS update, not a trip to L2 (one column ahead was not
-    // enough: a step is shorter than the latency).
-    constexpr int PF = 8;
-    {
-        double cur[PF], nxt[PF];
+    for (int i = tid; i < n; i += BS) {                           // P b: where element i ends
+        const double bi = b[i];
+        int cur = i;
+        for (int j = 0; j < n && j <= cur; j += 8) {              // (eight interchanges per trip: one LDS latency, not eight)
+            int q[8];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) nxt[u] = (u < n && tid > u && tid < n) ? a[(size_t)u * n + tid] : 0.0;
-        for (int j0 = 0; j0 < n; j0 += PF) {                       // L y = P b (unit diagonal)
+            for (int u = 0; u < 8; ++u) q[u] = ips[j + u];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
+            for (int u = 0; u < 8; ++u) cur = (cur == j + u) ? q[u] : ((cur == q[u]) ? j + u : cur);
+        }
+        bs[cur] = bi;
+    }
+#ifdef LU_DBG_CLK
+    sc[1] = wall_clock64();
+#endif
+    land(0);
+    int buf = 0;
+    // L y = P b (unit diagonal)
+    for (int k = 0; k < nblk; ++k, buf ^= 1) {
+        const int jb = k * W;
+        const int w = n - jb < W ? n - jb : W;
+        const int i0 = jb + W + tid;
+        issue(k + 1);
+        nlh_lds_barrier();
+        const double *tr = tri + buf * W * W;
+        if (wid == 0) {
+            double bl = (lane < w) ? bs[jb + lane] : 0.0;
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int jn = j0 + PF + u;
-                nxt[u] = (jn < n && tid > jn && tid < n) ? a[(size_t)jn * n + tid] : 0.0;
+            for (int j = 0; j < W; ++j) {
+                const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bl), j), __builtin_amdgcn_readlane(__double2loint(bl), j));
+                const double t = bl - yj * tr[j * W + (lane & (W - 1))];
+                bl = (yj != 0.0 && lane > j) ? t : bl;
             }
+            if (lane < w) bs[jb + lane] = bl;
+        }
+        nlh_lds_barrier();
+        for (int i = i0; i < n; i += BS) {
+            double bi = bs[i];
+            if (i == i0) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int j = j0 + u;
-                if (j < n) {                                       // uniform
-                    const double bj = bs[j];
-                    if (bj != 0.0) {
-                        const double *cj = a + (size_t)j * n;
-                        if (tid > j && tid < n) bs[tid] = bs[tid] - bj * cur[u];
-                        for (int i = tid + BS; i < n; i += BS)
-                            if (i > j) bs[i] = bs[i] - bj * cj[i];
-                    }
-                    __syncthreads();
+                for (int j = 0; j < W; ++j) {
+                    const double yj = bs[jb + (j < w ? j : 0)];
+                    const double t = bi - yj * pf[j];
+                    bi = (j < w && yj != 0.0) ? t : bi;
+                }
+            } else {
+                for (int j = 0; j < w; ++j) {
+                    const double yj = bs[jb + j];
+                    if (yj != 0.0) bi = bi - yj * a[(size_t)(jb + j) * n + i];
                 }
             }
+            bs[i] = bi;
         }
+        land(buf ^ 1);
     }
-    {
-        double cur[PF], nxt[PF], dcur[PF], dnxt[PF];
+#ifdef LU_DBG_CLK
+    sc[2] = wall_clock64();
+#endif
+    // U x = y
+    for (int k = nblk; k < 2 * nblk; ++k, buf ^= 1) {
+        const int jb = (2 * nblk - 1 - k) * W;
+        const int w = n - jb < W ? n - jb : W;
+        issue(k + 1);
+        nlh_lds_barrier();
+        const double *tr = tri + buf * W * W;
+        if (wid == 0) {
+            const int l = lane & (W - 1);
+            double bl = (lane < w) ? bs[jb + lane] : 0.0;
+            const double dl = tr[l * W + l];
+            unsigned ran = 0u;
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int j = n - 1 - u;
-            nxt[u] = (j >= 0 && tid < j) ? a[(size_t)j * n + tid] : 0.0;
-            dnxt[u] = (j >= 0) ? a[(size_t)j * n + j] : 1.0;
-        }
-        for (int j0 = n - 1; j0 >= 0; j0 -= PF) {                  // U x = y
-#pragma unroll
-            for (int u = 0; u < PF; ++u) { cur[u] = nxt[u]; dcur[u] = dnxt[u]; }
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int jn = j0 - PF - u;
-                nxt[u] = (jn >= 0 && tid < jn) ? a[(size_t)jn * n + tid] : 0.0;
-                dnxt[u] = (jn >= 0) ? a[(size_t)jn * n + jn] : 1.0;
+            for (int j = W - 1; j >= 0; --j) {
+                const double raw = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bl), j), __builtin_amdgcn_readlane(__double2loint(bl), j));
+                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dl), j), __builtin_amdgcn_readlane(__double2loint(dl), j));
+                const bool go = raw != 0.0;                       // (uniform) the sequential loop skips an exactly zero b(j)
+                const double xj = raw / d;
+                const double t = bl - xj * tr[j * W + l];
+                bl = (go && lane < j) ? t : ((go && lane == j) ? xj : bl);
+                ran |= go ? (1u << j) : 0u;
             }
+            if (lane < w) bs[jb + lane] = bl;
+            if (lane == 0) flag[0] = (int32_t)ran;
+        }
+        nlh_lds_barrier();
+        const unsigned ran = (unsigned)flag[0];
+        for (int i = tid; i < jb; i += BS) {
+            double bi = bs[i];
+            if (i == tid) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int j = j0 - u;
-                if (j >= 0) {                                      // uniform
-                    const double bjr = bs[j];
-                    if (bjr != 0.0) {
-                        const double *cj = a + (size_t)j * n;
-                        const double bj = bjr / dcur[u];
-                        __syncthreads();
-                        if (tid < j) bs[tid] = bs[tid] - bj * cur[u];
-                        for (int i = tid + BS; i < j; i += BS) bs[i] = bs[i] - bj * cj[i];
-                        if (tid == 0) bs[j] = bj;
-                    }
-                    __syncthreads();
+                for (int j = W - 1; j >= 0; --j) {
+                    const double xj = bs[jb + (j < w ? j : 0)];
+                    const double t = bi - xj * pf[j];
+                    bi = ((ran >> j) & 1u) ? t : bi;
                 }
+            } else {
+                for (int j = w - 1; j >= 0; --j)
+                    if ((ran >> j) & 1u) bi = bi - bs[jb + j] * a[(size_t)(jb + j) * n + i];
             }
+            bs[i] = bi;
         }
+        land(buf ^ 1);
     }
+#ifdef LU_DBG_CLK
+    sc[3] = wall_clock64();
+    if (tid == 0 && p == 0) printf("k_lu_solve n %d: interchanges %lld, forward %lld, backward %lld (x10 ns)\n", n, sc[1] - sc[0], sc[2] - sc[1], sc[3] - sc[2]);
+#endif
+    __syncthreads();
     for (int i = tid; i < n; i += BS) b[i] = bs[i];
 }
 
@@ -403,6 +490,7 @@ k_lu_swap_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipv
 
 // Trailing update A22 -= L21 U12 on 64x64 tiles; each thread owns a 4x4 register tile and
 // subtracts the nb products in j order (separate multiply and subtract).
+template <bool FAST>
 static __global__ void __launch_bounds__(256)
 k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__restrict__ st, int want)
 {
@@ -414,16 +502,16 @@ k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__res
     const int t0 = jb + nb;
     const int r0 = t0 + blockIdx.x * 64, c0 = t0 + blockIdx.y * 64;
     const int tid = threadIdx.x;
-    for (int e = tid; e < nb * 64; e += 256) {
-        const int j = e >> 6, q = e & 63;
-        // (loads unconditional with clamped indices: a load under a condition is waited for before the next is issued)
-        double lv = a[(size_t)(jb + j) * n + (r0 + q < n ? r0 + q : n - 1)];     // L21(r, j), contiguous in r
-        double uv = a[(size_t)(c0 + q < n ? c0 + q : n - 1) * n + jb + j];       // U12(j, c)
-        asm volatile("" : "+v"(lv), "+v"(uv));
-        Ls[e] = (r0 + q < n) ? lv : 0.0;
-        Us[e] = (c0 + q < n) ? uv : 0.0;
+    // Every load of the tile -- its L and U strips and its own sixteen entries -- is issued before any is used, with
+    // clamped indices (round 4: the staging loop used to wait for each pair, four to eight trips to L2 per tile).
+    constexpr int NST = LU_NB * 64 / 256;
+    double lv[NST], uv[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int e = tid + s * 256, j = e >> 6, q = e & 63, jc = j < nb ? j : nb - 1;
+        lv[s] = a[(size_t)(jb + jc) * n + (r0 + q < n ? r0 + q : n - 1)];      // L21(r, j), contiguous in r
+        uv[s] = a[(size_t)(c0 + q < n ? c0 + q : n - 1) * n + jb + jc];        // U12(j, c)
     }
-    __syncthreads();
     const int tr = (tid & 15) * 4, tc = (tid >> 4) * 4;
     double acc[4][4];
 #pragma unroll
@@ -433,6 +521,18 @@ k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__res
             const int r = r0 + tr + rr, c = c0 + tc + cc;
             acc[cc][rr] = a[(size_t)(c < n ? c : n - 1) * n + (r < n ? r : n - 1)];
         }
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int e = tid + s * 256, q = e & 63;
+        asm volatile("" : "+v"(lv[s]), "+v"(uv[s]));
+        Ls[e] = (r0 + q < n) ? lv[s] : 0.0;
+        Us[e] = (c0 + q < n) ? uv[s] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) asm volatile("" : "+v"(acc[cc][rr]));
     for (int j = 0; j < nb; ++j) {
         double l[4], u[4];
 #pragma unroll
@@ -440,7 +540,7 @@ k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__res
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) acc[cc][rr] = acc[cc][rr] - l[rr] * u[cc];
+            for (int rr = 0; rr < 4; ++rr) acc[cc][rr] = FAST ? __builtin_fma(-l[rr], u[cc], acc[cc][rr]) : acc[cc][rr] - l[rr] * u[cc];
     }
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc)
@@ -475,7 +575,6 @@ k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__res
 // are bit-identical to k_lu_panel_lds / the CPU restatement (FAST = false); FAST = true contracts them into one FMA.
 // NaN handling as in k_lu_panel_lds: a NaN on the diagonal is taken, a NaN below it never.
 // ---------------------------------------------------------------------------
-#define LU_PIN(x) asm volatile("" : "+v"(x))
 #define LU_MV_STRIDE 128   // ints per problem: [i < 32] source row of the row that ends at panel position i; [32] number of
                            // displaced rows; [33 + 2e], [34 + 2e] destination and source of displaced row e (panel-relative)
 
@@ -676,8 +775,16 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
     for (int q = 0; q < RPT; ++q)
         if (pos[q] >= 0) {
             const int fin = pos[q], cp = fin < nb ? fin : nb, slot = q * T + t;
-            for (int k = 0; k < cp; ++k) a[(size_t)k * n + fin] = lbuf[(size_t)k * RT + slot];
-            for (int k = cp; k < nb; ++k) a[(size_t)k * n + fin] = ubuf[cp][k - cp];
+            const int cpc = cp < NB ? cp : NB - 1;
+            double v[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {                       // (both LDS reads unconditional: all in flight together)
+                const double lv = lbuf[(size_t)k * RT + slot], uv = ubuf[cpc][k >= cp ? k - cp : 0];
+                v[k] = k < cp ? lv : uv;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (k < nb) a[(size_t)k * n + fin] = v[k];
             if (mv && fin >= nb && fin != slot) {                // displaced below the panel's block row
                 const int e = atomicAdd(&mvcnt, 1);
                 mv[33 + 2 * e] = fin;
@@ -711,21 +818,23 @@ k_lu_move_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ mv_
                const LmState *__restrict__ st, int want)
 {
     __shared__ double L11[TR * TR + TR];           // L11[i + j*TR], i > j used (+ TR: the shifting window reads past the end)
-    __shared__ int32_t mv[LU_MV_STRIDE];
     const int p = blockIdx.y;
     if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
     double *a = Aall + (size_t)p * n * n;
-    for (int e = threadIdx.x; e < TR * TR + TR; e += blockDim.x) {
-        const int i = e % TR, j = e / TR;
-        double v = a[(size_t)(jb + (j < nb ? j : nb - 1)) * n + jb + (i < nb ? i : nb - 1)];     // (unconditional, clamped)
-        LU_PIN(v);
-        L11[e] = (i < nb && j < nb) ? v : 0.0;
+    const int32_t *mv = mv_all + (size_t)p * LU_MV_STRIDE;       // (uniform addresses: scalar loads, no LDS copy, no barrier before use)
+    // this thread's elements of L11, its column's sources: all in flight together
+    constexpr int NL = (TR * TR + 255) / 256;
+    double lv[NL];
+#pragma unroll
+    for (int s = 0; s < NL; ++s) {
+        const int e = threadIdx.x + s * 256, i = e % TR, j = (e / TR) < TR ? e / TR : TR - 1;
+        lv[s] = a[(size_t)(jb + (j < nb ? j : nb - 1)) * n + jb + (i < nb ? i : nb - 1)];
     }
-    if (threadIdx.x < LU_MV_STRIDE) mv[threadIdx.x] = mv_all[(size_t)p * LU_MV_STRIDE + threadIdx.x];
-    __syncthreads();
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n - nb) return;
+    const bool live = k < n - nb;
+    if (!live) k = 0;
     if (k >= jb) k += nb;                          // skip the panel's own columns
+    if (k >= n) k = n - 1;
     double *ck = a + (size_t)k * n + jb;
     const int cnt2 = mv[32];
     // every source before any destination; the loads are unconditional (index 0 for unused entries): a load under a
@@ -735,6 +844,15 @@ k_lu_move_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ mv_
     for (int i = 0; i < TR; ++i) u[i] = ck[i < nb ? mv[i] : 0];
 #pragma unroll
     for (int e = 0; e < TR; ++e) d[e] = ck[e < cnt2 ? mv[34 + 2 * e] : 0];
+#pragma unroll
+    for (int s = 0; s < NL; ++s) {
+        const int e = threadIdx.x + s * 256, i = e % TR, j = e / TR;
+        LU_PIN(lv[s]);
+        if (e < TR * TR) L11[e] = (i < nb && j < nb) ? lv[s] : 0.0;
+    }
+    if (threadIdx.x < TR) L11[TR * TR + threadIdx.x] = 0.0;
+    __syncthreads();
+    if (!live) return;
 #pragma unroll
     for (int i = 0; i < TR; ++i) { LU_PIN(u[i]); LU_PIN(d[i]); }
 #pragma unroll

@@ -18,6 +18,7 @@ void nlh_square_init_device(int lds_max)
     hipFuncSetAttribute((const void *)k_lu_panel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     broyden_kernel_attrs(lds_max);
     lu_panel_reg_attrs<false>(lds_max);
+    lu_panel_reg_attrs<true>(lds_max);
 }
 
 // The register panel with several rows per thread (k_lu_panel_reg): instance by the number of panel rows.
@@ -47,6 +48,47 @@ static void lu_panel_reg_attrs(int lds_max)
     hipFuncSetAttribute((const void *)k_lu_panel_reg<4, 16, 256, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
 }
 
+template <bool FAST>
+static void lu_blocked(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipvt, int32_t *dinfo, const LmState *st, int want,
+                       int panel_mode)
+{
+    // panels factored in registers while they have at most 1024 rows (several rows per thread, implicit interchanges),
+    // 32-column panels in global memory before
+    for (int jb = 0; jb < n;) {
+        int nb = 0;
+        if (panel_mode >= 1) nb = launch_lu_panel_reg<FAST>(h, nprob, n, dA, dipvt, dinfo, jb, st, want, panel_mode >= 2);
+        const bool reg = nb != 0;
+        if (nb == 0) {
+            const bool lds = panel_mode == 0 && (n - jb) <= LU_PROWS;
+            const int pw = lds ? LU_PNB : LU_NB;
+            nb = (n - jb < pw) ? (n - jb) : pw;
+            if (lds)
+                // one thread per panel row: waves without rows would still run the step's instruction stream and barriers
+                hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(std::min(1024, (n - jb + 63) & ~63)), 0, h->stream, n, dA, dipvt, dinfo, jb, nb,
+                                   st, want);
+            else
+                hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb, st, want);
+        }
+        if (n - nb > 0) {
+            if (reg) {
+                if (nb <= 16)
+                    hipLaunchKernelGGL((k_lu_move_trsm<16, FAST>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
+                                       (const int32_t *)h->lumv.p, jb, nb, st, want);
+                else
+                    hipLaunchKernelGGL((k_lu_move_trsm<32, FAST>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
+                                       (const int32_t *)h->lumv.p, jb, nb, st, want);
+            } else {
+                hipLaunchKernelGGL(k_lu_swap_trsm, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
+                                   (const int32_t *)dipvt, jb, nb, st, want);
+            }
+        }
+        const int nt = n - jb - nb;
+        if (nt > 0)
+            hipLaunchKernelGGL(k_lu_gemm<FAST>, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, h->stream, n, dA, jb, nb, st, want);
+        jb += nb;
+    }
+}
+
 // lu_factor: unblocked single-workgroup kernel for small n, blocked multi-kernel path otherwise.
 void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipvt, int32_t *dinfo,
                              const LmState *st, int want)
@@ -62,39 +104,11 @@ void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipv
     if (panel_mode >= 1 && ensure(h, h->lumv, sizeof(int32_t) * LU_MV_STRIDE * (size_t)nprob)) panel_mode = 0;   // (no memory for the move lists)
     // panels factored in registers while they have at most 2048 rows (several rows per thread, implicit interchanges),
     // 32-column panels in global memory before
-    for (int jb = 0; jb < n;) {
-        int nb = 0;
-        if (panel_mode >= 1) nb = launch_lu_panel_reg<false>(h, nprob, n, dA, dipvt, dinfo, jb, st, want, panel_mode >= 2);
-        const bool reg = nb != 0;
-        if (nb == 0) {
-            const bool lds = panel_mode == 0 && (n - jb) <= LU_PROWS;
-            const int pw = lds ? LU_PNB : LU_NB;
-            nb = (n - jb < pw) ? (n - jb) : pw;
-            if (lds)
-                // one thread per panel row: waves without rows would still run the step's instruction stream and barriers
-                hipLaunchKernelGGL(k_lu_panel_lds, dim3(nprob), dim3(std::min(1024, (n - jb + 63) & ~63)), 0, h->stream, n, dA, dipvt, dinfo, jb, nb,
-                                   st, want);
-            else
-                hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb, st, want);
-        }
-        if (n - nb > 0) {
-            if (reg)
-                if (nb <= 16)
-                    hipLaunchKernelGGL((k_lu_move_trsm<16, false>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
-                                       (const int32_t *)h->lumv.p, jb, nb, st, want);
-                else
-                    hipLaunchKernelGGL((k_lu_move_trsm<32, false>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
-                                       (const int32_t *)h->lumv.p, jb, nb, st, want);
-            else
-                hipLaunchKernelGGL(k_lu_swap_trsm, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
-                                   (const int32_t *)dipvt, jb, nb, st, want);
-        }
-        const int nt = n - jb - nb;
-        if (nt > 0) {
-            hipLaunchKernelGGL(k_lu_gemm, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, h->stream, n, dA, jb, nb, st, want);
-        }
-        jb += nb;
-    }
+    // NLH_LU_CONTRACT=1 (measurement only): the same kernels with every multiply-subtract pair contracted
+    // into one FMA -- the pivots stay, the bits do not
+    static const bool contract = [] { const char *e = getenv("NLH_LU_CONTRACT"); return e && atoi(e) != 0; }();
+    if (contract && panel_mode >= 1) lu_blocked<true>(h, nprob, n, dA, dipvt, dinfo, st, want, panel_mode);
+    else lu_blocked<false>(h, nprob, n, dA, dipvt, dinfo, st, want, panel_mode);
 }
 
 
@@ -207,7 +221,7 @@ static int newton_core(nlh_handle *h, const nlh_options *o, int n, NewtonEval &e
             launch_lu_factor(h, 1, n, dLU, dipvt, (int32_t *)nullptr);
             for (int i = 0; i < n; ++i) rhs[i] = -fvec[i];
             HIPCHK(h, hipMemcpyAsync(drhs, rhs.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, s, n, (const double *)dLU, (const int32_t *)dipvt, drhs,
+            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(n >= 96 ? 1024 : 256), lu_solve_lds(n), s, n, (const double *)dLU, (const int32_t *)dipvt, drhs,
                                (const LmState *)nullptr, -1);
             HIPCHK(h, hipMemcpyAsync(dir.data(), drhs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipMemcpyAsync(grad.data(), dgrad, sizeof(double) * n, hipMemcpyDeviceToHost, s));
@@ -616,7 +630,7 @@ static int square_lockstep(nlh_handle *h, const nlh_options *o, bool broyden, in
             hipLaunchKernelGGL(k_nt_rhs, dim3((n + 255) / 256, nprob), dim3(256), 0, s, n, (const double *)dfvec, ddir,
                                (const LmState *)st);
             launch_lu_factor(h, nprob, n, dJ, dipvt, nullptr, st, NT_NEED_JAC);          // :570
-            hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, s, n, (const double *)dJ,
+            hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), lu_solve_lds(n), s, n, (const double *)dJ,
                                (const int32_t *)dipvt, ddir, (const LmState *)st, (int)NT_NEED_JAC);   // :577
             hipLaunchKernelGGL(k_nt_step_begin, dim3(nprob), dim3(256), 0, s, n, no, (int)NT_NEED_JAC, dx, dxold, ddir, (const double *)dgrad,
                                (const double *)dfvec, (double *)nullptr, st, ns);
@@ -757,7 +771,7 @@ int nlh_lu_solve(nlh_handle *h, int32_t nprob, int32_t n, const double *dLU, con
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
     HIPCHK(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), sizeof(double) * n, h->stream, n, dLU, dipvt, db,
+    hipLaunchKernelGGL(k_lu_solve, dim3(nprob), dim3(n >= 96 ? 1024 : 256), lu_solve_lds(n), h->stream, n, dLU, dipvt, db,
                        (const LmState *)nullptr, -1);
     HIPCHK(h, hipGetLastError());
     return 0;

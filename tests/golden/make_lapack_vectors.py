@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def lu_cases(rng):
     out = {}
-    for n in (2, 5, 17, 64, 96):
+    for n in (2, 5, 17, 64, 96, 160):
         a = rng.standard_normal((n, n))
         if n == 17:                                   # magnitudes over twelve decades: interchanges at every step
             a *= 10.0 ** rng.uniform(-6, 6, size=(n, 1))

@@ -1,5 +1,7 @@
 """GPU parity tests, one kernel family at a time, against the CPU oracle on the same seeded
 inputs.  Everything goes through the C ABI (nonlin_amd.device -> libnonlin_hip.so)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -161,9 +163,10 @@ def test_lmpar_binding_trust_region(ds, oracle, m, n, delta_scale):
     np.testing.assert_allclose(sdiag[0].cpu().numpy(), sdiag_o, rtol=1e-10)
 
 
-@pytest.mark.parametrize("n", [2, 37, 130, 300])
+@pytest.mark.parametrize("n", [2, 37, 130, 300, 600, 1024, 1100])
 def test_lu_bit_exact(ds, oracle, n):
-    """lu_factor / solve_lu stand-ins: same pivots, bit-identical factors and solution."""
+    """lu_factor / solve_lu stand-ins: same pivots, bit-identical factors and solution (n >= 128: the blocked path --
+    register panels with 1, 2 and 4 rows per thread by panel height, the global-memory panel above 1024 rows)."""
     import ctypes as C
     rng = np.random.default_rng(3)
     Ah = np.asfortranarray(rng.standard_normal((n, n)))
@@ -185,7 +188,57 @@ def test_lu_bit_exact(ds, oracle, n):
     assert np.array_equal(bd[0].cpu().numpy(), xo)
 
 
-@pytest.mark.parametrize("n", [40, 130, 300])
+def test_lu_batch_of_problems_bit_exact(ds, oracle):
+    """Several problems in one call (the lock-step Newton batches factor this way): every problem's factors are the
+    CPU loop's."""
+    import ctypes as C
+    n, nprob = 200, 5
+    rng = np.random.default_rng(11)
+    Ah = rng.standard_normal((nprob, n, n))
+    L = oracle.lib()
+    Ad = torch.tensor(np.ascontiguousarray(np.transpose(Ah, (0, 2, 1))), device="cuda")
+    ipvt, info = ds.lu_factor(Ad)
+    for p in range(nprob):
+        lu = np.asfortranarray(Ah[p])
+        ipo = np.zeros(n, dtype=np.int32)
+        L.nlo_lu_factor(n, lu.ctypes.data_as(C.POINTER(C.c_double)), n, ipo.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert int(info[p]) == 0
+        assert np.array_equal(ipvt[p].cpu().numpy(), ipo)
+        assert np.array_equal(Ad[p].cpu().numpy().T, lu)
+
+
+def _lapack_lu_names():
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lapack_vectors.npz"))
+    return [str(v) for v in g["lu_names"]]
+
+
+@pytest.mark.parametrize("name", _lapack_lu_names())
+def test_lu_follows_lapack_dgetrf(ds, name):
+    """The device factorisation against LAPACK itself (tests/golden/lapack_vectors.npz: scipy's DGETRF on seeded
+    matrices): the interchange sequence exactly, the factors to max(64, 4 n) ulp of the column scale.  linalg's lu_factor IS
+    DGETRF (call site src/nonlin_solve.f90:570), whose bits depend on the LAPACK build: this is the tightest pin the
+    reference's own arithmetic allows."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lapack_vectors.npz"))
+    a = g[f"lu_{name}_a"]
+    n = a.shape[0]
+    ref, piv, rinfo = g[f"lu_{name}_lu"], g[f"lu_{name}_piv"], int(g[f"lu_{name}_info"])
+    Ad = torch.tensor(np.ascontiguousarray(a.T), device="cuda").unsqueeze(0)
+    ipvt, info = ds.lu_factor(Ad)
+    lu = Ad[0].cpu().numpy().T
+    ip = ipvt[0].cpu().numpy()
+    assert int(info[0]) == rinfo
+    eps = np.finfo(float).eps
+    if name == "singular12":                       # equal columns: pivots agree up to the dependent column
+        assert np.array_equal(ip[:9], piv[:9])
+        assert np.abs(lu[:9, :] - ref[:9, :]).max() <= 64 * eps * np.abs(ref).max()
+        return
+    assert np.array_equal(ip, piv)
+    scale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), np.abs(a).max(axis=0, keepdims=True))
+    scale[scale == 0.0] = 1.0                      # (a zero column stays exactly zero)
+    assert (np.abs(lu - ref) / scale).max() <= max(64, 4 * n) * eps
+
+
+@pytest.mark.parametrize("n", [40, 130, 300, 700])
 def test_lu_singular_and_tied_pivots(ds, oracle, n):
     """A zero pivot column (info = its 1-based index, the update still runs) and exact ties in the pivot search
     (the first maximum wins): the factors stay bit-identical to the CPU loop."""
@@ -204,7 +257,7 @@ def test_lu_singular_and_tied_pivots(ds, oracle, n):
     assert np.array_equal(Ad[0].cpu().numpy().T, lu, equal_nan=True)
 
 
-@pytest.mark.parametrize("n", [40, 130, 300])
+@pytest.mark.parametrize("n", [40, 130, 300, 700])
 @pytest.mark.parametrize("kind", ["all_nan", "nan_column", "nan_diagonal", "scattered"])
 def test_lu_nan_entries_keep_a_valid_pivot(ds, oracle, n, kind):
     """NaN entries (a NaN Jacobian from a host callback, a NaN start point): the ordered pivot search of the CPU loop

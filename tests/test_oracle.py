@@ -448,7 +448,7 @@ def _lu_names():
 @pytest.mark.parametrize("name", _lu_names())
 def test_lu_factor_follows_lapack_dgetrf(oracle, name):
     """lu_factor / solve_lu (call sites src/nonlin_solve.f90:570,577; linalg -> DGETRF / DGETRS): same interchanges at
-    every step, same `info` for an exactly zero pivot column, L and U within 64 ulp of the growth-scaled matrix norm."""
+    every step, same `info` for an exactly zero pivot column, L and U within max(64, 4 n) ulp of the column scale."""
     import ctypes as C
     g = _lapack_vectors()
     a = np.array(g[f"lu_{name}_a"], order="F")
@@ -466,7 +466,7 @@ def test_lu_factor_follows_lapack_dgetrf(oracle, name):
         return
     assert np.array_equal(ipvt, piv)
     scale = np.abs(ref).max(axis=0, keepdims=True).clip(min=np.abs(a).max() * 1e-300)
-    assert (np.abs(lu - ref) / np.maximum(scale, np.abs(a).max(axis=0, keepdims=True))).max() <= 64 * np.finfo(float).eps
+    assert (np.abs(lu - ref) / np.maximum(scale, np.abs(a).max(axis=0, keepdims=True))).max() <= max(64, 4 * n) * np.finfo(float).eps
     if rinfo == 0:
         b = np.array(g[f"lu_{name}_b"])
         oracle.lib().nlo_lu_solve(n, lu.ctypes.data_as(C.POINTER(C.c_double)), n, ipvt.ctypes.data_as(C.POINTER(C.c_int32)),
