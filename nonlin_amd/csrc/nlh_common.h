@@ -745,9 +745,9 @@ __device__ __forceinline__ double nrm2_block(Get get, int len, double *red, doub
 
 // Left-to-right sum of buf[0..len) (LDS, 16-byte aligned) by the calling thread: the reads of a batch are
 // issued together and one batch ahead, so only the adds themselves are serial.
-__device__ __forceinline__ double ordered_sum_lds(const double *buf, int len)
+__device__ __forceinline__ double ordered_sum_lds(const double *buf, int len, double s0 = 0.0)
 {
-    double s = 0.0, a[8], b[8];
+    double s = s0, a[8], b[8];
     const double2 *src = reinterpret_cast<const double2 *>(buf);
     const int nb = len >> 3;
     auto load = [&](double (&d)[8], int g) {
@@ -767,6 +767,41 @@ __device__ __forceinline__ double ordered_sum_lds(const double *buf, int len)
     }
     for (int i = nb << 3; i < len; ++i) s = s + buf[i];
     return s;
+}
+
+// Left-to-right sum s0 + t(0) + t(1) + ... + t(len-1) by ONE WAVE, "down the lanes" (see norm2_flang_block_lanes): the
+// terms of a chunk of 64 * E are in registers, E consecutive ones per lane; at step l every lane takes its lower
+// neighbour's running sum and adds its own E terms -- only lane l's result is the true partial sum at that step, the
+// others' are never used.  The chain is register-to-register adds (~2.2 ns each) plus one DPP shift per E terms,
+// against 6 - 10 ns per term for a single thread that reads its terms from LDS.  Slots past the end hold -0.0, the
+// exact identity of IEEE addition (s + -0.0 == s for every s, signed zeros included).  get(i) must be callable by
+// every lane for any i in [0, len); all 64 lanes of the wave must call; the result is returned in every lane.
+template <int E, typename Get>
+__device__ __forceinline__ double ordered_sum_wave(Get get, int len, double s0)
+{
+    const int lane = threadIdx.x & 63;
+    double t = s0;
+    for (int base = 0; base < len; base += 64 * E) {
+        double d[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const int i = base + lane * E + u;
+            const double v = get(i < len ? i : len - 1);
+            d[u] = i < len ? v : -0.0;
+        }
+        const int rem = len - base, nl = rem >= 64 * E ? 64 : (rem + E - 1) / E;
+        // lane 0 starts from the carry; the others' start values are overwritten by the shift
+#pragma unroll
+        for (int u = 0; u < E; ++u) t = t + d[u];
+#pragma unroll 2
+        for (int l = 1; l < nl; ++l) {
+            t = nlh_wave_shr1(t);
+#pragma unroll
+            for (int u = 0; u < E; ++u) t = t + d[u];
+        }
+        t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), nl - 1), __builtin_amdgcn_readlane(__double2loint(t), nl - 1));
+    }
+    return t;
 }
 
 // Sum of term(0..len-1): left-to-right by one thread when EXACT, tree otherwise.  Broadcast.

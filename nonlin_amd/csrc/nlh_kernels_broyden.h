@@ -236,6 +236,8 @@ k_qn_house_dot2(int rows, int ncA, int ncE, int j, const double *__restrict__ Aa
 // per step.  The last step's update is applied by k_qn_house_apply.  w and st are double-buffered by step parity
 // ([problem][slot]); LDS: two reflectors + two product tiles, rows <= QN_FUSED_MAXROWS.
 #define QN_FUSED_MAXROWS 4096
+// dynamic LDS of k_qn_house_fused: two reflectors, two padded product tiles of 4096 entries (also the padded squares)
+static inline size_t qn_fused_lds(int rows) { return sizeof(double) * (2 * (size_t)rows + 2 * (4096 + 4096 / 16)); }
 // CG = columns per workgroup (16: wide matrices; 4: tall-skinny ones, so that enough workgroups exist); a tile is
 // (4096 / CG) rows x CG columns.
 template <int CG>
@@ -248,6 +250,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     double *vsp = sm3;                                  // previous reflector, scaled (rows >= j)
     double *vs = sm3 + rows;                            // this step's reflector (rows >= j+1)
     constexpr int RL = 256 / CG, TR = RL * 16;          // row lanes, rows per tile
+    constexpr int TRP = TR + TR / 16;                   // (tile rows + padding: QN_FUSED_LDS)
     double *prod = sm3 + 2 * (size_t)rows;              // [2][TR][CG]
     __shared__ double sq_sh, alpha_sh;
     const int p = blockIdx.y, tid = threadIdx.x, nc = ncA + ncE, jp = j - 1;
@@ -266,34 +269,60 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     // they get their final values: beta of step j-1, or the plain diagonal value if that step was H = I.
     const double dval_p = (j > 0) ? (pend ? stp[2] : stp[3]) : 0.0;
 
-    if (pend)
-        for (int i = j + tid; i < rows; i += 256) vsp[i] = vprev_g[i] * scal_p;
-    __syncthreads();
-    {   // column j with the pending update applied: alpha (row j) and the unscaled reflector (rows > j)
+    // (Round 4: every load of this prologue is issued before any is used, with clamped indices -- a load under a
+    // condition, or in a loop that consumes it at once, is waited for before the next one is issued: sixteen trips to
+    // L2 per loop instead of one.)
+    constexpr int PR = QN_FUSED_MAXROWS / 256;          // rows per thread
+#ifdef QN_DBG_CLK
+    long long ck[8]; ck[0] = wall_clock64();
+#endif
+    {
+        double vp[PR], cj[PR];
         const double wpj = pend ? wprev[j] : 0.0;
-        for (int i = j + tid; i < rows; i += 256) {
-            double t = A[(size_t)i * ncA + j];
-            if (pend) t = t - vsp[i] * wpj;
-            if (i == j) alpha_sh = t; else vs[i] = t;
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const int i = j + tid + 256 * u, ic = i < rows ? i : rows - 1;
+            vp[u] = vprev_g[ic];
+            cj[u] = A[(size_t)ic * ncA + j];
+        }
+#pragma unroll
+        for (int u = 0; u < PR; ++u) asm volatile("" : "+v"(vp[u]), "+v"(cj[u]));
+        // column j with the pending update applied: alpha (row j) and the unscaled reflector (rows > j)
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const int i = j + tid + 256 * u;
+            if (i < rows) {
+                double t = cj[u];
+                if (pend) {
+                    const double vsi = vp[u] * scal_p;
+                    vsp[i] = vsi;
+                    t = t - vsi * wpj;
+                }
+                if (i == j) alpha_sh = t; else vs[i] = t;
+            }
         }
     }
     __syncthreads();
+#ifdef QN_DBG_CLK
+    ck[1] = wall_clock64();
+#endif
     if (blockIdx.x == 0)
         for (int i = j + 1 + tid; i < rows; i += 256) vcur_g[i] = vs[i];
-    if (tid == 0) {
-        double s = 0.0;
-        int i = j + 1;
-        for (; i + 16 <= rows; i += 16) {
-            double t[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = vs[i + u];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) s = s + t[u] * t[u];
-        }
-        for (; i < rows; ++i) s = s + vs[i] * vs[i];
-        sq_sh = s;
+    // sum of squares in row order: the squares are formed by everybody (the same product the one-thread loop forms),
+    // one wave adds them down its lanes (round 4; the one-thread loop with the multiply inside ran the LDS reads, the
+    // multiplies and the adds of a group one after the other: 43 us at 4096 rows)
+    double *sqb = prod;                                 // (the product tiles are not in use yet)
+    // (term q at sqb[q + q/16]: a lane's run of sixteen starts 17 doubles after its neighbour's -- no bank conflicts)
+    for (int i = j + 1 + tid; i < rows; i += 256) { const double t = vs[i]; const int q = i - j - 1; sqb[q + (q >> 4)] = t * t; }
+    __syncthreads();
+    if (tid < 64) {                                     // one wave, down the lanes (nlh_common.h)
+        const double s = ordered_sum_wave<64>([&](int q) { return sqb[q + (q >> 4)]; }, rows - j - 1, 0.0);
+        if (tid == 0) sq_sh = s;
     }
     __syncthreads();
+#ifdef QN_DBG_CLK
+    ck[2] = wall_clock64();
+#endif
     const double sq = sq_sh, alpha = alpha_sh;
     const bool refl = sq != 0.0;                        // H_j != I
     double tau = 0.0, scal = 0.0, beta = 0.0;
@@ -329,29 +358,59 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
         if (upd) { t = isjp ? 0.0 : t - vsp[j] * wp; if (!isj) T[(size_t)j * ld] = t; }
         w = t;
     }
+    // CG == 4: wave wv sums column wv of the workgroup (its start value -- row j -- comes from the thread that formed it)
+    __shared__ double w0_sh[4];
+    const int wv = tid >> 6, kw = blockIdx.x * CG + wv;
+    const bool wlive = (CG == 4) && refl && kw < nc && !(kw < ncA && kw <= j);
+    double ww = 0.0;
+    if constexpr (CG == 4) {
+        if (r == 0) w0_sh[c] = w;
+        __syncthreads();
+        ww = w0_sh[wv];
+    }
     double tl[16];
     const int ibeg = j + 1;
+    // (unconditional, clamped row -- Tl points at a valid column -- and pinned where issued: the compiler would put the
+    // loads back under their condition, where each is waited for before the next is issued)
+    const double *Tl = (k < nc) ? T : A;
+    const size_t ldl = (k < nc) ? ld : (size_t)ncA;
 #define QN_F_LOAD(i0)                                                                      \
     _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                       \
         const int i = (i0) + r + RL * u;                                                   \
-        tl[u] = ((upd || live) && i < rows) ? T[(size_t)i * ld] : 0.0;                     \
+        tl[u] = Tl[(size_t)(i < rows ? i : rows - 1) * ldl];                               \
     }
+#define QN_F_PIN _Pragma("unroll") for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(tl[u]));
+#ifdef QN_DBG_CLK
+    ck[3] = wall_clock64();
+#endif
     QN_F_LOAD(ibeg)
+    QN_F_PIN
+#ifdef QN_DBG_CLK
+    ck[4] = wall_clock64();
+#endif
     int buf = 0;
     for (int i0 = ibeg; i0 < rows; i0 += TR) {
-        double *pb = prod + (size_t)buf * TR * CG;
+        double *pb = prod + (size_t)buf * TRP * CG;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int i = i0 + r + RL * u;
             if (i < rows) {
                 double t = tl[u];
                 if (upd) { t = isjp ? 0.0 : t - vsp[i] * wp; if (!isj) T[(size_t)i * ld] = t; }
-                if (refl) pb[(r + RL * u) * CG + c] = vs[i] * t;
+                if (refl) {
+                    if constexpr (CG == 4) pb[c * TRP + (r + RL * u) + ((r + RL * u) >> 4)] = vs[i] * t;      // column-major, padded
+                    else pb[(r + RL * u) * CG + c] = vs[i] * t;
+                }
             }
         }
         __syncthreads();
-        if (i0 + TR < rows) { QN_F_LOAD(i0 + TR) }
-        if (r == 0 && live) {
+        QN_F_LOAD(i0 + TR)                              // (clamped: the tile after the last reads row rows-1 again)
+        if constexpr (CG == 4) {                        // a wave per column, down its lanes: one chunk of 64 x 16 per tile
+            if (wlive) {
+                const double *pc = pb + wv * TRP;
+                ww = ordered_sum_wave<32>([&](int i) { return pc[i + (i >> 4)]; }, min(TR, rows - i0), ww);
+            }
+        } else if (r == 0 && live) {
             const int lim = min(TR, rows - i0);
             int ii = 0;
             for (; ii + 16 <= lim; ii += 16) {
@@ -363,10 +422,22 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
             }
             for (; ii < lim; ++ii) w = w + pb[ii * CG + c];
         }
+        QN_F_PIN
         buf ^= 1;
     }
 #undef QN_F_LOAD
-    if (r == 0 && live) wcur[k] = tau * w;
+#undef QN_F_PIN
+    if constexpr (CG == 4) {
+        if (wlive && (tid & 63) == 0) wcur[blockIdx.x * CG + wv] = tau * ww;
+    } else if (r == 0 && live) {
+        wcur[k] = tau * w;
+    }
+#ifdef QN_DBG_CLK
+    ck[5] = wall_clock64();
+    if (tid == 0 && p == 0 && blockIdx.x == gridDim.x - 2 && j == 10)
+        printf("k_qn_house_fused<%d> rows %d nc %d: prologue %lld, sumsq %lld, scale %lld, first tile load %lld, tiles %lld (x10 ns)\n", CG, rows, nc,
+               ck[1] - ck[0], ck[2] - ck[1], ck[3] - ck[2], ck[4] - ck[3], ck[5] - ck[4]);
+#endif
 }
 
 // Second half: T(j,k) -= w_k, T(i,k) -= v_i w_k (elementwise, one thread per column and QN_RC rows),

@@ -306,7 +306,7 @@ void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int ncE, do
     if (steps < 1) return;
     if (rows <= QN_FUSED_MAXROWS) {
         // one pass per step: the update of step j-1 rides along with the sums of step j
-        const size_t sh3 = sizeof(double) * (2 * (size_t)rows + 2 * QN_DOT2_TR * QN_DOT2_CG);
+        const size_t sh3 = qn_fused_lds(rows);
         const bool skinny = (long)nc * nprob < 1536;     // few columns in total: 4 per workgroup so that the chip has work
         for (int j = 0; j < steps; ++j) {
             if (skinny)
