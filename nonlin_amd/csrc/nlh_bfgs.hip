@@ -301,7 +301,7 @@ static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int
         if (need_grad > 0) {
             // fnh_grad_fcn: n perturbed evaluations, (f_j - f) / h_j (src/nonlin_multi_var.f90:182-246)
             launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, dP, st, BF_GRAD);
-            hipLaunchKernelGGL(k_bf_fd_gradient, dim3((n + 63) / 64, nprob), dim3(64), 0, s, m, n, (const double *)dP, (const double *)dx, 0.0, dg,
+            hipLaunchKernelGGL(k_bf_fd_gradient, dim3(n, nprob), dim3(64), 0, s, m, n, (const double *)dP, (const double *)dx, 0.0, dg,
                                fp_all, bstride, cst, (int)BF_GRAD);
             hipLaunchKernelGGL(k_bfl_after_grad, dim3(nprob), dim3(256), 0, s, n, bo, (const double *)dx, (const double *)dg, (const double *)dgold,
                                ddx, dy, dxnew, st, bs);
@@ -403,7 +403,7 @@ int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, 
         ev.grad = [&](double *xx, double fv, double *g) -> int {
             HIPCHK(h, hipMemcpyAsync(dxs, xx, sizeof(double) * n, hipMemcpyHostToDevice, s));
             launch_dq_panel(h, 1, m, n, A, b, gamma, dxs, (double *)h->P.p, nullptr, -1);
-            hipLaunchKernelGGL(k_bf_fd_gradient, dim3((n + 63) / 64), dim3(64), 0, s, m, n, (const double *)h->P.p, dxs, fv, dgs, (const double *)nullptr, (size_t)0, (const LmState *)nullptr, -1);
+            hipLaunchKernelGGL(k_bf_fd_gradient, dim3(n), dim3(64), 0, s, m, n, (const double *)h->P.p, dxs, fv, dgs, (const double *)nullptr, (size_t)0, (const LmState *)nullptr, -1);
             HIPCHK(h, hipMemcpyAsync(g, dgs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipStreamSynchronize(s));
             return 0;
