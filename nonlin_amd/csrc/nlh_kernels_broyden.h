@@ -237,14 +237,19 @@ k_qn_house_dot2(int rows, int ncA, int ncE, int j, const double *__restrict__ Aa
 // ([problem][slot]); LDS: two reflectors + two product tiles, rows <= QN_FUSED_MAXROWS.
 #define QN_FUSED_MAXROWS 4096
 // dynamic LDS of k_qn_house_fused: two reflectors, two padded product tiles of 4096 entries (also the padded squares)
-static inline size_t qn_fused_lds(int rows) { return sizeof(double) * (2 * (size_t)rows + 2 * (4096 + 4096 / 16)); }
+static inline size_t qn_fused_lds(int rows, int dbuf)
+{
+    const size_t tile = 4096 + 4096 / 16, sq = (size_t)rows + rows / 16 + 16;
+    return sizeof(double) * (2 * (size_t)rows + std::max((dbuf ? 2 : 1) * tile, sq));
+}
 // CG = columns per workgroup (16: wide matrices; 4: tall-skinny ones, so that enough workgroups exist); a tile is
 // (4096 / CG) rows x CG columns.
 template <int CG>
 __global__ void __launch_bounds__(256)
 k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
                  double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st,
-        const LmState *__restrict__ gst, int gwant)
+        const LmState *__restrict__ gst, int gwant, int dbuf /* 1: two product tiles (a lone problem: the next tile's
+        products are formed while this one is summed); 0: one (batches: 64 KB of LDS instead of 100, two workgroups per CU) */)
 {
     extern __shared__ double sm3[];
     double *vsp = sm3;                                  // previous reflector, scaled (rows >= j)
@@ -390,7 +395,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
 #endif
     int buf = 0;
     for (int i0 = ibeg; i0 < rows; i0 += TR) {
-        double *pb = prod + (size_t)buf * TRP * CG;
+        double *pb = prod + (size_t)(dbuf ? buf : 0) * TRP * CG;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int i = i0 + r + RL * u;
@@ -424,6 +429,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
         }
         QN_F_PIN
         buf ^= 1;
+        if (!dbuf) __syncthreads();                     // (uniform) the sums have read the tile before it is written again
     }
 #undef QN_F_LOAD
 #undef QN_F_PIN

@@ -306,15 +306,17 @@ void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int ncE, do
     if (steps < 1) return;
     if (rows <= QN_FUSED_MAXROWS) {
         // one pass per step: the update of step j-1 rides along with the sums of step j
-        const size_t sh3 = qn_fused_lds(rows);
         const bool skinny = (long)nc * nprob < 1536;     // few columns in total: 4 per workgroup so that the chip has work
+        // more workgroups than CUs: one product tile each, so that two workgroups share a CU (their chains overlap)
+        const int dbuf = (long)((nc + (skinny ? 3 : 15)) / (skinny ? 4 : 16)) * nprob > 256 ? 0 : 1;
+        const size_t sh3 = qn_fused_lds(rows, dbuf);
         for (int j = 0; j < steps; ++j) {
             if (skinny)
                 hipLaunchKernelGGL(k_qn_house_fused<4>, dim3((nc + 3) / 4, nprob), dim3(256), sh3, s,
-                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant);
+                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant, dbuf);
             else
                 hipLaunchKernelGGL(k_qn_house_fused<16>, dim3((nc + 15) / 16, nprob), dim3(256), sh3, s,
-                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant);
+                                   rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant, dbuf);
         }
         const int jl = steps - 1, slot = jl & 1;
         hipLaunchKernelGGL(k_qn_house_apply, dim3((nc + 255) / 256, (rows - jl + QN_RC - 1) / QN_RC, nprob), dim3(256), 0, s,
