@@ -10,6 +10,7 @@
 void nlh_bfgs_init_device(int lds_max)
 {
     hipFuncSetAttribute((const void *)k_bf_solve_upper_t, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_bf_chol_blocked, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_downdate_apply, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -163,7 +164,7 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
                 hipLaunchKernelGGL(k_bf_downdate_rot, dim3(1), dim3(64), 0, s, n, du, dc, dinfo, (const LmState *)nullptr, -1);
                 hipLaunchKernelGGL(k_bf_downdate_apply, dim3((n + 255) / 256), dim3(256), sizeof(double) * 2 * n, s, n, dR, dc, du, dinfo, (const LmState *)nullptr, -1);
             } else {
-                if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_factor<1>, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dB, dR, dinfo, (const LmState *)nullptr, -1);
+                if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_blocked, dim3(1), dim3(bs1), bf_chol_lds(n), s, n, dB, dR, dinfo, (const LmState *)nullptr, -1);
                 else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(1), dim3(1024), sizeof(double) * n, s, n, dB, dR, dinfo, (const LmState *)nullptr, -1);
             }
             // dx = -(R^T R)^-1 g (:727)
@@ -321,7 +322,7 @@ static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int
                                (const double *)dv, (const int *)dinfo, cst, (int)BF_UPD_RANK);
             hipLaunchKernelGGL(k_nt_advance, dim3(pb), dim3(256), 0, s, nprob, st, (int)BF_UPD_RANK, (int)BF_DIR);
             // :724: R = chol(B)
-            if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_factor<1>, dim3(nprob), dim3(bs1), sizeof(double) * n, s, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
+            if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_blocked, dim3(nprob), dim3(bs1), bf_chol_lds(n), s, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
             else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(nprob), dim3(1024), sizeof(double) * n, s, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
             hipLaunchKernelGGL(k_nt_advance, dim3(pb), dim3(256), 0, s, nprob, st, (int)BF_UPD_FACTOR, (int)BF_DIR);
             // :727: dx = -(R^T R)^-1 g

@@ -200,6 +200,145 @@ k_bf_chol_factor(int n, const double *__restrict__ B, double *__restrict__ Rt, i
     if (tid == 0) *info = bad;
 }
 
+// The same factorisation BLOCKED (round 4; n <= 1024, a thread per column): the column-at-a-time form above pays
+// global-memory round trips in every one of its n steps (n = 256: 1.55 ms a call, and bfgs calls it whenever the
+// curvature test fails).  Rows are taken BFC_W at a time.  For the panel's rows every thread first subtracts the
+// products of the rows above the panel (its own column's entries stream from global memory eight ahead, the panel
+// columns' entries of those rows sit in LDS) -- no barrier in that loop --, then the wave that holds the panel's own
+// columns finishes the BFC_W x BFC_W diagonal block with v_readlane broadcasts (no barrier either), and everybody else
+// solves its BFC_W rows against that block from LDS.  Every element still receives a(j,c) - sum_k r(k,j) r(k,c) with k
+// ascending, a separate multiply and subtract per term, then the division by r(j,j): the bits of the loop above.
+// A non-positive pivot stops at the same row with the same rows written.  Dynamic LDS: bf_chol_lds(n).
+#define BFC_W 16
+static inline size_t bf_chol_lds(int n) { return sizeof(double) * ((size_t)n * BFC_W + BFC_W * BFC_W); }
+
+static __global__ void __launch_bounds__(1024)
+k_bf_chol_blocked(int n, const double *__restrict__ B, double *__restrict__ Rt, int *__restrict__ info, const LmState *__restrict__ gst, int gwant)
+{
+    constexpr int W = BFC_W;
+    extern __shared__ double bfc_sm[];
+    double *pre = bfc_sm;                            // pre[k * W + jj] = r(k, jb + jj), k < jb
+    double *P = bfc_sm + (size_t)n * W;              // P[kk * W + jj] = r(jb + kk, jb + jj)
+    __shared__ int bad;
+    const int tid = threadIdx.x, BS = blockDim.x, p = blockIdx.x, c = tid, lane = tid & 63;
+    if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
+    B += (size_t)p * n * n; Rt += (size_t)p * n * n; info += p;
+    if (tid == 0) bad = 0;
+    // row-major copy of the symmetric B, zeros below the diagonal (loads unconditional, eight in flight)
+    for (size_t e0 = tid; e0 < (size_t)n * n; e0 += (size_t)8 * BS) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t e = e0 + (size_t)u * BS, ec = e < (size_t)n * n ? e : (size_t)n * n - 1;
+            v[u] = B[(ec % n) * n + ec / n];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t e = e0 + (size_t)u * BS;
+            asm volatile("" : "+v"(v[u]));
+            if (e < (size_t)n * n) Rt[e] = (e / n <= e % n) ? v[u] : 0.0;
+        }
+    }
+    const int cc_ = c < n ? c : n - 1;
+    for (int jb = 0; jb < n; jb += W) {
+        const int w = n - jb < W ? n - jb : W;
+        double acc[W];
+#pragma unroll
+        for (int jj = 0; jj < W; ++jj) acc[jj] = B[(size_t)cc_ * n + jb + (jj < w ? jj : w - 1)];
+        __syncthreads();                            // the rows of the earlier panels are in memory
+        for (int e0 = tid; e0 < jb * W; e0 += 4 * BS) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * BS, ec = e < jb * W ? e : jb * W - 1, jj = ec % W;
+                v[u] = Rt[(size_t)(ec / W) * n + jb + (jj < w ? jj : w - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * BS;
+                asm volatile("" : "+v"(v[u]));
+                if (e < jb * W) pre[e] = v[u];
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < W; ++jj) asm volatile("" : "+v"(acc[jj]));
+        __syncthreads();
+        // rows above the panel: k ascending, this column's entries eight ahead
+        if (jb > 0 && c >= jb) {                  // (finished columns have nothing to do)
+            double rk[8], rn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rk[u] = Rt[(size_t)u * n + cc_];
+            for (int k = 0; k < jb; k += 8) {
+                const int kn = k + 8 < jb ? k + 8 : k;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rn[u] = Rt[(size_t)(kn + u) * n + cc_];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    asm volatile("" : "+v"(rk[u]));
+                    const double *pk = pre + (size_t)(k + u) * W;
+#pragma unroll
+                    for (int jj = 0; jj < W; ++jj) acc[jj] = acc[jj] - pk[jj] * rk[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rk[u] = rn[u];
+            }
+        }
+        // the diagonal block: the wave that holds columns jb .. jb + W - 1 (all its lanes run the same steps, so its
+        // other columns are solved on the way); r(jb + kk, jb + jj) comes from lane L0 + jj's registers
+        int stop = w;
+        if ((tid >> 6) == (jb >> 6)) {
+            const int L0 = jb & 63;
+#pragma unroll
+            for (int jj = 0; jj < W; ++jj) {
+                if (jj < stop) {
+                    double t = acc[jj];
+#pragma unroll
+                    for (int kk = 0; kk < jj; ++kk) {
+                        const double pk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(acc[kk]), L0 + jj),
+                                                           __builtin_amdgcn_readlane(__double2loint(acc[kk]), L0 + jj));
+                        t = t - pk * acc[kk];
+                    }
+                    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), L0 + jj),
+                                                      __builtin_amdgcn_readlane(__double2loint(t), L0 + jj));
+                    if (!(d > 0.0)) {                // (uniform) not positive definite at row jb + jj
+                        stop = jj;
+                        if (lane == L0 + jj) bad = jb + jj + 1;
+                    } else {
+                        const double rjj = sqrt(d);
+                        acc[jj] = (lane == L0 + jj) ? rjj : t / rjj;
+                    }
+                }
+            }
+            if (lane >= L0 && lane < L0 + W) {
+#pragma unroll
+                for (int jj = 0; jj < W; ++jj) P[jj * W + (lane - L0)] = acc[jj];
+            }
+        }
+        __syncthreads();
+        const int badrow = bad;                      // (uniform after the barrier)
+        const int lim = badrow ? badrow - 1 - jb : w;
+        if ((tid >> 6) != (jb >> 6)) {
+#pragma unroll
+            for (int jj = 0; jj < W; ++jj) {
+                if (jj < lim) {
+                    double t = acc[jj];
+#pragma unroll
+                    for (int kk = 0; kk < jj; ++kk) t = t - P[kk * W + jj] * acc[kk];
+                    acc[jj] = t / P[jj * W + jj];
+                }
+            }
+        }
+        if (c < n) {
+#pragma unroll
+            for (int jj = 0; jj < W; ++jj)
+                if (jj < lim && c >= jb + jj) Rt[(size_t)(jb + jj) * n + c] = acc[jj];
+        }
+        if (badrow) break;
+    }
+    __syncthreads();
+    if (tid == 0) *info = bad;
+}
+
 // R <- temp * I (DLASET, :705)
 static __global__ void __launch_bounds__(256)
 k_bf_scaled_identity(int n, double temp, double *__restrict__ Rt, const double *__restrict__ tempall, size_t tstride,
