@@ -764,27 +764,94 @@ k_qn_retri(int n, double *__restrict__ Rt, double *__restrict__ c, double *__res
 }
 
 // x <- R^-1 x, column oriented (DTRSV 'U','N','N'); R row-major.  Dynamic LDS: n doubles.
+// Round 4: BLOCKED like k_lu_solve's back substitution (nlh_kernels_lu.h): columns sixteen at a time, one wave solves the
+// 16 x 16 triangle out of LDS (the solved entry of a step reaches the other lanes by v_readlane, no barrier), every thread
+// then applies the block's sixteen solved entries to its own row, whose entries (contiguous in the row-major R) were
+// fetched a block ahead; barriers wait for LDS only.  The column-at-a-time form paid a trip to L2 and two barriers per
+// column (n = 256: 96 us).  Every x(i) still receives x(i) - x(j) r(i,j) for j descending, skipped where x(j) is exactly
+// zero, and x(j) = x(j) / r(j,j) is the same division: the same bits.
 static __global__ void __launch_bounds__(1024)
 k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall, size_t stride_r, size_t stride_x,
         const LmState *__restrict__ gst, int gwant)
 {
+    constexpr int W = 16;
     extern __shared__ double bs[];
-    const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
+    __shared__ __attribute__((aligned(16))) double tri[2][W * W];     // tri[.][j * W + l] = r(jb + l, jb + j)
+    __shared__ int flag;
+    const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6;
     if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     const double *R = Rt + (size_t)p * stride_r;   // leading n x n block, row-major with leading dimension n
     double *x = xall + (size_t)p * stride_x;
-    for (int i = tid; i < n; i += BS) bs[i] = x[i];
-    __syncthreads();
-    for (int j = n - 1; j >= 0; --j) {
-        const double bj = bs[j];
-        if (bj != 0.0) {                                          // uniform
-            const double tj = bj / R[(size_t)j * n + j];
-            __syncthreads();
-            for (int i = tid; i < j; i += BS) bs[i] = bs[i] - tj * R[(size_t)i * n + j];
-            if (tid == 0) bs[j] = tj;
+    const int nblk = (n + W - 1) / W;
+    const unsigned rc = tid < n ? tid : n - 1;     // this thread's first row (clamped)
+    double pf[W], pf1[W], t1[4];
+    auto issue = [&](int kb) {                      // loads of block kb (columns kb * W ...): unconditional, clamped
+        const int kk = kb < 0 ? 0 : kb, jb = kk * W, w = n - jb < W ? n - jb : W;
+        const double *row = R + (size_t)rc * n + jb;
+#pragma unroll
+        for (int j = 0; j < W; ++j) pf1[j] = row[j < w ? j : w - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = (tid + u * BS) & (W * W - 1), j = e / W, l = e % W;
+            t1[u] = R[(size_t)(jb + (l < w ? l : w - 1)) * n + jb + (j < w ? j : w - 1)];
         }
-        __syncthreads();
+    };
+    auto land = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            asm volatile("" : "+v"(t1[u]));
+            if (tid + u * BS < W * W) tri[buf][tid + u * BS] = t1[u];
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) { asm volatile("" : "+v"(pf1[j])); pf[j] = pf1[j]; }
+    };
+    issue(nblk - 1);
+    for (int i = tid; i < n; i += BS) bs[i] = x[i];
+    land(0);
+    int buf = 0;
+    for (int kb = nblk - 1; kb >= 0; --kb, buf ^= 1) {
+        const int jb = kb * W, w = n - jb < W ? n - jb : W;
+        issue(kb - 1);
+        nlh_lds_barrier();
+        const double *tr = tri[buf];
+        if (wid == 0) {
+            const int l = lane & (W - 1);
+            double bl = (lane < w) ? bs[jb + lane] : 0.0;
+            const double dl = tr[l * W + l];
+            unsigned ran = 0u;
+#pragma unroll
+            for (int j = W - 1; j >= 0; --j) {
+                const double raw = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bl), j), __builtin_amdgcn_readlane(__double2loint(bl), j));
+                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dl), j), __builtin_amdgcn_readlane(__double2loint(dl), j));
+                const bool go = raw != 0.0;                       // (uniform) the column loop skips an exactly zero x(j)
+                const double xj = raw / d;
+                const double t = bl - xj * tr[j * W + l];
+                bl = (go && lane < j) ? t : ((go && lane == j) ? xj : bl);
+                ran |= go ? (1u << j) : 0u;
+            }
+            if (lane < w) bs[jb + lane] = bl;
+            if (lane == 0) flag = (int)ran;
+        }
+        nlh_lds_barrier();
+        const unsigned ran = (unsigned)flag;
+        for (int i = tid; i < jb; i += BS) {
+            double bi = bs[i];
+            if (i == tid) {
+#pragma unroll
+                for (int j = W - 1; j >= 0; --j) {
+                    const double xj = bs[jb + (j < w ? j : 0)];
+                    const double t = bi - xj * pf[j];
+                    bi = ((ran >> j) & 1u) ? t : bi;
+                }
+            } else {
+                for (int j = w - 1; j >= 0; --j)
+                    if ((ran >> j) & 1u) bi = bi - bs[jb + j] * R[(size_t)i * n + jb + j];
+            }
+            bs[i] = bi;
+        }
+        land(buf ^ 1);
     }
+    __syncthreads();
     for (int i = tid; i < n; i += BS) x[i] = bs[i];
 }
 
