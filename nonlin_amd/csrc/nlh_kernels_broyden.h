@@ -654,22 +654,44 @@ k_qn_rot_q(int n, double *__restrict__ Q, const double *__restrict__ c, const do
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= n || n < 2) return;
     double *q = Q + (size_t)p * n * n + row;
+    // (Round 4: the row's entries are fetched eight at a time -- unconditional, clamped -- instead of one trip to L2 per
+    // rotation: n = 1024 272 -> 50 us.  A store of one step never touches an entry a later step still has to read.)
     if (backward) {
         double y = q[(size_t)(n - 1) * n];
-        for (int i = n - 2; i >= 0; --i) {
-            const double x = q[(size_t)i * n];
-            const double ci = cs[i], si = cs[n + i];
-            q[(size_t)(i + 1) * n] = ci * y - si * x;
-            y = ci * x + si * y;
+        for (int i0 = n - 2; i0 >= 0; i0 -= 8) {
+            double xs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xs[u] = q[(size_t)(i0 - u >= 0 ? i0 - u : 0) * n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 - u;
+                asm volatile("" : "+v"(xs[u]));
+                if (i >= 0) {
+                    const double x = xs[u];
+                    const double ci = cs[i], si = cs[n + i];
+                    q[(size_t)(i + 1) * n] = ci * y - si * x;
+                    y = ci * x + si * y;
+                }
+            }
         }
         q[0] = y;
     } else {
         double x = q[0];
-        for (int i = 0; i < n - 1; ++i) {
-            const double y = q[(size_t)(i + 1) * n];
-            const double ci = cs[i], si = cs[n + i];
-            q[(size_t)i * n] = ci * x + si * y;
-            x = ci * y - si * x;
+        for (int i0 = 0; i0 < n - 1; i0 += 8) {
+            double ys[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ys[u] = q[(size_t)(i0 + 1 + u < n ? i0 + 1 + u : n - 1) * n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u;
+                asm volatile("" : "+v"(ys[u]));
+                if (i < n - 1) {
+                    const double y = ys[u];
+                    const double ci = cs[i], si = cs[n + i];
+                    q[(size_t)i * n] = ci * x + si * y;
+                    x = ci * y - si * x;
+                }
+            }
         }
         q[(size_t)(n - 1) * n] = x;
     }
@@ -693,11 +715,21 @@ k_qn_hess_r(int n, double *__restrict__ Rt, const double *__restrict__ c, const 
     double top;
     if (ii >= 0) {
         double t = r[(size_t)(ii + 1) * n];
-        for (int j = ii; j >= 0; --j) {
-            const double rj = r[(size_t)j * n];
-            const double cj = cs[j], sj = cs[n + j];
-            r[(size_t)(j + 1) * n] = cj * t - sj * rj;
-            t = cj * rj + sj * t;
+        for (int j0 = ii; j0 >= 0; j0 -= 8) {       // (eight entries of the column per trip to L2, as in k_qn_rot_q)
+            double rs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rs[u] = r[(size_t)(j0 - u >= 0 ? j0 - u : 0) * n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 - u;
+                asm volatile("" : "+v"(rs[u]));
+                if (j >= 0) {
+                    const double rj = rs[u];
+                    const double cj = cs[j], sj = cs[n + j];
+                    r[(size_t)(j + 1) * n] = cj * t - sj * rj;
+                    t = cj * rj + sj * t;
+                }
+            }
         }
         top = t;
     } else {
@@ -718,38 +750,59 @@ k_qn_retri(int n, double *__restrict__ Rt, double *__restrict__ c, double *__res
     const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
     if (gst && gst[p].stage != gwant) return;                    // lock-step batches: only problems in this stage
     double *R = Rt + (size_t)p * n * n;
-    double t[NC], nx[NC];
+    // Round 4: a thread's "entry below" of step j is simply the next entry of its own column, so the column is streamed
+    // eight rows ahead (unconditional, clamped loads), and the barrier of a step waits for LDS only -- the rotations are
+    // the only thing threads exchange; the form before paid a trip to L2 in every one of the n - 1 steps (the barrier
+    // waited for the prefetch it had just issued: 0.65 us a step).
+    constexpr int D = NC == 1 ? 8 : 2;                         // rows ahead (registers: 2 * NC * D doubles)
+    double t[NC], cur[NC][D], nxt[NC][D];
+    int colc[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
         const int col = tid + q * BS;
-        t[q] = (col < n) ? R[col] : 0.0;                          // R(0, col)
-        nx[q] = (col < n && n > 1) ? R[(size_t)n + col] : 0.0;    // R(1, col)
+        colc[q] = col < n ? col : n - 1;
+        t[q] = R[colc[q]];                                        // R(0, col)
+#pragma unroll
+        for (int u = 0; u < D; ++u) cur[q][u] = R[(size_t)(1 + u < n ? 1 + u : n - 1) * n + colc[q]];     // R(1 .. D, col)
     }
-    for (int j = 0; j < n - 1; ++j) {
-        const int oq = j / BS, ot = j - oq * BS;                  // owner of column j
-        if (tid == ot) {
+    for (int j0 = 0; j0 < n - 1; j0 += D) {
 #pragma unroll
-            for (int q = 0; q < NC; ++q)
-                if (q == oq) {
-                    double cj, sj, rd;
-                    givens_dev(t[q], nx[q], cj, sj, rd);
-                    cs[j] = cj; cs[n + j] = sj;
-                    R[(size_t)j * n + j] = rd;
-                    R[(size_t)(j + 1) * n + j] = 0.0;
+        for (int q = 0; q < NC; ++q)
+#pragma unroll
+            for (int u = 0; u < D; ++u) nxt[q][u] = R[(size_t)(j0 + D + 1 + u < n ? j0 + D + 1 + u : n - 1) * n + colc[q]];
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int j = j0 + u;
+            if (j < n - 1) {                                      // uniform
+                const int oq = j / BS, ot = j - oq * BS;          // owner of column j
+                if (tid == ot) {
+#pragma unroll
+                    for (int q = 0; q < NC; ++q)
+                        if (q == oq) {
+                            double cj, sj, rd;
+                            givens_dev(t[q], cur[q][u], cj, sj, rd);
+                            cs[j] = cj; cs[n + j] = sj;
+                            R[(size_t)j * n + j] = rd;
+                            R[(size_t)(j + 1) * n + j] = 0.0;
+                        }
                 }
-        }
-        __syncthreads();
-        const double cj = cs[j], sj = cs[n + j];
+                nlh_lds_barrier();
+                const double cj = cs[j], sj = cs[n + j];
 #pragma unroll
-        for (int q = 0; q < NC; ++q) {
-            const int col = tid + q * BS;
-            if (col > j && col < n) {
-                const double below = nx[q];
-                R[(size_t)j * n + col] = cj * t[q] + sj * below;
-                t[q] = cj * below - sj * t[q];
-                nx[q] = (j + 2 < n) ? R[(size_t)(j + 2) * n + col] : 0.0;
+                for (int q = 0; q < NC; ++q) {
+                    const int col = tid + q * BS;
+                    if (col > j && col < n) {
+                        const double below = cur[q][u];
+                        R[(size_t)j * n + col] = cj * t[q] + sj * below;
+                        t[q] = cj * below - sj * t[q];
+                    }
+                }
             }
         }
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+#pragma unroll
+            for (int u = 0; u < D; ++u) { asm volatile("" : "+v"(nxt[q][u])); cur[q][u] = nxt[q][u]; }
     }
     {                                                             // last column keeps its carried value
         const int col = n - 1, oq = col / BS, ot = col - oq * BS;

@@ -47,3 +47,9 @@ find "$OUT" -name "*.csv" -size +1500k -delete
 find "$OUT" -type d -name "*.stats" -prune -o -type d -name "*.FETCH_SIZE" -prune -o -type d -name "*.WRITE_SIZE" -prune
 rm -rf "$OUT"/*.stats "$OUT"/*.FETCH_SIZE "$OUT"/*.WRITE_SIZE "$OUT"/calib "$OUT"/mid_*.stats
 ls -la "$OUT"
+# (added later in round 4) the other solvers' kernels after the latency work on LU, the Householder step, the BFGS pieces and
+# the triangular solves: one bench pass with only the other_paths rows, per-kernel stats; the LU of n = 1024 alone
+OUT=$PWD/gpurun_out/prof_r04; mkdir -p "$OUT"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/other.stats" -o r04 -- python3 bench.py --steps 1 --warmup 0 --batch 16 --m 1024 --n 64 --cpu-sample 0 --extras 0 > "$OUT/other.stats.log" 2>&1
+f=$(find "$OUT/other.stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/r04_other_paths_kernel_stats.csv"
+rm -rf "$OUT/other.stats"
