@@ -281,6 +281,22 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
 #ifdef QN_DBG_CLK
     long long ck[8]; ck[0] = wall_clock64();
 #endif
+    const int c = tid % CG, r = tid / CG;
+    const int k = blockIdx.x * CG + c;
+    double *T = (k < ncA) ? A + k : E + (k - ncA);
+    const size_t ld = (k < ncA) ? ncA : ncE;
+    // (tile loads: unconditional, clamped row -- Tl points at a valid column -- and pinned where the values are needed: the
+    // compiler would put the loads back under their condition, where each is waited for before the next is issued)
+    const double *Tl = (k < nc) ? T : A;
+    const size_t ldl = (k < nc) ? ld : (size_t)ncA;
+    double tl[16], ejp0, tj0;
+    const int ibeg = j + 1;
+#define QN_F_LOAD(i0)                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                       \
+        const int i = (i0) + r + RL * u;                                                   \
+        tl[u] = Tl[(size_t)(i < rows ? i : rows - 1) * ldl];                               \
+    }
+#define QN_F_PIN _Pragma("unroll") for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(tl[u]));
     {
         double vp[PR], cj[PR];
         const double wpj = pend ? wprev[j] : 0.0;
@@ -290,6 +306,11 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
             vp[u] = vprev_g[ic];
             cj[u] = A[(size_t)ic * ncA + j];
         }
+        // ... and this thread's entries of the first tile, of row j and of row j - 1: they do not depend on the reflector,
+        // so they travel while it is being rebuilt and its squares are summed
+        QN_F_LOAD(ibeg)
+        ejp0 = Tl[(size_t)(j > 0 ? jp : 0) * ldl];
+        tj0 = Tl[(size_t)j * ldl];
 #pragma unroll
         for (int u = 0; u < PR; ++u) asm volatile("" : "+v"(vp[u]), "+v"(cj[u]));
         // column j with the pending update applied: alpha (row j) and the unscaled reflector (rows > j)
@@ -343,23 +364,20 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
         for (int i = j + 1 + tid; i < rows; i += 256) vs[i] = vs[i] * scal;
     __syncthreads();
 
-    const int c = tid % CG, r = tid / CG;
-    const int k = blockIdx.x * CG + c;
     const bool inr = k < nc;
     const bool isjp = (j > 0) && (k < ncA) && (k == jp);
     const bool isj = (k < ncA) && (k == j);             // never stored in this launch (other workgroups read it)
     const bool upd = inr && (isjp || (pend && !(k < ncA && k < jp)));  // columns written back: the update, or the finish of j-1
     const bool live = refl && inr && !(k < ncA && k <= j);           // columns that take part in step j's sums
-    double *T = (k < ncA) ? A + k : E + (k - ncA);
-    const size_t ld = (k < ncA) ? ncA : ncE;
     const double wp = (upd && !isjp && pend) ? wprev[k] : 0.0;
     double w = 0.0;
+    asm volatile("" : "+v"(ejp0), "+v"(tj0));
     if (r == 0 && inr) {
         if (upd) {                                      // row j-1: the pending update, or the diagonal of column j-1
             double *e = T + (size_t)jp * ld;
-            *e = isjp ? dval_p : *e - wp;
+            *e = isjp ? dval_p : ejp0 - wp;
         }
-        double t = T[(size_t)j * ld];                   // row j
+        double t = tj0;                                 // row j
         if (upd) { t = isjp ? 0.0 : t - vsp[j] * wp; if (!isj) T[(size_t)j * ld] = t; }
         w = t;
     }
@@ -373,23 +391,10 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
         __syncthreads();
         ww = w0_sh[wv];
     }
-    double tl[16];
-    const int ibeg = j + 1;
-    // (unconditional, clamped row -- Tl points at a valid column -- and pinned where issued: the compiler would put the
-    // loads back under their condition, where each is waited for before the next is issued)
-    const double *Tl = (k < nc) ? T : A;
-    const size_t ldl = (k < nc) ? ld : (size_t)ncA;
-#define QN_F_LOAD(i0)                                                                      \
-    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                       \
-        const int i = (i0) + r + RL * u;                                                   \
-        tl[u] = Tl[(size_t)(i < rows ? i : rows - 1) * ldl];                               \
-    }
-#define QN_F_PIN _Pragma("unroll") for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(tl[u]));
 #ifdef QN_DBG_CLK
     ck[3] = wall_clock64();
 #endif
-    QN_F_LOAD(ibeg)
-    QN_F_PIN
+    QN_F_PIN                                            // (the first tile was requested in the prologue)
 #ifdef QN_DBG_CLK
     ck[4] = wall_clock64();
 #endif
