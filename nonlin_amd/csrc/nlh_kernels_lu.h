@@ -25,7 +25,8 @@ k_lu_factor(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, in
         double bv = 0.0;
         int bk = 0x7fffffff;
         for (int i = j + tid; i < n; i += BS) {
-            const double v = fabs(cj[i]);
+            double v = fabs(cj[i]);
+            if (v != v) v = (i == j) ? __builtin_inf() : -1.0;    // the ordered search keeps a NaN diagonal entry and never takes a NaN below it
             if (bk == 0x7fffffff || v > bv) { bv = v; bk = i; }
         }
         const int piv = block_argmax_first(bv, bk, red, redi);
@@ -258,7 +259,8 @@ k_lu_panel(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int
         double bv = 0.0;
         int bk = 0x7fffffff;
         for (int i = j + tid; i < n; i += BS) {
-            const double v = fabs(cj[i]);
+            double v = fabs(cj[i]);
+            if (v != v) v = (i == j) ? __builtin_inf() : -1.0;    // the ordered search keeps a NaN diagonal entry and never takes a NaN below it
             if (bk == 0x7fffffff || v > bv) { bv = v; bk = i; }
         }
         const int piv = block_argmax_first(bv, bk, red, redi);
