@@ -86,9 +86,11 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
             int myok = 0;
             if (lane < RG && q0 + lane < nrot) {
                 const int j = jlo + q0 + lane, k = t - j;
-                const bool act = diagv[ipvt[j]] != 0.0;            // :721
+                // :721 (diag(l) == 0: the elimination is skipped) needs no test of its own: rot[j] starts as diag(l) and the
+                // working row of a skipped elimination stays zero, so sk == 0 covers it -- and the two dependent global loads
+                // diagv[ipvt[j]] cost every time step two trips to L2 on its critical path (round 4)
                 const double sk = rot[j];
-                if (act && sk != 0.0) {                            // :732
+                if (sk != 0.0) {                                   // :732
                     const double rkk = sdiag[k];
                     if (fabs(rkk) < fabs(sk)) {                    // :733-741
                         const double ctan = rkk / sk;
