@@ -7,10 +7,21 @@
 #include "nlh_kernels_bfgs.h"
 #include "nlh_kernels_bfgs_batch.h"
 
+// The blocked Cholesky of the Hessian approximation: as many thread groups per column as 1024 threads allow.
+static void launch_bf_chol_blocked(hipStream_t s, int nprob, int n, const double *dB, double *dR, int *dinfo, const LmState *st, int want)
+{
+    const int CT = ((n + 63) / 64) * 64;
+    if (CT * 4 <= 1024) hipLaunchKernelGGL(k_bf_chol_blocked<4>, dim3(nprob), dim3(CT * 4), bf_chol_lds(n), s, n, dB, dR, dinfo, st, want);
+    else if (CT * 2 <= 1024) hipLaunchKernelGGL(k_bf_chol_blocked<2>, dim3(nprob), dim3(CT * 2), bf_chol_lds(n), s, n, dB, dR, dinfo, st, want);
+    else hipLaunchKernelGGL(k_bf_chol_blocked<1>, dim3(nprob), dim3(CT), bf_chol_lds(n), s, n, dB, dR, dinfo, st, want);
+}
+
 void nlh_bfgs_init_device(int lds_max)
 {
     hipFuncSetAttribute((const void *)k_bf_solve_upper_t, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    hipFuncSetAttribute((const void *)k_bf_chol_blocked, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_bf_chol_blocked<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_bf_chol_blocked<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_bf_chol_blocked<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_downdate_apply, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -164,7 +175,7 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
                 hipLaunchKernelGGL(k_bf_downdate_rot, dim3(1), dim3(64), 0, s, n, du, dc, dinfo, (const LmState *)nullptr, -1);
                 hipLaunchKernelGGL(k_bf_downdate_apply, dim3((n + 255) / 256), dim3(256), sizeof(double) * 2 * n, s, n, dR, dc, du, dinfo, (const LmState *)nullptr, -1);
             } else {
-                if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_blocked, dim3(1), dim3(bs1), bf_chol_lds(n), s, n, dB, dR, dinfo, (const LmState *)nullptr, -1);
+                if (n <= 1024) launch_bf_chol_blocked(s, 1, n, dB, dR, dinfo, nullptr, -1);
                 else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(1), dim3(1024), sizeof(double) * n, s, n, dB, dR, dinfo, (const LmState *)nullptr, -1);
             }
             // dx = -(R^T R)^-1 g (:727)
@@ -322,7 +333,7 @@ static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int
                                (const double *)dv, (const int *)dinfo, cst, (int)BF_UPD_RANK);
             hipLaunchKernelGGL(k_nt_advance, dim3(pb), dim3(256), 0, s, nprob, st, (int)BF_UPD_RANK, (int)BF_DIR);
             // :724: R = chol(B)
-            if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_blocked, dim3(nprob), dim3(bs1), bf_chol_lds(n), s, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
+            if (n <= 1024) launch_bf_chol_blocked(s, nprob, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
             else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(nprob), dim3(1024), sizeof(double) * n, s, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
             hipLaunchKernelGGL(k_nt_advance, dim3(pb), dim3(256), 0, s, nprob, st, (int)BF_UPD_FACTOR, (int)BF_DIR);
             // :727: dx = -(R^T R)^-1 g
