@@ -245,7 +245,7 @@ static inline size_t qn_fused_lds(int rows, int dbuf)
 // CG = columns per workgroup (16: wide matrices; 4: tall-skinny ones, so that enough workgroups exist); a tile is
 // (4096 / CG) rows x CG columns.
 template <int CG>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(CG == 4 ? 512 : 256)
 k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, double *__restrict__ Eall,
                  double *__restrict__ vbuf, double *__restrict__ wbuf, double *__restrict__ st,
         const LmState *__restrict__ gst, int gwant, int dbuf /* 1: two product tiles (a lone problem: the next tile's
@@ -281,7 +281,11 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
 #ifdef QN_DBG_CLK
     long long ck[8]; ck[0] = wall_clock64();
 #endif
-    const int c = tid % CG, r = tid / CG;
+    // CG == 4 runs 512 threads: waves 0-3 PRODUCE (everything below but the column sums), waves 4-7 only SUM -- wave 4 + c
+    // adds column c's products of tile t down its lanes while the producers form tile t + 1 (two product tiles, one LDS-only
+    // barrier per tile); with four waves doing both in turn a tile cost 6 us, of which 2.7 are the sum.  CG == 16: 256 threads.
+    const bool prodw = (CG != 4) || tid < 256;
+    const int c = tid % CG, r = (tid & 255) / CG;
     const int k = blockIdx.x * CG + c;
     double *T = (k < ncA) ? A + k : E + (k - ncA);
     const size_t ld = (k < ncA) ? ncA : ncE;
@@ -289,7 +293,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     // compiler would put the loads back under their condition, where each is waited for before the next is issued)
     const double *Tl = (k < nc) ? T : A;
     const size_t ldl = (k < nc) ? ld : (size_t)ncA;
-    double tl[16], ejp0, tj0;
+    double tl[16] = {0.0}, ejp0 = 0.0, tj0 = 0.0;
     const int ibeg = j + 1;
 #define QN_F_LOAD(i0)                                                                      \
     _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                       \
@@ -297,7 +301,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
         tl[u] = Tl[(size_t)(i < rows ? i : rows - 1) * ldl];                               \
     }
 #define QN_F_PIN _Pragma("unroll") for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(tl[u]));
-    {
+    if (prodw) {
         double vp[PR], cj[PR];
         const double wpj = pend ? wprev[j] : 0.0;
 #pragma unroll
@@ -332,14 +336,15 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
 #ifdef QN_DBG_CLK
     ck[1] = wall_clock64();
 #endif
-    if (blockIdx.x == 0)
+    if (prodw && blockIdx.x == 0)
         for (int i = j + 1 + tid; i < rows; i += 256) vcur_g[i] = vs[i];
     // sum of squares in row order: the squares are formed by everybody (the same product the one-thread loop forms),
     // one wave adds them down its lanes (round 4; the one-thread loop with the multiply inside ran the LDS reads, the
     // multiplies and the adds of a group one after the other: 43 us at 4096 rows)
     double *sqb = prod;                                 // (the product tiles are not in use yet)
     // (term q at sqb[q + q/16]: a lane's run of sixteen starts 17 doubles after its neighbour's -- no bank conflicts)
-    for (int i = j + 1 + tid; i < rows; i += 256) { const double t = vs[i]; const int q = i - j - 1; sqb[q + (q >> 4)] = t * t; }
+    if (prodw)
+        for (int i = j + 1 + tid; i < rows; i += 256) { const double t = vs[i]; const int q = i - j - 1; sqb[q + (q >> 4)] = t * t; }
     __syncthreads();
     if (tid < 64) {                                     // one wave, down the lanes (nlh_common.h)
         const double s = ordered_sum_wave<64>([&](int q) { return sqb[q + (q >> 4)]; }, rows - j - 1, 0.0);
@@ -360,7 +365,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     if (blockIdx.x == 0 && tid == 0) { stc[0] = tau; stc[1] = scal; stc[2] = beta; stc[3] = alpha; }
     const bool hasjp = (j > 0) && (jp / CG == (int)blockIdx.x);     // this workgroup finishes column j-1
     if (!refl && !pend && !hasjp) return;               // nothing to sum, nothing outstanding (uniform)
-    if (refl)
+    if (refl && prodw)
         for (int i = j + 1 + tid; i < rows; i += 256) vs[i] = vs[i] * scal;
     __syncthreads();
 
@@ -372,7 +377,7 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     const double wp = (upd && !isjp && pend) ? wprev[k] : 0.0;
     double w = 0.0;
     asm volatile("" : "+v"(ejp0), "+v"(tj0));
-    if (r == 0 && inr) {
+    if (prodw && r == 0 && inr) {
         if (upd) {                                      // row j-1: the pending update, or the diagonal of column j-1
             double *e = T + (size_t)jp * ld;
             *e = isjp ? dval_p : ejp0 - wp;
@@ -383,17 +388,52 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
     }
     // CG == 4: wave wv sums column wv of the workgroup (its start value -- row j -- comes from the thread that formed it)
     __shared__ double w0_sh[4];
-    const int wv = tid >> 6, kw = blockIdx.x * CG + wv;
+    const int wv = (tid >> 6) & 3, kw = blockIdx.x * CG + wv;
     const bool wlive = (CG == 4) && refl && kw < nc && !(kw < ncA && kw <= j);
     double ww = 0.0;
     if constexpr (CG == 4) {
-        if (r == 0) w0_sh[c] = w;
+        if (prodw && r == 0) w0_sh[c] = w;
         __syncthreads();
         ww = w0_sh[wv];
     }
 #ifdef QN_DBG_CLK
     ck[3] = wall_clock64();
 #endif
+#ifdef QN_DBG_CLK
+    ck[4] = ck[3];
+#endif
+    if constexpr (CG == 4) {
+        if (prodw) {
+            QN_F_PIN                                    // (the first tile was requested in the prologue)
+            int buf = 0;
+            for (int i0 = ibeg; i0 < rows; i0 += TR, buf ^= 1) {
+                // tile buffer buf was last read by the sums of two tiles ago, which ended before their waves joined the
+                // barrier of the previous tile
+                double *pb = prod + (size_t)buf * TRP * CG;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = i0 + r + RL * u;
+                    if (i < rows) {
+                        double t = tl[u];
+                        if (upd) { t = isjp ? 0.0 : t - vsp[i] * wp; if (!isj) T[(size_t)i * ld] = t; }
+                        if (refl) pb[c * TRP + (r + RL * u) + ((r + RL * u) >> 4)] = vs[i] * t;      // column-major, padded
+                    }
+                }
+                QN_F_LOAD(i0 + TR)                      // (clamped: the tile after the last reads row rows-1 again)
+                nlh_lds_barrier();                      // publishes the tile; orders LDS traffic only, the loads stay in flight
+                QN_F_PIN
+            }
+        } else {
+            int buf = 0;
+            for (int i0 = ibeg; i0 < rows; i0 += TR, buf ^= 1) {
+                nlh_lds_barrier();
+                if (wlive) {
+                    const double *pc = prod + (size_t)buf * TRP * CG + wv * TRP;
+                    ww = ordered_sum_wave<32>([&](int i) { return pc[i + (i >> 4)]; }, min(TR, rows - i0), ww);
+                }
+            }
+        }
+    } else {
     QN_F_PIN                                            // (the first tile was requested in the prologue)
 #ifdef QN_DBG_CLK
     ck[4] = wall_clock64();
@@ -407,20 +447,12 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
             if (i < rows) {
                 double t = tl[u];
                 if (upd) { t = isjp ? 0.0 : t - vsp[i] * wp; if (!isj) T[(size_t)i * ld] = t; }
-                if (refl) {
-                    if constexpr (CG == 4) pb[c * TRP + (r + RL * u) + ((r + RL * u) >> 4)] = vs[i] * t;      // column-major, padded
-                    else pb[(r + RL * u) * CG + c] = vs[i] * t;
-                }
+                if (refl) pb[(r + RL * u) * CG + c] = vs[i] * t;
             }
         }
         __syncthreads();
         QN_F_LOAD(i0 + TR)                              // (clamped: the tile after the last reads row rows-1 again)
-        if constexpr (CG == 4) {                        // a wave per column, down its lanes: one chunk of 64 x 16 per tile
-            if (wlive) {
-                const double *pc = pb + wv * TRP;
-                ww = ordered_sum_wave<32>([&](int i) { return pc[i + (i >> 4)]; }, min(TR, rows - i0), ww);
-            }
-        } else if (r == 0 && live) {
+        if (r == 0 && live) {
             const int lim = min(TR, rows - i0);
             int ii = 0;
             for (; ii + 16 <= lim; ii += 16) {
@@ -436,10 +468,11 @@ k_qn_house_fused(int rows, int ncA, int ncE, int j, double *__restrict__ Aall, d
         buf ^= 1;
         if (!dbuf) __syncthreads();                     // (uniform) the sums have read the tile before it is written again
     }
+    }
 #undef QN_F_LOAD
 #undef QN_F_PIN
     if constexpr (CG == 4) {
-        if (wlive && (tid & 63) == 0) wcur[blockIdx.x * CG + wv] = tau * ww;
+        if (!prodw && wlive && (tid & 63) == 0) wcur[blockIdx.x * CG + wv] = tau * ww;
     } else if (r == 0 && live) {
         wcur[k] = tau * w;
     }

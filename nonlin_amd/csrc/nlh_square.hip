@@ -308,11 +308,12 @@ void launch_house_steps(nlh_handle *h, int nprob, int rows, int ncA, int ncE, do
         // one pass per step: the update of step j-1 rides along with the sums of step j
         const bool skinny = (long)nc * nprob < 1536;     // few columns in total: 4 per workgroup so that the chip has work
         // more workgroups than CUs: one product tile each, so that two workgroups share a CU (their chains overlap)
-        const int dbuf = (long)((nc + (skinny ? 3 : 15)) / (skinny ? 4 : 16)) * nprob > 256 ? 0 : 1;
+        // (the four-column form always has two tiles: its summing waves run a tile behind its producing waves)
+        const int dbuf = skinny ? 1 : ((long)((nc + 15) / 16) * nprob > 256 ? 0 : 1);
         const size_t sh3 = qn_fused_lds(rows, dbuf);
         for (int j = 0; j < steps; ++j) {
             if (skinny)
-                hipLaunchKernelGGL(k_qn_house_fused<4>, dim3((nc + 3) / 4, nprob), dim3(256), sh3, s,
+                hipLaunchKernelGGL(k_qn_house_fused<4>, dim3((nc + 3) / 4, nprob), dim3(512), sh3, s,
                                    rows, ncA, ncE, j, dA, dE, vbuf, wbuf, st, gst, gwant, dbuf);
             else
                 hipLaunchKernelGGL(k_qn_house_fused<16>, dim3((nc + 15) / 16, nprob), dim3(256), sh3, s,
