@@ -909,6 +909,9 @@ k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall
             const int l = lane & (W - 1);
             double bl = (lane < w) ? bs[jb + lane] : 0.0;
             const double dl = tr[l * W + l];
+            double trv[W];                                       // (all LDS reads of the triangle in flight together)
+#pragma unroll
+            for (int j = 0; j < W; ++j) trv[j] = tr[j * W + l];
             unsigned ran = 0u;
 #pragma unroll
             for (int j = W - 1; j >= 0; --j) {
@@ -916,7 +919,7 @@ k_qn_solve_upper(int n, const double *__restrict__ Rt, double *__restrict__ xall
                 const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dl), j), __builtin_amdgcn_readlane(__double2loint(dl), j));
                 const bool go = raw != 0.0;                       // (uniform) the column loop skips an exactly zero x(j)
                 const double xj = raw / d;
-                const double t = bl - xj * tr[j * W + l];
+                const double t = bl - xj * trv[j];
                 bl = (go && lane < j) ? t : ((go && lane == j) ? xj : bl);
                 ran |= go ? (1u << j) : 0u;
             }

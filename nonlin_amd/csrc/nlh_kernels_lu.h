@@ -150,10 +150,13 @@ k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ 
         const double *tr = tri + buf * W * W;
         if (wid == 0) {
             double bl = (lane < w) ? bs[jb + lane] : 0.0;
+            double trv[W];                                       // this lane's row of the triangle: all LDS reads in flight together
+#pragma unroll                                                   // (read inside the steps, each one is an LDS latency on the chain)
+            for (int j = 0; j < W; ++j) trv[j] = tr[j * W + (lane & (W - 1))];
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bl), j), __builtin_amdgcn_readlane(__double2loint(bl), j));
-                const double t = bl - yj * tr[j * W + (lane & (W - 1))];
+                const double t = bl - yj * trv[j];
                 bl = (yj != 0.0 && lane > j) ? t : bl;
             }
             if (lane < w) bs[jb + lane] = bl;
@@ -192,6 +195,9 @@ k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ 
             const int l = lane & (W - 1);
             double bl = (lane < w) ? bs[jb + lane] : 0.0;
             const double dl = tr[l * W + l];
+            double trv[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) trv[j] = tr[j * W + l];
             unsigned ran = 0u;
 #pragma unroll
             for (int j = W - 1; j >= 0; --j) {
@@ -199,7 +205,7 @@ k_lu_solve(int n, const double *__restrict__ LUall, const int32_t *__restrict__ 
                 const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dl), j), __builtin_amdgcn_readlane(__double2loint(dl), j));
                 const bool go = raw != 0.0;                       // (uniform) the sequential loop skips an exactly zero b(j)
                 const double xj = raw / d;
-                const double t = bl - xj * tr[j * W + l];
+                const double t = bl - xj * trv[j];
                 bl = (go && lane < j) ? t : ((go && lane == j) ? xj : bl);
                 ran |= go ? (1u << j) : 0u;
             }
