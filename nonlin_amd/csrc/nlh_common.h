@@ -514,6 +514,67 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
 // (s_waitcnt vmcnt(0)) -- a full memory latency per round of a pipelined loop.
 __device__ __forceinline__ void nlh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The left-to-right sum s0 + d(0) + d(1) + ... of NON-NEGATIVE terms WITHOUT the serial chain, bit for bit (round 4).
+// While the running sum s stays in the binade of s0, fl(s + d) = s + RNE(d to a multiple of ulp(s0)): additions of
+// multiples of ulp, exact and hence associative -- except where d / ulp ends in exactly one half, where round-half-even
+// looks at the parity of s / ulp.  A term is therefore a map "add c0 if the running sum is even (in ulps), c1 if it is
+// odd"; such maps compose into maps of the same form, so a lane folds its EL terms into one pair (c0, c1) and the wave
+// folds its 64 pairs in lane order with shuffles: 6 fp64 instructions a term instead of a dependent add, no chain.
+//   * RNE(d): t = C + d, q = t - C with C = 1.5 * 2^e (ulp(C) = ulp(s0)); the remainder r = d - q is exact, and the term
+//     is a tie iff |r| == ulp / 2 (the rounding of C + d resolves ties by C's parity, so ties are redone: floor part
+//     d - ulp / 2, plus one ulp where the running sum plus that floor is odd).  Zero and subnormal terms need no case.
+//   * parity of a multiple c of ulp: fract(c * (0.5 / ulp)) != 0.
+//   * ok = false -- the caller runs the chain instead -- when the sum leaves the binade (the term that carries it over
+//     must be rounded once, at the coarser ulp) or a term exceeds 2^e / 4 (C + d must stay in C's binade).
+// d[]: this lane's EL consecutive terms (all >= +0, no NaN); all 64 lanes call; s0 wave-uniform, normal, >= 4.
+// profiles/ubench/intsum2.py (and intsum.py, the integer formulation) are CPU prototypes: 1500 (3000) chunks of 3072 terms
+// incl. exact ties, zeros and sums next to a binade boundary against the plain loop, no mismatch.  Requires -ffp-contract=off.
+__device__ __forceinline__ bool nlh_odd_ulps(double c, double inv2ulp)
+{
+    const double z = c * inv2ulp;
+    return z != floor(z);
+}
+template <int EL>
+__device__ __forceinline__ double ordered_possum_wave_int(const double (&d)[EL], double s0, bool &ok)
+{
+    const long long sb = __double_as_longlong(s0);
+    const long long es = sb >> 52;                                   // (s0 > 0: no sign bit)
+    const double ulp = __longlong_as_double((es - 52) << 52), hu = 0.5 * ulp, inv2ulp = 0.5 / ulp;
+    const double C = __longlong_as_double((es << 52) | (1ll << 51)), lim = 0.25 * __longlong_as_double(es << 52);
+    double c0 = 0.0, c1 = 0.0;
+    bool fine = true;
+#pragma unroll
+    for (int u = 0; u < EL; ++u) {
+        const double x = d[u];
+        fine = fine && (x <= lim);
+        const double t = C + x, q = t - C, r = x - q;
+        const bool tie = fabs(r) == hu;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tie) != 0ull, 0)) {       // (uniform; one term in 2^12 or so)
+            const double f = x - hu;
+            const double a0 = tie ? f + (nlh_odd_ulps(c0 + f, inv2ulp) ? ulp : 0.0) : q;
+            const double a1 = tie ? f + (nlh_odd_ulps(c1 + f, inv2ulp) ? 0.0 : ulp) : q;
+            c0 = c0 + a0;
+            c1 = c1 + a1;
+        } else {
+            c0 = c0 + q;
+            c1 = c1 + q;
+        }
+    }
+    // fold the lanes in order: (left then right)(b) = left(b) + right(parity after left)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double r0 = __shfl_down(c0, off, 64), r1 = __shfl_down(c1, off, 64);
+        const double n0 = c0 + (nlh_odd_ulps(c0, inv2ulp) ? r1 : r0);         // running sum even on entry
+        const double n1 = c1 + (nlh_odd_ulps(c1, inv2ulp) ? r0 : r1);         // odd on entry
+        c0 = n0; c1 = n1;                                           // (lanes whose partner is out of range fold garbage: lane 0 does not)
+    }
+    const double totl = (sb & 1ll) ? c1 : c0;
+    const double tot = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(totl)), __builtin_amdgcn_readfirstlane(__double2loint(totl)));
+    const double out = s0 + tot;                                    // (exact while the binade holds)
+    ok = (__builtin_amdgcn_ballot_w64(!fine) == 0ull) && ((__double_as_longlong(out) >> 52) == es);
+    return out;
+}
+
 // norm2_flang_block_lanes for vectors of MANY chunks (a 65536-row column is 16), software-pipelined, with a wave that
 // does nothing but the chain.  In the plain form a chunk costs a memory latency for its elements, the prefix maximum
 // with two barriers, the divisions, an LDS hand-over and then the 64 * EL-add chain -- 21 us at EL = 64, of which the
@@ -631,7 +692,16 @@ __device__ double norm2_flang_block_lanes_pipe(Get get, int len, double *cd, dou
             for (int k = 0; k < TPR; ++k) nm |= (unsigned long long)(unsigned)tf[lane * TPR + k] << (k * E);
             const unsigned long long mask = __ballot(nm == 0);
             double t = s;
-            if (mask == ~0ull && nl == 64) {
+            bool viaint = false;
+            if (mask == ~0ull && nl == 64 && s >= 4.0 && s < 1.0e300) {
+                // the usual chunk once the sum has left the first binades: no chain at all (ordered_possum_wave_int);
+                // the chain below only if the sum crosses a binade inside the chunk (a few chunks per column)
+                const double r = ordered_possum_wave_int<EL>(d, s, viaint);
+                if (viaint) t = r;
+            }
+            if (viaint) {
+                // (t holds the chunk's sum in every lane; the read-back below takes lane nl - 1)
+            } else if (mask == ~0ull && nl == 64) {
                 // the usual chunk -- full, no new maximum in it: nothing in the loop but the shift and the adds (the mask
                 // test of the general loop below costs 25 ns a step, 1.6 us a chunk)
 #pragma unroll 1

@@ -50,6 +50,12 @@ def _matrix(kind, m, n, rng):
         a[rng.choice(m, size=m // 10, replace=False), :] = 0.0
     elif kind == "rank_one":
         a = np.outer(rng.standard_normal(m), rng.standard_normal(n))
+    elif kind == "quantized":                # multiples of 1/64: the squared ratios of NORM2 land on exact ties of its running sum
+        a = np.round(a * 64.0) / 64.0
+    elif kind == "plus_minus_one":           # every ratio exactly one
+        a = np.sign(a)
+    elif kind == "heavy_tail":               # a few huge entries late in the column: new maxima far down, tiny ratios before
+        a = a * (1.0 + 1e6 * (rng.random((m, n)) < 2e-4))
     else:
         raise ValueError(kind)
     return np.asfortranarray(a)
@@ -112,6 +118,19 @@ def test_lmfactor_exact_bitwise_long_columns(ds, oracle, kind, m, n, copies):
     a = _matrix(kind, m, n, rng)
     f = rng.standard_normal(m)
     _check(ds, oracle, a, f, copies=copies)
+
+
+@pytest.mark.parametrize("kind", ["random", "quantized", "plus_minus_one", "heavy_tail", "sparse", "graded_rows_down"])
+@pytest.mark.parametrize("m,n", [(40000, 6), (70001, 4)])
+def test_lmfactor_exact_long_columns_chain_free_norm2(ds, oracle, kind, m, n):
+    """Columns of a dozen and more NORM2 chunks: from the third chunk on the running sum of squared ratios is formed
+    WITHOUT the serial chain (ordered_possum_wave_int, nlh_common.h: per-binade exact additions with a two-state tie rule),
+    falling back to the chain where the sum crosses a binade or a new maximum appears.  Quantized data puts the ratios on
+    exact ties, +-1 makes every ratio one, heavy tails move the maximum late; every bit must be the oracle's."""
+    rng = np.random.default_rng(101 + m + n)
+    a = _matrix(kind, m, n, rng)
+    f = rng.standard_normal(m)
+    _check(ds, oracle, a, f)
 
 
 @pytest.mark.parametrize("copies", [1, 40, 60, 200, 300, 1100])
