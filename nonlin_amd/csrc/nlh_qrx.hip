@@ -603,18 +603,24 @@ k_qrx_gather_long(int m, int ld, size_t tst, size_t vst, int j, int cur, int np,
 
 // Split long-column step, part 3 of 3: NORM2 of the gathered column (pipelined: three preparing waves, a chain wave),
 // the sign, row j of the reflector and the step record; the rows below j are scaled by k_qrx_scale_long.
-__global__ void __launch_bounds__(QRX_LONG_THREADS)
+// (Round 4: since the running sum of most chunks is formed without the serial chain -- ordered_possum_wave_int -- the
+// kernel is bound by its PREPARING waves, divisions and prefix maxima: QRX_NORM_PREP / 64 of them instead of three.)
+#ifndef QRX_NORM_PREP
+#define QRX_NORM_PREP 384
+#endif
+#define QRX_NORM_THREADS (QRX_NORM_PREP + 64)
+__global__ void __launch_bounds__(QRX_NORM_THREADS)
 k_qrx_norm_long(int m, int n, size_t vst, int j, int cur, int np, int flush, QrxWs w, const LmState *__restrict__ st)
 {
     __shared__ __attribute__((aligned(16))) double cd[2 * (64 * QRX_LONG_EL + 128)];
-    __shared__ __attribute__((aligned(16))) double aux[8 + 256];
-    __shared__ double wmx[3 * QRX_LONG_MAXCH];
+    __shared__ __attribute__((aligned(16))) double aux[8 + QRX_NORM_PREP];
+    __shared__ double wmx[(QRX_NORM_PREP / 64) * QRX_LONG_MAXCH];
     const int p = blockIdx.x;
     if (st && st[p].stage != ST_NEED_QR) return;
     double *__restrict__ Vn = (flush & 1) ? w.V + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst
                                     : w.V + (((size_t)p * 2 + cur) * QRX_C + np) * vst;
     const double ejj = Vn[j];                                     // the diagonal entry before scaling
-    double ajnorm = norm2_flang_block_lanes_pipe<QRX_LONG_EL, 192>([&](int i) { return Vn[j + i]; }, m - j, cd, aux, wmx);   // :642
+    double ajnorm = norm2_flang_block_lanes_pipe<QRX_LONG_EL, QRX_NORM_PREP>([&](int i) { return Vn[j + i]; }, m - j, cd, aux, wmx);   // :642
     if (threadIdx.x == 0) {
         QrxStep s = w.step[p];
         double ajj = 0.0;
@@ -1861,7 +1867,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
                                        pf | 4 | 8, T, w, R, v, (const LmState *)st);
                     hipLaunchKernelGGL(k_qrx_gather_long, dim3((unsigned)(((m - (j & ~7)) / 2 + 1023) / 1024 + 1), nprob), dim3(256), 0, stream, m, ld, tst, vst,
                                        j, cur, np, pf, (const double *)T, w, (const LmState *)st);
-                    hipLaunchKernelGGL(k_qrx_norm_long, dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, m, n, vst, j, cur, np, pf, w, (const LmState *)st);
+                    hipLaunchKernelGGL(k_qrx_norm_long, dim3(nprob), dim3(QRX_NORM_THREADS), 0, stream, m, n, vst, j, cur, np, pf, w, (const LmState *)st);
                 } else
                 hipLaunchKernelGGL((k_qrx_pivot<64, true>), dim3(nprob), dim3(QRX_LONG_THREADS), 0, stream, 0, m, n, ld, coff, tst, vst, j, cur, np, pf | 4, T, w,
                                    R, v, (const LmState *)st);
