@@ -443,18 +443,14 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
             double dd[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                double d = 0.0;
+                // branch-free (sixteen independent divisions the compiler can interleave): a new maximum divides the
+                // old one by the element, anything else the element by the maximum; mx == 0: the element becomes the
+                // maximum and s stays (0/0 is discarded by the select); a zero element gives 0 / mx = +0.0
                 const double av = a[u + h];
-                if (prev == 0.0) {
-                    // mx was zero: element becomes the maximum, s untouched
-                } else if (av > prev) {
-                    const double t = prev / av, tsq = t * t;
-                    d = tsq;
-                    if (tsq != 1.0) newmax |= 1u << (u + h);         // s <- s * tsq + tsq
-                } else if (av != 0.0) {
-                    const double t = av / prev;
-                    d = t * t;
-                }
+                const bool gt = av > prev;
+                const double t = (gt ? prev : av) / (gt ? av : prev), tsq = t * t;
+                const double d = (prev == 0.0) ? 0.0 : tsq;
+                if (gt && prev != 0.0 && tsq != 1.0) newmax |= 1u << (u + h);    // s <- s * tsq + tsq
                 dd[h] = d;
                 prev = fmax(prev, av);
             }
@@ -473,31 +469,50 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
             for (int k = 0; k < TPR; ++k) nm |= (unsigned long long)(unsigned)tflags[lane * TPR + k] << (k * E);
             const unsigned long long mask = __ballot(nm == 0);       // runs without one
             double t = carry[1];
+            // Eight runs per trip, and a trip whose runs are all free of a new maximum is straight-line code: a taken
+            // branch costs ~40 cycles on this part and the test-and-branch per run was a quarter of the
+            // chain's time.  t is the same in every lane on entry, so the shift before run 0 changes nothing; the terms
+            // behind the vector's end are +0.0, so the runs that fill up the last trip hand the sum on unchanged (sums of
+            // squares are never -0.0) and the result is read from the last lane of the last trip.
+            const int ntrip = (nl + 7) >> 3;
 #pragma unroll 1
-            for (int l = 0; l < nl; ++l) {
-                if (l > 0) t = nlh_wave_shr1(t);
-                if ((mask >> l) & 1ull) {
+            for (int g = 0; g < ntrip; ++g) {
+                const unsigned m8 = (unsigned)(mask >> (8 * g)) & 0xffu;
+                if (m8 == 0xffu) {
 #pragma unroll
-                    for (int u = 0; u < EL; ++u) t = t + d[u];
-                } else if (REGGEN) {
+                    for (int q = 0; q < 8; ++q) {
+                        t = nlh_wave_shr1(t);
 #pragma unroll
-                    for (int u = 0; u < EL; ++u) {                   // s <- s * c + d with c = d at a new maximum, 1 elsewhere
-                        t = t * (((nm >> u) & 1ull) ? d[u] : 1.0);
-                        t = t + d[u];
+                        for (int u = 0; u < EL; ++u) t = t + d[u];
                     }
                 } else {
-                    // the same with the terms once more from LDS (no dynamic index into d[])
-                    const double *dm = dsv + lane * (EL + 2);
+#pragma unroll 1
+                    for (int q = 0; q < 8; ++q) {
+                        t = nlh_wave_shr1(t);
+                        if ((m8 >> q) & 1u) {
+#pragma unroll
+                            for (int u = 0; u < EL; ++u) t = t + d[u];
+                        } else if (REGGEN) {
+#pragma unroll
+                            for (int u = 0; u < EL; ++u) {           // s <- s * c + d with c = d at a new maximum, 1 elsewhere
+                                t = t * (((nm >> u) & 1ull) ? d[u] : 1.0);
+                                t = t + d[u];
+                            }
+                        } else {
+                            // the same with the terms once more from LDS (no dynamic index into d[])
+                            const double *dm = dsv + lane * (EL + 2);
 #pragma unroll 4
-                    for (int u = 0; u < EL; ++u) {
-                        const double dv = dm[u];
-                        if ((nm >> u) & 1ull) t = t * dv;
-                        t = t + dv;
+                            for (int u = 0; u < EL; ++u) {
+                                const double dv = dm[u];
+                                if ((nm >> u) & 1ull) t = t * dv;
+                                t = t + dv;
+                            }
+                        }
                     }
                 }
             }
-            const int lo = __builtin_amdgcn_readlane(__double2loint(t), nl - 1);
-            const int hi = __builtin_amdgcn_readlane(__double2hiint(t), nl - 1);
+            const int lo = __builtin_amdgcn_readlane(__double2loint(t), 8 * ntrip - 1);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(t), 8 * ntrip - 1);
             double mx = mx_in;
 #pragma unroll
             for (int w = 0; w < nw; ++w) mx = fmax(mx, wmax[w]);

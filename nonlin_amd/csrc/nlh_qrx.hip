@@ -408,7 +408,25 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
             if (move0 && i0 + u * BS < m) Tp[qrx_at(i0 + u * BS, srck, ld)] = mv[u];
         }
     };
-    if (staged) {
+    if (FEW && staged && np == 1 && !move0) {
+        // a handful of problems (one update pending: k_qrx_pass_col's regime): all of the thread's rows and their reflector
+        // entries in flight together -- four rows at a time were four dependent trips to memory (6 us of a 26 us step)
+        double e[KEEP], pv[KEEP];
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            const int row = min(j + tid + u * BS, m - 1);
+            e[u] = Tp[qrx_at(row, srck, ld)];
+            pv[u] = Vc[row];
+        }
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) { asm volatile("" : "+v"(e[u])); asm volatile("" : "+v"(pv[u])); }
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            e[u] = e[u] - tk[0] * pv[u];
+            keep[u] = e[u];
+            if (j + tid + u * BS < m) stage[tid + u * BS] = e[u];
+        }
+    } else if (staged) {
 #pragma unroll
         for (int it = 0; it < KEEP / 4; ++it) {
             const int i0 = j + tid + it * 4 * BS;
@@ -1596,12 +1614,15 @@ k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, dou
         loadchunk(0);
         for (int c = 0; c < nch; ++c) {
             const int base = c * CAP;
+            // the runs the chain wave reads: whole trips of eight (zeros behind the column's end); a single-chunk
+            // column's buffer is sized to exactly these
+            const int wl = ((((min(CAP, len - base) + EL - 1) / EL) + 7) & ~7) * EL;
             // buf[c & 1] was last read by the chain of chunk c - 2, which ended before the chain wave joined the barrier
             // of chunk c - 1
 #pragma unroll
             for (int u = 0; u < PPT; ++u) {
                 const int pr = tid + u * NPREP, rel = 2 * pr;
-                if (pr < NPAIR) {
+                if (pr < NPAIR && rel < wl) {
                     const int ra = base + rel, rbb = ra + 1;
                     const bool la = ra >= r0 && jb + ra < m, lb = rbb >= r0 && jb + rbb < m;
                     double2 e = av[u];
@@ -1650,23 +1671,21 @@ k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, dou
             cw += q1 - q0; cr += q2 - q1;
 #endif
             double t = s;
-            if (nl == 64) {
+            // eight runs per trip (a taken branch costs ~40 cycles here; t is the same in every lane on entry, so the shift
+            // before run 0 changes nothing; the terms behind the column's end are +0.0 and the sum is never -0.0, so the
+            // runs that fill up the last trip hand it on unchanged: the result is in the last lane of the last trip)
+            const int ntrip = (nl + 7) >> 3;
 #pragma unroll 1
-                for (int l = 0; l < 64; ++l) {
-                    if (l > 0) t = nlh_wave_shr1(t);
+            for (int g = 0; g < ntrip; ++g) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    t = nlh_wave_shr1(t);
 #pragma unroll
                     for (int u = 0; u < EL; ++u) t = t + d[u];         // :653, rows ascending (terms outside the rows: +0.0)
                 }
-            } else {
-#pragma unroll 1
-                for (int l = 0; l < nl; ++l) {
-                    if (l > 0) t = nlh_wave_shr1(t);
-#pragma unroll
-                    for (int u = 0; u < EL; ++u) t = t + d[u];
-                }
             }
-            const int lo_ = __builtin_amdgcn_readlane(__double2loint(t), nl - 1);
-            const int hi_ = __builtin_amdgcn_readlane(__double2hiint(t), nl - 1);
+            const int lo_ = __builtin_amdgcn_readlane(__double2loint(t), 8 * ntrip - 1);
+            const int hi_ = __builtin_amdgcn_readlane(__double2hiint(t), 8 * ntrip - 1);
             s = __hiloint2double(hi_, lo_);
 #ifdef QRX_DBG_CLK
             cc += wall_clock64() - q2;
@@ -1852,7 +1871,8 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         // two product buffers for columns of several chunks, one sized to the column otherwise
         auto coll_lds = [](int m_, int j_) {
             const int len = m_ - (j_ & ~7);
-            return sizeof(double) * (size_t)(len > 64 * QRX_COL_EL ? 2 * (64 * QRX_COL_EL + 128) : ((len + 1) & ~1) + 2 * (len / QRX_COL_EL) + 4);
+            const int nrun = (((len + QRX_COL_EL - 1) / QRX_COL_EL) + 7) & ~7;        // the chain wave adds whole trips of eight runs
+            return sizeof(double) * (size_t)(len > 64 * QRX_COL_EL ? 2 * (64 * QRX_COL_EL + 128) : nrun * (QRX_COL_EL + 2));
         };
         auto pivot = [&](int j, int cur, int np, int pf) {
             if (m <= 2048)
