@@ -264,7 +264,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     // pipelined NORM2 -- three preparing waves and the chain wave, one wave per SIMD (with four preparing waves, 320
     // threads, the chain wave shared its SIMD with one of them: 253 us per 65536-row step against 241), 105 KB of LDS,
     // one workgroup per CU, which is all a handful of long-column problems need
-    __shared__ __attribute__((aligned(16))) double cd[LONG ? 2 * (64 * QRX_LONG_EL + 128) : (64 * QRX_NL + 128)];
+    __shared__ __attribute__((aligned(16))) double cd[LONG ? 2 * (64 * QRX_LONG_EL + 128) : (64 * QRX_NL + (FEW ? 256 : 128))];
     __shared__ __attribute__((aligned(16))) double aux[LONG ? 8 + 256 : 40 + 128];
     __shared__ double wmx[LONG ? 3 * QRX_LONG_MAXCH : 1];
     __shared__ double red[64];
@@ -384,6 +384,9 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     // before it writes any) when it fits one NORM2 chunk, so that the norm does not start with another trip to memory.
     const bool staged = !LONG && (m - j <= 64 * QRX_NL);
     double *stage = cd;
+    // (handful instances: a word of padding per NORM2 thread's KEEP consecutive elements -- read back at a stride of KEEP
+    // doubles, every lane of a wave hit the same two banks: 1.2 us of a 4096-row step)
+    auto spos = [](int i) __attribute__((always_inline)) { return FEW ? i + i / (64 * QRX_NL / 256) : i; };
     // ... and in that case every thread KEEPS its rows (at most 64 * QRX_NL / 256 of them) in registers for the scaling
     // below: the raw column then never goes to memory -- one write of the reflector instead of write, read, write.
     constexpr int KEEP = 64 * QRX_NL / 256;                      // rows per thread when staged (16 or 8), four per iteration
@@ -424,7 +427,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
         for (int u = 0; u < KEEP; ++u) {
             e[u] = e[u] - tk[0] * pv[u];
             keep[u] = e[u];
-            if (j + tid + u * BS < m) stage[tid + u * BS] = e[u];
+            if (j + tid + u * BS < m) stage[spos(tid + u * BS)] = e[u];
         }
     } else if (staged) {
 #pragma unroll
@@ -436,7 +439,7 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     keep[it * 4 + u] = e[u];
-                    if (i0 + u * BS < m) stage[i0 + u * BS - j] = e[u];
+                    if (i0 + u * BS < m) stage[spos(i0 + u * BS - j)] = e[u];
                 }
             }
         }
@@ -480,14 +483,14 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
         }
     }
     __syncthreads();
-    const double ejj = staged ? stage[0] : Vn[j];
+    const double ejj = staged ? stage[0] : Vn[j];                 // (spos(0) = 0)
 #ifdef QRX_DBG_CLK
     clk[2] = wall_clock64();
 #endif
                  // the diagonal entry before scaling (read before NORM2 reuses the region)
     double ajnorm;                                                // :642
     if constexpr (LONG) ajnorm = norm2_flang_block_lanes_pipe<QRX_LONG_EL, 192>([&](int i) { return Vn[j + i]; }, m - j, cd, aux, wmx);
-    else ajnorm = staged ? norm2_flang_block_lanes<QRX_NL, 256, FEW>([&](int i) { return stage[i]; }, m - j, cd, aux)
+    else ajnorm = staged ? norm2_flang_block_lanes<QRX_NL, 256, FEW>([&](int i) { return stage[spos(i)]; }, m - j, cd, aux)
                          : norm2_flang_block_lanes<QRX_NL, 256, FEW>([&](int i) { return Vn[j + i]; }, m - j, cd, aux);
 #ifdef QRX_DBG_CLK
     clk[3] = wall_clock64();
