@@ -875,16 +875,32 @@ __device__ __forceinline__ double ordered_sum_wave(Get get, int len, double s0)
             d[u] = i < len ? v : -0.0;
         }
         const int rem = len - base, nl = rem >= 64 * E ? 64 : (rem + E - 1) / E;
-        // lane 0 starts from the carry; the others' start values are overwritten by the shift
+        // lane 0 starts from the carry (it keeps its value under the shift); the others' start values are overwritten
+        // by the shift.  Eight runs and more go in straight-line trips of eight (a taken branch costs ~40 cycles on this
+        // part): the lanes behind the last run hold -0.0 and hand the sum on unchanged, so the result is in the
+        // last lane of the last trip.
+        int last = nl - 1;
+        if (nl >= 8) {
+            const int ntrip = (nl + 7) >> 3;
+            last = 8 * ntrip - 1;
+#pragma unroll 1
+            for (int g = 0; g < ntrip; ++g) {
 #pragma unroll
-        for (int u = 0; u < E; ++u) t = t + d[u];
-#pragma unroll 2
-        for (int l = 1; l < nl; ++l) {
-            t = nlh_wave_shr1(t);
+                for (int q = 0; q < 8; ++q) {
+                    t = nlh_wave_shr1(t);
 #pragma unroll
-            for (int u = 0; u < E; ++u) t = t + d[u];
+                    for (int u = 0; u < E; ++u) t = t + d[u];
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int l = 0; l < nl; ++l) {
+                t = nlh_wave_shr1(t);
+#pragma unroll
+                for (int u = 0; u < E; ++u) t = t + d[u];
+            }
         }
-        t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), nl - 1), __builtin_amdgcn_readlane(__double2loint(t), nl - 1));
+        t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), last), __builtin_amdgcn_readlane(__double2loint(t), last));
     }
     return t;
 }
