@@ -1600,14 +1600,21 @@ k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, dou
     // A lane takes a PAIR of rows (16 bytes), four adjacent lanes a sector of the row-blocked matrix: a load or store
     // instruction of the wave covers 16 whole sectors of the column and 1 KB of each reflector.
     double2 av[PPT], vn[PPT], vp[PEND ? PPT : 1];
+    // (the reflector entries first: their addresses do not depend on the column index, so for chunk 0 they are on their
+    // way while that index is still being fetched)
     auto loadchunk = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
             const int pr = tid + u * NPREP, rb = c * CAP + 2 * pr;      // rel row of the pair
             const bool in = pr < NPAIR && rb < len;
-            av[u] = in ? *reinterpret_cast<const double2 *>(colp + (size_t)(rb >> 3) * blk + (rb & 7)) : make_double2(0.0, 0.0);
             vn[u] = in ? *reinterpret_cast<const double2 *>(vnew + rb) : make_double2(0.0, 0.0);
             if (PEND) vp[u] = in ? *reinterpret_cast<const double2 *>(vc + rb) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int pr = tid + u * NPREP, rb = c * CAP + 2 * pr;
+            const bool in = pr < NPAIR && rb < len;
+            av[u] = in ? *reinterpret_cast<const double2 *>(colp + (size_t)(rb >> 3) * blk + (rb & 7)) : make_double2(0.0, 0.0);
         }
     };
     double s = 0.0, rowj = 0.0;                                         // the running sum lives in the chain wave, row j in thread 0
