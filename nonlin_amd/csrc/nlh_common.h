@@ -394,14 +394,16 @@ __device__ __forceinline__ int nlh_chain_wave(int nwaves)
     return (int)((b + (b >> 3) + (b >> 8)) & (unsigned)(nwaves - 1));    // differs for ids 1, 8 and 256 apart
 }
 
-// REGGEN: the general runs (those with a new maximum) also work out of the registers, unrolled over d[] -- ~95 more
-// registers (one workgroup of 256 per CU instead of two) and a kernel that is faster when it has the CU to itself (a lone
-// 4096-row pivot step: 25.7 instead of 28 us), marginally slower in a batch that fills every CU twice over.
+// REGGEN: the general runs (those with a new maximum) multiply every term by a per-lane selected operand -- more
+// registers, faster when the workgroup has its CU to itself (a handful of problems); without it the flags of the one
+// lane that matters are read into a scalar and tested a quarter of a run at a time (see below): +1.4 % on the
+// 2048-problem headline over the form it replaced (the terms once more from LDS, a branch per element), 1 % slower
+// than REGGEN for a problem alone.
 template <int EL, int BSZ, bool REGGEN = false, typename Get>
 __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *aux)
 {
     constexpr int CAP = 64 * EL, E = CAP / BSZ, TPR = EL / E;   // E elements per thread, TPR threads per run
-    static_assert(CAP % BSZ == 0 && EL % E == 0 && E % 2 == 0, "chunk must split evenly");
+    static_assert(CAP % BSZ == 0 && EL % E == 0 && E % 2 == 0 && EL % 16 == 0, "chunk must split evenly");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int nw = BSZ / 64;
     const int cw = nlh_chain_wave(nw);                                   // the wave that runs the serial recurrence
@@ -499,13 +501,26 @@ __device__ double norm2_flang_block_lanes(Get get, int len, double *cd, double *
                                 t = t + d[u];
                             }
                         } else {
-                            // the same with the terms once more from LDS (no dynamic index into d[])
-                            const double *dm = dsv + lane * (EL + 2);
-#pragma unroll 4
-                            for (int u = 0; u < EL; ++u) {
-                                const double dv = dm[u];
-                                if ((nm >> u) & 1ull) t = t * dv;
-                                t = t + dv;
+                            // A run with new maxima: s <- s * c + d with c = d at a new maximum, 1 elsewhere.  Only lane
+                            // l's result of step l is ever used, so the flags of lane l serve every lane: a scalar,
+                            // tested sixteen elements at a time -- a quarter without a new maximum is sixteen plain adds,
+                            // the others multiply by a selected operand (x * 1.0 == x), no branch per element and no
+                            // second copy of the terms.
+                            const int l = 8 * g + q;
+                            const unsigned long long nml = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(nm >> 32), l) << 32)
+                                                           | (unsigned)__builtin_amdgcn_readlane((int)nm, l);
+#pragma unroll
+                            for (int qd = 0; qd < EL; qd += 16) {
+                                if (((nml >> qd) & 0xffffull) == 0) {
+#pragma unroll
+                                    for (int u = qd; u < qd + 16; ++u) t = t + d[u];
+                                } else {
+#pragma unroll
+                                    for (int u = qd; u < qd + 16; ++u) {
+                                        t = t * (((nml >> u) & 1ull) ? d[u] : 1.0);
+                                        t = t + d[u];
+                                    }
+                                }
                             }
                         }
                     }
