@@ -499,21 +499,17 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     if (staged) {
         // :645-646 from the registers (ajnorm == 0: the column is zero; the reflector slot still gets the column)
         if (ajnorm != 0.0 && ejj < 0.0) ajnorm = -ajnorm;         // :644
+        // the divisions of all the thread's rows first, unconditionally (x / 1.0 == x stands for "no reflector"): under
+        // the row and zero-norm conditions they were one division sequence after the other, 1.6 us of a 4096-row step
+        const double dn = (ajnorm != 0.0) ? ajnorm : 1.0;
 #pragma unroll
-        for (int it = 0; it < KEEP / 4; ++it) {
-            const int i0 = j + tid + it * 4 * BS;
+        for (int u = 0; u < KEEP; ++u) keep[u] = keep[u] / dn;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * BS;
-                if (i < m) {
-                    double t = keep[it * 4 + u];
-                    if (ajnorm != 0.0) {
-                        t = t / ajnorm;
-                        if (i == j) { t = t + 1.0; ajj = t; }
-                    }
-                    Vn[i] = t;
-                }
-            }
+        for (int u = 0; u < KEEP; ++u) {
+            const int i = j + tid + u * BS;
+            double t = keep[u];
+            if (ajnorm != 0.0 && i == j) { t = t + 1.0; ajj = t; }
+            if (i < m) Vn[i] = t;
         }
     } else if (LONG && (flush & 4) && ajnorm != 0.0) {
         // the scaling of the rows below j is left to k_qrx_scale_long, which spreads it over the chip (on this one
