@@ -131,6 +131,50 @@ __device__ __forceinline__ int block_argmax_first(double v, int idx, double *shv
     return bi;
 }
 
+// The same search when thread t holds candidate index base + t (indices ascend with the thread id) and the values are
+// norms (>= +0.0, or NaN): the maximum of the BIT PATTERNS by 32-bit DPP steps (high words, then the low words of the lanes
+// that hold the high maximum) instead of twelve shuffles of (value, index) pairs, one barrier instead of two.  Ties go to
+// the lowest thread; a NaN is never greater than anything and nothing is greater than a NaN, so a NaN wins if and only
+// if it is the very first candidate (thread 0), exactly as in the reference's scan from the left.  sh: 3 * (blockDim / 64)
+// words of LDS used for nothing else.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t nlh_dpp_umax_step(uint32_t v)
+{
+    // bound_ctrl: lanes without a source (and rows outside the mask) read 0 -- neutral for an unsigned maximum
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t nlh_wave_umax(uint32_t v)
+{
+    v = nlh_dpp_umax_step<0x111, 0xf>(v);
+    v = nlh_dpp_umax_step<0x112, 0xf>(v);
+    v = nlh_dpp_umax_step<0x114, 0xf>(v);
+    v = nlh_dpp_umax_step<0x118, 0xf>(v);
+    v = nlh_dpp_umax_step<0x142, 0xa>(v);
+    v = nlh_dpp_umax_step<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int block_argmax_first_norms(double v, bool valid, uint32_t *sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    unsigned long long key = (bits >> 63) ? 1ull : bits + 1ull;               // (-0.0 counts as +0.0; norms are never negative)
+    if (v != v) key = (tid == 0) ? 0x7ff0000000000002ull : 1ull;
+    if (!valid) key = 0ull;
+    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    const uint32_t mh = nlh_wave_umax(hi);
+    const uint32_t ml = nlh_wave_umax(hi == mh ? lo : 0u);
+    const unsigned long long hit = __ballot(hi == mh && lo == ml);
+    if (lane == 0) { sh[3 * wid] = mh; sh[3 * wid + 1] = ml; sh[3 * wid + 2] = (uint32_t)(wid * 64 + __ffsll((long long)hit) - 1); }
+    __syncthreads();
+    uint32_t bh = sh[0], bl = sh[1], bp = sh[2];
+    for (int w = 1; w < nw; ++w) {
+        const uint32_t oh = sh[3 * w], ol = sh[3 * w + 1];
+        if (oh > bh || (oh == bh && ol > bl)) { bh = oh; bl = ol; bp = sh[3 * w + 2]; }
+    }
+    return (int)bp;
+}
+
 #define NLH_SQRT_EPS 1.4901161193847656e-08   /* sqrt(epsilon(1d0)), multi_eqn_mult_var.f90:263-264 */
 #define NLH_EPS      2.220446049250313e-16
 #define NLH_DWARF    2.2250738585072014e-308  /* tiny(1d0), least_squares.f90:442 */

@@ -314,7 +314,10 @@ k_qrx_pivot(int p0, int m, int n, int ld, int coff, size_t tst, size_t vst, int 
     double rd_j = 0.0, wa_j = 0.0;
     int src_j = 0, ipvt_j = 0, src_0 = 0;
     if (tid == 0) { rd_j = rdiag[j]; wa_j = wa[j]; src_j = fresh ? coff + j : src[j]; ipvt_j = ipvt[j]; src_0 = src[0]; }
-    const int kmax = block_argmax_first(bv, bk, red, redi);
+    __shared__ uint32_t amx[3 * 16];
+    // (the DPP search in the m <= 2048 instances only: 2048x128 alone 13.2 -> 12.85 ms per solve; in the 4096-row instances
+    // it measured 0.8 % SLOWER per solve -- the compiler's schedule of what follows, not the search itself)
+    const int kmax = (QRX_NL == 32 && onecand) ? j + block_argmax_first_norms(bv, bk != 0x7fffffff, amx) : block_argmax_first(bv, bk, red, redi);
     double *pub = red + 40;                                      // [0 .. QRX_C-2] multipliers, then src, ipvt (as ints)
     int *pubi = reinterpret_cast<int *>(pub + QRX_C);
     if (onecand) {
