@@ -551,8 +551,12 @@ k_lm_update(int m, int n, int nblk, const double *__restrict__ part, LmVecs v,
 
     double fnorm1, tq = 0.0;                                    // fnorm1 = ||wa4|| (:299)
     if (EXACT) {
+        // NORM2 down the lanes of a wave (nlh_common.h; bit-identical to norm2_flang_block, whose one-thread recurrence
+        // took 110 of this kernel's 128 us at m = 4096)
+        __shared__ __attribute__((aligned(16))) double ncd[EXACT ? 64 * 64 + 128 : 2];
+        __shared__ __attribute__((aligned(16))) double naux[EXACT ? 40 + 128 : 2];
         const double *w = wa4 + (size_t)p * m;
-        fnorm1 = norm2_flang_block([&](int i) { return w[i]; }, m, scratch);
+        fnorm1 = norm2_flang_block_lanes<64, 256>([&](int i) { return w[i]; }, m, ncd, naux);
     } else {
         double sq = 0.0;
         for (int k = 0; k < nblk; ++k) {                        // fixed order
