@@ -265,6 +265,69 @@ int  nlh_dq_model_bfgs_solve(nlh_handle *h, const nlh_options *opts, const nlh_d
                              double *fout, nlh_iteration_behavior *ib, int32_t *status);
 
 
+/* ===========================================================================
+ * User-supplied DEVICE residuals: vecfcn / jacobianfcn as LAUNCHERS.
+ *
+ * The reference's plugin layer is "the user hands in a residual": vecfcn (src/nonlin_multi_eqn_mult_var.f90:14-25),
+ * set_fcn (:126-140), and the solvers call it at x, at the n perturbed points of the forward-difference Jacobian
+ * (:267-273) and at trial points.  A host procedure cannot run on the GPU, so the device form of the plugin is a
+ * launcher: a HOST function that ENQUEUES, on the HIP stream it is handed, device work which evaluates F at `npoints`
+ * points, and returns at once (0, or non-zero to abort the solve with NLH_ERR_HIP).  It must not synchronise and may be
+ * called from several host threads on different streams (sub-batches, device sets).
+ *   point q (0 <= q < npoints) belongs to problem dprob[q] (a DEVICE array: the index the problem has in the caller's
+ *   batch -- what the user's kernel selects its data with); its variables are dX[q*n .. q*n + n), its residuals go to
+ *   dF[q*m .. q*m + m).  For the Jacobian launcher point q's m-by-n Jacobian goes to dJ + q*m*n, column-major (ld = m).
+ * The library builds the points itself, on the device, in the reference's order: for a forward-difference Jacobian of
+ * problem p, points p*n + j = x with x(j) replaced by x(j) + h_j (:268-271); k_fd_jacobian then forms
+ * jac(:,j) = (F(point j) - F(x)) / h_j with a true division (:274).  Everything downstream is the state machine the
+ * dense-quadratic entry points run.  A problem's result does not depend on the batch it is solved in.
+ * ======================================================================== */
+typedef int (*nlh_device_vecfcn)(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n,
+                                 const double *dX, int32_t m, double *dF);
+typedef int (*nlh_device_jacfcn)(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n,
+                                 const double *dX, int32_t m, double *dJ);
+
+/* vecfcn_helper%jacobian (vfh_jac_fcn, :198-277) of every problem: jacfcn != NULL forwards to it (:241-243), otherwise
+ * forward differences.  dx [nprob][n], dfv [nprob][m] = F(x) or NULL (then evaluated first, :257-259), dJ [nprob][n][m]
+ * (each problem column-major m x n); DEVICE pointers. */
+int nlh_fd_jacobian_device(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn,
+                           nlh_device_jacfcn jacfcn, void *ctx, const double *dx, const double *dfv, double *dJ);
+/* least_squares_solver%solve (lss_solve, src/nonlin_least_squares.f90:118-391) on nprob problems of the user's family.
+ * dx [nprob][n] in/out, dfvec [nprob][m] out: DEVICE pointers; ib / status: host, [nprob] (NULL allowed). */
+int nlh_lm_solve_batch_device(nlh_handle *h, const nlh_options *opts, int32_t nprob, int32_t m, int32_t n,
+                              nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *dx, double *dfvec,
+                              nlh_iteration_behavior *ib, int32_t *status);
+/* newton_solver%solve (ns_solve, src/nonlin_solve.f90:452-638) / quasi_newton_solver%solve (qns_solve, :156-427) on
+ * nprob square problems of the user's family. */
+int nlh_newton_solve_batch_device(nlh_handle *h, const nlh_options *opts, int32_t nprob, int32_t n,
+                                  nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *dx, double *dfvec,
+                                  nlh_iteration_behavior *ib, int32_t *status);
+int nlh_quasi_newton_solve_batch_device(nlh_handle *h, const nlh_options *opts, int32_t jdelta, int32_t nprob, int32_t n,
+                                        nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *dx,
+                                        double *dfvec, nlh_iteration_behavior *ib, int32_t *status);
+/* The same three behind HOST arrays x [nprob][n] in/out, fvec [nprob][m] out (what the Fortran shim's
+ * vecfcn_helper%set_device_fcn + solver%solve / solve_batch call): staged through the handle's buffers. */
+int nlh_lm_solve_batch_device_h(nlh_handle *h, const nlh_options *opts, int32_t nprob, int32_t m, int32_t n,
+                                nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *x, double *fvec,
+                                nlh_iteration_behavior *ib, int32_t *status);
+int nlh_newton_solve_batch_device_h(nlh_handle *h, const nlh_options *opts, int32_t nprob, int32_t n,
+                                    nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *x, double *fvec,
+                                    nlh_iteration_behavior *ib, int32_t *status);
+int nlh_quasi_newton_solve_batch_device_h(nlh_handle *h, const nlh_options *opts, int32_t jdelta, int32_t nprob, int32_t n,
+                                          nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *x,
+                                          double *fvec, nlh_iteration_behavior *ib, int32_t *status);
+/* The built-in dense-quadratic family expressed as such launchers (ctx = nlh_dq_device_ctx): the same residual bits as
+ * the nlh_dq_* entry points, through the open path. */
+typedef struct nlh_dq_device_ctx {
+    const double *dA;     /* [nprob][n][m], device */
+    const double *db;     /* [nprob][m], device */
+    double gamma;
+} nlh_dq_device_ctx;
+int nlh_dq_device_fcn(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n, const double *dX,
+                      int32_t m, double *dF);
+int nlh_dq_device_jac(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n, const double *dX,
+                      int32_t m, double *dJ);
+
 /* Synthetic problem generator of SURVEY.md 8(d) (bench/test inputs, not part of the
  * reference): counter-based splitmix64, U_k = mix(seed + (k+1)*0x9E3779B97F4A7C15),
  * draw order A (column-major), x_true, noise, x0; problem p uses seed0 + p*seed_stride.

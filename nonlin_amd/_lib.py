@@ -16,6 +16,8 @@ VECFCN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, c_double_p, C.c_int32, c_doubl
 JACFCN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, c_double_p, C.c_int32, c_double_p)
 FCNNVAR = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int32, c_double_p)
 GRADFCN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, c_double_p, c_double_p)
+# nlh_device_vecfcn / nlh_device_jacfcn: launchers (ctx, hip_stream, npoints, dprob, n, dX, m, dF | dJ) -> int
+DEVFCN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p)
 
 
 class IterationBehavior(C.Structure):
@@ -26,6 +28,11 @@ class IterationBehavior(C.Structure):
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class DqDeviceCtx(C.Structure):
+    """nlh_dq_device_ctx: the dense-quadratic family behind the launchers nlh_dq_device_fcn / nlh_dq_device_jac."""
+    _fields_ = [("dA", C.c_void_p), ("db", C.c_void_p), ("gamma", C.c_double)]
 
 
 class Options(C.Structure):
@@ -123,6 +130,22 @@ SYMBOLS = {
                                          c_double_p, c_double_p, C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_dq_model_bfgs_solve": (C.c_int, [_H, C.POINTER(Options), C.c_void_p, c_double_p, c_double_p, c_double_p,
                                           C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_fd_jacobian_device": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "nlh_lm_solve_batch_device": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_newton_solve_batch_device": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_quasi_newton_solve_batch_device": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, DEVFCN, DEVFCN,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_lm_solve_batch_device_h": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p,
+                                              c_double_p, c_double_p, C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_newton_solve_batch_device_h": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p,
+                                                  c_double_p, c_double_p, C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_quasi_newton_solve_batch_device_h": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, DEVFCN, DEVFCN,
+                                                        C.c_void_p, c_double_p, c_double_p, C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_dq_device_fcn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "nlh_dq_device_jac": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "nlh_timing_enable": (None, [_H, C.c_int32]),
     "nlh_timing_reset": (None, [_H]),
     "nlh_timing_get": (C.c_int, [_H, C.c_int32, c_double_p, C.POINTER(C.c_int64)]),

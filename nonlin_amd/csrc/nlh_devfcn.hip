@@ -1,0 +1,407 @@
+// nlh_devfcn.hip -- the open device-residual path: a user's vecfcn / jacobianfcn (src/nonlin_multi_eqn_mult_var.f90:14-38)
+// handed in as LAUNCHERS (include/nonlin_hip.h: nlh_device_vecfcn, nlh_device_jacfcn) and everything the lock-step
+// drivers need around them:
+//   * residual_eval      F at one point per problem (the starting point :211, a trial point :297, the line search's trials);
+//   * residual_jacobian  vecfcn_helper%jacobian (vfh_jac_fcn, :198-277): the n perturbed points of every problem that is
+//                        due, built on the device in the reference's order (:267-273), ONE call of the user's launcher for
+//                        all of them, and the forward-difference column write (:274) -- k_fd_jacobian (column-major J) or
+//                        k_fd_jacobian_qrx (straight into the exact factorisation's row-blocked working matrix);
+//   * the dense-quadratic family as such launchers (nlh_dq_device_fcn / nlh_dq_device_jac) -- the same bits as the
+//     fused kernels of nlh_kernels_model.h, through the open path;
+//   * nlh_fd_jacobian_device.
+// A lock-step round serves the problems that are in a given stage; the user's launcher is only ever asked for those: the
+// problems are compacted on the device (ascending), the count comes back to the host (one read-back), and the launcher
+// sees npoints contiguous points with the problem index of each in dprob.
+#include "nlh_internal.h"
+#include "nlh_kernels_model.h"
+#include "nlh_qrx.h"
+
+// ---------------------------------------------------------------------------
+// compaction of the problems at one stage: list[k] = k-th such problem (ascending), *cnt = how many
+// ---------------------------------------------------------------------------
+static __global__ void __launch_bounds__(1024)
+k_dv_compact(int nprob, const LmState *__restrict__ st, int want, int32_t *__restrict__ list, int32_t *__restrict__ cnt)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < nprob; p0 += 1024) {
+        const int p = p0 + tid;
+        const bool on = p < nprob && (!st || st[p].stage == want);
+        const unsigned long long bal = __ballot(on);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wid] = __popcll(bal);
+        __syncthreads();
+        int off = base_s, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wid) off += c; tot += c; }
+        if (on) list[off + before] = p;
+        __syncthreads();
+        if (tid == 0) base_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *cnt = base_s;
+}
+
+// dprob for one point per listed problem (list == nullptr: the identity), and the gather of their x
+static __global__ void k_dv_gather_x(int cnt, int n, const int32_t *__restrict__ list, int pbase, const double *__restrict__ x,
+                                     double *__restrict__ X, int32_t *__restrict__ dprob)
+{
+    const int k = blockIdx.x;
+    const int p = list ? list[k] : k;
+    if (threadIdx.x == 0) dprob[k] = pbase + p;
+    if (X)
+        for (int c = threadIdx.x; c < n; c += blockDim.x) X[(size_t)k * n + c] = x[(size_t)p * n + c];
+}
+
+// compact residuals back to the problems' rows
+static __global__ void k_dv_scatter_f(int m, const int32_t *__restrict__ list, const double *__restrict__ F, double *__restrict__ f)
+{
+    const int k = blockIdx.y, p = list[k];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) f[(size_t)p * m + i] = F[(size_t)k * m + i];
+}
+
+// The n perturbed points of vfh_jac_fcn for the listed problems (:267-273): point k*n + j = x with x(j) = x(j) + h_j.
+static __global__ void k_dv_fd_points(int n, const int32_t *__restrict__ list, int pbase, const double *__restrict__ x,
+                                      double *__restrict__ X, int32_t *__restrict__ dprob)
+{
+    const int k = blockIdx.y, j = blockIdx.x;
+    const int p = list ? list[k] : k;
+    const double *xp = x + (size_t)p * n;
+    double *Xq = X + ((size_t)k * n + j) * n;
+    if (threadIdx.x == 0) dprob[(size_t)k * n + j] = pbase + p;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const double v = xp[c];
+        Xq[c] = (c == j) ? v + fd_step(v) : v;                  // x(j) = temp + h, :271
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The forward-difference column write (:274) into the exact factorisation's working matrix (nlh_qrx.hip: element (i, c)
+// at ((i / 8) * ld + c) * 8 + i % 8, Jacobian column j at c = coff + j).  The panel is column-major (a lane per row pair:
+// a wave reads 1 KB contiguous of one column); the working matrix keeps eight rows of a column per 64-byte sector and all
+// columns of a row block contiguous, so a tile of 128 rows x 32 columns is turned in LDS and leaves as sixteen runs of
+// 2 KB.  Streaming: 8 bytes read + 8 bytes written per element, f0 and h_j from cache.
+// Panel slot = blockIdx.z (compact), problem = list[blockIdx.z].
+// ---------------------------------------------------------------------------
+#define FDQ_ROWS 128
+#define FDQ_COLS 32
+#define FDQ_LDB (FDQ_COLS * 8 + 8)        // doubles between two row blocks of the tile in LDS (padded: 64 bytes)
+template <bool VEC2>
+__global__ void __launch_bounds__(256)
+k_fd_jacobian_qrx(int m, int n, const double *__restrict__ P, const double *__restrict__ f0, const double *__restrict__ x,
+                  double *__restrict__ T, const int32_t *__restrict__ list, const LmState *__restrict__ st, int want,
+                  int ld, int coff, size_t tst)
+{
+    __shared__ __attribute__((aligned(16))) double tile[(FDQ_ROWS / 8) * FDQ_LDB];
+    const int k = blockIdx.z;
+    const int p = list ? list[k] : k;
+    if (st && st[p].stage != want) return;
+    const double *Pp = P + (size_t)k * m * n;
+    const double *fp = f0 + (size_t)p * m;
+    const double *xp = x + (size_t)p * n;
+    double *Tp = T + (size_t)p * tst;
+    const int i0 = blockIdx.x * FDQ_ROWS, j0 = blockIdx.y * FDQ_COLS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    {
+        const int i = i0 + 2 * lane;
+        double fa = 0.0, fb = 0.0;
+        if (i < m) fa = fp[i];
+        if (i + 1 < m) fb = fp[i + 1];
+        double va[8], vb[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int j = j0 + w * 8 + c;
+            va[c] = 0.0; vb[c] = 0.0;
+            if (j < n) {
+                if (VEC2) {                                     // m even: i + 1 < m whenever i < m, 16-byte aligned
+                    if (i < m) {
+                        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Pp + (size_t)j * m + i));
+                        va[c] = v.x; vb[c] = v.y;
+                    }
+                } else {
+                    if (i < m) va[c] = Pp[(size_t)j * m + i];
+                    if (i + 1 < m) vb[c] = Pp[(size_t)j * m + i + 1];
+                }
+            }
+        }
+        double *tl = tile + (lane >> 2) * FDQ_LDB + (w * 8) * 8 + ((2 * lane) & 7);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int j = j0 + w * 8 + c;
+            const double h = fd_step(j < n ? xp[j] : 1.0);
+            v2d o;
+            o.x = (i < m) ? (va[c] - fa) / h : 0.0;             // rows beyond m: the zero padding of the last row block
+            o.y = (i + 1 < m) ? (vb[c] - fb) / h : 0.0;
+            *reinterpret_cast<v2d *>(tl + c * 8) = o;
+        }
+    }
+    __syncthreads();
+    const int mblk = (m + 7) >> 3;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int q = it * 256 + tid;                           // pair index inside the tile: 16 row blocks x 128 pairs
+        const int rb = q >> 7, wi = q & 127;                    // pair wi of row block rb: column wi / 4, rows 2 (wi % 4), + 1
+        const int c = wi >> 2;
+        if (i0 / 8 + rb < mblk && j0 + c < n) {
+            const v2d o = *reinterpret_cast<const v2d *>(tile + rb * FDQ_LDB + wi * 2);
+            __builtin_nontemporal_store(o, reinterpret_cast<v2d *>(Tp + ((size_t)(i0 / 8 + rb) * ld + coff + j0) * 8 + wi * 2));
+        }
+    }
+}
+
+// A user's analytic Jacobian (column-major, compact slots) into the working matrix / the problems' column-major slots.
+template <bool TOQRX>
+static __global__ void __launch_bounds__(256)
+k_dv_place_jac(int m, int n, const double *__restrict__ Jc, double *__restrict__ out, const int32_t *__restrict__ list, int ld, int coff,
+               size_t tst)
+{
+    const int k = blockIdx.z, p = list ? list[k] : k;
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int mp = (m + 7) & ~7;
+    if (i >= mp) return;
+    const double v = i < m ? Jc[((size_t)k * n + j) * m + i] : 0.0;
+    if (TOQRX) out[(size_t)p * tst + ((size_t)(i >> 3) * ld + coff + j) * 8 + (i & 7)] = v;
+    else if (i < m) out[((size_t)p * n + j) * m + i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static inline int32_t *dv_list(nlh_handle *h) { return (int32_t *)h->dvIdx.p + 16; }
+
+// Compacts the problems at `want` into the handle's list; returns their number (< 0: a library error).
+static int dv_select(nlh_handle *h, int nprob, const LmState *st, int want, size_t extra_ints)
+{
+    int rc;
+    if ((rc = ensure(h, h->dvIdx, sizeof(int32_t) * ((size_t)nprob + 16 + extra_ints)))) return rc < 0 ? rc : -1000 - rc;
+    if ((rc = ensure_pinned(h, 64))) return rc < 0 ? rc : -1000 - rc;
+    int32_t *dcnt = (int32_t *)h->dvIdx.p;
+    hipLaunchKernelGGL(k_dv_compact, dim3(1), dim3(1024), 0, h->stream, nprob, st, want, dv_list(h), dcnt);
+    // (the solvers keep their own read-back state at the start of the pinned block: the count lands behind it)
+    int32_t *hcnt = (int32_t *)h->pinned + 12;
+    if (hipMemcpyAsync(hcnt, dcnt, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "device residual: read-back of the active count"; return NLH_ERR_HIP; }
+    return *hcnt;
+}
+
+static int dv_fail(nlh_handle *h, int rc, const char *what)
+{
+    h->err = std::string(what) + ": the user's launcher returned " + std::to_string(rc);
+    return NLH_ERR_HIP;
+}
+
+void launch_sumsq_part(nlh_handle *h, int nprob, int m, int n, const double *f, double *part);
+
+int residual_eval(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int n, const double *x, double *f, double *part,
+                  const LmState *st, int want)
+{
+    if (!rs.user()) {
+        launch_dq_residual(h, nprob, m, n, rs.dA, rs.db, rs.gamma, x, f, part, st, want);
+        return 0;
+    }
+    int rc;
+    int cnt = nprob;
+    const bool all = st == nullptr;
+    if (!all) {
+        cnt = dv_select(h, nprob, st, want, (size_t)nprob);
+        if (cnt < 0) return cnt <= -1000 ? -(cnt + 1000) : cnt;
+        if (cnt == 0) return 0;
+    } else if ((rc = ensure(h, h->dvIdx, sizeof(int32_t) * ((size_t)2 * nprob + 16)))) return rc;
+    int32_t *list = dv_list(h), *dprob = list + nprob;
+    const bool direct = all || cnt == nprob;                    // every problem: no gather / scatter, the caller's arrays
+    const double *X = x;
+    double *F = f;
+    if (!direct) {
+        if ((rc = ensure(h, h->dvX, sizeof(double) * (size_t)cnt * n))) return rc;
+        if ((rc = ensure(h, h->dvF, sizeof(double) * (size_t)cnt * m))) return rc;
+        X = (const double *)h->dvX.p; F = (double *)h->dvF.p;
+    }
+    hipLaunchKernelGGL(k_dv_gather_x, dim3(cnt), dim3(64), 0, h->stream, cnt, n, direct ? (const int32_t *)nullptr : (const int32_t *)list,
+                       (int)rs.pbase, x, direct ? (double *)nullptr : (double *)h->dvX.p, dprob);
+    {
+        Timed t(h, NLH_K_DQ_RESIDUAL);
+        const int urc = rs.fcn(rs.ctx, (void *)h->stream, cnt, dprob, n, X, m, F);
+        if (urc) return dv_fail(h, urc, "vecfcn");
+    }
+    if (!direct)
+        hipLaunchKernelGGL(k_dv_scatter_f, dim3((m + 255) / 256, cnt), dim3(256), 0, h->stream, m, (const int32_t *)list, (const double *)F, f);
+    if (part) launch_sumsq_part(h, nprob, m, n, f, part);       // (every problem's row: only the ones at `want` are read)
+    return 0;
+}
+
+int residual_jacobian(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int n, const double *x, const double *f0,
+                      double *out, double *panel, const LmState *st, int want, bool to_qrx, bool fuse, bool use_jac)
+{
+    if (!rs.user()) {
+        if (fuse) launch_dq_panel(h, nprob, m, n, rs.dA, rs.db, rs.gamma, x, out, st, want, f0, to_qrx);
+        else {
+            launch_dq_panel(h, nprob, m, n, rs.dA, rs.db, rs.gamma, x, panel, st, want);
+            launch_fd(h, nprob, m, n, panel, f0, x, out, st, want);      // (to_qrx is the fused form's)
+        }
+        return 0;
+    }
+    int rc;
+    int cnt = nprob;
+    const bool all = st == nullptr;
+    const size_t npts_max = (size_t)nprob * n;
+    if (!all) {
+        cnt = dv_select(h, nprob, st, want, (size_t)nprob + npts_max);
+        if (cnt < 0) return cnt <= -1000 ? -(cnt + 1000) : cnt;
+        if (cnt == 0) return 0;
+    } else if ((rc = ensure(h, h->dvIdx, sizeof(int32_t) * ((size_t)2 * nprob + 16 + npts_max)))) return rc;
+    int32_t *list = dv_list(h), *dprob = list + 2 * (size_t)nprob;
+    const int32_t *lp = (all || cnt == nprob) ? nullptr : list;
+    const int ld = qrx_ld(n), coff = ld - (n + 1);
+    const size_t tst = qrx_matrix_stride(m, n);
+    if (use_jac && rs.jac) {                                    // :241-243: the user's jacobianfcn, one point per problem
+        if ((rc = ensure(h, h->dvX, sizeof(double) * (size_t)cnt * n))) return rc;
+        hipLaunchKernelGGL(k_dv_gather_x, dim3(cnt), dim3(64), 0, h->stream, cnt, n, lp, (int)rs.pbase, x, (double *)h->dvX.p, dprob);
+        {
+            Timed t(h, NLH_K_DQ_JACOBIAN);
+            const int urc = rs.jac(rs.ctx, (void *)h->stream, cnt, dprob, n, (const double *)h->dvX.p, m, panel);
+            if (urc) return dv_fail(h, urc, "jacobianfcn");
+        }
+        const dim3 grid((((m + 7) & ~7) + 255) / 256, n, cnt);
+        if (to_qrx) hipLaunchKernelGGL(k_dv_place_jac<true>, grid, dim3(256), 0, h->stream, m, n, (const double *)panel, out, lp, ld, coff, tst);
+        else hipLaunchKernelGGL(k_dv_place_jac<false>, grid, dim3(256), 0, h->stream, m, n, (const double *)panel, out, lp, ld, coff, tst);
+        return 0;
+    }
+    if ((rc = ensure(h, h->dvX, sizeof(double) * (size_t)cnt * n * n))) return rc;
+    double *X = (double *)h->dvX.p;
+    hipLaunchKernelGGL(k_dv_fd_points, dim3(n, cnt), dim3(64), 0, h->stream, n, lp, (int)rs.pbase, x, X, dprob);
+    {
+        Timed t(h, NLH_K_DQ_PANEL);                             // the n perturbed evaluations of every problem that is due
+        const int urc = rs.fcn(rs.ctx, (void *)h->stream, cnt * n, dprob, n, (const double *)X, m, panel);
+        if (urc) return dv_fail(h, urc, "vecfcn");
+    }
+    {
+        Timed t(h, NLH_K_FD_JACOBIAN);                          // :274
+        if (to_qrx) {
+            const dim3 grid((m + FDQ_ROWS - 1) / FDQ_ROWS, (n + FDQ_COLS - 1) / FDQ_COLS, cnt);
+            const bool vec2 = (m % 2 == 0) && (((uintptr_t)panel & 15) == 0);
+            if (vec2) hipLaunchKernelGGL(k_fd_jacobian_qrx<true>, grid, dim3(256), 0, h->stream, m, n, (const double *)panel, f0, x, out, lp,
+                                         (const LmState *)nullptr, -1, ld, coff, tst);
+            else hipLaunchKernelGGL(k_fd_jacobian_qrx<false>, grid, dim3(256), 0, h->stream, m, n, (const double *)panel, f0, x, out, lp,
+                                    (const LmState *)nullptr, -1, ld, coff, tst);
+        } else {
+            constexpr int CJ = 8;
+            const bool vec2 = (m % 2 == 0) && ((((uintptr_t)panel | (uintptr_t)out | (uintptr_t)f0) & 15) == 0);
+            if (vec2)
+                hipLaunchKernelGGL((k_fd_jacobian<RB, CJ, true>), dim3((m / 2 + RB - 1) / RB, (n + CJ - 1) / CJ, cnt), dim3(RB), 0, h->stream, m, n,
+                                   (const double *)panel, f0, x, out, (const LmState *)nullptr, -1, lp);
+            else
+                hipLaunchKernelGGL((k_fd_jacobian<RB, CJ, false>), dim3((m + RB - 1) / RB, (n + CJ - 1) / CJ, cnt), dim3(RB), 0, h->stream, m, n,
+                                   (const double *)panel, f0, x, out, (const LmState *)nullptr, -1, lp);
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// the dense-quadratic family as launchers
+// ---------------------------------------------------------------------------
+// One residual row per thread, a point per blockIdx: the row sum in ascending j, one multiply and one add per term --
+// the bits of k_dq_residual and of every column of k_dq_panel.
+static __global__ void __launch_bounds__(256)
+k_dqv_fcn(int m, int n, int nblk, const double *__restrict__ A, const double *__restrict__ b, double gamma, const int32_t *__restrict__ dprob,
+          const double *__restrict__ X, double *__restrict__ F)
+{
+    extern __shared__ double xs[];
+    const int q = blockIdx.x / nblk, rb = blockIdx.x - q * nblk;
+    const int p = dprob[q];
+    for (int c = threadIdx.x; c < n; c += 256) xs[c] = X[(size_t)q * n + c];
+    __syncthreads();
+    const int i = rb * 256 + threadIdx.x;
+    if (i >= m) return;
+    const double *a = A + (size_t)p * m * n + i;
+    double u = 0.0;
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        double av[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) av[t] = a[(size_t)(k + t) * m];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) u = u + av[t] * xs[k + t];
+    }
+    for (; k < n; ++k) u = u + a[(size_t)k * m] * xs[k];
+    F[(size_t)q * m + i] = (u + (gamma * u) * u) - b[(size_t)p * m + i];
+}
+
+static __global__ void __launch_bounds__(256)
+k_dqv_jac(int m, int n, int nblk, const double *__restrict__ A, double gamma, const int32_t *__restrict__ dprob, const double *__restrict__ X,
+          double *__restrict__ J)
+{
+    extern __shared__ double xs[];
+    const int q = blockIdx.x / nblk, rb = blockIdx.x - q * nblk;
+    const int p = dprob[q];
+    for (int c = threadIdx.x; c < n; c += 256) xs[c] = X[(size_t)q * n + c];
+    __syncthreads();
+    const int i = rb * 256 + threadIdx.x;
+    if (i >= m) return;
+    const double *a = A + (size_t)p * m * n + i;
+    double u = 0.0;
+    for (int k = 0; k < n; ++k) u = u + a[(size_t)k * m] * xs[k];
+    const double s = 1.0 + 2.0 * gamma * u;                     // k_dq_jacobian's expression
+    double *Jq = J + (size_t)q * m * n + i;
+    for (int k = 0; k < n; ++k) Jq[(size_t)k * m] = s * a[(size_t)k * m];
+}
+
+int nlh_dq_device_fcn(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n, const double *dX, int32_t m,
+                      double *dF)
+{
+    const nlh_dq_device_ctx *c = (const nlh_dq_device_ctx *)ctx;
+    if (!c || npoints <= 0) return c ? 0 : 1;
+    const int nblk = (m + 255) / 256;
+    hipLaunchKernelGGL(k_dqv_fcn, dim3((unsigned)((size_t)npoints * nblk)), dim3(256), sizeof(double) * (size_t)n, (hipStream_t)hip_stream, m, n, nblk,
+                       c->dA, c->db, c->gamma, dprob, dX, dF);
+    return 0;
+}
+
+int nlh_dq_device_jac(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n, const double *dX, int32_t m,
+                      double *dJ)
+{
+    const nlh_dq_device_ctx *c = (const nlh_dq_device_ctx *)ctx;
+    if (!c || npoints <= 0) return c ? 0 : 1;
+    const int nblk = (m + 255) / 256;
+    hipLaunchKernelGGL(k_dqv_jac, dim3((unsigned)((size_t)npoints * nblk)), dim3(256), sizeof(double) * (size_t)n, (hipStream_t)hip_stream, m, n, nblk,
+                       c->dA, c->gamma, dprob, dX, dJ);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// vecfcn_helper%jacobian for a device residual, every problem
+// ---------------------------------------------------------------------------
+int nlh_fd_jacobian_device(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn,
+                           void *ctx, const double *dx, const double *dfv, double *dJ)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :240
+    if (nprob <= 0) return 0;
+    if (m < 1 || n < 1 || !dx || !dJ) return NLH_INVALID_INPUT_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    ResidualSource rs;
+    rs.fcn = fcn; rs.jac = jacfcn; rs.ctx = ctx;
+    // slices keep the point count of one launcher call (nprob * n) and the panel inside 31 bits / a bounded workspace
+    const int32_t per = (int32_t)std::max<size_t>(1, std::min<size_t>((size_t)nprob, ((size_t)1 << 30) / ((size_t)n * std::max(m, n))));
+    for (int32_t p0 = 0; p0 < nprob; p0 += per) {
+        const int32_t cnt = std::min(per, nprob - p0);
+        int rc;
+        if ((rc = ensure(h, h->P, sizeof(double) * (size_t)cnt * m * n))) return rc;
+        const double *f0 = dfv ? dfv + (size_t)p0 * m : nullptr;
+        ResidualSource r = rs.shifted(p0, m, n);
+        if (!f0 && !(jacfcn)) {                                 // :257-259
+            if ((rc = ensure(h, h->fdev, sizeof(double) * (size_t)cnt * m))) return rc;
+            if ((rc = residual_eval(h, r, cnt, m, n, dx + (size_t)p0 * n, (double *)h->fdev.p, nullptr, nullptr, -1))) return rc;
+            f0 = (const double *)h->fdev.p;
+        }
+        if ((rc = residual_jacobian(h, r, cnt, m, n, dx + (size_t)p0 * n, f0, dJ + (size_t)p0 * m * n, (double *)h->P.p, nullptr, -1, false,
+                                    false, true))) return rc;
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}

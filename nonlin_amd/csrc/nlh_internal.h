@@ -51,7 +51,8 @@ struct nlh_handle {
     std::vector<DevBuf *> bufs;       // every workspace buffer, for destroy
     // named workspace buffers (grown on demand, reused across calls)
     DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2, R,
-           qnQ, qnR, qnV, bfB, bfR, bfV, qxV, lumv;
+           qnQ, qnR, qnV, bfB, bfR, bfV, qxV, lumv,
+           dvX, dvF, dvIdx;               // user device residuals: points, compact residuals, problem lists (nlh_devfcn.hip)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     DevBuf cholmc;                     // side buffer of the multi-CU Cholesky (solved panels, bad-pivot flags)
@@ -106,6 +107,37 @@ void launch_dq_panel(nlh_handle *h, int nprob, int m, int n, const double *A, co
                      double *P, const LmState *st, int want, const double *f0_fused = nullptr, bool to_qrx = false);
 void launch_fd(nlh_handle *h, int nprob, int m, int n, const double *P, const double *f0, const double *x, double *J,
                const LmState *st, int want);
+// Which residual a lock-step driver evaluates (nlh_devfcn.hip): the built-in dense-quadratic family (dA, db, gamma), or a
+// user's launchers (include/nonlin_hip.h: nlh_device_vecfcn / nlh_device_jacfcn).  pbase: index, in the caller's batch,
+// of the first problem of the range the driver works on (slices, sub-batches) -- what the user's dprob entries count from.
+struct ResidualSource {
+    const double *dA = nullptr, *db = nullptr;
+    double gamma = 0.0;
+    nlh_device_vecfcn fcn = nullptr;
+    nlh_device_jacfcn jac = nullptr;
+    void *ctx = nullptr;
+    int32_t pbase = 0;
+    bool user() const { return fcn != nullptr; }
+    ResidualSource shifted(int32_t p0, int m, int n) const
+    {
+        ResidualSource r = *this;
+        if (user()) r.pbase += p0;
+        else { r.dA += (size_t)p0 * m * n; r.db += (size_t)p0 * m; }
+        return r;
+    }
+};
+// F(x) for the problems at stage `want` (st == nullptr: every problem): x [nprob][n] -> f [nprob][m]; part (optional):
+// the per-block partial sums of squares k_dq_residual leaves (the non-exact policies' norms).
+int residual_eval(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int n, const double *x, double *f, double *part,
+                  const LmState *st, int want);
+// vfh_jac_fcn for the problems at stage `want`: the n perturbed evaluations + jac(:,j) = (f_j - f0) / h_j (or the user's
+// jacobianfcn when use_jac and one is set).  out: column-major [nprob][n][m], or -- to_qrx -- the exact factorisation's
+// working matrix; panel: scratch of nprob * m * n doubles, distinct from out.  fuse: dense-quadratic family only.
+int residual_jacobian(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int n, const double *x, const double *f0,
+                      double *out, double *panel, const LmState *st, int want, bool to_qrx, bool fuse, bool use_jac);
+
+void launch_sumsq_part(nlh_handle *h, int nprob, int m, int n, const double *f, double *part);   // nlh_lm.hip
+
 // nlh_square.hip
 void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipvt, int32_t *dinfo, const LmState *st = nullptr,
                       int want = -1);

@@ -103,6 +103,11 @@ __global__ void k_sumsq_part(int m, int n, const double *__restrict__ f, double 
     }
 }
 
+void launch_sumsq_part(nlh_handle *h, int nprob, int m, int n, const double *f, double *part)
+{
+    hipLaunchKernelGGL(k_sumsq_part<RB>, dim3((m + RB - 1) / RB, nprob), dim3(RB), 0, h->stream, m, n, f, part);
+}
+
 // K-splits of the Gram contraction.  The split count and the kernel are functions of the problem SHAPE only, never of how
 // many problems share the launch: G = sum over splits (in split order) of a row-ascending accumulation, so a problem's
 // bits do not depend on its batch, the round it is active in, the sub-batch or the rank it was dealt to.
@@ -339,13 +344,18 @@ static int check_opts_lm(const nlh_options *o, int m, int n)
 // Device-model LM, batched: lss_solve as a lock-step state machine.
 // ===========================================================================
 static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n,
-                          const double *dA, const double *db, double gamma, double *dx, double *dfvec,
+                          const ResidualSource &rs, double *dx, double *dfvec,
                           nlh_iteration_behavior *ib, int32_t *status)
 {
     int rc;
     HIPCHK(h, hipSetDevice(h->device));
     LmWs w;
-    const bool jac_in_place = o->fuse_fd && o->factor_policy == NLH_FACTOR_EXACT;
+    const bool exact = o->factor_policy == NLH_FACTOR_EXACT;
+    // the dense-quadratic family's fused epilogue writes the Jacobian straight into the exact factorisation's working
+    // matrix; a user's residual leaves a panel (in the J buffer) that k_fd_jacobian_qrx turns into the same matrix
+    const bool fuse = o->fuse_fd && !rs.user();
+    const bool jac_in_place = fuse && exact;
+    const bool to_qrx = exact && (fuse || rs.user());
     if ((rc = lm_workspace(h, nprob, m, n, w, true, !jac_in_place))) return rc;
     if ((rc = ensure_pinned(h, sizeof(LmState) * (size_t)nprob + 64))) return rc;
     int *d_active = (int *)(w.info + nprob);
@@ -355,7 +365,7 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     const int first_stage = ST_NEED_JAC;
 
     // :211-213  f(x0), fnorm
-    launch_dq_residual(h, nprob, m, n, dA, db, gamma, dx, dfvec, w.part, nullptr, -1);
+    if ((rc = residual_eval(h, rs, nprob, m, n, dx, dfvec, exact && rs.user() ? (double *)nullptr : w.part, nullptr, -1))) return rc;
     if (o->factor_policy == NLH_FACTOR_EXACT)
         hipLaunchKernelGGL(k_lm_init_exact, dim3(nprob), dim3(256), 0, h->stream, m, dfvec, w.st, first_stage);
     else
@@ -367,21 +377,16 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     int nact = nprob;                                           // problems still iterating (from the previous round)
     for (int round = 0; round < max_rounds; ++round) {
         // outer-loop head for problems that need a Jacobian (:221): n perturbed evaluations + FD
-        if (o->fuse_fd && o->factor_policy == NLH_FACTOR_EXACT) {
-            // the Jacobian is only ever read by the exact factorisation: written in its working layout, no re-layout pass
-            launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.P, w.st, ST_NEED_JAC, dfvec, true);
-        } else if (o->fuse_fd) {
-            launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.J, w.st, ST_NEED_JAC, dfvec);
-        } else {
-            launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, w.P, w.st, ST_NEED_JAC);
-            launch_fd(h, nprob, m, n, w.P, dfvec, dx, w.J, w.st, ST_NEED_JAC);
-        }
+        // (the exact factorisation is the Jacobian's only reader: to_qrx writes it in that working layout, no re-layout
+        // pass; the panel of the unfused forms lives in whichever of the two big buffers the Jacobian does not)
+        if ((rc = residual_jacobian(h, rs, nprob, m, n, dx, dfvec, to_qrx ? w.P : w.J, to_qrx ? w.J : w.P, w.st, ST_NEED_JAC, to_qrx,
+                                    fuse, true))) return rc;
         hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_NEED_JAC,
                            o->factor_policy != NLH_FACTOR_AUTO ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
-        if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec, nact,
-                                     o->fuse_fd && o->factor_policy == NLH_FACTOR_EXACT))) return rc;
+        if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec, nact, to_qrx))) return rc;
         // trial residual (:297-299)
-        launch_dq_residual(h, nprob, m, n, dA, db, gamma, w.v.wa2, w.wa4, w.part, w.st, ST_TRIAL_READY);
+        if ((rc = residual_eval(h, rs, nprob, m, n, w.v.wa2, w.wa4, exact && rs.user() ? (double *)nullptr : w.part, w.st,
+                                ST_TRIAL_READY))) return rc;
         hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_TRIAL_READY,
                            (int)ST_TRIAL_DONE, 0);
         lm_update(h, o, nprob, m, n, w, dx, dfvec);
@@ -427,27 +432,30 @@ static int lm_sub_batches(const nlh_options *o, int nprob, int m, int n)
     return S < 1 ? 1 : S;
 }
 
-int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n,
-                          const double *dA, const double *db, double gamma, double *dx, double *dfvec,
-                          nlh_iteration_behavior *ib, int32_t *status)
+static int lm_solve_batch_rs(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n, const ResidualSource &rs,
+                             double *dx, double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (nprob <= 0) return 0;
     int rc = check_opts_lm(o, m, n);
     if (rc) return rc;
-    if (nprob > NLH_MAX_LOCKSTEP)
-        return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {
-            return nlh_dq_lm_solve_batch(h, o, cnt, m, n, dA + (size_t)p0 * m * n, db + (size_t)p0 * m, gamma, dx + (size_t)p0 * n,
-                                         dfvec + (size_t)p0 * m, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
-        });
+    // a user's launcher is asked for nprob * n points at once and its panel is addressed with 31-bit point counts
+    const int32_t slice = rs.user() ? (int32_t)std::max<int64_t>(1, std::min<int64_t>(NLH_MAX_LOCKSTEP, ((int64_t)1 << 30) / n)) : NLH_MAX_LOCKSTEP;
+    if (nprob > slice) {
+        for (int32_t p0 = 0; p0 < nprob; p0 += slice) {
+            const int32_t cnt = std::min<int32_t>(slice, nprob - p0);
+            if ((rc = lm_solve_batch_rs(h, o, cnt, m, n, rs.shifted(p0, m, n), dx + (size_t)p0 * n, dfvec + (size_t)p0 * m, ib ? ib + p0 : nullptr,
+                                        status ? status + p0 : nullptr))) return rc;
+        }
+        return 0;
+    }
     const int S = lm_sub_batches(o, nprob, m, n);
-    if (S == 1) return lm_solve_range(h, o, nprob, m, n, dA, db, gamma, dx, dfvec, ib, status);
+    if (S == 1) return lm_solve_range(h, o, nprob, m, n, rs, dx, dfvec, ib, status);
     if ((rc = ensure_workers(h, S))) return rc;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));                 // inputs written on the caller's stream are complete
     std::vector<int> rcs(S, 0);
     std::vector<std::thread> pool;
-    const size_t mn = (size_t)m * n;
     for (int t = 0; t < S; ++t) {
         // (equal shares: shares skewed by +-15 / 30 / 50 % so that the sub-batches' phases drift apart were measured --
         // 3,626 / 3,579 / 3,486 against 3,640 LM it/s for three equal sub-batches of the 2048 batch -- and dropped)
@@ -455,9 +463,8 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         pool.emplace_back([&, t, p0, p1]() {
             nlh_handle *wk = h->workers[t];
             wk->timing = h->timing;
-            rcs[t] = lm_solve_range(wk, o, p1 - p0, m, n, dA + (size_t)p0 * mn, db + (size_t)p0 * m, gamma,
-                                    dx + (size_t)p0 * n, dfvec + (size_t)p0 * m, ib ? ib + p0 : nullptr,
-                                    status ? status + p0 : nullptr);
+            rcs[t] = lm_solve_range(wk, o, p1 - p0, m, n, rs.shifted(p0, m, n), dx + (size_t)p0 * n, dfvec + (size_t)p0 * m,
+                                    ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
         });
     }
     for (auto &th : pool) th.join();
@@ -469,6 +476,56 @@ int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         }
         if (rcs[t]) { h->err = wk->err; return rcs[t]; }
     }
+    return 0;
+}
+
+int nlh_dq_lm_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n,
+                          const double *dA, const double *db, double gamma, double *dx, double *dfvec,
+                          nlh_iteration_behavior *ib, int32_t *status)
+{
+    ResidualSource rs;
+    rs.dA = dA; rs.db = db; rs.gamma = gamma;
+    return lm_solve_batch_rs(h, o, nprob, m, n, rs, dx, dfvec, ib, status);
+}
+
+// least_squares_solver%solve on a batch of problems whose residual is the USER'S device function (launchers,
+// include/nonlin_hip.h): the same lock-step state machine, the same kernels downstream of the Jacobian.
+int nlh_lm_solve_batch_device(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn,
+                              nlh_device_jacfcn jacfcn, void *ctx, double *dx, double *dfvec, nlh_iteration_behavior *ib,
+                              int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (ib && nprob > 0) memset(ib, 0, sizeof(*ib) * (size_t)nprob);          // :177-185
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :188
+    if (!o || (nprob > 0 && (!dx || !dfvec))) return NLH_INVALID_INPUT_ERROR;
+    ResidualSource rs;
+    rs.fcn = fcn; rs.jac = jacfcn; rs.ctx = ctx;
+    nlh_options oq = *o;
+    if (nprob > 1) oq.print_status = 0;                         // the status block is a single solve's (:372-374)
+    return lm_solve_batch_rs(h, &oq, nprob, m, n, rs, dx, dfvec, ib, status);
+}
+
+// The same behind host arrays (the Fortran shim's set_device_fcn + solve / solve_batch).
+int nlh_lm_solve_batch_device_h(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn,
+                                nlh_device_jacfcn jacfcn, void *ctx, double *x, double *fvec, nlh_iteration_behavior *ib,
+                                int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (nprob <= 0) return 0;
+    if (!x || !fvec || !o) return NLH_INVALID_INPUT_ERROR;
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;
+    int rc = check_opts_lm(o, m, n);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = ensure(h, h->xdev, sizeof(double) * (size_t)nprob * n))) return rc;
+    if ((rc = ensure(h, h->fdev, sizeof(double) * (size_t)nprob * m))) return rc;
+    double *dx = (double *)h->xdev.p, *df = (double *)h->fdev.p;
+    HIPCHK(h, hipMemcpyAsync(dx, x, sizeof(double) * (size_t)nprob * n, hipMemcpyHostToDevice, h->stream));
+    rc = nlh_lm_solve_batch_device(h, o, nprob, m, n, fcn, jacfcn, ctx, dx, df, ib, status);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(x, dx, sizeof(double) * (size_t)nprob * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(fvec, df, sizeof(double) * (size_t)nprob * m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -565,15 +565,17 @@ int nlh_newton_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_vecfcn 
 // or from Broyden's rank-one update of B, Q and R (:294-310); then grad = B^T F, step = -R^-1 Q^T F (:313-328).  The ones
 // with a trial point get F(x) and one turn of the search loop / the convergence test.  One 12-byte read-back per round.
 static int square_lockstep(nlh_handle *h, const nlh_options *o, bool broyden, int jdelta, int32_t nprob, int32_t n,
-                           const double *dA, const double *db, double gamma, int32_t analytic, double *dx, double *dfvec,
+                           const ResidualSource &rs, int32_t analytic, double *dx, double *dfvec,
                            nlh_iteration_behavior *ib, int32_t *status)
 {
+    const double *dA = rs.dA; const double gamma = rs.gamma;
+    if (rs.user()) analytic = rs.jac != nullptr;                 // is_jacobian_defined (src/nonlin_multi_eqn_mult_var.f90:241)
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     if (broyden && n > QN_MAX_N) return NLH_ARRAY_SIZE_ERROR;
     const size_t nn = (size_t)n * n, np = (size_t)nprob;
     if ((rc = ensure(h, h->J, sizeof(double) * nn * np))) return rc;
-    if (!analytic && (rc = ensure(h, h->P, sizeof(double) * nn * np))) return rc;
+    if ((!analytic || rs.user()) && (rc = ensure(h, h->P, sizeof(double) * nn * np))) return rc;
     if ((rc = ensure(h, h->vecs, sizeof(double) * (broyden ? 17 : 3) * n * np + sizeof(double) * 16 * np))) return rc;
     if ((rc = ensure(h, h->ipvt, sizeof(int32_t) * n * np))) return rc;
     if ((rc = ensure(h, h->state, sizeof(LmState) * np))) return rc;
@@ -603,20 +605,23 @@ static int square_lockstep(nlh_handle *h, const nlh_options *o, bool broyden, in
     no.broyden = broyden ? 1 : 0; no.jdelta = jdelta; no.pad = 0;
     const int pb = (nprob + 255) / 256;
     const bool echo = o->print_status && nprob == 1;             // the status block is a single solve's (:611-613)
-    auto jacobian = [&]() {                                      // for the problems in stage NT_NEED_JAC
+    auto jacobian = [&]() -> int {                               // for the problems in stage NT_NEED_JAC
+        if (rs.user())                                           // the user's jacobianfcn, or vfh_jac_fcn on the user's vecfcn
+            return residual_jacobian(h, rs, nprob, n, n, dx, dfvec, dJ, dP, st, NT_NEED_JAC, false, false, true);
         if (analytic) {
             Timed t(h, NLH_K_DQ_JACOBIAN);
             hipLaunchKernelGGL(k_dq_jacobian<RB>, dim3((n + RB - 1) / RB, nprob), dim3(RB), sizeof(double) * n, s,
                                n, n, dA, gamma, (const double *)dx, dJ, (const LmState *)st, (int)NT_NEED_JAC);
         } else {                                                 // vfh_jac_fcn: n perturbed evaluations, (f1 - f0) / h
-            launch_dq_panel(h, nprob, n, n, dA, db, gamma, dx, dP, st, NT_NEED_JAC);
+            launch_dq_panel(h, nprob, n, n, dA, rs.db, gamma, dx, dP, st, NT_NEED_JAC);
             launch_fd(h, nprob, n, n, dP, dfvec, dx, dJ, st, NT_NEED_JAC);
         }
+        return 0;
     };
 
     // (ns_solve :535 asks for a Jacobian before fvec is defined and discards it: nothing observable for a device model.)
     hipLaunchKernelGGL(k_nt_reset, dim3(pb), dim3(256), 0, s, nprob, st, ns);
-    launch_dq_residual(h, nprob, n, n, dA, db, gamma, dx, dfvec, nullptr, st, NT_START);       // :538 / :261
+    if ((rc = residual_eval(h, rs, nprob, n, n, dx, dfvec, nullptr, st, NT_START))) return rc;   // :538 / :261
     hipLaunchKernelGGL(k_nt_start, dim3(nprob), dim3(256), 0, s, n, no, (const double *)dx, (const double *)dfvec, st, ns);
     int need_jac = nprob, update = 0;                            // upper bounds until the first read-back
     // a round advances every live problem by one evaluation at least (or, quasi-Newton, turns an iteration without a
@@ -624,7 +629,7 @@ static int square_lockstep(nlh_handle *h, const nlh_options *o, bool broyden, in
     const long max_rounds = broyden ? 11L * o->max_evals + (long)o->ls_max_evals + 128 : (long)o->max_evals + (long)o->ls_max_evals + 8;
     for (long round = 0; round < max_rounds; ++round) {
         if (!broyden && need_jac > 0) {
-            jacobian();
+            if ((rc = jacobian())) return rc;
             {
                 Timed t(h, NLH_K_JTF);                           // :565-567
                 hipLaunchKernelGGL(k_jtf_exact, dim3((n + 255) / 256, nprob), dim3(256), 0, s, n, n, (const double *)dJ,
@@ -640,7 +645,7 @@ static int square_lockstep(nlh_handle *h, const nlh_options *o, bool broyden, in
         }
         if (broyden && (need_jac > 0 || update > 0)) {
             if (need_jac > 0) {                                  // :284-292: B = J(x), QR with Q formed
-                jacobian();
+                if ((rc = jacobian())) return rc;
                 launch_qn_qr(h, nprob, n, dJ, dQ, dRt, dvb, st, NT_NEED_JAC);
                 hipLaunchKernelGGL(k_nt_advance, dim3(pb), dim3(256), 0, s, nprob, st, (int)NT_NEED_JAC, (int)NT_DIR);
             }
@@ -664,7 +669,7 @@ static int square_lockstep(nlh_handle *h, const nlh_options *o, bool broyden, in
             hipLaunchKernelGGL(k_nt_step_begin, dim3(nprob), dim3(256), 0, s, n, no, (int)NT_DIR, dx, dxold, ddir, (const double *)dgrad,
                                (const double *)dfvec, dfvold, st, ns);
         }
-        launch_dq_residual(h, nprob, n, n, dA, db, gamma, dx, dfvec, nullptr, st, NT_TRIAL);
+        if ((rc = residual_eval(h, rs, nprob, n, n, dx, dfvec, nullptr, st, NT_TRIAL))) return rc;
         hipLaunchKernelGGL(k_nt_trial, dim3(nprob), dim3(256), 0, s, n, no, dx, (const double *)dxold, (const double *)ddir,
                            (const double *)dgrad, (const double *)dfvec, st, ns);
         hipLaunchKernelGGL(k_nt_count, dim3(1), dim3(256), 0, s, nprob, (const LmState *)st, dcounts);
@@ -690,16 +695,96 @@ static int square_lockstep(nlh_handle *h, const nlh_options *o, bool broyden, in
     return 0;
 }
 
+// One square solver over a batch, in slices the lock-step kernels' grid dimensions (and, for a user's launcher, the point
+// count of one Jacobian call) hold.
+static int square_batch_rs(nlh_handle *h, const nlh_options *o, bool broyden, int jdelta, int32_t nprob, int32_t n, const ResidualSource &rs,
+                           int32_t analytic, double *dx, double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (!o || n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
+    const int32_t slice = rs.user() ? (int32_t)std::max<int64_t>(1, std::min<int64_t>(NLH_MAX_LOCKSTEP, ((int64_t)1 << 30) / n)) : NLH_MAX_LOCKSTEP;
+    for (int32_t p0 = 0; p0 < nprob; p0 += slice) {
+        const int32_t cnt = std::min<int32_t>(slice, nprob - p0);
+        const int rc = square_lockstep(h, o, broyden, jdelta, cnt, n, rs.shifted(p0, n, n), analytic, dx + (size_t)p0 * n, dfvec + (size_t)p0 * n,
+                                       ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int nlh_dq_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t n, const double *dA,
                               const double *db, double gamma, int32_t analytic, double *dx, double *dfvec,
                               nlh_iteration_behavior *ib, int32_t *status)
 {
+    ResidualSource rs;
+    rs.dA = dA; rs.db = db; rs.gamma = gamma;
+    return square_batch_rs(h, o, false, 0, nprob, n, rs, analytic, dx, dfvec, ib, status);
+}
+
+// newton_solver%solve / quasi_newton_solver%solve on a batch of square problems whose residual (and, optionally, Jacobian)
+// is the USER'S device function (launchers, include/nonlin_hip.h).
+static int square_device(nlh_handle *h, const nlh_options *o, bool broyden, int jdelta, int32_t nprob, int32_t n, nlh_device_vecfcn fcn,
+                         nlh_device_jacfcn jacfcn, void *ctx, double *dx, double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
+{
     if (!h) return NLH_ERR_BAD_HANDLE;
-    if (!o || n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
-    return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {
-        return square_lockstep(h, o, false, 0, cnt, n, dA + (size_t)p0 * n * n, db + (size_t)p0 * n, gamma, analytic, dx + (size_t)p0 * n,
-                               dfvec + (size_t)p0 * n, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
-    });
+    if (ib && nprob > 0) memset(ib, 0, sizeof(*ib) * (size_t)nprob);
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // src/nonlin_solve.f90:516 / :238
+    if (nprob <= 0) return 0;
+    if (!o || !dx || !dfvec) return NLH_INVALID_INPUT_ERROR;
+    ResidualSource rs;
+    rs.fcn = fcn; rs.jac = jacfcn; rs.ctx = ctx;
+    nlh_options oq = *o;
+    if (nprob > 1) oq.print_status = 0;                         // the status block is a single solve's (:611-613)
+    return square_batch_rs(h, &oq, broyden, jdelta, nprob, n, rs, 0, dx, dfvec, ib, status);
+}
+
+static int square_device_h(nlh_handle *h, const nlh_options *o, bool broyden, int jdelta, int32_t nprob, int32_t n, nlh_device_vecfcn fcn,
+                           nlh_device_jacfcn jacfcn, void *ctx, double *x, double *fvec, nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (nprob <= 0) return 0;
+    if (!o || !x || !fvec || n < 1) return NLH_INVALID_INPUT_ERROR;
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t cnt = (size_t)nprob * n;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * cnt))) return rc;
+    if ((rc = ensure(h, h->fdev, sizeof(double) * cnt))) return rc;
+    double *dx = (double *)h->xdev.p, *df = (double *)h->fdev.p;
+    HIPCHK(h, hipMemcpyAsync(dx, x, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    if ((rc = square_device(h, o, broyden, jdelta, nprob, n, fcn, jacfcn, ctx, dx, df, ib, status))) return rc;
+    HIPCHK(h, hipMemcpyAsync(x, dx, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(fvec, df, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int nlh_newton_solve_batch_device(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t n, nlh_device_vecfcn fcn,
+                                  nlh_device_jacfcn jacfcn, void *ctx, double *dx, double *dfvec, nlh_iteration_behavior *ib,
+                                  int32_t *status)
+{
+    return square_device(h, o, false, 0, nprob, n, fcn, jacfcn, ctx, dx, dfvec, ib, status);
+}
+
+int nlh_quasi_newton_solve_batch_device(nlh_handle *h, const nlh_options *o, int32_t jdelta, int32_t nprob, int32_t n,
+                                        nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *dx, double *dfvec,
+                                        nlh_iteration_behavior *ib, int32_t *status)
+{
+    return square_device(h, o, true, jdelta, nprob, n, fcn, jacfcn, ctx, dx, dfvec, ib, status);
+}
+
+int nlh_newton_solve_batch_device_h(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t n, nlh_device_vecfcn fcn,
+                                    nlh_device_jacfcn jacfcn, void *ctx, double *x, double *fvec, nlh_iteration_behavior *ib,
+                                    int32_t *status)
+{
+    return square_device_h(h, o, false, 0, nprob, n, fcn, jacfcn, ctx, x, fvec, ib, status);
+}
+
+int nlh_quasi_newton_solve_batch_device_h(nlh_handle *h, const nlh_options *o, int32_t jdelta, int32_t nprob, int32_t n,
+                                          nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *x, double *fvec,
+                                          nlh_iteration_behavior *ib, int32_t *status)
+{
+    return square_device_h(h, o, true, jdelta, nprob, n, fcn, jacfcn, ctx, x, fvec, ib, status);
 }
 
 // quasi_newton_solver%solve -- qns_solve, src/nonlin_solve.f90:156-427
@@ -755,10 +840,9 @@ int nlh_dq_quasi_newton_solve_batch(nlh_handle *h, const nlh_options *o, int32_t
 {
     if (!h) return NLH_ERR_BAD_HANDLE;
     if (!o || n < 1 || nprob < 1) return NLH_INVALID_INPUT_ERROR;
-    return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {                                           // the same state machine
-        return square_lockstep(h, o, true, jdelta, cnt, n, dA + (size_t)p0 * n * n, db + (size_t)p0 * n, gamma, analytic, dx + (size_t)p0 * n,
-                               dfvec + (size_t)p0 * n, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
-    });
+    ResidualSource rs;
+    rs.dA = dA; rs.db = db; rs.gamma = gamma;
+    return square_batch_rs(h, o, true, jdelta, nprob, n, rs, analytic, dx, dfvec, ib, status);   // the same state machine
 }
 
 int nlh_lu_factor(nlh_handle *h, int32_t nprob, int32_t n, double *dA, int32_t *dipvt, int32_t *dinfo)

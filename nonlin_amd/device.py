@@ -150,6 +150,71 @@ class DeviceSolver:
             raise RuntimeError(f"nlh_dq_bfgs_solve_batch returned {rc}")
         return [float(v) for v in fout], [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
 
+    # -- user-supplied device residuals (launchers) ------------------------------
+    @staticmethod
+    def _devfcn(f):
+        """A launcher as ctypes sees it: a symbol of a user's shared object, an address, or None."""
+        if f is None:
+            return C.cast(None, _lib.DEVFCN)
+        return f if isinstance(f, _lib.DEVFCN) else C.cast(f, _lib.DEVFCN)
+
+    def dq_launchers(self, A, b, gamma):
+        """The built-in dense-quadratic family expressed through the open path: (fcn, jac, ctx) for the *_device entry
+        points.  Keep the returned ctx (and A, b) alive while solving."""
+        ctx = _lib.DqDeviceCtx(A.data_ptr(), b.data_ptr(), float(gamma))
+        return (C.cast(self.lib.nlh_dq_device_fcn, _lib.DEVFCN), C.cast(self.lib.nlh_dq_device_jac, _lib.DEVFCN), ctx)
+
+    def _ctxp(self, ctx):
+        return ctx if isinstance(ctx, (int, C.c_void_p)) or ctx is None else C.cast(C.byref(ctx), C.c_void_p)
+
+    def lm_solve_batch_device(self, fcn, ctx, m, x, jac=None, opts=None):
+        """least_squares_solver%solve on x.shape[0] problems of a USER'S device residual (launcher fcn, context ctx).
+        x [nprob, n] is updated in place.  Returns (fvec, ib_list, status_list)."""
+        nprob, n = x.shape
+        _chk(x, (nprob, n), "x")
+        fvec = torch.empty((nprob, m), dtype=torch.float64, device=x.device)
+        ib = (_lib.IterationBehavior * nprob)()
+        status = (C.c_int32 * nprob)()
+        o = opts or self.options()
+        rc = self.lib.nlh_lm_solve_batch_device(self.h.ptr, C.byref(o), nprob, m, n, self._devfcn(fcn), self._devfcn(jac),
+                                                self._ctxp(ctx), x.data_ptr(), fvec.data_ptr(), ib, status)
+        self.h.check(rc, "nlh_lm_solve_batch_device")
+        if rc:
+            raise RuntimeError(f"nlh_lm_solve_batch_device returned {rc}")
+        return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
+
+    def square_solve_batch_device(self, fcn, ctx, x, jac=None, opts=None, broyden=False, jdelta=5):
+        """newton_solver%solve (or quasi_newton_solver%solve) on x.shape[0] square problems of a user's device residual."""
+        nprob, n = x.shape
+        _chk(x, (nprob, n), "x")
+        fvec = torch.empty((nprob, n), dtype=torch.float64, device=x.device)
+        ib = (_lib.IterationBehavior * nprob)()
+        status = (C.c_int32 * nprob)()
+        o = opts or self.options()
+        if broyden:
+            rc = self.lib.nlh_quasi_newton_solve_batch_device(self.h.ptr, C.byref(o), int(jdelta), nprob, n, self._devfcn(fcn),
+                                                              self._devfcn(jac), self._ctxp(ctx), x.data_ptr(), fvec.data_ptr(),
+                                                              ib, status)
+        else:
+            rc = self.lib.nlh_newton_solve_batch_device(self.h.ptr, C.byref(o), nprob, n, self._devfcn(fcn), self._devfcn(jac),
+                                                        self._ctxp(ctx), x.data_ptr(), fvec.data_ptr(), ib, status)
+        self.h.check(rc, "nlh_newton_solve_batch_device")
+        if rc:
+            raise RuntimeError(f"square solve on a device residual returned {rc}")
+        return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
+
+    def fd_jacobian_device(self, fcn, ctx, m, x, fv=None, jac=None):
+        """vecfcn_helper%jacobian of every problem of a user's device residual: J [nprob, n, m]."""
+        nprob, n = x.shape
+        _chk(x, (nprob, n), "x")
+        J = torch.empty((nprob, n, m), dtype=torch.float64, device=x.device)
+        rc = self.lib.nlh_fd_jacobian_device(self.h.ptr, nprob, m, n, self._devfcn(fcn), self._devfcn(jac), self._ctxp(ctx),
+                                             x.data_ptr(), fv.data_ptr() if fv is not None else None, J.data_ptr())
+        self.h.check(rc, "nlh_fd_jacobian_device")
+        if rc:
+            raise RuntimeError(f"nlh_fd_jacobian_device returned {rc}")
+        return J
+
     # -- stage-level kernels (parity tests, roofline) --------------------------
     def residual(self, A, b, gamma, x):
         nprob, n, m = A.shape
