@@ -430,6 +430,96 @@ def mode_h_rows(ds):
     return rows
 
 
+def device_vecfcn_rows(ds):
+    """The OPEN device-residual path (include/nonlin_hip.h: nlh_device_vecfcn; reference plugin layer
+    src/nonlin_multi_eqn_mult_var.f90:14-25, 126-140, 198-277): least_squares_solver on residuals the LIBRARY DOES NOT KNOW,
+    handed in as launchers.  Per row: LM iterations/s of the whole solve, and the forward-difference kernel
+    (k_fd_jacobian_qrx: panel of perturbed residuals -> Jacobian columns in the factorisation's working layout, :274)
+    against the HBM roofline, timed with HIP events INSIDE that solve, algorithmic bytes 8 (2 m n + m + 2 n) per Jacobian
+    (SURVEY 8(d)).  Rows: the dense-quadratic family re-expressed through the launcher (the headline's 4096 x 256 shape,
+    bitwise the built-in entry point), once as one lock-step batch (the kernel alone on the chip: the roofline row) and
+    once with library defaults (sub-batches on private streams: the kernel shares the chip with other sub-batches'
+    kernels, its event time says less); and a family written outside the library (tests/device_model/user_models.hip,
+    Lorentzian peak fits) checked bit for bit against the CPU oracle driving the same arithmetic as a host callback."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import user_models as UM
+    from oracle import pyoracle as O
+    rows = []
+
+    def timed_solve(f, m, n):
+        f()
+        torch.cuda.synchronize()
+        ds.h.timing_enable(kernels=["fd_jacobian", "dq_panel", "dq_residual"])
+        ds.h.timing_reset()
+        t0 = time.perf_counter()
+        x, fv, ibs, st = f()
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        fd_ms, fd_cnt = ds.h.timing("fd_jacobian")
+        u_ms = ds.h.timing("dq_panel")[0] + ds.h.timing("dq_residual")[0]
+        ds.h.timing_enable(False)
+        nj = sum(i["jacobian_count"] for i in ibs)
+        gbs = fd_bytes(m, n) * nj / max(fd_ms * 1e-3, 1e-30) / 1e9
+        return x, fv, ibs, st, {"solve_ms": 1e3 * t, "lm_iterations": nj, "lm_iterations_per_s": nj / t,
+                                "user_function_ms": u_ms,
+                                "fd_jacobian": {"kernel": "k_fd_jacobian_qrx (timed inside the solve)", "bound": "hbm", "achieved": gbs,
+                                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "launches": int(fd_cnt),
+                                                "kernel_ms": fd_ms, "bytes_per_jacobian": fd_bytes(m, n), "jacobians": nj}}
+
+    nb, m, n = 512, 4096, 256
+    A, b, xt, x0 = ds.generate(nb, m, n, seed0=SEED0, gamma=GAMMA, sigma=SIGMA, spread=SPREAD)
+    fcn, jac, ctx = ds.dq_launchers(A, b, GAMMA)
+    xb = x0.clone()
+    fb, ibb, stb = ds.lm_solve_batch(A, b, GAMMA, xb, ds.options(max_evals=500))
+    for label, sb in (("one lock-step batch", 1), ("library defaults (sub-batches automatic)", 0)):
+        def run():
+            x = x0.clone()
+            fv, ibs, st = ds.lm_solve_batch_device(fcn, ctx, m, x, opts=ds.options(max_evals=500, sub_batches=sb))
+            return x, fv, ibs, st
+        x, fv, ibs, st, r = timed_solve(run, m, n)
+        r.update({"path": f"least_squares_solver on a user device vecfcn (dense-quadratic family through nlh_dq_device_fcn), "
+                          f"{nb} x {m}x{n}, {label}",
+                  "bitwise_equal_builtin_entry_point": bool(torch.equal(x, xb) and torch.equal(fv, fb) and ibs == ibb and st == stb)})
+        rows.append(r)
+    del A, b, xt, x0, xb, fb
+    torch.cuda.empty_cache()
+
+    nb, m, K = 4096, 2048, 8
+    n = 3 * K
+    t, y, xt, x0 = UM.lorentz_problems(nb, m, K, seed=2024)
+    batch = UM.LorentzBatch(t, y)
+    xd0 = torch.tensor(x0, device=ds.device)
+
+    def run_l():
+        x = xd0.clone()
+        fv, ibs, st = ds.lm_solve_batch_device(batch.launch, batch.ctx, m, x, opts=ds.options(max_evals=500))
+        return x, fv, ibs, st
+    x, fv, ibs, st, r = timed_solve(run_l, m, n)
+    xg = x.cpu().numpy()
+    dp = C.POINTER(C.c_double)
+    ok, tc = True, 0.0
+    sample = (0, 1, nb // 2, nb - 1)
+    for p in sample:
+        hc = batch.host_ctx(p)
+        oo = O.default_options(max_evals=500)
+        xo, fo, ibo = x0[p].copy(), np.zeros(m), O.IterationBehavior()
+        t0 = time.perf_counter()
+        rc = O.lib().nlo_lm_solve(C.byref(oo), C.cast(batch.host_fcn, O.VECFCN), C.cast(None, O.JACFCN), C.byref(hc), m, n,
+                                  xo.ctypes.data_as(dp), fo.ctypes.data_as(dp), C.byref(ibo))
+        tc += time.perf_counter() - t0
+        ok = ok and rc == st[p] and np.array_equal(xo, xg[p]) and all(ibs[p][k] == ibo.as_dict()[k] for k in ("iter_count", "fcn_count", "jacobian_count"))
+    r.update({"path": f"least_squares_solver on a family written outside the library (Lorentzian peaks, n = 3 x {K}), {nb} x {m}x{n}, "
+                      "library defaults",
+              "bitwise_equal_oracle_host_callback": bool(ok), "problems_compared": len(sample),
+              "cpu_oracle_ms": 1e3 * tc * nb / len(sample), "cpu_sample": f"{len(sample)} problems on one core, scaled to {nb}"})
+    rows.append(r)
+    batch.close()
+    return rows
+
+
 def predicted_scaling(ds, m=2048, n=128):
     """What ONE GPU can say about the 1/2/4/8-GPU curves before an 8-GPU node measures them: the batch sizes each rank of
     BASELINE config 4 (1024 problems of 2048x128) and of north_star's strong-scaling workload (8192 problems) gets at
@@ -819,6 +909,7 @@ def main():
             out["predicted_scaling"] = predicted_scaling(ds)
         if world == 1 and args.other_paths:
             out["other_paths"] = other_paths(ds) + mode_h_rows(ds)
+            out["device_vecfcn"] = device_vecfcn_rows(ds)
         if cpu is not None:
             cpu["gpu_over_one_core"] = out["value"] / cpu["value"]
             if isinstance(cpu.get("all_cores"), dict) and "value" in cpu["all_cores"]:

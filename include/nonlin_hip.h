@@ -328,6 +328,15 @@ int nlh_dq_device_fcn(void *ctx, void *hip_stream, int32_t npoints, const int32_
 int nlh_dq_device_jac(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n, const double *dX,
                       int32_t m, double *dJ);
 
+/* A user's device residual as a MODEL object (what the Fortran shim's vecfcn_helper%set_device_fcn and
+ * device_model_batch%create_from_device_fcn hold): nprob problems of m equations in n unknowns each, evaluated by the
+ * launchers; nlh_dq_model_eval / _lm_solve / _newton_solve / _quasi_newton_solve accept it (host arrays, the caller's
+ * handle; `analytic` selects the jacobianfcn launcher), the bounded least-squares and bfgs forms return
+ * NLH_INVALID_OPERATION_ERROR.  Lives on the handle's device (not dealt over a device set: the user's data is wherever the
+ * user put it).  Freed with nlh_dq_model_destroy; ctx stays the caller's. */
+int nlh_device_fcn_model_create(int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx,
+                                nlh_dq_model **model);
+
 /* Synthetic problem generator of SURVEY.md 8(d) (bench/test inputs, not part of the
  * reference): counter-based splitmix64, U_k = mix(seed + (k+1)*0x9E3779B97F4A7C15),
  * draw order A (column-major), x_true, noise, x0; problem p uses seed0 + p*seed_stride.

@@ -144,6 +144,7 @@ SYMBOLS = {
                                                   c_double_p, c_double_p, C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_quasi_newton_solve_batch_device_h": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, DEVFCN, DEVFCN,
                                                         C.c_void_p, c_double_p, c_double_p, C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_device_fcn_model_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p, C.POINTER(C.c_void_p)]),
     "nlh_dq_device_fcn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "nlh_dq_device_jac": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "nlh_timing_enable": (None, [_H, C.c_int32]),

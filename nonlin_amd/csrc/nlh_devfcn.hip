@@ -89,19 +89,19 @@ static __global__ void k_dv_fd_points(int n, const int32_t *__restrict__ list, i
 #define FDQ_ROWS 128
 #define FDQ_COLS 32
 #define FDQ_LDB (FDQ_COLS * 8 + 8)        // doubles between two row blocks of the tile in LDS (padded: 64 bytes)
-template <bool VEC2>
+template <bool VEC2, bool NT>
 __global__ void __launch_bounds__(256)
 k_fd_jacobian_qrx(int m, int n, const double *__restrict__ P, const double *__restrict__ f0, const double *__restrict__ x,
                   double *__restrict__ T, const int32_t *__restrict__ list, const LmState *__restrict__ st, int want,
-                  int ld, int coff, size_t tst)
-{
+                  int ld, int coff, size_t tst, int nfull)
+{   // n: columns of this launch's panel per problem (a column group of ONE problem when n < nfull: x, T arrive shifted)
     __shared__ __attribute__((aligned(16))) double tile[(FDQ_ROWS / 8) * FDQ_LDB];
     const int k = blockIdx.z;
     const int p = list ? list[k] : k;
     if (st && st[p].stage != want) return;
     const double *Pp = P + (size_t)k * m * n;
     const double *fp = f0 + (size_t)p * m;
-    const double *xp = x + (size_t)p * n;
+    const double *xp = x + (size_t)p * nfull;
     double *Tp = T + (size_t)p * tst;
     const int i0 = blockIdx.x * FDQ_ROWS, j0 = blockIdx.y * FDQ_COLS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -119,7 +119,8 @@ k_fd_jacobian_qrx(int m, int n, const double *__restrict__ P, const double *__re
             if (j < n) {
                 if (VEC2) {                                     // m even: i + 1 < m whenever i < m, 16-byte aligned
                     if (i < m) {
-                        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Pp + (size_t)j * m + i));
+                        const v2d *src = reinterpret_cast<const v2d *>(Pp + (size_t)j * m + i);
+                        const v2d v = NT ? __builtin_nontemporal_load(src) : *src;
                         va[c] = v.x; vb[c] = v.y;
                     }
                 } else {
@@ -234,6 +235,17 @@ int residual_eval(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int
     return 0;
 }
 
+// Bytes of panel the user's launcher fills before k_fd_jacobian turns them into Jacobian columns: a cap on the panel
+// buffer (16 GiB), not a tuning knob -- measured at 512 x 4096x256 inside a solve (scratch/devfcn_fd.sh), chunks small
+// enough for the Infinity Cache to serve the panel read do NOT pay: 16 / 32 / 64 / 128 / 256 MiB chunks ran the
+// forward-difference kernel at 0.42 / 0.56 / 0.67 / 0.74 / 0.77 of 8 TB/s, one 8.6 GB launch at 0.756 (6.0 TB/s of
+// algorithmic traffic; without the non-temporal hint on the panel loads 0.726).  NLH_FD_CHUNK_MB overrides (0: no cap).
+static size_t fd_chunk_bytes()
+{
+    static const long mb = [] { const char *e = getenv("NLH_FD_CHUNK_MB"); return e ? atol(e) : 16384L; }();
+    return mb <= 0 ? ~(size_t)0 : (size_t)mb << 20;
+}
+
 int residual_jacobian(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int n, const double *x, const double *f0,
                       double *out, double *panel, const LmState *st, int want, bool to_qrx, bool fuse, bool use_jac)
 {
@@ -258,45 +270,67 @@ int residual_jacobian(nlh_handle *h, const ResidualSource &rs, int nprob, int m,
     const int32_t *lp = (all || cnt == nprob) ? nullptr : list;
     const int ld = qrx_ld(n), coff = ld - (n + 1);
     const size_t tst = qrx_matrix_stride(m, n);
-    if (use_jac && rs.jac) {                                    // :241-243: the user's jacobianfcn, one point per problem
-        if ((rc = ensure(h, h->dvX, sizeof(double) * (size_t)cnt * n))) return rc;
-        hipLaunchKernelGGL(k_dv_gather_x, dim3(cnt), dim3(64), 0, h->stream, cnt, n, lp, (int)rs.pbase, x, (double *)h->dvX.p, dprob);
-        {
-            Timed t(h, NLH_K_DQ_JACOBIAN);
-            const int urc = rs.jac(rs.ctx, (void *)h->stream, cnt, dprob, n, (const double *)h->dvX.p, m, panel);
-            if (urc) return dv_fail(h, urc, "jacobianfcn");
-        }
-        const dim3 grid((((m + 7) & ~7) + 255) / 256, n, cnt);
-        if (to_qrx) hipLaunchKernelGGL(k_dv_place_jac<true>, grid, dim3(256), 0, h->stream, m, n, (const double *)panel, out, lp, ld, coff, tst);
-        else hipLaunchKernelGGL(k_dv_place_jac<false>, grid, dim3(256), 0, h->stream, m, n, (const double *)panel, out, lp, ld, coff, tst);
-        return 0;
-    }
-    if ((rc = ensure(h, h->dvX, sizeof(double) * (size_t)cnt * n * n))) return rc;
+    const bool analytic = use_jac && rs.jac;                    // :241-243: the user's jacobianfcn, one point per problem
+    // chunks: whole problems while one problem's panel fits the chunk, otherwise one problem in groups of 32 columns
+    const size_t per = sizeof(double) * (size_t)m * n, cb = fd_chunk_bytes();
+    int pc = (int)std::min<size_t>((size_t)cnt, std::max<size_t>(1, cb / per));       // problems per chunk
+    int jc = n;                                                                         // columns per chunk
+    if (per > cb && !analytic) { pc = 1; jc = (int)std::min<size_t>((size_t)n, std::max<size_t>(32, (cb / (sizeof(double) * m)) / 32 * 32)); }
+    if ((rc = ensure(h, h->dvP, sizeof(double) * (size_t)pc * jc * m))) return rc;
+    double *Pc = (double *)h->dvP.p;
+    if ((rc = ensure(h, h->dvX, sizeof(double) * (size_t)cnt * n * (analytic ? 1 : n)))) return rc;
     double *X = (double *)h->dvX.p;
-    hipLaunchKernelGGL(k_dv_fd_points, dim3(n, cnt), dim3(64), 0, h->stream, n, lp, (int)rs.pbase, x, X, dprob);
-    {
-        Timed t(h, NLH_K_DQ_PANEL);                             // the n perturbed evaluations of every problem that is due
-        const int urc = rs.fcn(rs.ctx, (void *)h->stream, cnt * n, dprob, n, (const double *)X, m, panel);
-        if (urc) return dv_fail(h, urc, "vecfcn");
-    }
-    {
-        Timed t(h, NLH_K_FD_JACOBIAN);                          // :274
-        if (to_qrx) {
-            const dim3 grid((m + FDQ_ROWS - 1) / FDQ_ROWS, (n + FDQ_COLS - 1) / FDQ_COLS, cnt);
-            const bool vec2 = (m % 2 == 0) && (((uintptr_t)panel & 15) == 0);
-            if (vec2) hipLaunchKernelGGL(k_fd_jacobian_qrx<true>, grid, dim3(256), 0, h->stream, m, n, (const double *)panel, f0, x, out, lp,
-                                         (const LmState *)nullptr, -1, ld, coff, tst);
-            else hipLaunchKernelGGL(k_fd_jacobian_qrx<false>, grid, dim3(256), 0, h->stream, m, n, (const double *)panel, f0, x, out, lp,
-                                    (const LmState *)nullptr, -1, ld, coff, tst);
-        } else {
-            constexpr int CJ = 8;
-            const bool vec2 = (m % 2 == 0) && ((((uintptr_t)panel | (uintptr_t)out | (uintptr_t)f0) & 15) == 0);
-            if (vec2)
-                hipLaunchKernelGGL((k_fd_jacobian<RB, CJ, true>), dim3((m / 2 + RB - 1) / RB, (n + CJ - 1) / CJ, cnt), dim3(RB), 0, h->stream, m, n,
-                                   (const double *)panel, f0, x, out, (const LmState *)nullptr, -1, lp);
-            else
-                hipLaunchKernelGGL((k_fd_jacobian<RB, CJ, false>), dim3((m + RB - 1) / RB, (n + CJ - 1) / CJ, cnt), dim3(RB), 0, h->stream, m, n,
-                                   (const double *)panel, f0, x, out, (const LmState *)nullptr, -1, lp);
+    if (analytic) hipLaunchKernelGGL(k_dv_gather_x, dim3(cnt), dim3(64), 0, h->stream, cnt, n, lp, (int)rs.pbase, x, X, dprob);
+    else hipLaunchKernelGGL(k_dv_fd_points, dim3(n, cnt), dim3(64), 0, h->stream, n, lp, (int)rs.pbase, x, X, dprob);
+    for (int k0 = 0; k0 < cnt; k0 += pc) {
+        const int kc = std::min(pc, cnt - k0);
+        for (int j0 = 0; j0 < n; j0 += jc) {
+            const int jn = std::min(jc, n - j0);
+            // slots k0 .. k0 + kc of the compact order, columns j0 .. j0 + jn of each (jn == n unless kc == 1)
+            const int32_t *lq = lp ? lp + k0 : nullptr;
+            const size_t pshift = lp ? 0 : (size_t)k0;         // identity order: the problems' own arrays start at slot k0
+            const double *xq = x + pshift * n + j0, *fq = f0 ? f0 + pshift * m : nullptr;
+            if (analytic) {
+                {
+                    Timed t(h, NLH_K_DQ_JACOBIAN);
+                    const int urc = rs.jac(rs.ctx, (void *)h->stream, kc, dprob + k0, n, X + (size_t)k0 * n, m, Pc);
+                    if (urc) return dv_fail(h, urc, "jacobianfcn");
+                }
+                const dim3 grid((((m + 7) & ~7) + 255) / 256, n, kc);
+                if (to_qrx) hipLaunchKernelGGL(k_dv_place_jac<true>, grid, dim3(256), 0, h->stream, m, n, (const double *)Pc, out + pshift * tst, lq, ld, coff, tst);
+                else hipLaunchKernelGGL(k_dv_place_jac<false>, grid, dim3(256), 0, h->stream, m, n, (const double *)Pc, out + pshift * m * n, lq, ld, coff, tst);
+                continue;
+            }
+            {
+                Timed t(h, NLH_K_DQ_PANEL);                     // (a share of) the n perturbed evaluations of the problems that are due
+                const size_t q0 = (size_t)k0 * n + j0;
+                const int urc = rs.fcn(rs.ctx, (void *)h->stream, kc * jn, dprob + q0, n, (const double *)X + q0 * n, m, Pc);
+                if (urc) return dv_fail(h, urc, "vecfcn");
+            }
+            Timed t(h, NLH_K_FD_JACOBIAN);                      // :274
+            // (a column group of one problem: the kernels see a problem of jn columns whose arrays start at column j0)
+            if (to_qrx) {
+                const dim3 grid((m + FDQ_ROWS - 1) / FDQ_ROWS, (jn + FDQ_COLS - 1) / FDQ_COLS, kc);
+                double *Tq = out + pshift * tst;
+                const bool vec2 = (m % 2 == 0) && (((uintptr_t)Pc & 15) == 0);
+                static const int nt_env = [] { const char *e = getenv("NLH_FDQ_NT"); return e ? atoi(e) : 1; }();
+                if (vec2 && nt_env) hipLaunchKernelGGL((k_fd_jacobian_qrx<true, true>), grid, dim3(256), 0, h->stream, m, jn, (const double *)Pc, fq, xq, Tq, lq,
+                                                       (const LmState *)nullptr, -1, ld, coff + j0, tst, n);
+                else if (vec2) hipLaunchKernelGGL((k_fd_jacobian_qrx<true, false>), grid, dim3(256), 0, h->stream, m, jn, (const double *)Pc, fq, xq, Tq, lq,
+                                                  (const LmState *)nullptr, -1, ld, coff + j0, tst, n);
+                else hipLaunchKernelGGL((k_fd_jacobian_qrx<false, false>), grid, dim3(256), 0, h->stream, m, jn, (const double *)Pc, fq, xq, Tq, lq,
+                                        (const LmState *)nullptr, -1, ld, coff + j0, tst, n);
+            } else {
+                constexpr int CJ = 8;
+                double *Jq = out + pshift * m * n + (size_t)j0 * m;
+                const bool vec2 = (m % 2 == 0) && ((((uintptr_t)Pc | (uintptr_t)Jq | (uintptr_t)fq) & 15) == 0);
+                if (vec2)
+                    hipLaunchKernelGGL((k_fd_jacobian<RB, CJ, true>), dim3((m / 2 + RB - 1) / RB, (jn + CJ - 1) / CJ, kc), dim3(RB), 0, h->stream, m, jn,
+                                       (const double *)Pc, fq, xq, Jq, (const LmState *)nullptr, -1, lq, n);
+                else
+                    hipLaunchKernelGGL((k_fd_jacobian<RB, CJ, false>), dim3((m + RB - 1) / RB, (jn + CJ - 1) / CJ, kc), dim3(RB), 0, h->stream, m, jn,
+                                       (const double *)Pc, fq, xq, Jq, (const LmState *)nullptr, -1, lq, n);
+            }
         }
     }
     return 0;
@@ -391,7 +425,6 @@ int nlh_fd_jacobian_device(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, n
     for (int32_t p0 = 0; p0 < nprob; p0 += per) {
         const int32_t cnt = std::min(per, nprob - p0);
         int rc;
-        if ((rc = ensure(h, h->P, sizeof(double) * (size_t)cnt * m * n))) return rc;
         const double *f0 = dfv ? dfv + (size_t)p0 * m : nullptr;
         ResidualSource r = rs.shifted(p0, m, n);
         if (!f0 && !(jacfcn)) {                                 // :257-259
@@ -399,7 +432,7 @@ int nlh_fd_jacobian_device(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, n
             if ((rc = residual_eval(h, r, cnt, m, n, dx + (size_t)p0 * n, (double *)h->fdev.p, nullptr, nullptr, -1))) return rc;
             f0 = (const double *)h->fdev.p;
         }
-        if ((rc = residual_jacobian(h, r, cnt, m, n, dx + (size_t)p0 * n, f0, dJ + (size_t)p0 * m * n, (double *)h->P.p, nullptr, -1, false,
+        if ((rc = residual_jacobian(h, r, cnt, m, n, dx + (size_t)p0 * n, f0, dJ + (size_t)p0 * m * n, nullptr, nullptr, -1, false,
                                     false, true))) return rc;
     }
     HIPCHK(h, hipGetLastError());

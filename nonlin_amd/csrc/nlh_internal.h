@@ -52,7 +52,7 @@ struct nlh_handle {
     // named workspace buffers (grown on demand, reused across calls)
     DevBuf J, P, wa4, scratch, G, Gpart, vecs, ipvt, gvec, part, state, info, misc, lu, xdev, fdev, Adev, bdev, W2, R,
            qnQ, qnR, qnV, bfB, bfR, bfV, qxV, lumv,
-           dvX, dvF, dvIdx;               // user device residuals: points, compact residuals, problem lists (nlh_devfcn.hip)
+           dvX, dvF, dvIdx, dvP;          // user device residuals: points, compact residuals, problem lists, panel chunk (nlh_devfcn.hip)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     DevBuf cholmc;                     // side buffer of the multi-CU Cholesky (solved panels, bad-pivot flags)
@@ -132,7 +132,8 @@ int residual_eval(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int
                   const LmState *st, int want);
 // vfh_jac_fcn for the problems at stage `want`: the n perturbed evaluations + jac(:,j) = (f_j - f0) / h_j (or the user's
 // jacobianfcn when use_jac and one is set).  out: column-major [nprob][n][m], or -- to_qrx -- the exact factorisation's
-// working matrix; panel: scratch of nprob * m * n doubles, distinct from out.  fuse: dense-quadratic family only.
+// working matrix; panel: scratch of nprob * m * n doubles, distinct from out (the dense-quadratic family's unfused form
+// only: a user's panel lives in a chunk buffer of the handle).  fuse: dense-quadratic family only.
 int residual_jacobian(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int n, const double *x, const double *f0,
                       double *out, double *panel, const LmState *st, int want, bool to_qrx, bool fuse, bool use_jac);
 

@@ -236,15 +236,17 @@ template <int BS, int CJ, bool VEC2>
 __global__ void __launch_bounds__(BS)
 k_fd_jacobian(int m, int n, const double *__restrict__ P, const double *__restrict__ f0,
               const double *__restrict__ x, double *__restrict__ J,
-              const LmState *__restrict__ st, int want_stage, const int32_t *__restrict__ list = nullptr)
+              const LmState *__restrict__ st, int want_stage, const int32_t *__restrict__ list = nullptr, int nfull = 0)
 {
-    // list (the open device-residual path, nlh_devfcn.hip): the panel of compact slot blockIdx.z belongs to problem list[slot]
+    // list (the open device-residual path, nlh_devfcn.hip): the panel of compact slot blockIdx.z belongs to problem list[slot];
+    // nfull > n: the panel holds a group of n columns of ONE problem of nfull columns (J and x arrive shifted to the group)
     const int p = list ? list[blockIdx.z] : blockIdx.z;
     if (st && st[p].stage != want_stage) return;
+    const int ns = nfull ? nfull : n;
     const double *Pp = P + (size_t)blockIdx.z * m * n;
-    double *Jp = J + (size_t)p * m * n;
+    double *Jp = J + (size_t)p * m * ns;
     const double *fp = f0 + (size_t)p * m;
-    const double *xp = x + (size_t)p * n;
+    const double *xp = x + (size_t)p * ns;
     const int jbeg = blockIdx.y * CJ;
     const int jend = min(n, jbeg + CJ);
     if (VEC2) {

@@ -354,9 +354,8 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     // the dense-quadratic family's fused epilogue writes the Jacobian straight into the exact factorisation's working
     // matrix; a user's residual leaves a panel (in the J buffer) that k_fd_jacobian_qrx turns into the same matrix
     const bool fuse = o->fuse_fd && !rs.user();
-    const bool jac_in_place = fuse && exact;
     const bool to_qrx = exact && (fuse || rs.user());
-    if ((rc = lm_workspace(h, nprob, m, n, w, true, !jac_in_place))) return rc;
+    if ((rc = lm_workspace(h, nprob, m, n, w, true, !to_qrx))) return rc;   // (to_qrx: nothing reads a column-major Jacobian)
     if ((rc = ensure_pinned(h, sizeof(LmState) * (size_t)nprob + 64))) return rc;
     int *d_active = (int *)(w.info + nprob);
     int *h_active = (int *)h->pinned;

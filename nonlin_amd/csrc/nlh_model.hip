@@ -79,7 +79,25 @@ struct nlh_dq_model {
     double gamma;
     nlh_device_set *set = nullptr;     // not owned
     std::vector<DqPart> parts;
+    // a USER'S device residual instead of the dense-quadratic family (nlh_device_fcn_model_create): launchers + context,
+    // no data of the library's own; the solves go through the *_batch_device_h entry points on the caller's handle
+    nlh_device_vecfcn ufcn = nullptr;
+    nlh_device_jacfcn ujac = nullptr;
+    void *uctx = nullptr;
 };
+
+int nlh_device_fcn_model_create(int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx,
+                                nlh_dq_model **out)
+{
+    if (!out || nprob < 1 || m < 1 || n < 1) return NLH_INVALID_INPUT_ERROR;
+    *out = nullptr;
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;
+    nlh_dq_model *md = new nlh_dq_model();
+    md->nprob = nprob; md->m = m; md->n = n; md->gamma = 0.0;
+    md->ufcn = fcn; md->ujac = jacfcn; md->uctx = ctx;
+    *out = md;
+    return 0;
+}
 
 static int model_part_upload(nlh_handle *h, const nlh_dq_model *md, DqPart &pt, const double *A, const double *b)
 {
@@ -247,6 +265,22 @@ static int model_run(nlh_handle *h, const nlh_dq_model *md, double *x, bool x_ou
 int nlh_dq_model_eval(nlh_handle *h, const nlh_dq_model *md, const double *x, double *f)
 {
     if (!md) return NLH_INVALID_INPUT_ERROR;
+    if (md->ufcn) {                                              // a user's device function: one point per problem
+        if (!h) return NLH_ERR_BAD_HANDLE;
+        if (!x || !f) return NLH_INVALID_INPUT_ERROR;
+        HIPCHK(h, hipSetDevice(h->device));
+        int rc;
+        const size_t nx = (size_t)md->nprob * md->n, nf = (size_t)md->nprob * md->m;
+        if ((rc = ensure(h, h->xdev, sizeof(double) * nx))) return rc;
+        if ((rc = ensure(h, h->fdev, sizeof(double) * nf))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->xdev.p, x, sizeof(double) * nx, hipMemcpyHostToDevice, h->stream));
+        ResidualSource rs;
+        rs.fcn = md->ufcn; rs.jac = md->ujac; rs.ctx = md->uctx;
+        if ((rc = residual_eval(h, rs, md->nprob, md->m, md->n, (const double *)h->xdev.p, (double *)h->fdev.p, nullptr, nullptr, -1))) return rc;
+        HIPCHK(h, hipMemcpyAsync(f, h->fdev.p, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return 0;
+    }
     return model_run(h, md, const_cast<double *>(x), false, f, nullptr, nullptr,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *, int32_t *) -> int {
                          launch_dq_residual(ph, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma, pt.dx, pt.df, nullptr, nullptr, -1);
@@ -264,6 +298,7 @@ int nlh_dq_model_lm_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mode
     nlh_options oq = *o;
     if (md->nprob > 1) oq.print_status = 0;
     o = &oq;
+    if (md->ufcn) return nlh_lm_solve_batch_device_h(h, o, md->nprob, md->m, md->n, md->ufcn, md->ujac, md->uctx, x, fvec, ib, status);
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          return nlh_dq_lm_solve_batch(ph, o, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma, pt.dx, pt.df, pib, pst);
@@ -280,6 +315,8 @@ int nlh_dq_model_newton_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_
     if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
     o = &oq;
     if (md->m != md->n) return NLH_INVALID_INPUT_ERROR;         // src/nonlin_solve.f90:519
+    if (md->ufcn)                                                // (analytic: whether to use the user's jacobianfcn launcher)
+        return nlh_newton_solve_batch_device_h(h, o, md->nprob, md->n, md->ufcn, analytic ? md->ujac : nullptr, md->uctx, x, fvec, ib, status);
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          return nlh_dq_newton_solve_batch(ph, o, pt.cnt, md->n, pt.dA, pt.db, md->gamma, analytic, pt.dx, pt.df, pib, pst);
@@ -295,6 +332,9 @@ int nlh_dq_model_quasi_newton_solve(nlh_handle *h, const nlh_options *o, const n
     if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
     o = &oq;
     if (md->m != md->n) return NLH_INVALID_INPUT_ERROR;         // src/nonlin_solve.f90:241
+    if (md->ufcn)
+        return nlh_quasi_newton_solve_batch_device_h(h, o, jdelta, md->nprob, md->n, md->ufcn, analytic ? md->ujac : nullptr, md->uctx, x, fvec,
+                                                     ib, status);
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          return nlh_dq_quasi_newton_solve_batch(ph, o, jdelta, pt.cnt, md->n, pt.dA, pt.db, md->gamma, analytic, pt.dx, pt.df, pib, pst);
@@ -311,6 +351,7 @@ int nlh_dq_model_cls_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mod
     nlh_options oq = *o;
     if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
     o = &oq;
+    if (md->ufcn) return NLH_INVALID_OPERATION_ERROR;     // (the open path serves lss_solve, ns_solve and qns_solve)
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          return nlh_dq_cls_solve_batch(ph, o, delta0, stepscale0, xl, xu, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma,
@@ -327,6 +368,7 @@ int nlh_dq_model_bfgs_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mo
     nlh_options oq = *o;
     if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
     o = &oq;
+    if (md->ufcn) return NLH_INVALID_OPERATION_ERROR;
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          std::vector<double> fo(pt.cnt, 0.0);

@@ -144,6 +144,16 @@ module nonlin_hip_c
             type(c_ptr), intent(out) :: model
             integer(c_int) :: rc
         end function
+        ! a USER'S device residual (launchers, include/nonlin_hip.h: nlh_device_vecfcn / nlh_device_jacfcn) as a model object
+        function nlh_device_fcn_model_create(nprob, m, n, fcn, jacfcn, ctx, model) &
+                bind(C, name="nlh_device_fcn_model_create") result(rc)
+            import :: c_ptr, c_funptr, c_int, c_int32_t
+            integer(c_int32_t), value :: nprob, m, n
+            type(c_funptr), value :: fcn, jacfcn
+            type(c_ptr), value :: ctx
+            type(c_ptr), intent(out) :: model
+            integer(c_int) :: rc
+        end function
         ! ---- several GPUs behind the boundary (include/nonlin_hip.h: nlh_device_set_*) ----
         function nlh_device_set_create(set, devices, ndev) bind(C, name="nlh_device_set_create") result(rc)
             import :: c_ptr, c_int, c_int32_t

@@ -53,6 +53,7 @@ module nonlin_multi_eqn_mult_var
         logical, private :: analytic_ = .false.
     contains
         procedure, public :: create => dmb_create
+        procedure, public :: create_from_device_fcn => dmb_create_fcn
         procedure, public :: destroy => dmb_destroy
         procedure, public :: is_defined => dmb_defined
         procedure, public :: get_problem_count => dmb_nprob
@@ -71,6 +72,7 @@ module nonlin_multi_eqn_mult_var
         type(device_model_batch), private :: model_      ! set_device_model: one problem on the device
     contains
         procedure, public :: set_device_model => helper_bind_model
+        procedure, public :: set_device_fcn => helper_bind_device_fcn
         procedure, public :: clear_device_model => helper_drop_model
         procedure, public :: is_device_model_defined => helper_has_model
         procedure, public :: device_model => helper_model
@@ -172,6 +174,23 @@ contains
         this%nvar_ = size(a, 2)
     end subroutine
 
+    !> Extension: the residual is the USER'S OWN device function -- the device form of set_fcn (reference :126-140).  fcn is a
+    !> launcher with the C signature nlh_device_vecfcn of include/nonlin_hip.h (a host procedure, bind(C) or written in
+    !> C / HIP, that enqueues the user's kernel on the stream it is handed), ctx whatever that launcher needs (its device
+    !> data); jac, optional, a launcher for the analytic Jacobian (the device form of set_jacobian, :143-153).
+    !> solver%solve(obj, x, fvec, ib) stays the reference's call; the whole iteration then runs on the GPU.
+    subroutine helper_bind_device_fcn(this, fcn, ctx, nfcn, nvar, jac)
+        class(vecfcn_helper), intent(inout) :: this
+        type(c_funptr), intent(in) :: fcn
+        type(c_ptr), intent(in) :: ctx
+        integer(int32), intent(in) :: nfcn
+        integer(int32), intent(in) :: nvar
+        type(c_funptr), intent(in), optional :: jac
+        call this%model_%create_from_device_fcn(fcn, ctx, 1, nfcn, nvar, jac)
+        this%neqn_ = nfcn
+        this%nvar_ = nvar
+    end subroutine
+
     subroutine helper_drop_model(this)
         class(vecfcn_helper), intent(inout) :: this
         call this%model_%destroy()
@@ -217,6 +236,29 @@ contains
         this%nprob_ = size(a, 3)
         this%analytic_ = .false.
         if (present(analytic)) this%analytic_ = analytic
+    end subroutine
+
+    !> nprob problems of the user's own device residual family (launchers: see vecfcn_helper%set_device_fcn); the user's
+    !> kernel tells the problems apart by the index the launcher is handed for every point (0-based, position in x(:, k)).
+    subroutine dmb_create_fcn(this, fcn, ctx, nprob, nfcn, nvar, jac)
+        class(device_model_batch), intent(inout) :: this
+        type(c_funptr), intent(in) :: fcn
+        type(c_ptr), intent(in) :: ctx
+        integer(int32), intent(in) :: nprob, nfcn, nvar
+        type(c_funptr), intent(in), optional :: jac
+        type(c_funptr) :: jentry
+        integer(c_int) :: rc
+        if (.not.c_associated(fcn)) error stop NL_UNDEFINED_FUNCTION_ERROR
+        call this%destroy()
+        jentry = c_null_funptr
+        if (present(jac)) jentry = jac
+        rc = nlh_device_fcn_model_create(int(nprob, c_int32_t), int(nfcn, c_int32_t), int(nvar, c_int32_t), fcn, jentry, ctx, &
+            this%model_)
+        if (rc /= 0) error stop rc
+        this%neqn_ = nfcn
+        this%nvar_ = nvar
+        this%nprob_ = nprob
+        this%analytic_ = c_associated(jentry)
     end subroutine
 
     subroutine dmb_destroy(this)

@@ -299,3 +299,75 @@ def test_launcher_failure_is_reported(ds):
                                           None, x.data_ptr(), x.data_ptr(), ib, None)
     assert rc == 211                                          # NL_UNDEFINED_FUNCTION_ERROR (:188)
     batch.close()
+
+
+# ---------------------------------------------------------------------------------------------------- GPU: Fortran
+@pytest.mark.gpu
+def test_user_device_fcn_through_the_fortran_shim(ds, oracle, tmp_path):
+    """vecfcn_helper%set_device_fcn + solver%solve (the reference's own call) and device_model_batch%create_from_device_fcn
+    + solve_batch, from a Fortran program linked with the shim, libnonlin_hip.so and the user's own library
+    (tests/fortran/device_fcn_suite.f90): least squares on the Lorentzian family, Newton and quasi-Newton on Broyden's
+    tridiagonal family (analytic jacobianfcn launcher, and forward differences) -- every problem bitwise the oracle's."""
+    import os
+    import shutil
+    import struct
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "fortran", "build", "device_fcn_suite")
+    if not os.path.exists(exe):
+        if not (shutil.which("amdflang") or os.path.exists("/opt/rocm/bin/amdflang")):
+            pytest.skip("no Fortran compiler and no prebuilt tests/fortran/build/device_fcn_suite")
+        root = os.path.dirname(here)
+        subprocess.check_call(["make", "-C", os.path.join(root, "nonlin_amd", "fortran"), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(here, "device_model"), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(here, "fortran"), "-s"])
+    nprob, m, K, nq = 7, 256, 2, 40
+    n = 3 * K
+    t, y, xt, x0 = UM.lorentz_problems(nprob, m, K, seed=77, hard_every=3)
+    c, xs = UM.btri_problems(nprob, nq, seed=5)
+    path = str(tmp_path / "df.bin")
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<iii", nprob, m, n))
+        fh.write(t.tobytes()); fh.write(y.tobytes()); fh.write(x0.tobytes())
+        fh.write(struct.pack("<i", nq))
+        fh.write(c.tobytes()); fh.write(xs.tobytes())
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    unhex = lambda h: struct.unpack(">d", bytes.fromhex(h))[0]
+    res = {}
+    for line in out.stdout.splitlines():
+        tk = line.split()
+        res.setdefault(tk[0], []).append({"status": int(tk[1]), "counts": (int(tk[2]), int(tk[3]), int(tk[4])), "flags": tuple(tk[5:8]),
+                                          "x": np.array([unhex(h) for h in tk[8:]])})
+
+    def cmp(r, rc, xo, ibo):
+        assert r["status"] == rc == 0
+        assert r["counts"] == (ibo["iter_count"], ibo["fcn_count"], ibo["jacobian_count"]), (r, ibo)
+        assert r["flags"] == tuple("T" if ibo[k] else "F" for k in ("converge_on_fcn", "converge_on_chng", "converge_on_zero_diff"))
+        assert np.array_equal(r["x"], xo)
+
+    so = UM.lib()
+    sols = []
+    for p in range(nprob):
+        hc = UM.LorentzHost(m, t[p].ctypes.data_as(dp), y[p].ctypes.data_as(dp), 0)
+        sols.append(_oracle_lm(oracle, so.lorentz_host_fcn, hc, m, n, x0[p], max_evals=500))
+    rc, xo, fo, ibo = sols[0]
+    cmp(res["df_lm_single"][0], rc, xo, ibo)
+    assert np.array_equal(res["df_lm_single_fvec"][0]["x"], np.array([fo[0], fo[-1]]))
+    f0 = UM.lorentz_row_numpy(x0[0], t[0], y[0])
+    assert np.array_equal(res["df_eval"][0]["x"], np.array([f0[0], f0[-1]]))
+    assert len(res["df_lm_batch"]) == nprob
+    for p in range(nprob):
+        cmp(res["df_lm_batch"][p], *sols[p][:1], *sols[p][1:2], sols[p][3])
+
+    class B:                                                   # the host twins of the square family, per problem
+        host_fcn, host_jac = so.btri_host_fcn, so.btri_host_jac
+
+        @staticmethod
+        def host_ctx(p):
+            return UM.BtriHost(float(c[p]), 0, 0)
+    for key, broyden, analytic in (("df_newton_batch", False, True), ("df_broyden_batch", True, True), ("df_newton_fd_batch", False, False)):
+        assert len(res[key]) == nprob
+        for p in range(nprob):
+            rc, xo, fo, ibo = _oracle_square(oracle, B, p, nq, xs[p], broyden, analytic, max_evals=500)
+            cmp(res[key][p], rc, xo, ibo)
