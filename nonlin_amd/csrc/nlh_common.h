@@ -34,6 +34,9 @@ struct LmState {
     int32_t head_done;     // the outer-loop head already ran in this outer iteration
     int32_t signs_done;    // normal-equations factors already carry lmfactor's row signs
     int32_t pivoted;       // normal-equations factors use lmfactor's pivot order (else natural order)
+    int32_t slow_lmpar;    // how often lmpar's iteration ran (the Gauss-Newton step was not accepted at :477-481)
+    int32_t rejects;       // trial points rejected (:340 not taken)
+    int32_t first_slow;    // outer iteration of the first of either (0: none yet)
 };
 
 __device__ __forceinline__ double wave_reduce_sum(double v)

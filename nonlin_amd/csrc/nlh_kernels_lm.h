@@ -423,12 +423,13 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
     const double *qtf = v.qtf + (size_t)p * n;
     const double *xc = xall + (size_t)p * n;
     const int ne_mode = (want_stage == ST_NE_READY);
+    double *Wp = Wall + (size_t)p * m * n;
 
     double par = s->par;
     const double delta = s->delta;
     int rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, s->tailsq,
                               wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
-                              Wall + (size_t)p * m * n, rot, ne_mode);
+                              Wp, rot, ne_mode);
     __syncthreads();
     if (rc && !EXACT) {
         // Deviation A (:531) adds ||wa4(n+1:m)|| to ||D x|| inside the loop.  If that tail alone exceeds
@@ -485,7 +486,7 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
         par = s->par;
         rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, tailsq,
                               wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
-                              Wall + (size_t)p * m * n, rot, 0);
+                              Wp, rot, 0);
         __syncthreads();
 #ifdef NLH_DEBUG_TIMING
         if (tid == 0) printf("[lmpar p=%d] signs %.3f ms, full lmpar %.3f ms, par=%g\n", p, (tt1 - tt0) * 1e-5,
@@ -528,6 +529,7 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
         s->temp1n = t1;
         if (s->iter == 1) s->delta = fmin(delta, pnorm);       // :294
         s->inner_pass += 1;
+        if (par != 0.0) { s->slow_lmpar += 1; if (!s->first_slow) s->first_slow = s->iter; }   // (par == 0: the early exit of :481)
         s->stage = ST_TRIAL_READY;
     }
 }
@@ -626,5 +628,9 @@ k_lm_update(int m, int n, int nblk, const double *__restrict__ part, LmVecs v,
     s->flag = flag;
     if (fcnvrg || xcnvrg || flag) s->stage = ST_DONE;
     else if (accept) { s->stage = ST_NEED_JAC; s->inner_pass = 0; s->head_done = 0; s->signs_done = 0; s->pivoted = 0; }
-    else s->stage = (fkind == 1) ? ST_QR_READY : ST_NE_READY;   // inner loop again
+    else {                                                      // inner loop again
+        s->stage = (fkind == 1) ? ST_QR_READY : ST_NE_READY;
+        s->rejects += 1;
+        if (!s->first_slow) s->first_slow = iter;
+    }
 }

@@ -78,11 +78,15 @@ static __global__ void k_count_active(int nprob, const LmState *st, int *out)
     __shared__ int cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    int c = 0;
-    for (int p = threadIdx.x; p < nprob; p += blockDim.x) c += (st[p].stage != ST_DONE);
-    atomicAdd(&cnt, c);
+    __shared__ int cntj;
+    if (threadIdx.x == 0) cntj = 0;
     __syncthreads();
-    if (threadIdx.x == 0) *out = cnt;
+    int c = 0, cj = 0;
+    for (int p = threadIdx.x; p < nprob; p += blockDim.x) { c += (st[p].stage != ST_DONE); cj += (st[p].stage == ST_NEED_JAC); }
+    atomicAdd(&cnt, c);
+    atomicAdd(&cntj, cj);
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = cnt; out[1] = cntj; }      // still iterating; of those, due for a Jacobian + factorisation
 }
 
 // partial sums of squares of a device vector, same block structure as k_dq_residual
@@ -218,14 +222,14 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
 // One pass over the factorisation + lmpar stages for every problem whose Jacobian is in
 // w.J (stage ST_HAVE_JAC or ST_NEED_QR) or whose factors are ready (inner-loop repeat).
 static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, int m, int n, LmWs &w,
-                              double *dx, const double *dfvec, int nact = -1, bool jac_in_qrx_layout = false)
-{
+                              double *dx, const double *dfvec, int nact = -1, bool jac_in_qrx_layout = false, bool any_fresh = true)
+{   // any_fresh = false: no problem has a fresh Jacobian this round (the exact policy then skips the factorisation's launches)
     const int ft = factor_threads(n);
     const size_t shl = sizeof(double) * (size_t)(6 * n + 72);
     if (o->factor_policy == NLH_FACTOR_EXACT) {
         // reference operation order: exact lmfactor + Q^T f (streaming form, the batch advances through the
         // Householder steps in lock step: nlh_qrx.hip), exact lmpar
-        {
+        if (any_fresh) {
             int rc;
             if ((rc = ensure(h, h->qxV, qrx_workspace_bytes(nprob, m, n)))) return rc;
             QrxTimer tm{h, [](void *c, int which, hipStream_t s) { qrx_time_begin((nlh_handle *)c, which, s); },
@@ -234,6 +238,12 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
                        w.scratch, dx, w.st, o->factor, o->gtol, h->qxV.p, &tm, nact);
         }
         {
+            // (Measured and dropped in round 5: lmpar's ITERATION -- the few problems whose Gauss-Newton step is not accepted; ten
+            // lmsolve sweeps, milliseconds of one workgroup -- on a side stream, the problems joining the next round at their
+            // trial point.  It happens only in a problem's LAST outer iteration on these families (deviation A sends par to
+            // +Inf), the round it is pushed into exists anyway, and every extra round costs the batch its launches: 3,603 ->
+            // 3,585 LM it/s for one lock-step batch of 2048 x 4096x256, 3,681 -> 3,511 with sub-batches; 47 x 4096x256 153.5 ->
+            // 155.7 ms.  docs/lab_notebook.md.)
             Timed t(h, NLH_K_LMPAR);
             hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(ft), shl + sizeof(double) * (3 * NLH_NCH + 8),
                                h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY);
@@ -251,7 +261,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
         const char *mc_e = getenv("NLH_CHOL_MC");                   // (read per call: tests switch between the two forms)
         const int mc_max = mc_e ? atoi(mc_e) : 8;
         const int na = nact < 0 ? nprob : nact;
-        if (sh <= 150 * 1024 && n >= 192 && na <= mc_max) {
+        // (its launches cover every problem of the batch, active or not: only for batches that are small themselves)
+        if (sh <= 150 * 1024 && n >= 192 && na <= mc_max && nprob <= 4 * std::max(mc_max, 1)) {
             int rc2;
             if ((rc2 = ensure(h, h->cholmc, sizeof(double) * (size_t)nprob * 2 * (NB * n + NB * NB + NB) + sizeof(int32_t) * (size_t)nprob + 64))) return rc2;
             double *side = (double *)h->cholmc.p;
@@ -370,19 +381,23 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     else
         hipLaunchKernelGGL(k_lm_init, dim3(pb), dim3(256), 0, h->stream, nprob, w.nblk, w.part, w.st, first_stage);
 
-    const int max_rounds = o->max_evals + 8;
     const bool echo = o->print_status && nprob == 1;
+    const int max_rounds = o->max_evals + 8;
     int last_printed_iter = -1;
-    int nact = nprob;                                           // problems still iterating (from the previous round)
+    int nact = nprob, njac_due = nprob;                         // problems still iterating / due for a Jacobian (from the previous round)
     for (int round = 0; round < max_rounds; ++round) {
         // outer-loop head for problems that need a Jacobian (:221): n perturbed evaluations + FD
         // (the exact factorisation is the Jacobian's only reader: to_qrx writes it in that working layout, no re-layout
         // pass; the panel of the unfused forms lives in whichever of the two big buffers the Jacobian does not)
-        if ((rc = residual_jacobian(h, rs, nprob, m, n, dx, dfvec, to_qrx ? w.P : w.J, to_qrx ? w.J : w.P, w.st, ST_NEED_JAC, to_qrx,
-                                    fuse, true))) return rc;
-        hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_NEED_JAC,
-                           o->factor_policy != NLH_FACTOR_AUTO ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
-        if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec, nact, to_qrx))) return rc;
+        // A round in which no problem is due for a Jacobian (rejected trial points only) skips the Jacobian and the factorisation's ~3 n launches; lmpar for the repeats still runs.
+        const bool any_jac = njac_due > 0;
+        if (any_jac) {
+            if ((rc = residual_jacobian(h, rs, nprob, m, n, dx, dfvec, to_qrx ? w.P : w.J, to_qrx ? w.J : w.P, w.st, ST_NEED_JAC, to_qrx,
+                                        fuse, true))) return rc;
+            hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_NEED_JAC,
+                               o->factor_policy != NLH_FACTOR_AUTO ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
+        }
+        if ((rc = lm_factor_and_step(h, o, nprob, m, n, w, dx, dfvec, std::min(nact, std::max(njac_due, 1)), to_qrx, any_jac))) return rc;
         // trial residual (:297-299)
         if ((rc = residual_eval(h, rs, nprob, m, n, w.v.wa2, w.wa4, exact && rs.user() ? (double *)nullptr : w.part, w.st,
                                 ST_TRIAL_READY))) return rc;
@@ -390,7 +405,7 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
                            (int)ST_TRIAL_DONE, 0);
         lm_update(h, o, nprob, m, n, w, dx, dfvec);
         hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, h->stream, nprob, w.st, d_active);
-        HIPCHK(h, hipMemcpyAsync(h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h_active, d_active, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         if (echo) HIPCHK(h, hipMemcpyAsync(h_state, w.st, sizeof(LmState), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         // a single solve with print_status set: the reference's status block at the end of every outer iteration that
@@ -400,11 +415,16 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
             last_printed_iter = h_state[0].iter;
         }
         if (*h_active == 0) break;
-        nact = *h_active;
+        nact = h_active[0];
+        njac_due = h_active[1];
     }
     HIPCHK(h, hipMemcpyAsync(h_state, w.st, sizeof(LmState) * (size_t)nprob, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    if (getenv("NLH_DEBUG_LAG"))
+        for (int p = 0; p < nprob; ++p)
+            fprintf(stderr, "lag %d njac %d slow_lmpar %d rejects %d first %d\n", p + rs.pbase, h_state[p].njac, h_state[p].slow_lmpar,
+                    h_state[p].rejects, h_state[p].first_slow);
     for (int p = 0; p < nprob; ++p) {
         if (ib) fill_ib(h_state[p], &ib[p]);
         if (status) status[p] = (h_state[p].flag != 0 || h_state[p].stage != ST_DONE) ? NLH_CONVERGENCE_ERROR : 0;  // :388-390

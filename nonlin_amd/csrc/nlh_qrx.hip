@@ -1230,6 +1230,11 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
 #ifndef QRX_FEW_MAX
 #define QRX_FEW_MAX 256                 // batches of at most this many active problems take the pivot kernel's FEW instance
 #endif                                  // (32 x 4096x256: 111 instead of 122 ms per solve)
+#ifndef QRX_RPW_MAXNP
+#define QRX_RPW_MAXNP 4                 // pending reflectors the wide form keeps (sixteen SGPRs per slot and round): flush period MAXNP + 1
+                                        // (ms per solve at 3 / 4: 32 x 4096x256 104 / 99, 47: 153 / 152, 64: 164 / 160, 128 x 2048x128 39.4 / 39.1;
+                                        // 5: the slots no longer fit the scalar registers -- 231-394 spilled -- and the kernel faults)
+#endif
 #define QRX_RPW_G 8                     // rows per producer and round: one 64-byte sector per lane
 #define QRX_RPW_AH 4                    // row groups in flight per producer
 __device__ __forceinline__ double qrx_readlane_f64(double x, int l)
@@ -1783,9 +1788,9 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     if constexpr (NP >= 8) rp = 0;
     // the wide row-parallel form keeps its reflector entries in scalar registers (sixteen per slot): at most three pending
     // updates; a launch that inherits more from the form before it takes the four-wave form until the next flush
-    if constexpr (NP >= 4) { if (rp == 16) rp = 4; }
+    if constexpr (NP > QRX_RPW_MAXNP) { if (rp == 16) rp = 4; }
     if constexpr (NP < 8) {
-    if constexpr (NP < 4) {
+    if constexpr (NP <= QRX_RPW_MAXNP) {
     if (rp == 16)
         hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16>), grid, dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
@@ -1804,7 +1809,7 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
 }
 
 // A pass with np pending updates; flushing ones exist for np = 1, 3 and QRX_C - 1 (flush periods 2, 4 and QRX_C).
-static constexpr bool qrx_can_flush(int np) { return np == 1 || np == 3 || (QRX_C > 8 && np == 7) || np == QRX_C - 1; }
+static constexpr bool qrx_can_flush(int np) { return np == 1 || np == 3 || np == QRX_RPW_MAXNP || (QRX_C > 8 && np == 7) || np == QRX_C - 1; }
 
 template <int NP>
 static void dispatch_pass(int np, bool flush, int rp, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst,
@@ -1830,7 +1835,7 @@ static void qrx_rpw_attr()
     hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     if constexpr (qrx_can_flush(NP))
         hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    if constexpr (NP < 3) qrx_rpw_attr<NP + 1>();
+    if constexpr (NP < QRX_RPW_MAXNP) qrx_rpw_attr<NP + 1>();
 }
 
 void qrx_init_device()
@@ -1858,7 +1863,11 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         hipLaunchKernelGGL(k_qrx_transpose, dim3(gx, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, J, T, (const LmState *)st);
     }
     if (nact <= 0 || nact > nprob) nact = nprob;
-    if ((long)nact * n <= QRX_COL_MAX_WG) {                      // a handful of problems: a workgroup per column for the norms
+    // a workgroup per column for the initial norms while the launch's chains would otherwise leave the chip idle (a thread
+    // per column walks its 4096 rows alone: 800 us for 47 x 4096x256, whatever the count; k_qrx_init<true> is HBM-bound
+    // only from ~1000 problems on)
+    static const long initn_env = [] { const char *e = getenv("NLH_QRX_INITN"); return e ? atol(e) : 32768L; }();
+    if ((long)nact * n <= std::max<long>(QRX_COL_MAX_WG, initn_env)) {
         hipLaunchKernelGGL(k_qrx_init<false>, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
         hipLaunchKernelGGL(k_qrx_init_norms, dim3(n, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, (const double *)T, w, v,
                            (const LmState *)st);
@@ -1955,7 +1964,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         const int rp = nwg <= rpw16_max ? 16 : nwg <= rp_max ? 4 : 0;
         // the wide form keeps at most three pending reflectors (scalar registers): a flush every 4th step; the four-wave
         // form every 8th; full launches every QRX_C-th
-        const int period = forced_period ? forced_period : (rp == 16 ? 4 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
+        const int period = forced_period ? forced_period : (rp == 16 ? QRX_RPW_MAXNP + 1 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
         const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
         const int pf = (flush ? 1 : 0) | (prev_flushed ? 2 : 0);
