@@ -42,9 +42,11 @@ extern "C" {
 #define NLH_UNDEFINED_FUNCTION_ERROR   211   /* (:34) */
 #define NLH_UNDERDEFINED_PROBLEM_ERROR 212   /* (:37) */
 /* Size limits of this implementation (the reference has none); an entry point given a larger problem returns
- * NLH_ARRAY_SIZE_ERROR and touches nothing: least squares (nlh_lm_solve, nlh_dq_lm_solve_batch, ...) n <= 3000;
- * quasi-Newton and BFGS n <= 4096 (what is kept in LDS inside a workgroup).  Row counts are not limited: polynomial fits
- * and bounded least squares beyond 18000 rows keep the Householder reflector in global memory instead of LDS.
+ * NLH_ARRAY_SIZE_ERROR and touches nothing: quasi-Newton and BFGS n <= 8192 (columns per thread of the single-workgroup
+ * rotation kernels); least squares under the opt-in NLH_FACTOR_AUTO / NLH_FACTOR_QR policies n <= 3000 (n-vectors in LDS).
+ * Least squares under the default NLH_FACTOR_EXACT policy takes any n <= m (beyond 3000 columns lmpar's n-vectors live in
+ * global memory).  Row counts are not limited: polynomial fits and bounded least squares beyond 18000 rows keep the
+ * Householder reflector in global memory instead of LDS.
  * The number of problems of a batch is NOT limited: the lock-step drivers carry the problem index in a grid dimension
  * that holds 65535, and a larger batch is solved in slices of 65535 problems, one after the other, inside the entry point
  * (independent problems: the same bits). */

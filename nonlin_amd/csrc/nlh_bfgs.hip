@@ -24,6 +24,7 @@ void nlh_bfgs_init_device(int lds_max)
     hipFuncSetAttribute((const void *)k_bf_chol_blocked<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_chol_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_bf_chol_update<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_bf_downdate_apply, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     broyden_kernel_attrs(lds_max);
 }
@@ -169,6 +170,7 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
                 for (int i = 0; i < n; ++i) v[i] = bdx[i] / s2;
                 HIPCHK(h, hipMemcpyAsync(du, u.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
                 if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_update<1>, dim3(1), dim3(bs1), sizeof(double) * 2 * n, s, n, dR, du, (const LmState *)nullptr, -1);
+                else if (qn_nc8(n)) hipLaunchKernelGGL(k_bf_chol_update<8>, dim3(1), dim3(1024), sizeof(double) * 2 * n, s, n, dR, du, (const LmState *)nullptr, -1);
                 else hipLaunchKernelGGL(k_bf_chol_update<4>, dim3(1), dim3(1024), sizeof(double) * 2 * n, s, n, dR, du, (const LmState *)nullptr, -1);
                 HIPCHK(h, hipMemcpyAsync(du, v.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
                 hipLaunchKernelGGL(k_bf_solve_upper_t, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dR, du, (const LmState *)nullptr, -1);
@@ -176,6 +178,7 @@ static int bfgs_core(nlh_handle *h, const nlh_options *o, int n, BfgsEval &ev, d
                 hipLaunchKernelGGL(k_bf_downdate_apply, dim3((n + 255) / 256), dim3(256), sizeof(double) * 2 * n, s, n, dR, dc, du, dinfo, (const LmState *)nullptr, -1);
             } else {
                 if (n <= 1024) launch_bf_chol_blocked(s, 1, n, dB, dR, dinfo, nullptr, -1);
+                else if (qn_nc8(n)) hipLaunchKernelGGL(k_bf_chol_factor<8>, dim3(1), dim3(1024), sizeof(double) * n, s, n, dB, dR, dinfo, (const LmState *)nullptr, -1);
                 else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(1), dim3(1024), sizeof(double) * n, s, n, dB, dR, dinfo, (const LmState *)nullptr, -1);
             }
             // dx = -(R^T R)^-1 g (:727)
@@ -326,7 +329,8 @@ static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int
             hipLaunchKernelGGL(k_bfl_split, dim3(nprob), dim3(256), 0, s, n, (const double *)ddx, (const double *)dbdx, (const double *)dy, du, dv, st, bs);
             // :716-722: R^T R += u u^T, then -= v v^T
             if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_update<1>, dim3(nprob), dim3(bs1), sizeof(double) * 2 * n, s, n, dR, (const double *)du, cst, (int)BF_UPD_RANK);
-            else hipLaunchKernelGGL(k_bf_chol_update<4>, dim3(nprob), dim3(1024), sizeof(double) * 2 * n, s, n, dR, (const double *)du, cst, (int)BF_UPD_RANK);
+            else if (qn_nc8(n)) hipLaunchKernelGGL(k_bf_chol_update<8>, dim3(nprob), dim3(1024), sizeof(double) * 2 * n, s, n, dR, (const double *)du, cst, (int)BF_UPD_RANK);
+                else hipLaunchKernelGGL(k_bf_chol_update<4>, dim3(nprob), dim3(1024), sizeof(double) * 2 * n, s, n, dR, (const double *)du, cst, (int)BF_UPD_RANK);
             hipLaunchKernelGGL(k_bf_solve_upper_t, dim3(nprob), dim3(bs1), sizeof(double) * n, s, n, (const double *)dR, dv, cst, (int)BF_UPD_RANK);
             hipLaunchKernelGGL(k_bf_downdate_rot, dim3(nprob), dim3(64), 0, s, n, dv, dc, dinfo, cst, (int)BF_UPD_RANK);
             hipLaunchKernelGGL(k_bf_downdate_apply, dim3((n + 255) / 256, nprob), dim3(256), sizeof(double) * 2 * n, s, n, dR, (const double *)dc,
@@ -334,7 +338,8 @@ static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int
             hipLaunchKernelGGL(k_nt_advance, dim3(pb), dim3(256), 0, s, nprob, st, (int)BF_UPD_RANK, (int)BF_DIR);
             // :724: R = chol(B)
             if (n <= 1024) launch_bf_chol_blocked(s, nprob, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
-            else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(nprob), dim3(1024), sizeof(double) * n, s, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
+            else if (qn_nc8(n)) hipLaunchKernelGGL(k_bf_chol_factor<8>, dim3(nprob), dim3(1024), sizeof(double) * n, s, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
+                else hipLaunchKernelGGL(k_bf_chol_factor<4>, dim3(nprob), dim3(1024), sizeof(double) * n, s, n, (const double *)dB, dR, dinfo, cst, (int)BF_UPD_FACTOR);
             hipLaunchKernelGGL(k_nt_advance, dim3(pb), dim3(256), 0, s, nprob, st, (int)BF_UPD_FACTOR, (int)BF_DIR);
             // :727: dx = -(R^T R)^-1 g
             hipLaunchKernelGGL(k_bfl_neg, dim3((n + 255) / 256, nprob), dim3(256), 0, s, n, (const double *)dg, dw, cst);
@@ -455,7 +460,8 @@ int nlh_chol_rank1(nlh_handle *h, int32_t n, int32_t downdate, double *dRt, doub
     int info = 0;
     if (!downdate) {
         if (n <= 1024) hipLaunchKernelGGL(k_bf_chol_update<1>, dim3(1), dim3(bs1), sizeof(double) * 2 * n, s, n, dRt, du, (const LmState *)nullptr, -1);
-        else hipLaunchKernelGGL(k_bf_chol_update<4>, dim3(1), dim3(1024), sizeof(double) * 2 * n, s, n, dRt, du, (const LmState *)nullptr, -1);
+        else if (qn_nc8(n)) hipLaunchKernelGGL(k_bf_chol_update<8>, dim3(1), dim3(1024), sizeof(double) * 2 * n, s, n, dRt, du, (const LmState *)nullptr, -1);
+                else hipLaunchKernelGGL(k_bf_chol_update<4>, dim3(1), dim3(1024), sizeof(double) * 2 * n, s, n, dRt, du, (const LmState *)nullptr, -1);
     } else {
         hipLaunchKernelGGL(k_bf_solve_upper_t, dim3(1), dim3(bs1), sizeof(double) * n, s, n, dRt, du, (const LmState *)nullptr, -1);
         hipLaunchKernelGGL(k_bf_downdate_rot, dim3(1), dim3(64), 0, s, n, du, dc, dinfo, (const LmState *)nullptr, -1);

@@ -227,13 +227,22 @@ void launch_dq_residual(nlh_handle *h, int nprob, int m, int n, const double *A,
                                const LmState *st, int want)
 {
     Timed t(h, NLH_K_DQ_RESIDUAL);
-    dim3 grid((m + RB - 1) / RB, nprob);
     size_t sh = sizeof(double) * (size_t)(n + 32);
     const bool vec2 = (m % 2 == 0) && ((((uintptr_t)A | (uintptr_t)b | (uintptr_t)f) & 15) == 0);
-    if (vec2)       // two rows per thread, 16-byte accesses; a block covers the same RB rows
-        hipLaunchKernelGGL(k_dq_residual2<RB / 2>, grid, dim3(RB / 2), sh, h->stream, m, n, A, b, gamma, x, f, part, st, want);
-    else
-        hipLaunchKernelGGL(k_dq_residual<RB>, grid, dim3(RB), sh, h->stream, m, n, A, b, gamma, x, f, part, st, want);
+    const int nblk = (m + RB - 1) / RB;
+    // the problem index rides in gridDim.y (65535 at most): more problems than that go in slices (the lock-step drivers
+    // slice their batches themselves; the stage-level and model entry points come here with whatever the caller has)
+    for (int p0 = 0; p0 < nprob; p0 += NLH_MAX_LOCKSTEP) {
+        const int cnt = std::min<int>(NLH_MAX_LOCKSTEP, nprob - p0);
+        dim3 grid(nblk, cnt);
+        const double *Ap = A + (size_t)p0 * m * n, *bp = b + (size_t)p0 * m, *xp = x + (size_t)p0 * n;
+        double *fp = f + (size_t)p0 * m, *pp = part ? part + (size_t)p0 * nblk * 2 : nullptr;
+        const LmState *sp = st ? st + p0 : nullptr;
+        if (vec2)       // two rows per thread, 16-byte accesses; a block covers the same RB rows
+            hipLaunchKernelGGL(k_dq_residual2<RB / 2>, grid, dim3(RB / 2), sh, h->stream, m, n, Ap, bp, gamma, xp, fp, pp, sp, want);
+        else
+            hipLaunchKernelGGL(k_dq_residual<RB>, grid, dim3(RB), sh, h->stream, m, n, Ap, bp, gamma, xp, fp, pp, sp, want);
+    }
 }
 
 void launch_dq_panel(nlh_handle *h, int nprob, int m, int n, const double *A, const double *b,

@@ -208,5 +208,11 @@ void print_status(int iter, int nfeval, int njaceval, double xnorm, double fnorm
 static const int32_t NLH_MAX_LOCKSTEP = 65535;
 int lockstep_slices(int32_t nprob, const std::function<int(int32_t, int32_t)> &run);         // run(first, count)
 
-static const int QN_MAX_N = 4096;      // k_qn_retri: 4 columns per thread at most
+static const int QN_MAX_N = 8192;      // k_qn_retri / k_bf_chol_*: 8 columns per thread at most (4 up to n = 4096)
+// eight columns per thread: beyond 4096 columns -- or, NLH_QN_FORCE_NC8 (tests), wherever the four-column instance would run
+static inline bool qn_nc8(int n)
+{
+    static const bool force = [] { const char *e = getenv("NLH_QN_FORCE_NC8"); return e && atoi(e) != 0; }();
+    return n > 4096 || force;
+}
 static const int QN_LDS_ROWS = 18000;  // up to here k_qn_house_dot keeps the reflector (rows doubles) in LDS; beyond: in global memory

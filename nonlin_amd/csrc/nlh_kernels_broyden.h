@@ -982,6 +982,7 @@ static void broyden_kernel_attrs(int lds_max)
     hipFuncSetAttribute((const void *)k_qn_hess_r, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_retri<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_retri<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_qn_retri<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_solve_upper, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_qn_resid, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
 }

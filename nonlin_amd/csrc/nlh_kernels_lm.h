@@ -406,17 +406,20 @@ __global__ void __launch_bounds__(1024)
 k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
         const double *__restrict__ wa4all, double *__restrict__ Wall /* [nprob][m*n] scratch */,
         const double *__restrict__ Jall, double *__restrict__ W2all /* [nprob][n*n] scratch */,
-        LmState *__restrict__ st, int want_stage)
-{
+        LmState *__restrict__ st, int want_stage, double *__restrict__ gv = nullptr)
+{   // gv: [nprob][6 n + 8] doubles of global memory for lmpar's n-vectors when they do not fit LDS (n > 3000; the
+    // reference allocates for any n, src/nonlin_least_squares.f90:199-208): the same code through other pointers --
+    // a workgroup's barriers order its own global accesses -- at L2 instead of LDS latency
     extern __shared__ double smem[];
     const int p = blockIdx.x;
     LmState *s = st + p;
     if (s->stage != want_stage) return;
     const int tid = threadIdx.x, BS = blockDim.x;
-    double *xs = smem, *sdiag = smem + n, *wa1 = smem + 2 * n, *wa2n = smem + 3 * n, *z = smem + 4 * n;
-    double *red = smem + 5 * n;
-    double *rot = red + 64;             // n + 8
-    double *scratch = rot + n + 8;
+    double *nv = gv ? gv + (size_t)p * (6 * (size_t)n + 8) : smem;
+    double *xs = nv, *sdiag = nv + n, *wa1 = nv + 2 * n, *wa2n = nv + 3 * n, *z = nv + 4 * n;
+    double *rot = nv + 5 * n;           // n + 8
+    double *red = gv ? smem : nv + 6 * n + 8;
+    double *scratch = red + 64;
     double *R = Rall + (size_t)p * n * n;
     const int32_t *ipvt = v.ipvt + (size_t)p * n;
     const double *diag = v.diag + (size_t)p * n;

@@ -176,6 +176,10 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
     return 0;
 }
 
+// up to here k_lmpar's six n-vectors (+ the exact reductions' scratch) fit 158 KB of LDS (NLH_LM_LDS_MAX_N: a smaller bound,
+// so that tests reach the global-memory form at sizes the CPU oracle finishes in seconds)
+static const int LM_LDS_MAX_N = [] { const char *e = getenv("NLH_LM_LDS_MAX_N"); const int v = e ? atoi(e) : 3000; return v < 3000 ? v : 3000; }();
+
 struct LmWs {
     double *J, *P, *wa4, *scratch, *G, *g, *part, *W2, *R;
     LmVecs v;
@@ -245,8 +249,15 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
             // 3,585 LM it/s for one lock-step batch of 2048 x 4096x256, 3,681 -> 3,511 with sub-batches; 47 x 4096x256 153.5 ->
             // 155.7 ms.  docs/lab_notebook.md.)
             Timed t(h, NLH_K_LMPAR);
-            hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(ft), shl + sizeof(double) * (3 * NLH_NCH + 8),
-                               h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY);
+            if (n <= LM_LDS_MAX_N)
+                hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(ft), shl + sizeof(double) * (3 * NLH_NCH + 8),
+                                   h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY, (double *)nullptr);
+            else {                                              // lmpar's n-vectors in global memory (the misc buffer)
+                int rc2;
+                if ((rc2 = ensure(h, h->misc, sizeof(double) * (size_t)nprob * (6 * (size_t)n + 8)))) return rc2;
+                hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(ft), sizeof(double) * (size_t)(64 + 3 * NLH_NCH + 8),
+                                   h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY, (double *)h->misc.p);
+            }
         }
         return 0;
     }
@@ -346,7 +357,9 @@ static int check_opts_lm(const nlh_options *o, int m, int n)
     if (!o) return NLH_INVALID_INPUT_ERROR;
     if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;          // :189
     if (n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
-    if (n > 3000) return NLH_ARRAY_SIZE_ERROR;                 // LDS-resident n-vectors
+    // the normal-equations and tree-reduced QR policies keep n-vectors in LDS; the exact policy (the default) moves
+    // lmpar's to global memory beyond that and takes any n
+    if (n > LM_LDS_MAX_N && o->factor_policy != NLH_FACTOR_EXACT) return NLH_ARRAY_SIZE_ERROR;
     return 0;
 }
 

@@ -284,6 +284,7 @@ int nlh_dq_model_eval(nlh_handle *h, const nlh_dq_model *md, const double *x, do
     return model_run(h, md, const_cast<double *>(x), false, f, nullptr, nullptr,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *, int32_t *) -> int {
                          launch_dq_residual(ph, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma, pt.dx, pt.df, nullptr, nullptr, -1);
+                         HIPCHK(ph, hipGetLastError());          // a launch that failed must not return stale residuals as success
                          return 0;
                      });
 }
@@ -377,6 +378,7 @@ int nlh_dq_model_bfgs_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mo
                          if (fout)
                              for (int i = 0; i < pt.cnt; ++i) fout[(size_t)pt.first + (size_t)i * pt.stride] = fo[i];
                          launch_dq_residual(ph, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma, pt.dx, pt.df, nullptr, nullptr, -1);
+                         HIPCHK(ph, hipGetLastError());
                          return 0;
                      });
 }

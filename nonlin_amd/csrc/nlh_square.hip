@@ -93,15 +93,17 @@ static void lu_blocked(nlh_handle *h, int nprob, int n, double *dA, int32_t *dip
 void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipvt, int32_t *dinfo,
                              const LmState *st, int want)
 {
+    static const int panel_env = [] { const char *e = getenv("NLH_LU_PANEL"); return e ? atoi(e) : 1; }();
+    int panel_mode = panel_env;
+    // the move lists of the register panel: allocated BEFORE the timed bracket and the first launch (growing a workspace
+    // frees the old one, a device-wide synchronisation).  Without the memory the global-memory panel serves: say nothing
+    if (n >= 128 && panel_mode >= 1 && ensure(h, h->lumv, sizeof(int32_t) * LU_MV_STRIDE * (size_t)nprob)) { panel_mode = 0; h->err.clear(); }
     Timed t(h, NLH_K_LU);
     if (n < 128) {
         hipLaunchKernelGGL(k_lu_factor, dim3(nprob), dim3(n >= 96 ? 1024 : 256), 0, h->stream, n, dA, dipvt, dinfo, st, want);
         return;
     }
     if (dinfo) hipMemsetAsync(dinfo, 0, sizeof(int32_t) * (size_t)nprob, h->stream);
-    static const int panel_env = [] { const char *e = getenv("NLH_LU_PANEL"); return e ? atoi(e) : 1; }();
-    int panel_mode = panel_env;
-    if (panel_mode >= 1 && ensure(h, h->lumv, sizeof(int32_t) * LU_MV_STRIDE * (size_t)nprob)) panel_mode = 0;   // (no memory for the move lists)
     // panels factored in registers while they have at most 2048 rows (several rows per thread, implicit interchanges),
     // 32-column panels in global memory before
     // NLH_LU_CONTRACT=1 (measurement only): the same kernels with every multiply-subtract pair contracted
@@ -369,6 +371,8 @@ static void launch_qn_update(nlh_handle *h, int nprob, int n, double *dQ, double
     if (n <= 1024) {
         const int bs = std::min(1024, ((n + 63) / 64) * 64);
         hipLaunchKernelGGL(k_qn_retri<1>, dim3(nprob), dim3(bs), sizeof(double) * 2 * n, s, n, dRt, dc, dsn, gst, gwant);
+    } else if (qn_nc8(n)) {
+        hipLaunchKernelGGL(k_qn_retri<8>, dim3(nprob), dim3(1024), sizeof(double) * 2 * n, s, n, dRt, dc, dsn, gst, gwant);
     } else {
         hipLaunchKernelGGL(k_qn_retri<4>, dim3(nprob), dim3(1024), sizeof(double) * 2 * n, s, n, dRt, dc, dsn, gst, gwant);
     }

@@ -376,6 +376,16 @@ void nlo_lmpar(int32_t m, int32_t n, double *r, int32_t ldr, const int32_t *ipvt
 /* ---------------------------------------------------------------------------
  * lss_solve (MINPACK lmdif, mode-1 scaling): src/nonlin_least_squares.f90:118-391
  * ------------------------------------------------------------------------- */
+/* TEST-ONLY switch (tests/golden/make_fast_policy_study.py): replaces lmfactor (:225) and the Q^T f sweep (:241-253) of
+ * lss_solve by a caller-supplied factorisation, so that the study "can ANY factorisation other than the reference's own
+ * operation order meet 1e-10 on these problem families?" runs the rest of the reference's iteration unchanged.  The hook
+ * receives J (column-major, lda = m) and f and must leave: the n x n upper triangle of jac = R (diagonal included), jpvt
+ * (0-based), rdiag = diag(R), acnorm = the column norms of J, qtf (n), and wa4 (m) with wa4(0:n) = qtf and a tail whose
+ * norm is ||(Q^T f)(n+1:m)|| (deviation A reads it).  Never set by anything the product or the parity tests run. */
+static nlo_factor_hook g_factor_hook = NULL;
+static void *g_factor_hook_ctx = NULL;
+void nlo_set_factor_hook(nlo_factor_hook hook, void *hctx) { g_factor_hook = hook; g_factor_hook_ctx = hctx; }
+
 int nlo_lm_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_null,
                  void *ctx, int32_t m, int32_t n, double *x, double *fvec,
                  nlo_iteration_behavior *ib)
@@ -411,6 +421,8 @@ int nlo_lm_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_null,
         nlo_fd_jacobian(fcn, jac_or_null, ctx, m, n, x, fvec, jac);   /* :221 */
         njac = njac + 1;
 
+        if (g_factor_hook) g_factor_hook(g_factor_hook_ctx, m, n, jac, m, fvec, jpvt, wa1, wa2, qtf, wa4);   /* test-only, see above */
+        else
         nlo_lmfactor(m, n, jac, m, 1, jpvt, wa1, wa2, wa3);  /* :225 */
 
         if (iter == 1) {                                     /* :229-238 */
@@ -424,6 +436,7 @@ int nlo_lm_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_null,
             if (delta == 0.0) delta = fac;
         }
 
+        if (!g_factor_hook) {
         memcpy(wa4, fvec, sizeof(double) * (size_t)m);       /* :241-253 */
         for (int32_t j = 0; j < n; ++j) {
             if (A_(jac, m, j, j) != 0.0) {
@@ -434,6 +447,7 @@ int nlo_lm_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_null,
             }
             A_(jac, m, j, j) = wa1[j];
             qtf[j] = wa4[j];
+        }
         }
 
         gnorm = 0.0;                                         /* :256-267 */

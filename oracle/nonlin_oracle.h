@@ -119,6 +119,12 @@ int nlo_lm_solve(const nlo_options *opt, nlo_vecfcn fcn, nlo_jacfcn jac_or_null,
                  void *ctx, int32_t m, int32_t n, double *x, double *fvec,
                  nlo_iteration_behavior *ib);
 
+/* TEST-ONLY: a caller-supplied factorisation in place of lmfactor + Q^T f inside nlo_lm_solve (NULL restores the
+ * reference's).  See nonlin_oracle.c; used by tests/golden/make_fast_policy_study.py and nothing else. */
+typedef void (*nlo_factor_hook)(void *hctx, int32_t m, int32_t n, double *jac, int32_t lda, const double *fvec,
+                                int32_t *jpvt, double *rdiag, double *acnorm, double *qtf, double *wa4);
+void nlo_set_factor_hook(nlo_factor_hook hook, void *hctx);
+
 /* Partial-pivot LU stand-in for linalg's lu_factor/solve_lu
  * (call sites src/nonlin_solve.f90:570,577).  PARITY-UNPINNED. */
 int  nlo_lu_factor(int32_t n, double *a, int32_t lda, int32_t *ipvt);

@@ -33,3 +33,24 @@ void dq_user_fcn(void *ctx, int32_t n, const double *x, int32_t m, double *f)
     }
     for (int32_t i = 0; i < m; ++i) f[i] = (u[i] + c->gamma * u[i] * u[i]) - c->b[i];
 }
+
+/* The analytic Jacobian of the same family as a compiled jacobianfcn (src/nonlin_multi_eqn_mult_var.f90:27-38; C shape
+ * nlh_jacfcn): jac(i,j) = (1 + 2 gamma u_i) A(i,j), column-major with leading dimension m -- BASELINE config 3's
+ * "analytic Jacobian callback" taken literally (newton_solver, n = 1024: 8 MB per call, host to device every iteration). */
+void dq_user_jac(void *ctx, int32_t n, const double *x, int32_t m, double *jac)
+{
+    dq_user_ctx *c = (dq_user_ctx *)ctx;
+    double *u = c->u;
+    for (int32_t i = 0; i < m; ++i) u[i] = 0.0;
+    for (int32_t j = 0; j < n; ++j) {
+        const double xj = x[j];
+        const double *col = c->A + (size_t)j * (size_t)m;
+        for (int32_t i = 0; i < m; ++i) u[i] = u[i] + col[i] * xj;
+    }
+    for (int32_t i = 0; i < m; ++i) u[i] = 1.0 + 2.0 * c->gamma * u[i];
+    for (int32_t j = 0; j < n; ++j) {
+        const double *col = c->A + (size_t)j * (size_t)m;
+        double *out = jac + (size_t)j * (size_t)m;
+        for (int32_t i = 0; i < m; ++i) out[i] = u[i] * col[i];
+    }
+}

@@ -2,6 +2,7 @@
 square least-squares systems, start points with exact zeros, a start point that is already a solution, bounds that
 pin every variable, and the error codes of the C ABI."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -157,3 +158,106 @@ def test_full_size_c5_fd_jacobian_columns_bit_exact(ds, oracle):
         xp[j] = xp[j] + hj
         col = (oracle.dq_residual(Ah, bh, 0.5, xp) - f0h) / hj
         assert np.array_equal(J[0, j].cpu().numpy(), col), j
+
+
+# ---- sizes beyond what fits LDS / four columns per thread (round 5: the reference allocates for any n,
+# src/nonlin_least_squares.f90:199-208) -----------------------------------------------------------------------------------
+def _run_py(code, env):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=e,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+_LM_GLOBAL_VECS = '''
+import numpy as np, sys
+sys.path.insert(0, "tests")
+from nonlin_amd.device import DeviceSolver
+from oracle import pyoracle as O
+ds = DeviceSolver(0)
+for m, n, gen, opt in ((300, 37, dict(gamma=2.0, sigma=0.1, spread=5.0), dict(factor=0.1)), (512, 64, {}, {}), (256, 32, dict(gamma=10.0, sigma=1.0, spread=50.0), dict(factor=0.1))):
+    A, b, xt, x0 = ds.generate(3, m, n, seed0=12345, **gen)
+    x = x0.clone()
+    f, ibs, st = ds.lm_solve_batch(A, b, gen.get("gamma", 0.5), x, ds.options(max_evals=500, **opt))
+    for p in range(3):
+        rc, xo, fo, ibo = O.dq_lm_solve(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), gen.get("gamma", 0.5), x0[p].cpu().numpy(),
+                                        opts=O.default_options(max_evals=500, **opt))[:4]
+        assert st[p] == rc and all(ibs[p][k] == ibo[k] for k in ("iter_count", "fcn_count", "jacobian_count")), (p, ibs[p], ibo)
+        assert np.array_equal(x[p].cpu().numpy(), xo) and np.array_equal(f[p].cpu().numpy(), fo)
+print("ok")
+'''
+
+
+@pytest.mark.gpu
+def test_lmpar_with_its_vectors_in_global_memory_is_bitwise():
+    """The form k_lmpar takes beyond n = 3000 (lmpar's n-vectors in global memory instead of LDS), forced at sizes the oracle
+    finishes in seconds (NLH_LM_LDS_MAX_N=16), trust-region-binding families included: x, fvec, counts bit for bit."""
+    assert "ok" in _run_py(_LM_GLOBAL_VECS, {"NLH_LM_LDS_MAX_N": "16"})
+
+
+@pytest.mark.gpu
+def test_least_squares_beyond_3000_columns(ds, oracle):
+    """n = 3008 > the LDS bound, m = 3040: a linear zero-residual problem (gamma = 0, sigma = 0) -- one Jacobian, one
+    factorisation of 3008 Householder steps, converged after the first step -- bit for bit against the oracle."""
+    m, n = 3040, 3008
+    A, b, xt, x0 = ds.generate(1, m, n, seed0=99, gamma=0.0, sigma=0.0, spread=0.1)
+    x = x0.clone()
+    f, ibs, st = ds.lm_solve_batch(A, b, 0.0, x, ds.options(max_evals=50))
+    rc, xo, fo, ibo = oracle.dq_lm_solve(np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), 0.0, x0[0].cpu().numpy(),
+                                         opts=oracle.default_options(max_evals=50))[:4]
+    assert st[0] == rc == 0
+    assert all(ibs[0][k] == ibo[k] for k in ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn", "converge_on_chng"))
+    assert np.array_equal(x[0].cpu().numpy(), xo) and np.array_equal(f[0].cpu().numpy(), fo)
+
+
+_QN_NC8 = '''
+import numpy as np, sys
+from nonlin_amd.device import DeviceSolver
+from oracle import pyoracle as O
+ds = DeviceSolver(0)
+n = 1100                                                          # > 1024: the several-columns-per-thread instances
+A, b, xt, x0 = ds.generate(2, n, n, seed0=12345, sigma=0.0, spread=0.03, square_shift=True)
+x = x0.clone()
+f, ibs, st = ds.quasi_newton_solve_batch(A, b, 0.5, x, analytic=True, opts=ds.options(max_evals=500))
+for p in range(2):
+    rc, xo, fo, ibo = O.dq_quasi_newton_solve(np.asfortranarray(A[p].cpu().numpy().T), b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy(), analytic=True,
+                                              opts=O.default_options(max_evals=500))[:4]
+    assert st[p] == rc and all(ibs[p][k] == ibo[k] for k in ("iter_count", "fcn_count", "jacobian_count")), (ibs[p], ibo)
+    assert np.array_equal(x[p].cpu().numpy(), xo)
+m, nb = 1300, 1100
+A, b, xt, x0 = ds.generate(1, m, nb, seed0=77, spread=0.1)
+x = x0.clone()
+fo_g, ibs, st = ds.bfgs_solve_batch(A, b, 0.5, x, ds.options(max_evals=60, gtol=1e-8, xtol=1e-12))
+rc, xo, fo, ibo = O.dq_bfgs_solve(np.asfortranarray(A[0].cpu().numpy().T), b[0].cpu().numpy(), 0.5, x0[0].cpu().numpy(),
+                                  opts=O.default_options(max_evals=60, gtol=1e-8, xtol=1e-12))[:4]
+assert st[0] == rc and ibs[0]["iter_count"] == ibo["iter_count"] and ibs[0]["fcn_count"] == ibo["fcn_count"], (ibs[0], ibo)
+assert np.array_equal(x[0].cpu().numpy(), xo)
+print("ok")
+'''
+
+
+@pytest.mark.gpu
+def test_eight_columns_per_thread_instances_are_bitwise():
+    """The rotation / Cholesky-update kernels' instance for n in (4096, 8192] (eight columns per thread), forced at
+    n = 1100 (NLH_QN_FORCE_NC8=1) where the oracle is affordable: quasi-Newton and BFGS bit for bit."""
+    assert "ok" in _run_py(_QN_NC8, {"NLH_QN_FORCE_NC8": "1"})
+
+
+@pytest.mark.gpu
+def test_quasi_newton_beyond_4096_unknowns(ds):
+    """n = 5000 Broyden: no oracle at this size (its O(n^3) QR with Q formed takes minutes); the solve must converge on the
+    function values, the residual evaluated independently at the returned x must be what the solver reports, and x must be a
+    root next to the one the problem was generated from (sigma = 0: F(x_true) = 0, start 2 % away; every equation is
+    quadratic in u_i = (A x)_i, so rows with 1 + u_i near 0 have a second root |2 (1 + u_i)| away -- not the same x to 1e-8)."""
+    n = 5000
+    A, b, xt, x0 = ds.generate(1, n, n, seed0=5, sigma=0.0, spread=0.02, square_shift=True)
+    x = x0.clone()
+    f, ibs, st = ds.quasi_newton_solve_batch(A, b, 0.5, x, analytic=True, opts=ds.options(max_evals=500))
+    assert st[0] == 0 and ibs[0]["converge_on_fcn"] == 1
+    assert float(f.abs().max()) < 1e-8
+    assert torch.equal(ds.residual(A, b, 0.5, x), f)
+    assert float((x - xt).abs().max()) < 1e-2

@@ -38,7 +38,7 @@ def test_compiled_callback_is_the_oracle_residual(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,n,kw,factor", [(512, 64, {}, 100.0), (300, 37, dict(gamma=2.0, sigma=0.1, spread=5.0), 0.1),
-                                           (2100, 40, {}, 100.0)])
+                                           (2100, 40, {}, 100.0), (4096, 256, {}, 100.0)])   # the last: BASELINE config 2, full size
 def test_lm_solve_with_compiled_host_callback_bitwise(ds, oracle, m, n, kw, factor):
     from nonlin_amd import _lib
     cb = _cb()
@@ -63,3 +63,34 @@ def test_lm_solve_with_compiled_host_callback_bitwise(ds, oracle, m, n, kw, fact
     assert ib.as_dict() == ibo.as_dict()
     assert calls == int(ctx.ncalls) == ib.fcn_count + n * ib.jacobian_count      # n + 1 evaluations per Jacobian, none extra
     assert np.array_equal(x, xo) and np.array_equal(f, fo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 1024])
+def test_newton_solve_with_compiled_jacobian_callback_bitwise(ds, oracle, n):
+    """BASELINE config 3 taken literally: newton_solver through nlh_newton_solve with a COMPILED vecfcn AND a compiled
+    analytic jacobianfcn (n = 1024: the 8 MB Jacobian crosses PCIe every iteration), line search on.  The oracle drives the
+    same two callbacks; x, fvec, counts and flags must be the same bits, and the callbacks must have been called exactly
+    as often (fcn_count evaluations; one Jacobian per iteration plus the reference's uncounted one at :535)."""
+    from nonlin_amd import _lib
+    cb = _cb()
+    dp = C.POINTER(C.c_double)
+    A, b, xt, x0 = oracle.dq_generate(12345, n, n, sigma=0.0, square_shift=True)
+    u = np.zeros(n)
+    ctx = Ctx(n, n, A.ctypes.data_as(dp), b.ctypes.data_as(dp), 0.5, 0, u.ctypes.data_as(dp))
+    og = _lib.default_options()
+    og.max_evals = 500
+    x, f, ib = x0.copy(), np.zeros(n), _lib.IterationBehavior()
+    rc = ds.lib.nlh_newton_solve(ds.h.ptr, C.byref(og), n, C.cast(cb.dq_user_fcn, _lib.VECFCN), C.cast(cb.dq_user_jac, _lib.JACFCN),
+                                 C.byref(ctx), x.ctypes.data_as(dp), f.ctypes.data_as(dp), C.byref(ib))
+    calls = int(ctx.ncalls)
+    oo = oracle.default_options(max_evals=500)
+    xo, fo, ibo = x0.copy(), np.zeros(n), oracle.IterationBehavior()
+    ctx.ncalls = 0
+    rco = oracle.lib().nlo_newton_solve(C.byref(oo), C.cast(cb.dq_user_fcn, oracle.VECFCN), C.cast(cb.dq_user_jac, oracle.JACFCN),
+                                        C.byref(ctx), n, xo.ctypes.data_as(dp), fo.ctypes.data_as(dp), C.byref(ibo))
+    assert rc == rco == 0
+    assert ib.as_dict() == ibo.as_dict()
+    assert calls == int(ctx.ncalls) == ib.fcn_count
+    assert np.array_equal(x, xo) and np.array_equal(f, fo)
+    assert ib.jacobian_count >= 2
