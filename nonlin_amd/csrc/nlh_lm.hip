@@ -177,7 +177,7 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
 }
 
 // up to here k_lmpar's six n-vectors (+ the exact reductions' scratch) fit 158 KB of LDS (NLH_LM_LDS_MAX_N: a smaller bound,
-// so that tests reach the global-memory form at sizes the CPU oracle finishes in seconds)
+// so that tests reach the global-memory form at small sizes)
 static const int LM_LDS_MAX_N = [] { const char *e = getenv("NLH_LM_LDS_MAX_N"); const int v = e ? atoi(e) : 3000; return v < 3000 ? v : 3000; }();
 
 struct LmWs {
