@@ -331,7 +331,7 @@ def other_paths(ds):
         ro, tc = cpu(lambda: csolve(Ah, bh, 0.5, xh, opts=O.default_options(max_evals=500)))
         row = {"path": name, "gpu_ms": 1e3 * tg, "cpu_oracle_ms": 1e3 * tc, "iterations": ibs[0]["iter_count"],
                "bitwise_equal": bool(np.array_equal(ro[1], xg[0][0].cpu().numpy()))}
-        if "newton_solver" in name:
+        if name.startswith("newton_solver"):
             row.update(lapack_priced(O, Ah, bh, xh, 1e3 * tc, ibs[0]["jacobian_count"], 1e3 * tg))
         rows.append(row)
     # a BATCH of Newton problems: the lock-step device state machine (nlh_kernels_newton.h); CPU: the first 8 on one core
@@ -911,6 +911,19 @@ def main():
                 "avg_launch_ms": roof_ms / max(roof_launches, 1),
             },
         }
+        if args.policy == 2:
+            # The builder's own ceiling beside the spec peak: what the memory system delivers for THIS traffic shape, from the
+            # stream microbenchmarks (profiles/ubench/rw_stream.hip, numbers in profiles/r04_ubench.txt: a read-only stream in
+            # the pass's access shape 6,068 GB/s; read + write in place with contiguous stores 5,018 GB/s).  Of QRX_C = 10
+            # consecutive passes nine only read the trailing matrices and one reads and rewrites them, so 10 X algorithmic
+            # bytes cost at best 9 X / 6068 + 2 X / 5018 seconds.
+            rd, rw, per = 6068.0, 5018.0, 10
+            ach_peak = per / ((per - 1) / rd + 2.0 / rw)
+            out["roofline"]["achievable_peak"] = ach_peak
+            out["roofline"]["frac_of_achievable"] = achieved / ach_peak
+            out["roofline"]["achievable_note"] = ("measured stream rates on this part for the pass's traffic mix (nine read-only passes at "
+                                                  "6,068 GB/s, one read + write pass at 5,018 GB/s per flush period of ten): the ceiling of "
+                                                  "this DESIGN, not of the chip; `frac` against the 8 TB/s spec stays the headline fraction")
         if args.policy == 2 and roof_samples and len(roof_samples) % (n * args.steps) == 0:
             # A step is a sequence of lock-step rounds of n launches each; in the first round of a step every problem of
             # the batch is active (later rounds serve ever fewer problems and are bound by the serial row recurrences of

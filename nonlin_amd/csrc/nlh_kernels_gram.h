@@ -185,7 +185,7 @@ k_gram_mfma(int m, int n, int rows_per_split, const double *__restrict__ J,
             for (int r = 0; r < 4; ++r) {
                 const int gr = bi * GRAM_BT + (a == 0 ? ai0 : ai1) * 16 + (lane >> 4) + 4 * r;   // A-side column of J
                 const int gc = bj * GRAM_BT + (c == 0 ? bt0 : bt1) * 16 + (lane & 15);           // B-side column of J
-                if (gr < n && gc < n) Gp[(size_t)gc * n + gr] = acc[a][c][r];
+                if (gr < n && gc < n) Gp[(size_t)gr * n + gc] = acc[a][c][r];     // ROW-major slab: see k_gram_reduce
             }
         }
 }
@@ -283,7 +283,7 @@ __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, 
         for (int r = 0; r < 4; ++r) {
             const int gr = RL * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
             if (gr < n && gcol < n) {
-                if (!direct) Gp[(size_t)gcol * ldg + gr] = accL[c][r];
+                if (!direct) Gp[(size_t)gr * ldg + gcol] = accL[c][r];           // (slab: row-major, k_gram_reduce)
                 else if (gr >= gcol) { Gp[(size_t)gcol * ldg + gr] = accL[c][r]; Gp[(size_t)gr * ldg + gcol] = accL[c][r]; }
             }
         }
@@ -293,7 +293,7 @@ __device__ __forceinline__ void gram_tri_wave(double *tA, double *fs, int kbeg, 
         for (int r = 0; r < 4; ++r) {
             const int gr = RS * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
             if (gr < n && gcol < n) {
-                if (!direct) Gp[(size_t)gcol * ldg + gr] = accS[c][r];
+                if (!direct) Gp[(size_t)gr * ldg + gcol] = accS[c][r];
                 else if (gr >= gcol) { Gp[(size_t)gcol * ldg + gr] = accS[c][r]; Gp[(size_t)gr * ldg + gcol] = accS[c][r]; }
             }
         }
@@ -351,28 +351,186 @@ k_gram_tri(int m, int n, int rows_per_split, const double *__restrict__ J, doubl
 // 64 x 64 blocks stage it 9 times, and a barrier pair covers 128-136 MFMAs per wave instead of 32.
 // Same accumulation order (rows ascending inside a split, splits summed by k_gram_reduce), same slabs: bitwise the same
 // G and g as k_gram_mfma.
-template <int W>      // wave index
-__device__ __forceinline__ void gram_sq_wave(double *tB, double *tA, int kbeg, int kend, int m, int nA, const double *JpB,
-                                             const double *JpA, double *Gp, int ldg)
+// ---------------------------------------------------------------------------------------------
+// Round 5: the two wave bodies of k_gram_512 with DOUBLE-BUFFERED 16-row tiles and ONE barrier per tile.
+// With one 512-thread workgroup per CU (BASELINE config 5: 64 K-splits x 4 units = 256 workgroups) nothing hides a
+// barrier: all eight waves -- both waves of every SIMD -- leave it together, write the next tile, issue their loads and
+// wait for their first operands at the same moment, and the MFMA pipe idles meanwhile (362 us for 232 us of MFMA time).
+// Here the tile being multiplied and the tile being written are different buffers: the LDS writes of tile t + 1 and the
+// global loads of tile t + 2 are issued in the middle of the MFMA phase of tile t, and the one barrier at the end of the
+// phase both publishes tile t + 1 and retires tile t.  Rows are still accumulated in ascending groups of four inside a
+// split and g = J^T f keeps its four partial sums per column (rows mod 32 in [0,8), [8,16), [16,24), [24,32)): the same
+// bits as the single-buffered bodies and as k_gram_mfma.
+#define GRAM_KT2 16
+#define GRAM_LD2 (GRAM_KT2 + 2)
+template <int W>
+__device__ __forceinline__ void gram_tri_wave_db(double *tA0, double *fs0, int kbeg, int kend, int m, int n, const double *Jp,
+                                                 const double *fp, double *Gp, double *gout, double *gscr, int ldg)
 {
-    // B side: panel 0, 256 columns (tile columns 0..15); A side: this unit's 128 columns of panel 1 (8 tile rows, nA valid)
-    constexpr int RP = W >> 1, CH = W & 1;                           // tile rows 2 RP, 2 RP + 1; tile columns 8 CH .. 8 CH + 7
+    constexpr int NT = 16, NL = NT - W, NS = W + 1, RL = NT - 1 - W, RS = W;
+    constexpr int NTH = 512, TN = 256;
+    constexpr int TSZ = TN * GRAM_LD2;                               // doubles per tile buffer
+    double *tA1 = tA0 + TSZ;
+    (void)fs0; (void)gscr;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int lr = tid % GRAM_KT, lc0 = tid / GRAM_KT;                // loader: row lr, columns lc0 + 16 cc
-    constexpr int LSTEP = 512 / GRAM_KT, NLB = 256 / LSTEP, NLA = 128 / LSTEP;
+    const int lr = tid % GRAM_KT2, lc0 = tid / GRAM_KT2;             // loader: row lr, columns lc0 + 32 cc
+    constexpr int LSTEP = NTH / GRAM_KT2, NLD = TN / LSTEP;
+    v4d accL[NL], accS[NS];
+#pragma unroll
+    for (int c = 0; c < NL; ++c) accL[c] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < NS; ++c) accS[c] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int lrow = (lane & 15) * GRAM_LD2 + (lane >> 4);
+    // (Loads stay under their conditions: made unconditional through clamped addresses with the value selected afterwards,
+    // the compiler placed each select -- and a wait for its load -- right behind the load: 350 -> 388 us.)
+    // Whole tiles and a whole panel (uniform for the workgroup: every split of BASELINE config 5): plain loads, nothing to select.
+    double ra[NLD], rf = 0.0;
+    const bool whole = ((kend - kbeg) % GRAM_KT2 == 0) && n == TN;
+    const double *c0p = Jp + (size_t)lc0 * m + lr;
+    auto load_tile = [&](int k0) {
+        if (whole) {
+#pragma unroll
+            for (int cc = 0; cc < NLD; ++cc) ra[cc] = c0p[(size_t)(LSTEP * cc) * m + k0];
+            if (fp) rf = fp[k0 + lr];
+            return;
+        }
+        const int row = k0 + lr;
+        const bool rok = row < kend;
+#pragma unroll
+        for (int cc = 0; cc < NLD; ++cc) {
+            const int col = lc0 + LSTEP * cc;
+            ra[cc] = (rok && col < n) ? Jp[(size_t)col * m + row] : 0.0;
+        }
+        if (fp) rf = rok ? fp[row] : 0.0;
+    };
+    auto put_tile = [&](double *t) {
+#pragma unroll
+        for (int cc = 0; cc < NLD; ++cc) t[(lc0 + LSTEP * cc) * GRAM_LD2 + lr] = ra[cc];
+    };
+    // g = J^T f out of the loader's registers: thread (row lr, its NLD columns) adds J(row, col) * f(row) for its rows
+    // lr, lr + 16, ... of the split in ascending order -- no LDS traffic, eight multiply / add pairs per tile -- and the
+    // sixteen row classes of a column are added in ascending lr at the end (sixteen partial sums per column and split where
+    // k_gram_mfma keeps four: the same g to rounding, not to the bit; G is unaffected).
+    double gacc[NLD];
+#pragma unroll
+    for (int cc = 0; cc < NLD; ++cc) gacc[cc] = 0.0;
+    auto g_tile = [&]() {
+#pragma unroll
+        for (int cc = 0; cc < NLD; ++cc) gacc[cc] = gacc[cc] + ra[cc] * rf;
+    };
+    const int nst = (kend - kbeg + GRAM_KT2 - 1) / GRAM_KT2;
+    if (nst > 0) { load_tile(kbeg); put_tile(tA0); if (fp) g_tile(); }
+    if (nst > 1) load_tile(kbeg + GRAM_KT2);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        double *cur = (st & 1) ? tA1 : tA0, *nxt = (st & 1) ? tA0 : tA1;
+        const unsigned baddr = (unsigned)(size_t)(cur + lrow);
+        const unsigned aaddrL = (unsigned)(size_t)(cur + RL * 16 * GRAM_LD2 + lrow);
+        const unsigned aaddrS = (unsigned)(size_t)(cur + RS * 16 * GRAM_LD2 + lrow);
+#pragma unroll
+        for (int ks = 0; ks < GRAM_KT2 / 4; ++ks) {
+            double aL, aS, b[NL];
+            asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4"
+                         : "=&v"(aL), "=&v"(aS) : "v"(aaddrL), "v"(aaddrS), "n"(ks * 32) : "memory");
+#pragma unroll
+            for (int c = 0; c < NL; ++c)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(b[c]) : "v"(baddr), "n"(c * 16 * GRAM_LD2 * 8 + ks * 32) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aL), "+v"(aS));
+#pragma unroll
+            for (int c = 0; c < NL; ++c) asm volatile("" : "+v"(b[c]));
+#pragma unroll
+            for (int c = 0; c < NL; ++c) {
+                accL[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL, b[c], accL[c], 0, 0, 0);
+                if (c < NS) accS[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS, b[c], accS[c], 0, 0, 0);
+            }
+#ifndef GRAM_DBG_NOLOAD
+            if (ks == 0 && st + 1 < nst) {                          // in the shadow of this tile's MFMAs: the next tile ...
+                put_tile(nxt);
+#ifndef GRAM_DBG_NOG
+                if (fp) g_tile();
+#endif
+            }
+            if (ks == 1 && st + 2 < nst) load_tile(kbeg + (st + 2) * GRAM_KT2);   // ... and the loads of the one after
+#endif
+        }
+#ifndef GRAM_DBG_NOBAR
+        __syncthreads();
+#endif
+    }
+    if (fp) {                                                       // the sixteen row classes of every column, ascending
+        double *gs = tA0;                                           // (both tile buffers are free: the loop ended on a barrier)
+#pragma unroll
+        for (int cc = 0; cc < NLD; ++cc) gs[(lc0 + LSTEP * cc) * GRAM_KT2 + lr] = gacc[cc];
+        __syncthreads();
+        if (tid < TN && tid < n) {
+            double sg = 0.0;
+#pragma unroll
+            for (int i = 0; i < GRAM_KT2; ++i) sg = sg + gs[tid * GRAM_KT2 + i];
+            gout[tid] = sg;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NL; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = RL * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
+            if (gr < n && gcol < n) Gp[(size_t)gr * ldg + gcol] = accL[c][r];
+        }
+#pragma unroll
+    for (int c = 0; c < NS; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = RS * 16 + (lane >> 4) + 4 * r, gcol = c * 16 + (lane & 15);
+            if (gr < n && gcol < n) Gp[(size_t)gr * ldg + gcol] = accS[c][r];
+        }
+}
+
+template <int W>
+__device__ __forceinline__ void gram_sq_wave_db(double *tB0, int kbeg, int kend, int m, int nA, const double *JpB, const double *JpA,
+                                                double *Gp, int ldg, const double *fp, double *goutB, double *goutA)
+{   // fp != null: g = J^T f rides along HERE (the square units have 128 tiles to the triangle units' 136: the slack pays for it)
+    // out of the loader's registers -- goutB != null: for panel 0's 256 columns, goutA: for this unit's own columns
+    // one buffer = panel 0's 256 columns followed by this unit's 128 columns of panel 1
+    constexpr int RP = W >> 1, CH = W & 1;
+    constexpr int TSZ = 384 * GRAM_LD2;
+    double *tB1 = tB0 + TSZ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int lr = tid % GRAM_KT2, lc0 = tid / GRAM_KT2;
+    constexpr int LSTEP = 512 / GRAM_KT2, NLB = 256 / LSTEP, NLA = 128 / LSTEP;
     v4d acc[2][8];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[a][c] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int lrow = (lane & 15) * GRAM_LD + (lane >> 4);
-    const unsigned baddr = (unsigned)(size_t)(tB + CH * 8 * 16 * GRAM_LD + lrow);
-    const unsigned aaddr0 = (unsigned)(size_t)(tA + (2 * RP) * 16 * GRAM_LD + lrow);
-    const unsigned aaddr1 = (unsigned)(size_t)(tA + (2 * RP + 1) * 16 * GRAM_LD + lrow);
+    const int lrow = (lane & 15) * GRAM_LD2 + (lane >> 4);
     double rb[NLB], ra[NLA];
+    const bool whole = ((kend - kbeg) % GRAM_KT2 == 0) && nA == 128;
+    const double *b0p = JpB + (size_t)lc0 * m + lr, *a0p = JpA + (size_t)lc0 * m + lr;
+    double rf = 0.0, gaccB[NLB], gaccA[NLA];
+#pragma unroll
+    for (int cc = 0; cc < NLB; ++cc) gaccB[cc] = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < NLA; ++cc) gaccA[cc] = 0.0;
+    auto g_tile = [&]() {                                           // thread (row lr, its columns): rows lr, lr + 16, ... ascending
+        if (goutB) {
+#pragma unroll
+            for (int cc = 0; cc < NLB; ++cc) gaccB[cc] = gaccB[cc] + rb[cc] * rf;
+        }
+#pragma unroll
+        for (int cc = 0; cc < NLA; ++cc) gaccA[cc] = gaccA[cc] + ra[cc] * rf;
+    };
     auto load_tile = [&](int k0) {
+        if (whole) {                                                // (see the triangle body)
+#pragma unroll
+            for (int cc = 0; cc < NLB; ++cc) rb[cc] = b0p[(size_t)(LSTEP * cc) * m + k0];
+#pragma unroll
+            for (int cc = 0; cc < NLA; ++cc) ra[cc] = a0p[(size_t)(LSTEP * cc) * m + k0];
+            if (fp) rf = fp[k0 + lr];
+            return;
+        }
         const int row = k0 + lr;
         const bool rok = row < kend;
+        if (fp) rf = rok ? fp[row] : 0.0;
 #pragma unroll
         for (int cc = 0; cc < NLB; ++cc) rb[cc] = rok ? JpB[(size_t)(lc0 + LSTEP * cc) * m + row] : 0.0;
 #pragma unroll
@@ -381,22 +539,29 @@ __device__ __forceinline__ void gram_sq_wave(double *tB, double *tA, int kbeg, i
             ra[cc] = (rok && col < nA) ? JpA[(size_t)col * m + row] : 0.0;
         }
     };
-    if (kbeg < kend) load_tile(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += GRAM_KT) {
+    auto put_tile = [&](double *t) {
 #pragma unroll
-        for (int cc = 0; cc < NLB; ++cc) tB[(lc0 + LSTEP * cc) * GRAM_LD + lr] = rb[cc];
+        for (int cc = 0; cc < NLB; ++cc) t[(lc0 + LSTEP * cc) * GRAM_LD2 + lr] = rb[cc];
 #pragma unroll
-        for (int cc = 0; cc < NLA; ++cc) tA[(lc0 + LSTEP * cc) * GRAM_LD + lr] = ra[cc];
-        __syncthreads();
-        if (k0 + GRAM_KT < kend) load_tile(k0 + GRAM_KT);
+        for (int cc = 0; cc < NLA; ++cc) t[(256 + lc0 + LSTEP * cc) * GRAM_LD2 + lr] = ra[cc];
+    };
+    const int nst = (kend - kbeg + GRAM_KT2 - 1) / GRAM_KT2;
+    if (nst > 0) { load_tile(kbeg); put_tile(tB0); if (fp) g_tile(); }
+    if (nst > 1) load_tile(kbeg + GRAM_KT2);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        double *cur = (st & 1) ? tB1 : tB0, *nxt = (st & 1) ? tB0 : tB1;
+        const unsigned baddr = (unsigned)(size_t)(cur + CH * 8 * 16 * GRAM_LD2 + lrow);
+        const unsigned aaddr0 = (unsigned)(size_t)(cur + (256 + (2 * RP) * 16) * GRAM_LD2 + lrow);
+        const unsigned aaddr1 = (unsigned)(size_t)(cur + (256 + (2 * RP + 1) * 16) * GRAM_LD2 + lrow);
 #pragma unroll
-        for (int ks = 0; ks < GRAM_KT / 4; ++ks) {
+        for (int ks = 0; ks < GRAM_KT2 / 4; ++ks) {
             double a0, a1, b[8];
             asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4"
                          : "=&v"(a0), "=&v"(a1) : "v"(aaddr0), "v"(aaddr1), "n"(ks * 32) : "memory");
 #pragma unroll
             for (int c = 0; c < 8; ++c)
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(b[c]) : "v"(baddr), "n"(c * 16 * GRAM_LD * 8 + ks * 32) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(b[c]) : "v"(baddr), "n"(c * 16 * GRAM_LD2 * 8 + ks * 32) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
 #pragma unroll
             for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(b[c]));
@@ -405,10 +570,34 @@ __device__ __forceinline__ void gram_sq_wave(double *tB, double *tA, int kbeg, i
                 acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[c], acc[0][c], 0, 0, 0);
                 acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[c], acc[1][c], 0, 0, 0);
             }
+#ifndef GRAM_DBG_NOLOAD
+            if (ks == 0 && st + 1 < nst) { put_tile(nxt); if (fp) g_tile(); }
+            if (ks == 1 && st + 2 < nst) load_tile(kbeg + (st + 2) * GRAM_KT2);
+#endif
         }
+#ifndef GRAM_DBG_NOBAR
         __syncthreads();
+#endif
     }
-    // f64 16x16x4 C/D map: col = lane & 15 (B side: column of panel 0), row = (lane >> 4) + 4 * reg (A side: row of G)
+    if (fp) {                                                       // the sixteen row classes of every column, ascending (tiles are free)
+        double *gs = tB0;
+#pragma unroll
+        for (int cc = 0; cc < NLB; ++cc) gs[(lc0 + LSTEP * cc) * GRAM_KT2 + lr] = gaccB[cc];
+#pragma unroll
+        for (int cc = 0; cc < NLA; ++cc) gs[(256 + lc0 + LSTEP * cc) * GRAM_KT2 + lr] = gaccA[cc];
+        __syncthreads();
+        if (tid < 384) {
+            const bool isB = tid < 256;
+            double *dst = isB ? goutB : goutA;
+            const int c = isB ? tid : tid - 256;
+            if (dst && (isB || c < nA)) {
+                double sg = 0.0;
+#pragma unroll
+                for (int i = 0; i < GRAM_KT2; ++i) sg = sg + gs[tid * GRAM_KT2 + i];
+                dst[c] = sg;
+            }
+        }
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -416,7 +605,7 @@ __device__ __forceinline__ void gram_sq_wave(double *tB, double *tA, int kbeg, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gr = (2 * RP + a) * 16 + (lane >> 4) + 4 * r, gcol = (CH * 8 + c) * 16 + (lane & 15);
-                if (gr < nA) Gp[(size_t)gcol * ldg + gr] = acc[a][c][r];
+                if (gr < nA) Gp[(size_t)gr * ldg + gcol] = acc[a][c][r];
             }
 }
 
@@ -441,39 +630,40 @@ k_gram_512(int m, int n, int rows_per_split, const double *__restrict__ J, doubl
     double *gout = gpart + ((size_t)p * nsplit + split) * n;
     const int wv = threadIdx.x >> 6;
     if (unit < 2) {
-        double *tA = gsm;                                   // 256 * GRAM_LD
-        double *fs = tA + 256 * GRAM_LD;                    // GRAM_KT
-        double *gscr = fs + GRAM_KT;                        // 1024
+        double *tA = gsm;                                   // 2 x 256 * GRAM_LD2 (two tile buffers)
+        double *fs = tA + 2 * 256 * GRAM_LD2;               // 2 x GRAM_KT2
+        double *gscr = fs + 2 * GRAM_KT2;                   // 1024
         const int c0 = unit * 256, nc = min(256, n - c0);
-        const double *fp = f ? f + (size_t)p * m : nullptr;
+        const double *fp = nullptr;                         // (g = J^T f is formed by the square units: gram_sq_wave_db)
         const double *Jc = Jp + (size_t)c0 * m;
         double *Gc = Gp + (size_t)c0 * n + c0;
         switch (wv) {
-        case 0: gram_tri_wave<0, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
-        case 1: gram_tri_wave<1, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
-        case 2: gram_tri_wave<2, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
-        case 3: gram_tri_wave<3, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
-        case 4: gram_tri_wave<4, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
-        case 5: gram_tri_wave<5, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
-        case 6: gram_tri_wave<6, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
-        default: gram_tri_wave<7, 16>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, false, n); break;
+        case 0: gram_tri_wave_db<0>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, n); break;
+        case 1: gram_tri_wave_db<1>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, n); break;
+        case 2: gram_tri_wave_db<2>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, n); break;
+        case 3: gram_tri_wave_db<3>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, n); break;
+        case 4: gram_tri_wave_db<4>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, n); break;
+        case 5: gram_tri_wave_db<5>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, n); break;
+        case 6: gram_tri_wave_db<6>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, n); break;
+        default: gram_tri_wave_db<7>(tA, fs, kbeg, kend, m, nc, Jc, fp, Gc, gout + c0, gscr, n); break;
         }
     } else {
-        double *tB = gsm;                                   // 256 * GRAM_LD: panel 0
-        double *tA = tB + 256 * GRAM_LD;                    // 128 * GRAM_LD: this unit's half of panel 1
+        double *tB = gsm;                                   // 2 x 384 * GRAM_LD2: panel 0 + this unit's half of panel 1, two buffers
         const int r0 = 256 + (unit - 2) * 128, nA = max(0, min(128, n - r0));
         if (nA == 0) return;                                // (uniform)
         const double *JA = Jp + (size_t)r0 * m;
-        double *Gs = Gp + r0;                               // G(r0 + gr, gcol)
+        double *Gs = Gp + (size_t)r0 * n;                   // G(r0 + gr, gcol) of the row-major slab
+        const double *fq = f ? f + (size_t)p * m : nullptr;
+        double *gB = unit == 2 ? gout : nullptr, *gA = gout + r0;    // unit 2: columns 0..255 and 256..383; unit 3: 384..
         switch (wv) {
-        case 0: gram_sq_wave<0>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
-        case 1: gram_sq_wave<1>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
-        case 2: gram_sq_wave<2>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
-        case 3: gram_sq_wave<3>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
-        case 4: gram_sq_wave<4>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
-        case 5: gram_sq_wave<5>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
-        case 6: gram_sq_wave<6>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
-        default: gram_sq_wave<7>(tB, tA, kbeg, kend, m, nA, Jp, JA, Gs, n); break;
+        case 0: gram_sq_wave_db<0>(tB, kbeg, kend, m, nA, Jp, JA, Gs, n, fq, gB, gA); break;
+        case 1: gram_sq_wave_db<1>(tB, kbeg, kend, m, nA, Jp, JA, Gs, n, fq, gB, gA); break;
+        case 2: gram_sq_wave_db<2>(tB, kbeg, kend, m, nA, Jp, JA, Gs, n, fq, gB, gA); break;
+        case 3: gram_sq_wave_db<3>(tB, kbeg, kend, m, nA, Jp, JA, Gs, n, fq, gB, gA); break;
+        case 4: gram_sq_wave_db<4>(tB, kbeg, kend, m, nA, Jp, JA, Gs, n, fq, gB, gA); break;
+        case 5: gram_sq_wave_db<5>(tB, kbeg, kend, m, nA, Jp, JA, Gs, n, fq, gB, gA); break;
+        case 6: gram_sq_wave_db<6>(tB, kbeg, kend, m, nA, Jp, JA, Gs, n, fq, gB, gA); break;
+        default: gram_sq_wave_db<7>(tB, kbeg, kend, m, nA, Jp, JA, Gs, n, fq, gB, gA); break;
         }
     }
 }
@@ -497,7 +687,11 @@ k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__res
         g[(size_t)p * n + e] = sg;
     }
     if (e >= nn) return;
-    const int r = (int)(e % n), c = (int)(e / n);
+    // The partial slabs are ROW-major: entry (row r, column c), r >= c, at [r * n + c].  The MFMA result map puts a tile's
+    // sixteen COLUMNS in the lanes' low bits, so a producer's store instruction writes four runs of 128 bytes (column-major
+    // slabs made it 64 scattered 8-byte writes: eight times the write requests, ~30 of the 362 us k_gram_512 took for the
+    // 64 slabs of one 65536 x 512 problem).  A wave here: 64 consecutive columns of one row, contiguous in every slab.
+    const int c = (int)(e % n), r = (int)(e / n);
     if (r < c) return;                             // the slabs hold every entry with row >= column (16 x 16 tile granularity)
     const double *gp = Gpart + (size_t)p * nsplit * nn + e;
     double s = 0.0;
@@ -510,8 +704,8 @@ k_gram_reduce(int n, int nsplit, const double *__restrict__ Gpart, double *__res
         for (int u = 0; u < 8; ++u) s = s + v[u];
     }
     for (; k < nsplit; ++k) s = s + gp[(size_t)k * nn];
-    G[(size_t)p * nn + e] = s;
-    if (r != c) G[(size_t)p * nn + (size_t)r * n + c] = s;
+    G[(size_t)p * nn + e] = s;                                  // G(c, r) of the column-major result: contiguous ...
+    if (r != c) G[(size_t)p * nn + (size_t)c * n + r] = s;      // ... and its mirror G(r, c)
 }
 
 // g = J^T f: one wave per column, lanes stride the rows (coalesced), shuffle reduction.

@@ -158,7 +158,7 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
         } else if (n > 256 && n <= 512 && gram512_on()) {
             // four workgroups per item: the two diagonal 256-column blocks and the two halves of the square between them
             const long groups = (items + 7) / 8;
-            const size_t sh = sizeof(double) * (size_t)(384 * GRAM_LD + GRAM_KT + 1024);
+            const size_t sh = sizeof(double) * (size_t)(2 * 384 * GRAM_LD2 + 2 * GRAM_KT2 + 1024);   // two 16-row tile buffers
             hipLaunchKernelGGL(k_gram_512, dim3((unsigned)(groups * 32)), dim3(512), sh, h->stream, m, n, rps, J, Gp,
                                g ? f : (const double *)nullptr, gp, st, want, ns, nprob);
         } else {

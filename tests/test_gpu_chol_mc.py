@@ -60,7 +60,7 @@ def test_multi_cu_cholesky_hands_over_on_a_bad_pivot(ds):
 def test_gram_512_same_bits_as_block_kernel(ds, nb, m, n):
     """k_gram_512 (256 < n <= 512: the two diagonal 256-column blocks and the two halves of the square between them as
     four workgroups per (problem, K-split)) against k_gram_mfma (64 x 64 blocks): the same accumulation order, hence
-    the same bits of G and g; and both against a float64 reference."""
+    the same bits of G (g to rounding); and both against a float64 reference."""
     g = torch.Generator(device="cpu").manual_seed(5)
     J = torch.randn((nb, n, m), dtype=torch.float64, generator=g).cuda()
     f = torch.randn((nb, m), dtype=torch.float64, generator=g).cuda()
@@ -76,7 +76,10 @@ def test_gram_512_same_bits_as_block_kernel(ds, nb, m, n):
             os.environ.pop("NLH_GRAM512", None)
         else:
             os.environ["NLH_GRAM512"] = old
-    assert torch.equal(G0, G1) and torch.equal(g0, g1)
+    assert torch.equal(G0, G1)
+    # g = J^T f: k_gram_512 adds sixteen partial sums per column and split (out of its loader's registers), the block kernel
+    # four: the same vector to rounding, not to the bit
+    assert float((g0 - g1).abs().max()) <= 1e-14 * float(g0.abs().max()) * np.sqrt(m)
     Gref = torch.matmul(J, J.transpose(1, 2))
     gref = torch.matmul(J, f.unsqueeze(-1)).squeeze(-1)
     assert float((G1 - Gref).abs().max()) <= 1e-13 * float(Gref.abs().max()) * np.sqrt(m)
