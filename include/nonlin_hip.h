@@ -307,6 +307,16 @@ int nlh_newton_solve_batch_device(nlh_handle *h, const nlh_options *opts, int32_
 int nlh_quasi_newton_solve_batch_device(nlh_handle *h, const nlh_options *opts, int32_t jdelta, int32_t nprob, int32_t n,
                                         nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *dx,
                                         double *dfvec, nlh_iteration_behavior *ib, int32_t *status);
+/* constrained_least_squares_solver%solve (cls_solve, src/nonlin_least_squares.f90:938-1176) on the user's family; xl / xu:
+ * [n] host arrays shared by every problem, or NULL (as nlh_dq_cls_solve_batch). */
+int nlh_cls_solve_batch_device(nlh_handle *h, const nlh_options *opts, double delta0, double stepscale0, const double *xl,
+                               const double *xu, int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn,
+                               nlh_device_jacfcn jacfcn, void *ctx, double *dx, double *dfvec, nlh_iteration_behavior *ib,
+                               int32_t *status);
+int nlh_cls_solve_batch_device_h(nlh_handle *h, const nlh_options *opts, double delta0, double stepscale0, const double *xl,
+                                 const double *xu, int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn,
+                                 nlh_device_jacfcn jacfcn, void *ctx, double *x, double *fvec, nlh_iteration_behavior *ib,
+                                 int32_t *status);
 /* The same three behind HOST arrays x [nprob][n] in/out, fvec [nprob][m] out (what the Fortran shim's
  * vecfcn_helper%set_device_fcn + solver%solve / solve_batch call): staged through the handle's buffers. */
 int nlh_lm_solve_batch_device_h(nlh_handle *h, const nlh_options *opts, int32_t nprob, int32_t m, int32_t n,
@@ -333,8 +343,8 @@ int nlh_dq_device_jac(void *ctx, void *hip_stream, int32_t npoints, const int32_
 /* A user's device residual as a MODEL object (what the Fortran shim's vecfcn_helper%set_device_fcn and
  * device_model_batch%create_from_device_fcn hold): nprob problems of m equations in n unknowns each, evaluated by the
  * launchers; nlh_dq_model_eval / _lm_solve / _newton_solve / _quasi_newton_solve accept it (host arrays, the caller's
- * handle; `analytic` selects the jacobianfcn launcher), the bounded least-squares and bfgs forms return
- * NLH_INVALID_OPERATION_ERROR.  Lives on the handle's device (not dealt over a device set: the user's data is wherever the
+ * handle; `analytic` selects the jacobianfcn launcher) and so does nlh_dq_model_cls_solve; the bfgs form returns
+ * NLH_INVALID_OPERATION_ERROR (bfgs minimises a scalar fcnnvar, not a vecfcn).  Lives on the handle's device (not dealt over a device set: the user's data is wherever the
  * user put it).  Freed with nlh_dq_model_destroy; ctx stays the caller's. */
 int nlh_device_fcn_model_create(int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx,
                                 nlh_dq_model **model);

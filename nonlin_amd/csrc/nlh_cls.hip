@@ -292,9 +292,9 @@ int nlh_cls_solve(nlh_handle *h, const nlh_options *o, double delta0, double ste
 // J g and J p where the step needs them) to its trial point, evaluates F there and runs the ratio test; problems inside
 // the projected backtracking get one more trial point evaluated.  One 8-byte read-back per round.
 static int cls_lockstep(nlh_handle *h, const nlh_options *o, double delta0, double stepscale0, const double *xl_in,
-                        const double *xu_in, int32_t nprob, int32_t m, int32_t n, const double *dA, const double *db,
-                        double gamma, double *dx, double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
-{
+                        const double *xu_in, int32_t nprob, int32_t m, int32_t n, const ResidualSource &rs,
+                        double *dx, double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
+{   // rs: the built-in dense-quadratic family, or a user's device vecfcn / jacobianfcn launchers (nlh_devfcn.hip)
     int rc;
     const size_t mn = (size_t)m * n, np = (size_t)nprob;
     if ((rc = ensure(h, h->J, sizeof(double) * mn * np))) return rc;
@@ -340,14 +340,15 @@ static int cls_lockstep(nlh_handle *h, const nlh_options *o, double delta0, doub
 
     hipLaunchKernelGGL(k_cls_reset, dim3(pb), dim3(256), 0, s, nprob, delta0, st, cs);
     hipLaunchKernelGGL(k_cls_limits, dim3((n + 255) / 256, nprob), dim3(256), 0, s, n, (const double *)dxl, (const double *)dxu, dx);   // :1023
-    launch_dq_residual(h, nprob, m, n, dA, db, gamma, dx, dfvec, nullptr, st, CL_START);
+    if ((rc = residual_eval(h, rs, nprob, m, n, dx, dfvec, nullptr, st, CL_START))) return rc;
     hipLaunchKernelGGL(k_cls_start, dim3(nprob), dim3(256), 0, s, m, n, (const double *)dx, (const double *)dfvec, st, cs);
     int need_jac = nprob;                                        // upper bound until the first read-back
     // a round is an iteration or one backtracking trial: every one of them costs its problem an evaluation
     const long max_rounds = (long)o->max_evals + 16;
     for (long round = 0; round < max_rounds; ++round) {
         if (need_jac > 0) {
-            launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, dJ, st, CL_NEED_JAC, dfvec);     // :1038, fused FD column write
+            // :1038 fcn%jacobian: forward differences (the built-in family: fused into the panel kernel) or the user's jacobianfcn
+            if ((rc = residual_jacobian(h, rs, nprob, m, n, dx, dfvec, dJ, nullptr, st, CL_NEED_JAC, false, true, true))) return rc;
             hipLaunchKernelGGL(k_cls_qr_prep, dim3((m + 255) / 256, nprob), dim3(256), 0, s, m, (const double *)dfvec, dE, (const LmState *)st);
             {
                 dim3 grid((m + 31) / 32, (n + 31) / 32, nprob);
@@ -369,12 +370,12 @@ static int cls_lockstep(nlh_handle *h, const nlh_options *o, double delta0, doub
                                (const double *)dp, dJv, (const LmState *)st, (int)CL_PRED);
             hipLaunchKernelGGL(k_cls_pred, dim3(nprob), dim3(256), 0, s, m, n, (const double *)dx, (const double *)dg, (const double *)dp,
                                (const double *)dJv, (const double *)dsc, dxnew, st, cs);
-            launch_dq_residual(h, nprob, m, n, dA, db, gamma, dxnew, dfnew, nullptr, st, CL_TRIAL);
+            if ((rc = residual_eval(h, rs, nprob, m, n, dxnew, dfnew, nullptr, st, CL_TRIAL))) return rc;
             hipLaunchKernelGGL(k_cls_judge, dim3(nprob), dim3(256), 0, s, m, n, co, dx, dxnew, dfvec, (const double *)dfnew, (const double *)dg,
                                (const double *)dp, (const double *)dxl, (const double *)dxu, st, cs);
         }
         // (a problem that has just entered the backtracking gets its first point evaluated in the same round)
-        launch_dq_residual(h, nprob, m, n, dA, db, gamma, dxnew, dfnew, nullptr, st, CL_BT);
+        if ((rc = residual_eval(h, rs, nprob, m, n, dxnew, dfnew, nullptr, st, CL_BT))) return rc;
         hipLaunchKernelGGL(k_cls_bt, dim3(nprob), dim3(256), 0, s, m, n, co, dx, dxnew, dfvec, (const double *)dfnew, (const double *)dp,
                            (const double *)dxl, (const double *)dxu, st, cs);
         hipLaunchKernelGGL(k_cls_count, dim3(1), dim3(256), 0, s, nprob, (const LmState *)st, dcounts);
@@ -411,11 +412,14 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
     if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     static const int cls_host = [] { const char *e = getenv("NLH_CLS_HOSTLOOP"); return e ? atoi(e) : 0; }();
-    if (!cls_host)
+    if (!cls_host) {
+        ResidualSource rs;
+        rs.dA = dA; rs.db = db; rs.gamma = gamma;
         return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {
-            return cls_lockstep(h, o, delta0, stepscale0, xl, xu, cnt, m, n, dA + (size_t)p0 * m * n, db + (size_t)p0 * m, gamma,
+            return cls_lockstep(h, o, delta0, stepscale0, xl, xu, cnt, m, n, rs.shifted(p0, m, n),
                                 dx + (size_t)p0 * n, dfvec + (size_t)p0 * m, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
         });
+    }
     // one problem per call; run_problems deals the problems to worker threads with private handles
     auto solve_one = [&](nlh_handle *h, int p) -> int {
         int rc;
@@ -458,5 +462,54 @@ int nlh_dq_cls_solve_batch(nlh_handle *h, const nlh_options *o, double delta0, d
     const int rcb = run_problems(h, nprob, solve_one);
     if (rcb) return rcb;
     HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+
+// constrained_least_squares_solver%solve (cls_solve, src/nonlin_least_squares.f90:938-1176) on a batch of problems whose
+// residual is the USER'S device function (launchers, include/nonlin_hip.h): the lock-step state machine above.
+int nlh_cls_solve_batch_device(nlh_handle *h, const nlh_options *o, double delta0, double stepscale0, const double *xl, const double *xu,
+                               int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *dx,
+                               double *dfvec, nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (ib && nprob > 0) memset(ib, 0, sizeof(*ib) * (size_t)nprob);
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // :988
+    if (nprob <= 0) return 0;
+    if (!o || n < 1 || m < 1 || !dx || !dfvec) return NLH_INVALID_INPUT_ERROR;
+    if (n > m) return NLH_UNDERDEFINED_PROBLEM_ERROR;           // :989
+    HIPCHK(h, hipSetDevice(h->device));
+    ResidualSource rs;
+    rs.fcn = fcn; rs.jac = jacfcn; rs.ctx = ctx;
+    nlh_options oq = *o;
+    if (nprob > 1) oq.print_status = 0;
+    const int32_t slice = (int32_t)std::max<int64_t>(1, std::min<int64_t>(NLH_MAX_LOCKSTEP, ((int64_t)1 << 30) / n));
+    for (int32_t p0 = 0; p0 < nprob; p0 += slice) {
+        const int32_t cnt = std::min<int32_t>(slice, nprob - p0);
+        const int rc = cls_lockstep(h, &oq, delta0, stepscale0, xl, xu, cnt, m, n, rs.shifted(p0, m, n), dx + (size_t)p0 * n,
+                                    dfvec + (size_t)p0 * m, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int nlh_cls_solve_batch_device_h(nlh_handle *h, const nlh_options *o, double delta0, double stepscale0, const double *xl, const double *xu,
+                                 int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx, double *x,
+                                 double *fvec, nlh_iteration_behavior *ib, int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (nprob <= 0) return 0;
+    if (!o || !x || !fvec || n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->xdev, sizeof(double) * (size_t)nprob * n))) return rc;
+    if ((rc = ensure(h, h->fdev, sizeof(double) * (size_t)nprob * m))) return rc;
+    double *dx = (double *)h->xdev.p, *df = (double *)h->fdev.p;
+    HIPCHK(h, hipMemcpyAsync(dx, x, sizeof(double) * (size_t)nprob * n, hipMemcpyHostToDevice, h->stream));
+    if ((rc = nlh_cls_solve_batch_device(h, o, delta0, stepscale0, xl, xu, nprob, m, n, fcn, jacfcn, ctx, dx, df, ib, status))) return rc;
+    HIPCHK(h, hipMemcpyAsync(x, dx, sizeof(double) * (size_t)nprob * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(fvec, df, sizeof(double) * (size_t)nprob * m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }

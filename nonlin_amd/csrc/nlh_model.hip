@@ -352,7 +352,8 @@ int nlh_dq_model_cls_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mod
     nlh_options oq = *o;
     if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
     o = &oq;
-    if (md->ufcn) return NLH_INVALID_OPERATION_ERROR;     // (the open path serves lss_solve, ns_solve and qns_solve)
+    if (md->ufcn) return nlh_cls_solve_batch_device_h(h, o, delta0, stepscale0, xl, xu, md->nprob, md->m, md->n, md->ufcn, md->ujac, md->uctx, x,
+                                                      fvec, ib, status);
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          return nlh_dq_cls_solve_batch(ph, o, delta0, stepscale0, xl, xu, pt.cnt, md->m, md->n, pt.dA, pt.db, md->gamma,
@@ -369,7 +370,7 @@ int nlh_dq_model_bfgs_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mo
     nlh_options oq = *o;
     if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
     o = &oq;
-    if (md->ufcn) return NLH_INVALID_OPERATION_ERROR;
+    if (md->ufcn) return NLH_INVALID_OPERATION_ERROR;     // (bfgs minimises a scalar fcnnvar: a vector launcher is not its plugin)
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          std::vector<double> fo(pt.cnt, 0.0);

@@ -183,6 +183,27 @@ class DeviceSolver:
             raise RuntimeError(f"nlh_lm_solve_batch_device returned {rc}")
         return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
 
+    def cls_solve_batch_device(self, fcn, ctx, m, x, jac=None, opts=None, lower=None, upper=None, delta=1.0, stepscale=1.0):
+        """constrained_least_squares_solver%solve on x.shape[0] problems of a user's device residual (the same box for all)."""
+        import numpy as np
+        nprob, n = x.shape
+        _chk(x, (nprob, n), "x")
+        fvec = torch.empty((nprob, m), dtype=torch.float64, device=x.device)
+        ib = (_lib.IterationBehavior * nprob)()
+        status = (C.c_int32 * nprob)()
+        o = opts or self.options()
+        lo = None if lower is None else np.ascontiguousarray(lower, dtype=np.float64)
+        hi = None if upper is None else np.ascontiguousarray(upper, dtype=np.float64)
+        plo = None if lo is None else lo.ctypes.data_as(_lib.c_double_p)
+        phi = None if hi is None else hi.ctypes.data_as(_lib.c_double_p)
+        rc = self.lib.nlh_cls_solve_batch_device(self.h.ptr, C.byref(o), float(delta), float(stepscale), plo, phi, nprob, m, n,
+                                                 self._devfcn(fcn), self._devfcn(jac), self._ctxp(ctx), x.data_ptr(), fvec.data_ptr(),
+                                                 ib, status)
+        self.h.check(rc, "nlh_cls_solve_batch_device")
+        if rc:
+            raise RuntimeError(f"nlh_cls_solve_batch_device returned {rc}")
+        return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
+
     def square_solve_batch_device(self, fcn, ctx, x, jac=None, opts=None, broyden=False, jdelta=5):
         """newton_solver%solve (or quasi_newton_solver%solve) on x.shape[0] square problems of a user's device residual."""
         nprob, n = x.shape

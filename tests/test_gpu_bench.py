@@ -44,10 +44,22 @@ def test_bench_single_process():
     assert d["fd_jacobian_mode_h"]["bound"] == "hbm" and d["fd_jacobian_mode_h"]["achieved"] > 0
     rows = d["other_paths"]        # Newton, quasi-Newton, bounded LSQ, BFGS, their three lock-step batches, polynomial,
     #                                and the two mode-H rows (nlh_lm_solve with a compiled host callback)
-    assert len(rows) == 10 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
+    #                                the two mode-H LM rows (nlh_lm_solve with a compiled host callback) and the mode-H Newton row
+    #                                (compiled vecfcn + compiled analytic jacobianfcn, BASELINE config 3 taken literally)
+    assert len(rows) == 11 and all(r["bitwise_equal"] and r["gpu_ms"] > 0 and r["cpu_oracle_ms"] > 0 for r in rows)
     assert sum("lock-step" in r["path"] for r in rows) == 3
     mh = [r for r in rows if "mode H" in r["path"]]
-    assert len(mh) == 2 and all(r["counts_equal"] and r["callbacks"] > 0 and r["status"] == [0, 0] for r in mh)
+    assert len(mh) == 3 and all(r["counts_equal"] and r["status"] == [0, 0] for r in mh)
+    assert sum(1 for r in mh if r.get("callbacks", 0) > 0) == 2
+    nt = [r for r in rows if r["path"].startswith("newton_solver")]           # Newton rows are priced against LAPACK, not the oracle's LU
+    assert len(nt) == 3 and all(r["cpu_lapack_ms"] > 0 and 0 < r["cpu_lapack_ms"] <= r["cpu_oracle_ms"] and r["gpu_over_cpu_lapack"] > 0
+                                for r in nt)
+    assert not any("cpu_lapack_ms" in r for r in rows if r["path"].startswith("quasi_newton"))
+    dv = d["device_vecfcn"]        # the open device-residual path: a user launcher, k_fd_jacobian_qrx timed inside the solve
+    assert len(dv) == 3 and all(r["lm_iterations_per_s"] > 0 and 0.0 < r["fd_jacobian"]["frac"] < 1.0 for r in dv)
+    assert dv[0]["bitwise_equal_builtin_entry_point"] and dv[1]["bitwise_equal_builtin_entry_point"]
+    assert dv[2]["bitwise_equal_oracle_host_callback"]
+    assert 0.0 < d["roofline"]["frac_of_achievable"] < 1.2 and d["roofline"]["achievable_peak"] < d["roofline"]["peak"]
     ps = d["predicted_scaling"]    # per-rank batch sizes of config 4 / the 8192-problem run at 1, 2, 4, 8 GPUs, timed on this one
     for key, total in (("config4_1024_problems", 1024), ("strong_8192_problems", 8192)):
         assert [r["gpus"] for r in ps[key]] == [1, 2, 4, 8]

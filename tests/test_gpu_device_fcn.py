@@ -371,3 +371,35 @@ def test_user_device_fcn_through_the_fortran_shim(ds, oracle, tmp_path):
         for p in range(nprob):
             rc, xo, fo, ibo = _oracle_square(oracle, B, p, nq, xs[p], broyden, analytic, max_evals=500)
             cmp(res[key][p], rc, xo, ibo)
+
+
+# ---------------------------------------------------------------------------------------------------- GPU: bounded least squares
+@pytest.mark.gpu
+@pytest.mark.parametrize("nprob,m,K", [(1, 300, 2), (40, 256, 3)])
+def test_user_family_bounded_least_squares_bitwise(ds, oracle, nprob, m, K):
+    """constrained_least_squares_solver%solve (bounded dog-leg, src/nonlin_least_squares.f90:938-1176) on the user's family
+    through the launcher, a box that binds some unknowns: == the oracle's cls_solve driving the host twin."""
+    import torch
+    n = 3 * K
+    t, y, xt, x0 = UM.lorentz_problems(nprob, m, K, seed=31, hard_every=3)
+    lo = np.tile([0.4, -1.0, 0.02], K)                        # amplitudes >= 0.4, widths >= 0.02
+    hi = np.tile([1.2, 2.0, 0.2], K)                          # amplitudes <= 1.2: binds where a_k in (1.2, 1.5)
+    batch = UM.LorentzBatch(t, y)
+    x = torch.tensor(x0, device=ds.device)
+    fvec, ibs, status = ds.cls_solve_batch_device(batch.launch, batch.ctx, m, x, opts=ds.options(max_evals=500), lower=lo, upper=hi)
+    xg, fg = x.cpu().numpy(), fvec.cpu().numpy()
+    L = oracle.lib()
+    bound = 0
+    for p in range(nprob):
+        hc = batch.host_ctx(p)
+        oo = oracle.default_options(max_evals=500)
+        xo, fo, ibo = x0[p].copy(), np.zeros(m), oracle.IterationBehavior()
+        rc = L.nlo_cls_solve(C.byref(oo), C.c_double(1.0), C.c_double(1.0), lo.ctypes.data_as(dp), hi.ctypes.data_as(dp),
+                             C.cast(batch.host_fcn, oracle.VECFCN), C.cast(None, oracle.JACFCN), C.byref(hc), m, n,
+                             xo.ctypes.data_as(dp), fo.ctypes.data_as(dp), C.byref(ibo))
+        assert status[p] == rc, (p, status[p], rc)
+        assert _same(ibs[p], ibo.as_dict()), (p, ibs[p], ibo.as_dict())
+        assert np.array_equal(xg[p], xo) and np.array_equal(fg[p], fo), p
+        bound += int(np.any(xo == lo) or np.any(xo == hi))
+    assert nprob == 1 or bound > 0                            # the box did bind somewhere
+    batch.close()
