@@ -175,19 +175,22 @@ k_dv_place_jac(int m, int n, const double *__restrict__ Jc, double *__restrict__
 // ---------------------------------------------------------------------------
 static inline int32_t *dv_list(nlh_handle *h) { return (int32_t *)h->dvIdx.p + 16; }
 
-// Compacts the problems at `want` into the handle's list; returns their number (< 0: a library error).
-static int dv_select(nlh_handle *h, int nprob, const LmState *st, int want, size_t extra_ints)
+// Compacts the problems at `want` into the handle's list and reads their number back (*cnt); returns 0 or a library error.
+// The count lands in the pinned block's header, behind the words the solvers keep their own round read-backs in.
+static const int DV_PINNED_SLOT = 12;                            // int32 index inside the 64-byte header of h->pinned
+static int dv_select(nlh_handle *h, int nprob, const LmState *st, int want, size_t extra_ints, int *cnt)
 {
     int rc;
-    if ((rc = ensure(h, h->dvIdx, sizeof(int32_t) * ((size_t)nprob + 16 + extra_ints)))) return rc < 0 ? rc : -1000 - rc;
-    if ((rc = ensure_pinned(h, 64))) return rc < 0 ? rc : -1000 - rc;
+    *cnt = 0;
+    if ((rc = ensure(h, h->dvIdx, sizeof(int32_t) * ((size_t)nprob + 16 + extra_ints)))) return rc;
+    if ((rc = ensure_pinned(h, 64))) return rc;
     int32_t *dcnt = (int32_t *)h->dvIdx.p;
     hipLaunchKernelGGL(k_dv_compact, dim3(1), dim3(1024), 0, h->stream, nprob, st, want, dv_list(h), dcnt);
-    // (the solvers keep their own read-back state at the start of the pinned block: the count lands behind it)
-    int32_t *hcnt = (int32_t *)h->pinned + 12;
-    if (hipMemcpyAsync(hcnt, dcnt, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-        hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "device residual: read-back of the active count"; return NLH_ERR_HIP; }
-    return *hcnt;
+    int32_t *hcnt = (int32_t *)h->pinned + DV_PINNED_SLOT;
+    HIPCHK(h, hipMemcpyAsync(hcnt, dcnt, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *cnt = *hcnt;
+    return 0;
 }
 
 static int dv_fail(nlh_handle *h, int rc, const char *what)
@@ -195,8 +198,6 @@ static int dv_fail(nlh_handle *h, int rc, const char *what)
     h->err = std::string(what) + ": the user's launcher returned " + std::to_string(rc);
     return NLH_ERR_HIP;
 }
-
-void launch_sumsq_part(nlh_handle *h, int nprob, int m, int n, const double *f, double *part);
 
 int residual_eval(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int n, const double *x, double *f, double *part,
                   const LmState *st, int want)
@@ -209,8 +210,7 @@ int residual_eval(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int
     int cnt = nprob;
     const bool all = st == nullptr;
     if (!all) {
-        cnt = dv_select(h, nprob, st, want, (size_t)nprob);
-        if (cnt < 0) return cnt <= -1000 ? -(cnt + 1000) : cnt;
+        if ((rc = dv_select(h, nprob, st, want, (size_t)nprob, &cnt))) return rc;
         if (cnt == 0) return 0;
     } else if ((rc = ensure(h, h->dvIdx, sizeof(int32_t) * ((size_t)2 * nprob + 16)))) return rc;
     int32_t *list = dv_list(h), *dprob = list + nprob;
@@ -262,8 +262,7 @@ int residual_jacobian(nlh_handle *h, const ResidualSource &rs, int nprob, int m,
     const bool all = st == nullptr;
     const size_t npts_max = (size_t)nprob * n;
     if (!all) {
-        cnt = dv_select(h, nprob, st, want, (size_t)nprob + npts_max);
-        if (cnt < 0) return cnt <= -1000 ? -(cnt + 1000) : cnt;
+        if ((rc = dv_select(h, nprob, st, want, (size_t)nprob + npts_max, &cnt))) return rc;
         if (cnt == 0) return 0;
     } else if ((rc = ensure(h, h->dvIdx, sizeof(int32_t) * ((size_t)2 * nprob + 16 + npts_max)))) return rc;
     int32_t *list = dv_list(h), *dprob = list + 2 * (size_t)nprob;
@@ -366,6 +365,71 @@ k_dqv_fcn(int m, int n, int nblk, const double *__restrict__ A, const double *__
     F[(size_t)q * m + i] = (u + (gamma * u) * u) - b[(size_t)p * m + i];
 }
 
+// The same for DQV_PT consecutive points at a time.  A forward-difference Jacobian asks for n points of the same problem
+// in a row: a workgroup takes a block of 256 rows and a tile of DQV_PT points, reads its rows of A ONCE for the tile (the
+// per-point form reads them once per point: n times per Jacobian, 240 of the 875 ms of a 512 x 4096x256 solve) and keeps
+// one accumulator per point -- each still the plain sum over j ascending, one multiply and one add per term, of that
+// point's own x: the same bits.  A tile whose points belong to more than one problem (the seam between two problems when n
+// is not a multiple of the tile, mixed calls) is taken point by point by the same workgroup.
+#define DQV_PT 16
+static __global__ void __launch_bounds__(256)
+k_dqv_fcn_tile(int m, int n, int nblk, int npoints, const double *__restrict__ A, const double *__restrict__ b, double gamma,
+               const int32_t *__restrict__ dprob, const double *__restrict__ X, double *__restrict__ F)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];  // [n][DQV_PT]
+    const int tile = blockIdx.x / nblk, rb = blockIdx.x - tile * nblk;
+    const int q0 = tile * DQV_PT, nq = min(DQV_PT, npoints - q0);
+    const int p = dprob[q0];
+    bool same = true;
+    for (int t = 1; t < nq; ++t) same = same && dprob[q0 + t] == p;          // (uniform: scalar loads)
+    const int i = rb * 256 + threadIdx.x;
+    if (!same) {                                                 // a seam between two problems: this tile point by point
+        for (int t = 0; t < nq; ++t) {
+            const int pt = dprob[q0 + t];
+            __syncthreads();
+            for (int c = threadIdx.x; c < n; c += 256) xs[c] = X[(size_t)(q0 + t) * n + c];
+            __syncthreads();
+            if (i < m) {
+                const double *a = A + (size_t)pt * m * n + i;
+                double u = 0.0;
+                for (int k = 0; k < n; ++k) u = u + a[(size_t)k * m] * xs[k];
+                F[(size_t)(q0 + t) * m + i] = (u + (gamma * u) * u) - b[(size_t)pt * m + i];
+            }
+        }
+        return;
+    }
+    // x of the tile's points, index-major ([k][point]: the sixteen values a step needs are 128 contiguous bytes)
+    for (int e = threadIdx.x; e < DQV_PT * n; e += 256) {
+        const int t = e / n, k = e - t * n;
+        xs[k * DQV_PT + t] = t < nq ? X[(size_t)q0 * n + e] : 0.0;
+    }
+    __syncthreads();
+    if (i >= m) return;
+    const double *a = A + (size_t)p * m * n + i;
+    double u[DQV_PT];
+#pragma unroll
+    for (int t = 0; t < DQV_PT; ++t) u[t] = 0.0;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        double av[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) av[c] = a[(size_t)(k + c) * m];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < DQV_PT; ++t) u[t] = u[t] + av[c] * xs[(k + c) * DQV_PT + t];
+    }
+    for (; k < n; ++k) {
+        const double av = a[(size_t)k * m];
+#pragma unroll
+        for (int t = 0; t < DQV_PT; ++t) u[t] = u[t] + av * xs[k * DQV_PT + t];
+    }
+    const double bi = b[(size_t)p * m + i];
+#pragma unroll
+    for (int t = 0; t < DQV_PT; ++t)
+        if (t < nq) F[(size_t)(q0 + t) * m + i] = (u[t] + (gamma * u[t]) * u[t]) - bi;
+}
+
 static __global__ void __launch_bounds__(256)
 k_dqv_jac(int m, int n, int nblk, const double *__restrict__ A, double gamma, const int32_t *__restrict__ dprob, const double *__restrict__ X,
           double *__restrict__ J)
@@ -391,7 +455,15 @@ int nlh_dq_device_fcn(void *ctx, void *hip_stream, int32_t npoints, const int32_
     const nlh_dq_device_ctx *c = (const nlh_dq_device_ctx *)ctx;
     if (!c || npoints <= 0) return c ? 0 : 1;
     const int nblk = (m + 255) / 256;
-    hipLaunchKernelGGL(k_dqv_fcn, dim3((unsigned)((size_t)npoints * nblk)), dim3(256), sizeof(double) * (size_t)n, (hipStream_t)hip_stream, m, n, nblk,
+    hipStream_t s = (hipStream_t)hip_stream;
+    // a handful of points (a trial point per problem), or x vectors that do not fit LDS sixteen at a time: point by point
+    if (npoints < 4 * DQV_PT || sizeof(double) * (size_t)DQV_PT * n > 64 * 1024) {
+        hipLaunchKernelGGL(k_dqv_fcn, dim3((unsigned)((size_t)npoints * nblk)), dim3(256), sizeof(double) * (size_t)n, s, m, n, nblk,
+                           c->dA, c->db, c->gamma, dprob, dX, dF);
+        return 0;
+    }
+    const int ntile = (npoints + DQV_PT - 1) / DQV_PT;
+    hipLaunchKernelGGL(k_dqv_fcn_tile, dim3((unsigned)((size_t)ntile * nblk)), dim3(256), sizeof(double) * (size_t)DQV_PT * n, s, m, n, nblk, npoints,
                        c->dA, c->db, c->gamma, dprob, dX, dF);
     return 0;
 }
