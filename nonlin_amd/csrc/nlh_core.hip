@@ -129,6 +129,9 @@ void nlh_destroy(nlh_handle *h)
     for (auto *b : h->bufs) if (b->p) hipFree(b->p);
     if (h->pinned) hipHostFree(h->pinned);
     if (h->staging) hipHostFree(h->staging);
+    if (h->lu_side) { hipStreamSynchronize(h->lu_side); hipStreamDestroy(h->lu_side); }
+    if (h->lu_panel_done) hipEventDestroy(h->lu_panel_done);
+    for (auto e : h->lu_bulk_done) if (e) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }

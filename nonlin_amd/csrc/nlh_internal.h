@@ -60,6 +60,8 @@ struct nlh_handle {
     size_t staging_bytes = 0;
     bool qrx_open_on = false; hipEvent_t qrx_a{}, qrx_b{}; int qrx_kid = 0;   // open bracket of a nlh_qrx.hip launch
     std::vector<nlh_handle *> workers;   // private handles (own stream + workspace) for concurrent host-loop solves
+    hipStream_t lu_side = nullptr;       // the blocked LU's look-ahead: the bulk of a step's update runs here, under the next panel
+    hipEvent_t lu_panel_done = nullptr, lu_bulk_done[2] = {nullptr, nullptr};
 };
 
 #define HIPCHK(h, call)                                                                 \

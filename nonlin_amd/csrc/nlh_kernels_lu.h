@@ -500,8 +500,8 @@ k_lu_swap_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ ipv
 // subtracts the nb products in j order (separate multiply and subtract).
 template <bool FAST>
 static __global__ void __launch_bounds__(256)
-k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__restrict__ st, int want)
-{
+k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__restrict__ st, int want, int cskip = 0)
+{   // cskip > 0 (the look-ahead of lu_blocked): the first cskip trailing columns are the next panel's, updated by its own kernel
     __shared__ double Ls[LU_NB * 64];              // Ls[j*64 + r]
     __shared__ double Us[LU_NB * 64];              // Us[j*64 + c]
     const int p = blockIdx.z;
@@ -555,7 +555,7 @@ k_lu_gemm(int n, double *__restrict__ Aall, int jb, int nb, const LmState *__res
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = r0 + tr + rr, c = c0 + tc + cc;
-            if (r < n && c < n) a[(size_t)c * n + r] = acc[cc][rr];
+            if (r < n && c < n && c - t0 >= cskip) a[(size_t)c * n + r] = acc[cc][rr];
         }
 }
 
@@ -617,8 +617,11 @@ static inline size_t lu_panel_reg_lds(int rpt, int nbw, int threads) { return si
 template <int RPT, int NB, int TMAX, bool FAST>
 static __global__ void __launch_bounds__(TMAX)
 k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all, int32_t *__restrict__ info,
-               int32_t *__restrict__ mv_all, int jb, int nb, const LmState *__restrict__ st, int want)
-{
+               int32_t *__restrict__ mv_all, int jb, int nb, const LmState *__restrict__ st, int want,
+               int pnb = 0, const int32_t *__restrict__ pmv_all = nullptr)
+{   // pnb > 0 (the look-ahead of lu_blocked): the PREVIOUS panel [jb - pnb, jb) has not been applied to this panel's columns
+    // yet -- this kernel does it first, for exactly its own columns (row moves from pmv_all, the block row by forward
+    // substitution, the trailing product), with the operations k_lu_move_trsm / k_lu_gemm would have performed, in their order
     constexpr int NWMAX = TMAX / 64;
     constexpr int WS = NB + 2;                                   // doubles per published row: the window, then 1 / its entry
     __shared__ __attribute__((aligned(16))) uint32_t red_hi[2][NWMAX];
@@ -647,6 +650,76 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
 #endif
     // loads are unconditional (clamped indices) and all issued before any is used: the compiler puts a load under a
     // condition back under it, and a load in a conditional block is waited for before the next one is issued
+    if (pnb > 0) {
+        // ---- the previous panel's update of THESE columns (uniform branch) ----------------------------------------------
+        __shared__ __attribute__((aligned(16))) double u12[32][NB];          // the block row: U(pjb + j, jb + k)
+        __shared__ __attribute__((aligned(16))) double l11[32 * 32];         // l11[i + j * pnb], i > j used
+        const int pjb = jb - pnb;
+        const int32_t *pmv = pmv_all + (size_t)p * LU_MV_STRIDE;
+        const int cnt2 = pmv[32];
+        double *ab = Aall + (size_t)p * n * n;
+        // this thread's rows as the moves leave them: position pnb + r of the previous panel's frame holds what was at `src`
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = q * T + t;
+            pos[q] = r < rows ? r : -1;
+            const int i = pnb + (r < rows ? r : rows - 1);
+            int src = i;
+            for (int e = 0; e < cnt2; ++e) src = (pmv[33 + 2 * e] == i) ? pmv[34 + 2 * e] : src;     // (uniform list: scalar loads)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) w[q][k] = ab[(size_t)(jb + (k < nb ? k : nb - 1)) * n + pjb + src];
+        }
+        for (int e = t; e < pnb * pnb; e += T) { const int i = e % pnb, j = e / pnb; l11[e] = ab[(size_t)(pjb + j) * n + pjb + i]; }
+        double ut[32];
+        const int uk = t < nb ? t : nb - 1;
+        if (t < NB) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) ut[i] = ab[(size_t)(jb + uk) * n + pjb + pmv[i < pnb ? i : 0]];   // the rows that end in the block row
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) LU_PIN(w[q][k]);
+        if (t < NB) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) LU_PIN(ut[i]);
+        }
+        __syncthreads();                                         // every old value is in registers: the block row may be overwritten
+        if (t < NB) {                                            // U12 = L11^-1 (moved rows), column t: j ascending, separate multiply / subtract
+            for (int j = 0; j < pnb; ++j) {
+                const double uj = ut[0];
+                if (t < nb) ab[(size_t)(jb + t) * n + pjb + j] = uj;
+                u12[j][t] = t < nb ? uj : 0.0;
+#pragma unroll
+                for (int i = 1; i < 32; ++i) {
+                    const double li = (j + i < pnb) ? l11[(j + i) + j * pnb] : 0.0;
+                    ut[i - 1] = FAST ? __builtin_fma(-li, uj, ut[i]) : ut[i] - li * uj;
+                }
+                ut[31] = 0.0;
+            }
+        }
+        __syncthreads();
+        // the trailing product: a(i, k) -= l(i, j) u(j, k), j ascending (l: the previous panel's multipliers at the rows' final places)
+        for (int j0 = 0; j0 < pnb; j0 += 8) {
+            double lq[RPT][8];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = q * T + t, rc = r < rows ? r : rows - 1;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) lq[q][jj] = ab[(size_t)(pjb + (j0 + jj < pnb ? j0 + jj : pnb - 1)) * n + jb + rc];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                if (j0 + jj < pnb) {                              // (uniform)
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q)
+#pragma unroll
+                        for (int k = 0; k < NB; ++k)
+                            w[q][k] = FAST ? __builtin_fma(-lq[q][jj], u12[j0 + jj][k], w[q][k]) : w[q][k] - lq[q][jj] * u12[j0 + jj][k];
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         const int r = q * T + t;
@@ -654,6 +727,7 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
         const int rc = r < rows ? r : rows - 1;
 #pragma unroll
         for (int k = 0; k < NB; ++k) w[q][k] = a[(size_t)(k < nb ? k : nb - 1) * n + rc];
+    }
     }
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
@@ -823,8 +897,8 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
 template <int TR, bool FAST>
 static __global__ void __launch_bounds__(256)
 k_lu_move_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ mv_all, int jb, int nb,
-               const LmState *__restrict__ st, int want)
-{
+               const LmState *__restrict__ st, int want, int skip_lo = 0, int skip_hi = 0)
+{   // skip_lo .. skip_hi (outside-column indices; the look-ahead of lu_blocked): columns the next panel's kernel updates itself
     __shared__ double L11[TR * TR + TR];           // L11[i + j*TR], i > j used (+ TR: the shifting window reads past the end)
     const int p = blockIdx.y;
     if (st && st[p].stage != want) return;                       // lock-step batches: only problems in this stage
@@ -839,7 +913,7 @@ k_lu_move_trsm(int n, double *__restrict__ Aall, const int32_t *__restrict__ mv_
         lv[s] = a[(size_t)(jb + (j < nb ? j : nb - 1)) * n + jb + (i < nb ? i : nb - 1)];
     }
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = k < n - nb;
+    const bool live = k < n - nb && !(k >= skip_lo && k < skip_hi);
     if (!live) k = 0;
     if (k >= jb) k += nb;                          // skip the panel's own columns
     if (k >= n) k = n - 1;

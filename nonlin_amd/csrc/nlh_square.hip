@@ -22,16 +22,25 @@ void nlh_square_init_device(int lds_max)
 }
 
 // The register panel with several rows per thread (k_lu_panel_reg): instance by the number of panel rows.
+// Width of the register panel that starts with `rows` rows left (0: beyond the register panel's reach) -- the rule of
+// launch_lu_panel_reg below.
+static int lu_panel_reg_width(int rows)
+{
+    if (rows <= 0 || rows > 1024) return 0;
+    return std::min(rows <= 512 ? 32 : 16, rows);
+}
+
+// mvbuf: where this panel leaves its move list; pnb / pmv: the previous panel, not yet applied to this panel's columns (look-ahead)
 template <bool FAST>
 static int launch_lu_panel_reg(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipvt, int32_t *dinfo, int jb,
-                               const LmState *st, int want, int wide)
+                               const LmState *st, int want, int wide, int32_t *mvbuf, int pnb = 0, const int32_t *pmv = nullptr)
 {
     const int rows = n - jb;
     auto go = [&](auto kern, int rpt, int pw) {
         const int nb = std::min(pw, rows);
         const int T = std::max(64, (((rows + rpt - 1) / rpt) + 63) & ~63);
-        hipLaunchKernelGGL(kern, dim3(nprob), dim3(T), lu_panel_reg_lds(rpt, pw, T), h->stream, n, dA, dipvt, dinfo, (int32_t *)h->lumv.p,
-                           jb, nb, st, want);
+        hipLaunchKernelGGL(kern, dim3(nprob), dim3(T), lu_panel_reg_lds(rpt, pw, T), h->stream, n, dA, dipvt, dinfo, mvbuf,
+                           jb, nb, st, want, pnb, pmv);
         return nb;
     };
     if (rows <= 256) return go(k_lu_panel_reg<1, 32, 256, FAST>, 1, 32);
@@ -53,10 +62,39 @@ static void lu_blocked(nlh_handle *h, int nprob, int n, double *dA, int32_t *dip
                        int panel_mode)
 {
     // panels factored in registers while they have at most 1024 rows (several rows per thread, implicit interchanges),
-    // 32-column panels in global memory before
-    for (int jb = 0; jb < n;) {
+    // 32-column panels in global memory before.
+    // LOOK-AHEAD (opt-in, NLH_LU_LOOKAHEAD=1; a handful of problems, n <= 1024): the panel kernel applies the previous panel
+    // to ITS OWN columns itself (k_lu_panel_reg, pnb > 0) and starts as soon as that panel is done; the rest of a step's
+    // update -- the moves left of the panel, the block row and the trailing product of every other column -- runs on a side
+    // stream under the next panel, which is one workgroup per problem and leaves the chip idle (n = 1024: 1.8 of 2.9 ms are
+    // panels).  Every element still receives the same operations in the same order: the same bits (tests force it on).
+    // OFF by default: measured at n = 1024, the fused update costs the panel kernel 23 us (16 wide) to 37 us (32 wide) where
+    // the two update launches it takes off the critical path cost 21 -- 2.93 -> 3.67 ms.  One workgroup of four waves forms
+    // its 1024 x 16 x 16 product at a wave per SIMD; the stream-level variant before it (narrow launches of the update
+    // kernels for the next panel's columns) bought nothing either, those kernels being latency-bound whatever their width.
+    // docs/lab_notebook.md.
+    static const int la_env = [] { const char *e = getenv("NLH_LU_LOOKAHEAD"); return e ? atoi(e) : 0; }();
+    const bool la_ok = la_env > 0 && panel_mode == 1 && (long)nprob * n <= 8192 && n <= 1024 && n >= 256;
+    if (la_ok && !h->lu_side) {
+        bool ok = hipStreamCreateWithFlags(&h->lu_side, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&h->lu_panel_done, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&h->lu_bulk_done[0], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&h->lu_bulk_done[1], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); h->lu_side = nullptr; }
+    }
+    const bool la = la_ok && h->lu_side;
+    int32_t *mvb[2] = {(int32_t *)h->lumv.p, h->lumv.p ? (int32_t *)h->lumv.p + (size_t)LU_MV_STRIDE * nprob : nullptr};
+    bool bulk_rec[2] = {false, false};                           // lu_bulk_done[i] has been recorded (by the bulk update of a step of parity i)
+    int pnb = 0, step = 0;                                       // pnb > 0: the previous panel is still to be applied to the next panel's columns
+    for (int jb = 0; jb < n; ++step) {
         int nb = 0;
-        if (panel_mode >= 1) nb = launch_lu_panel_reg<FAST>(h, nprob, n, dA, dipvt, dinfo, jb, st, want, panel_mode >= 2);
+        int32_t *mv = mvb[la ? (step & 1) : 0];
+        if (panel_mode >= 1) {
+            // this panel's columns were last touched by the bulk update two steps back (it also read the move list this panel overwrites)
+            if (la && bulk_rec[step & 1]) { hipStreamWaitEvent(h->stream, h->lu_bulk_done[step & 1], 0); bulk_rec[step & 1] = false; }
+            nb = launch_lu_panel_reg<FAST>(h, nprob, n, dA, dipvt, dinfo, jb, st, want, panel_mode >= 2, mv, pnb, pnb ? mvb[(step - 1) & 1] : nullptr);
+        }
+        pnb = 0;
         const bool reg = nb != 0;
         if (nb == 0) {
             const bool lds = panel_mode == 0 && (n - jb) <= LU_PROWS;
@@ -69,24 +107,42 @@ static void lu_blocked(nlh_handle *h, int nprob, int n, double *dA, int32_t *dip
             else
                 hipLaunchKernelGGL(k_lu_panel, dim3(nprob), dim3(1024), 0, h->stream, n, dA, dipvt, dinfo, jb, nb, st, want);
         }
+        const int nt = n - jb - nb;
+        const int nb2 = (la && reg) ? lu_panel_reg_width(nt) : 0;            // the next panel's width: its columns are left to its own kernel
+        hipStream_t us = h->stream;
+        if (nb2 > 0) {
+            hipEventRecord(h->lu_panel_done, h->stream);
+            hipStreamWaitEvent(h->lu_side, h->lu_panel_done, 0);
+            us = h->lu_side;
+        } else {                                                 // back on the panel's stream: behind whatever the side stream still holds
+            for (int i = 0; i < 2; ++i)
+                if (bulk_rec[i]) { hipStreamWaitEvent(h->stream, h->lu_bulk_done[i], 0); bulk_rec[i] = false; }
+        }
         if (n - nb > 0) {
             if (reg) {
+                const int slo = nb2 > 0 ? jb : 0, shi = nb2 > 0 ? jb + nb2 : 0;   // outside-column indices jb .. jb + nb2 = the next panel's columns
                 if (nb <= 16)
-                    hipLaunchKernelGGL((k_lu_move_trsm<16, FAST>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
-                                       (const int32_t *)h->lumv.p, jb, nb, st, want);
+                    hipLaunchKernelGGL((k_lu_move_trsm<16, FAST>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, us, n, dA,
+                                       (const int32_t *)mv, jb, nb, st, want, slo, shi);
                 else
-                    hipLaunchKernelGGL((k_lu_move_trsm<32, FAST>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
-                                       (const int32_t *)h->lumv.p, jb, nb, st, want);
+                    hipLaunchKernelGGL((k_lu_move_trsm<32, FAST>), dim3((n - nb + 255) / 256, nprob), dim3(256), 0, us, n, dA,
+                                       (const int32_t *)mv, jb, nb, st, want, slo, shi);
             } else {
-                hipLaunchKernelGGL(k_lu_swap_trsm, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, h->stream, n, dA,
+                hipLaunchKernelGGL(k_lu_swap_trsm, dim3((n - nb + 255) / 256, nprob), dim3(256), 0, us, n, dA,
                                    (const int32_t *)dipvt, jb, nb, st, want);
             }
         }
-        const int nt = n - jb - nb;
         if (nt > 0)
-            hipLaunchKernelGGL(k_lu_gemm<FAST>, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, h->stream, n, dA, jb, nb, st, want);
+            hipLaunchKernelGGL(k_lu_gemm<FAST>, dim3((nt + 63) / 64, (nt + 63) / 64, nprob), dim3(256), 0, us, n, dA, jb, nb, st, want, nb2);
+        if (nb2 > 0) {
+            hipEventRecord(h->lu_bulk_done[step & 1], h->lu_side);
+            bulk_rec[step & 1] = true;
+            pnb = nb;
+        }
         jb += nb;
     }
+    for (int i = 0; i < 2; ++i)
+        if (bulk_rec[i]) hipStreamWaitEvent(h->stream, h->lu_bulk_done[i], 0);
 }
 
 // lu_factor: unblocked single-workgroup kernel for small n, blocked multi-kernel path otherwise.
@@ -97,7 +153,7 @@ void launch_lu_factor(nlh_handle *h, int nprob, int n, double *dA, int32_t *dipv
     int panel_mode = panel_env;
     // the move lists of the register panel: allocated BEFORE the timed bracket and the first launch (growing a workspace
     // frees the old one, a device-wide synchronisation).  Without the memory the global-memory panel serves: say nothing
-    if (n >= 128 && panel_mode >= 1 && ensure(h, h->lumv, sizeof(int32_t) * LU_MV_STRIDE * (size_t)nprob)) { panel_mode = 0; h->err.clear(); }
+    if (n >= 128 && panel_mode >= 1 && ensure(h, h->lumv, sizeof(int32_t) * 2 * LU_MV_STRIDE * (size_t)nprob)) { panel_mode = 0; h->err.clear(); }
     Timed t(h, NLH_K_LU);
     if (n < 128) {
         hipLaunchKernelGGL(k_lu_factor, dim3(nprob), dim3(n >= 96 ? 1024 : 256), 0, h->stream, n, dA, dipvt, dinfo, st, want);

@@ -286,3 +286,38 @@ def test_lu_nan_entries_keep_a_valid_pivot(ds, oracle, n, kind):
     ip = ipvt[0].cpu().numpy()
     assert ip.min() >= 0 and ip.max() < n
     assert np.array_equal(ip, ipo)                # (round 4: scattered NaNs too -- every search form maps a NaN below the diagonal to "never")
+
+
+_LU_LOOKAHEAD = '''
+import ctypes as C, numpy as np, torch
+from nonlin_amd.device import DeviceSolver
+from oracle import pyoracle as O
+ds = DeviceSolver(0)
+L = O.lib()
+for n in (256, 300, 513, 700, 1024):
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n, n))
+    if n == 300: a = rng.integers(-3, 4, size=(n, n)).astype(float)          # ties in every pivot search
+    if n == 513: a[:, 7] = 0.0                                                # a zero column
+    lu = np.array(a, order="F"); ipo = np.zeros(n, dtype=np.int32)
+    L.nlo_lu_factor(n, lu.ctypes.data_as(C.POINTER(C.c_double)), n, ipo.ctypes.data_as(C.POINTER(C.c_int32)))
+    Ad = torch.tensor(np.ascontiguousarray(a.T), device="cuda").reshape(1, n, n)
+    ipvt, info = ds.lu_factor(Ad)
+    assert np.array_equal(Ad[0].cpu().numpy().T, lu, equal_nan=True), n
+    assert np.array_equal(ipvt[0].cpu().numpy(), ipo), n
+print("ok")
+'''
+
+
+@pytest.mark.gpu
+def test_lu_look_ahead_form_is_bitwise():
+    """NLH_LU_LOOKAHEAD=1 (off by default: measured slower): every panel applies the previous panel to its own columns inside
+    its kernel and the rest of the update runs on a side stream under it -- factors and interchanges bit for bit the
+    oracle's, across the panel-width switches, with ties and a zero column."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NLH_LU_LOOKAHEAD="1")
+    out = subprocess.run([sys.executable, "-c", _LU_LOOKAHEAD], capture_output=True, text=True, timeout=600, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
