@@ -264,14 +264,28 @@ contains
         end if
 
         call this%export_options(opts)
-        ctx%helper => fcn
-        if (present(args)) ctx%args => args
-        jac_entry = c_null_funptr
-        if (fcn%is_jacobian_defined()) jac_entry = c_funloc(nlh_jacfcn_trampoline)
         allocate(xwork(n), source = x)
         allocate(fwork(m))
-        rc = nlh_cls_solve(nlh_default_handle(), opts, this%radius0_, this%dogleg_scale_, lo, hi, m, n, &
-            c_funloc(nlh_vecfcn_trampoline), jac_entry, c_loc(ctx), xwork, fwork, counters)
+        if (fcn%is_device_model_defined()) then
+            ! a device residual (set_device_model / set_device_fcn): the bounded dog-leg iteration entirely on the GPU
+            block
+                type(device_model_batch) :: onchip
+                type(nlh_iteration_behavior) :: c1(1)
+                integer(c_int32_t) :: outcome(1)
+                onchip = fcn%device_model()
+                rc = nlh_dq_model_cls_solve(nlh_default_handle(), opts, onchip%c_handle(), this%radius0_, this%dogleg_scale_, lo, hi, &
+                    xwork, fwork, c1, outcome)
+                if (rc == 0) rc = outcome(1)
+                counters = c1(1)
+            end block
+        else
+            ctx%helper => fcn
+            if (present(args)) ctx%args => args
+            jac_entry = c_null_funptr
+            if (fcn%is_jacobian_defined()) jac_entry = c_funloc(nlh_jacfcn_trampoline)
+            rc = nlh_cls_solve(nlh_default_handle(), opts, this%radius0_, this%dogleg_scale_, lo, hi, m, n, &
+                c_funloc(nlh_vecfcn_trampoline), jac_entry, c_loc(ctx), xwork, fwork, counters)
+        end if
         x = xwork
         fvec = fwork
         if (present(ib)) call behavior_import(ib, counters)

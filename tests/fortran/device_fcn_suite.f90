@@ -108,6 +108,37 @@ program device_fcn_suite
         call report("df_lm_batch", ibs(k), st(k), x(:,k))
     end do
     call batch%destroy()
+
+    ! ---- bounded least squares (constrained_least_squares_solver) on the same family: every problem inside one box
+    block
+        type(constrained_least_squares_solver) :: tr
+        real(real64), allocatable :: lo(:), hi(:)
+        integer(int32) :: q
+        allocate(lo(n), hi(n))
+        do q = 1, n, 3
+            lo(q) = 0.4d0;  hi(q) = 1.2d0                      ! amplitudes
+            lo(q + 1) = -1.0d0; hi(q + 1) = 2.0d0              ! centres
+            lo(q + 2) = 0.02d0; hi(q + 2) = 0.2d0              ! widths
+        end do
+        call tr%set_max_fcn_evals(500)
+        call tr%set_lower_limits(lo)
+        call tr%set_upper_limits(hi)
+        call batch%create_from_device_fcn(c_funloc(lorentz_launch), ctx, nprob, m, n)
+        x = x0
+        call tr%solve_batch(batch, x, f, ibs, st)
+        do k = 1, nprob
+            call report("df_cls_batch", ibs(k), st(k), x(:,k))
+        end do
+        call batch%destroy()
+        ! one problem through the reference's own call
+        ctx1 = lorentz_create(1, m, t(:,2), y(:,2))
+        call obj%set_device_fcn(c_funloc(lorentz_launch), ctx1, m, n)
+        x1 = x0(:,2)
+        call tr%solve(obj, x1, f1, ib)
+        call report("df_cls_single", ib, 0, x1)
+        call obj%clear_device_model()
+        call lorentz_destroy(ctx1)
+    end block
     call lorentz_destroy(ctx)
 
     ! ---- a square family with an analytic jacobianfcn launcher: newton_solver and quasi_newton_solver
@@ -137,6 +168,16 @@ program device_fcn_suite
         call report("df_newton_fd_batch", ibs(k), st(k), x(:,k))
     end do
     call batch%destroy()
+    call btri_destroy(bctx)
+    ! one square problem through quasi_newton_solver%solve itself (analytic jacobianfcn launcher)
+    bctx = btri_create(1, c(3:3))
+    call obj%set_device_fcn(c_funloc(btri_launch), bctx, nq, nq, c_funloc(btri_launch_jac))
+    deallocate(x1, f1)
+    allocate(x1(nq), f1(nq))
+    x1 = xs(:,3)
+    call qn%solve(obj, x1, f1, ib)
+    call report("df_broyden_single", ib, 0, x1)
+    call obj%clear_device_model()
     call btri_destroy(bctx)
 
 contains

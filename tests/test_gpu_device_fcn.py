@@ -371,6 +371,26 @@ def test_user_device_fcn_through_the_fortran_shim(ds, oracle, tmp_path):
         for p in range(nprob):
             rc, xo, fo, ibo = _oracle_square(oracle, B, p, nq, xs[p], broyden, analytic, max_evals=500)
             cmp(res[key][p], rc, xo, ibo)
+    rc, xo, fo, ibo = _oracle_square(oracle, B, 2, nq, xs[2], True, True, max_evals=500)       # quasi_newton_solver%solve itself
+    cmp(res["df_broyden_single"][0], rc, xo, ibo)
+    # constrained_least_squares_solver: solve_batch and solve on the user's device function, the box of the Fortran program
+    lo, hi = np.tile([0.4, -1.0, 0.02], K), np.tile([1.2, 2.0, 0.2], K)
+    L = oracle.lib()
+
+    def cls_oracle(p):
+        hc = UM.LorentzHost(m, t[p].ctypes.data_as(dp), y[p].ctypes.data_as(dp), 0)
+        oo = oracle.default_options(max_evals=500)
+        xo, fo, ibo = x0[p].copy(), np.zeros(m), oracle.IterationBehavior()
+        rc = L.nlo_cls_solve(C.byref(oo), C.c_double(1.0), C.c_double(1.0), lo.ctypes.data_as(dp), hi.ctypes.data_as(dp),
+                             C.cast(so.lorentz_host_fcn, oracle.VECFCN), C.cast(None, oracle.JACFCN), C.byref(hc), m, n,
+                             xo.ctypes.data_as(dp), fo.ctypes.data_as(dp), C.byref(ibo))
+        return rc, xo, ibo.as_dict()
+    assert len(res["df_cls_batch"]) == nprob
+    for p in range(nprob):
+        rc, xo, ibo = cls_oracle(p)
+        cmp(res["df_cls_batch"][p], rc, xo, ibo)
+    rc, xo, ibo = cls_oracle(1)
+    cmp(res["df_cls_single"][0], rc, xo, ibo)
 
 
 # ---------------------------------------------------------------------------------------------------- GPU: bounded least squares
