@@ -236,7 +236,7 @@ int residual_eval(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int
 }
 
 // Bytes of panel the user's launcher fills before k_fd_jacobian turns them into Jacobian columns: a cap on the panel
-// buffer (16 GiB), not a tuning knob -- measured at 512 x 4096x256 inside a solve (scratch/devfcn_fd.sh), chunks small
+// buffer (16 GiB), not a tuning knob -- measured at 512 x 4096x256 inside a solve (profiles/scripts/devfcn_fd.sh), chunks small
 // enough for the Infinity Cache to serve the panel read do NOT pay: 16 / 32 / 64 / 128 / 256 MiB chunks ran the
 // forward-difference kernel at 0.42 / 0.56 / 0.67 / 0.74 / 0.77 of 8 TB/s, one 8.6 GB launch at 0.756 (6.0 TB/s of
 // algorithmic traffic; without the non-temporal hint on the panel loads 0.726).  NLH_FD_CHUNK_MB overrides (0: no cap).

@@ -57,7 +57,7 @@ if f and t:
 PY
 rm -rf "$OUT/c5auto.MFMA"
 # 3. the open device-residual path: kernel stats of the device_vecfcn rows (k_fd_jacobian_qrx inside the solves)
-stats devfcn python3 scratch/devfcn_time.py
+stats devfcn python3 profiles/scripts/devfcn_time.py
 # 4. mid regime: solve times between a handful and a chipful (46 / 47: the first six-iteration problem), kernel shares at 47 and 128
 timeout 900 python3 profiles/sweep_mid.py 4096x256:1,4,8,16,32,46,47,64,128,256 2048x128:1,8,32,64,128,256,512,1024 > "$OUT/r05_sweep_mid.txt" 2>&1
 stats mid_4096x256_47 python3 profiles/sweep_mid.py 4096x256:47
