@@ -89,16 +89,27 @@ static __global__ void k_count_active(int nprob, const LmState *st, int *out)
     if (threadIdx.x == 0) { out[0] = cnt; out[1] = cntj; }      // still iterating; of those, due for a Jacobian + factorisation
 }
 
-// partial sums of squares of a device vector, same block structure as k_dq_residual
-template <int BS>
+// partial sums of squares of a device vector: the block structure AND the in-block order of k_dq_residual (PAIR false) /
+// k_dq_residual2 (PAIR true: two rows per thread, their squares added first), so that a residual that arrives from a
+// launcher or a host callback gives the normal-equations policies the bits the built-in family's fused sums give
+template <int BS, bool PAIR>
 __global__ void k_sumsq_part(int m, int n, const double *__restrict__ f, double *__restrict__ part)
 {
     __shared__ double red[16];
     const int p = blockIdx.y;
-    const int i = blockIdx.x * BS + threadIdx.x;
-    const double v = (i < m) ? f[(size_t)p * m + i] : 0.0;
-    const double sq = v * v;
-    const double tq = (i >= n) ? sq : 0.0;
+    double sq, tq;
+    if (PAIR) {
+        const int i = (blockIdx.x * BS + threadIdx.x) * 2;      // m even: i + 1 < m as well
+        const double v0 = (i < m) ? f[(size_t)p * m + i] : 0.0, v1 = (i < m) ? f[(size_t)p * m + i + 1] : 0.0;
+        const double q0 = v0 * v0, q1 = v1 * v1;
+        sq = q0 + q1;
+        tq = ((i < m && i >= n) ? q0 : 0.0) + ((i < m && i + 1 >= n) ? q1 : 0.0);
+    } else {
+        const int i = blockIdx.x * BS + threadIdx.x;
+        const double v = (i < m) ? f[(size_t)p * m + i] : 0.0;
+        sq = v * v;
+        tq = (i >= n) ? sq : 0.0;
+    }
     const double s = block_reduce_sum(sq, red);
     const double t = block_reduce_sum(tq, red);
     if (threadIdx.x == 0) {
@@ -109,7 +120,9 @@ __global__ void k_sumsq_part(int m, int n, const double *__restrict__ f, double 
 
 void launch_sumsq_part(nlh_handle *h, int nprob, int m, int n, const double *f, double *part)
 {
-    hipLaunchKernelGGL(k_sumsq_part<RB>, dim3((m + RB - 1) / RB, nprob), dim3(RB), 0, h->stream, m, n, f, part);
+    const dim3 grid((m + RB - 1) / RB, nprob);
+    if (m % 2 == 0) hipLaunchKernelGGL((k_sumsq_part<RB / 2, true>), grid, dim3(RB / 2), 0, h->stream, m, n, f, part);
+    else hipLaunchKernelGGL((k_sumsq_part<RB, false>), grid, dim3(RB), 0, h->stream, m, n, f, part);
 }
 
 // K-splits of the Gram contraction.  The split count and the kernel are functions of the problem SHAPE only, never of how
@@ -589,7 +602,7 @@ int nlh_lm_solve(nlh_handle *h, const nlh_options *o, int32_t m, int32_t n, nlh_
     fcn(ctx, n, x, m, fvec);                                    // :211
     HIPCHK(h, hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(dfvec, fvec, sizeof(double) * m, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_sumsq_part<RB>, dim3(w.nblk, 1), dim3(RB), 0, s, m, n, dfvec, w.part);
+    launch_sumsq_part(h, 1, m, n, dfvec, w.part);
     if (o->factor_policy == NLH_FACTOR_EXACT)
         hipLaunchKernelGGL(k_lm_init_exact, dim3(1), dim3(256), 0, s, m, dfvec, w.st, (int)ST_NEED_JAC);
     else
@@ -634,7 +647,7 @@ int nlh_lm_solve(nlh_handle *h, const nlh_options *o, int32_t m, int32_t n, nlh_
         if (hs->stage != ST_TRIAL_READY) { h->err = "lm: unexpected stage"; return NLH_ERR_HIP; }
         fcn(ctx, n, hx, m, hf);                                 // :297
         HIPCHK(h, hipMemcpyAsync(w.wa4, hf, sizeof(double) * m, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_sumsq_part<RB>, dim3(w.nblk, 1), dim3(RB), 0, s, m, n, w.wa4, w.part);
+        launch_sumsq_part(h, 1, m, n, w.wa4, w.part);
         hipLaunchKernelGGL(k_stage_advance, dim3(1), dim3(64), 0, s, 1, w.st, (int)ST_TRIAL_READY, (int)ST_TRIAL_DONE, 0);
         const int iter_before = hs->iter;
         lm_update(h, o, 1, m, n, w, dx, dfvec);

@@ -175,6 +175,27 @@ def test_dense_quadratic_family_through_the_launcher_reproduces_its_bits(ds, npr
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("policy", [0, 1])
+@pytest.mark.parametrize("nprob,m,n,hard", [(20, 488, 5, False), (3, 132, 102, True), (20, 138, 101, True), (7, 386, 36, True)])
+def test_launcher_sum_of_squares_is_the_built_in_familys(ds, nprob, m, n, hard, policy):
+    """The normal-equations policies read ||f||^2 as per-block partial sums; a launcher's residual gets them from
+    k_sumsq_part, which must add in the order of the built-in family's fused sums (two rows per thread when m is even) or
+    trials near the ratio thresholds drift by an ulp (tests/soak_device_fcn.py found these shapes)."""
+    gen = dict(gamma=2.0, sigma=0.1, spread=5.0) if hard else dict(gamma=0.5, sigma=1e-3, spread=0.3)
+    fcn = jac = ctx = None
+    for seed in (3, 1001, 77777):
+        A, b, xt, x0 = ds.generate(nprob, m, n, seed0=seed, **gen)
+        o = ds.options(max_evals=500, factor_policy=policy, fuse_fd=0)
+        x1, x2 = x0.clone(), x0.clone()
+        f1, ib1, st1 = ds.lm_solve_batch(A, b, gen["gamma"], x1, o)
+        fcn, jac, ctx = ds.dq_launchers(A, b, gen["gamma"])
+        f2, ib2, st2 = ds.lm_solve_batch_device(fcn, ctx, m, x2, opts=o)
+        assert st1 == st2 and ib1 == ib2
+        assert np.array_equal(x1.cpu().numpy(), x2.cpu().numpy())
+        assert np.array_equal(f1.cpu().numpy(), f2.cpu().numpy())
+
+
+@pytest.mark.gpu
 def test_dense_quadratic_launcher_with_user_jacobian(ds, oracle):
     """A user's jacobianfcn launcher replaces the forward differences (:241-243): LM with the analytic Jacobian of the
     dense-quadratic family == the oracle given the same Jacobian callback."""
