@@ -1222,7 +1222,9 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
 // its faster passes (ms per solve, this form up to 128 / 256 / 384 pairs: 64 x 4096x256 172 / 184 / 184, 128 x 4096x256
 // 232 / 240 / 253, 192 x 2048x128 60 / 58 / 66; eight-wave workgroups for 257-512 pairs: 128 x 4096x256 257, dropped).
 #ifndef QRX_RPW16_MAX_WG
-#define QRX_RPW16_MAX_WG 128            // launches of at most this many (problem, window) pairs take the wide form
+#define QRX_RPW16_MAX_WG 256            // launches of at most this many (problem, window) pairs take the wide form (128 until
+                                        // its producers read whole sectors per lane quad; ms per solve at 128 / 256 / 384 with them:
+                                        // 44 x 4096x256 105.8 / 97.0 / 97.0, 64: 159 / 156 / 156, 128: 225 / 227 / 229, 256 x 2048x128 66.5 / 64.4 / 64.4)
 #endif
 #ifndef QRX_PIV32_MAXM
 #define QRX_PIV32_MAXM 2048
@@ -1237,12 +1239,21 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
 #endif
 #define QRX_RPW_G 8                     // rows per producer and round: one 64-byte sector per lane
 #define QRX_RPW_AH 4                    // row groups in flight per producer
+#ifndef QRX_RPW_QSTR
+#define QRX_RPW_QSTR 132                // QUAD: doubles between two row pairs of a product buffer (64 x 2 + 4: lane (c4, r) writes
+                                        // pair r of column c4 -- eight lanes, eight different 16-byte groups of the 32 banks;
+                                        // ms per solve at 132 / 136: 16 x 4096x256 69.8 / 71.7, 44: 92.3 / 93.3, 128 x 2048x128 34.6 / 34.9)
+#endif
+#define QRX_RPW_NVB 4                   // QUAD: rounds of staged reflector entries in LDS
+#ifndef QRX_RPW_AHQ
+#define QRX_RPW_AHQ 3                   // QUAD: row groups in flight per producer (tcp_pattern2: two, three and four groups run alike)
+#endif
 __device__ __forceinline__ double qrx_readlane_f64(double x, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 
-template <int NP, bool FLUSH, int W>
+template <int NP, bool FLUSH, int W, bool QUAD>
 __global__ void __launch_bounds__(64 * W)
 k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
                double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
@@ -1255,11 +1266,13 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
     // NP).  The W waves of the workgroup land W / 4 on each SIMD; the waves that share wave 0's SIMD retire at once and the
     // other 3 W / 4 are the producers.  (Which waves those are is read from the hardware id at run time; if the placement
     // is ever uneven, waves of the adder's SIMD fill in, or surplus ones retire: always exactly NPR producers.)
-    constexpr int NPR = 3 * W / 4, G = QRX_RPW_G, AH = QRX_RPW_AH, D = AH, RR = NPR * G;                 // D: rounds per trip of the outer loops
+    constexpr int NPR = 3 * W / 4, G = QRX_RPW_G, AH = QUAD ? QRX_RPW_AHQ : QRX_RPW_AH, D = AH, RR = NPR * G;   // D: rounds per trip of the outer loops
+    constexpr int PSTR = QUAD ? QRX_RPW_QSTR : 128;                     // doubles between two row pairs of a product buffer
     static_assert(G == 8, "a row group is one sector per lane");
     __shared__ int simd_of[W];
     constexpr int NPI = NP < QRX_C ? NP : 0;
-    extern __shared__ __attribute__((aligned(16))) double pbw[];         // [2][RR / 2][64][2]: the products of a round, row pairs
+    extern __shared__ __attribute__((aligned(16))) double pbw[];         // [2][RR / 2][PSTR]: the products of a round, row pairs x 64 columns x 2
+                                                                         // (QUAD: then [QRX_RPW_NVB][NP + 1][RR], the staged reflector entries)
     const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
     const int pl = grp * 8 + (r_ & 7), win = r_ >> 3;
     if (pl >= nprob) return;
@@ -1287,7 +1300,8 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
         if (!adder) {
             const bool o = simd_of[wv] != as;
             pw = o ? mine_other : other + mine_same;                     // off-SIMD waves first, then fill-ins
-            if (pw >= NPR) return;                                       // shares the adder's SIMD (or surplus): retire
+            if (QUAD) pw = __builtin_amdgcn_readfirstlane(pw);           // (wave-uniform by construction: keeps the loads' block offsets scalar)
+            if (pw >= NPR + (QUAD ? 1 : 0)) return;                      // shares the adder's SIMD (or surplus): retire (QUAD: one of them stays as the stager)
         }
     }
     if (adder) __builtin_amdgcn_s_setprio(3);
@@ -1324,7 +1338,7 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
     const unsigned ldb = (unsigned)ld * 64u;
     const int nround = (mrel + RR - 1) / RR;                            // producers: rounds 0 .. nround-1, adder: 1 .. nround
     const int ntile = (nround + 1 + D - 1) / D;
-    double *pb0 = pbw, *pb1 = pbw + (size_t)(RR / 2) * 128;
+    double *pb0 = pbw, *pb1 = pbw + (size_t)(RR / 2) * PSTR;
 
     if (adder) {
         // ------------------------------------------------------------------------------------------------------------
@@ -1342,10 +1356,11 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
             asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"                       \
                          "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                           \
                          : "=&v"(w4[(c) & 3][0]), "=&v"(w4[(c) & 3][1]), "=&v"(w4[(c) & 3][2]), "=&v"(w4[(c) & 3][3])  \
-                         : "v"(addr), "n"((c) * 4096), "n"((c) * 4096 + 1024), "n"((c) * 4096 + 2048), "n"((c) * 4096 + 3072) : "memory")
+                         : "v"(addr), "n"(((c) * 4) * PSTR * 8), "n"(((c) * 4 + 1) * PSTR * 8), "n"(((c) * 4 + 2) * PSTR * 8),              \
+                           "n"(((c) * 4 + 3) * PSTR * 8) : "memory")
 #define QRX_WAIT4(c, N)                                                                                             \
             asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(w4[(c) & 3][0]), "+v"(w4[(c) & 3][1]), "+v"(w4[(c) & 3][2]), "+v"(w4[(c) & 3][3]))
-            static_assert(NPR >= 3 && NPR * 4096 <= 65536, "three chunks in flight; immediate offsets of the reads");
+            static_assert(NPR >= 3 && NPR * 4 * PSTR * 8 <= 65536, "three chunks in flight; immediate offsets of the reads");
             QRX_RD4(0); QRX_RD4(1); QRX_RD4(2);
 #pragma unroll
             for (int c = 0; c < NPR; ++c) {
@@ -1375,7 +1390,7 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
             const double2 *src2 = reinterpret_cast<const double2 *>(half) + lane;
 #pragma unroll 1
             for (int pr = 0; pr < RR / 2; ++pr) {
-                const double2 ww = src2[(size_t)pr * 64];
+                const double2 ww = src2[(size_t)pr * (PSTR / 2)];
                 const int row = rbase + 2 * pr;
                 if (row >= r0 && row < mrel) s = s + ww.x;              // uniform
                 if (row + 1 >= r0 && row + 1 < mrel) s = s + ww.y;
@@ -1415,6 +1430,162 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
         if (!act) return;
         qrx_pass_tail<NP, FLUSH>(p, j, k, col, coff + k, m, n, ld, cur, vst, s, rowj, rk0, wa0, refl, ajj, tq, Tp, vc, vo, tpall,
                                  rdall, waall, Rall, qtfall);
+        return;
+    }
+    if constexpr (QUAD) {
+        // ------------------------------------------------------------------------------------------------------------
+        // Producers that read WHOLE SECTORS PER LANE QUAD.  In the lane-per-column shape every 16-byte load instruction
+        // touches 64 sectors for a quarter of each, and that is what bounds a CU that has the pass to itself
+        // (profiles/ubench/tcp_pattern2.hip, us per 4096 x 64 window at 32 / 88 / 128 / 188 / 256 workgroups: 49 / 52 / 74 /
+        // 91 / 103, and 123 / 133 / 207 / 262 / 285 with the flush's stores).  Here lanes 4c .. 4c+3 read column c's sector
+        // (1 KB contiguous per instruction, sixteen columns; 26 / 30 / 43 / 62 / 91 us, and 48 / 53 / 131 / 147 / 216 with
+        // stores: whole sectors written by one instruction): lane (c4, r) holds rows 2r, 2r+1 of the four columns 16 q + c4.
+        // The reflector entries are then no longer wave-uniform; as extra vector loads they cost as much as the matrix loads
+        // (+ 60 % with five slots: the CU's limit is load INSTRUCTIONS), so one otherwise idle wave on the adder's SIMD -- the
+        // stager -- copies each round's entries into LDS three rounds ahead and the producers read their row pair back
+        // (one 16-byte LDS read per slot and group).  Same operands, same operations, same order per element: bit-identical.
+        constexpr int NVB = QRX_RPW_NVB;
+        double *vsb = pbw + (size_t)2 * (RR / 2) * PSTR;                 // [NVB][NP + 1][RR]
+        auto vsrc = [&](int q, int t) __attribute__((always_inline)) {  // rounds past the last re-read the last (never used)
+            const int row = min(t, nround - 1) * RR;
+            return ((q < NP) ? vc + (size_t)q * vst : (FLUSH ? vo : vc + (size_t)NPI * vst)) + row;
+        };
+        if (pw == NPR) {
+            // the stager: entries of round t + 3 into LDS during round t (loaded two rounds before that)
+            const bool on = lane < RR / 2;                               // 48 lanes x 16 bytes = the 96 rows of a round
+            double2 hold[2][NP + 1];
+            auto fetch = [&](double2 (&h)[NP + 1], int t) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q <= NP; ++q) h[q] = on ? *reinterpret_cast<const double2 *>(vsrc(q, t) + 2 * lane) : make_double2(0.0, 0.0);
+            };
+            auto stage = [&](const double2 (&h)[NP + 1], int t) __attribute__((always_inline)) {
+                if (on) {
+#pragma unroll
+                    for (int q = 0; q <= NP; ++q)
+                        *reinterpret_cast<double2 *>(vsb + ((size_t)(t % NVB) * (NP + 1) + q) * RR + 2 * lane) = h[q];
+                }
+            };
+            fetch(hold[0], 0); fetch(hold[1], 1);
+            stage(hold[0], 0); stage(hold[1], 1);
+            fetch(hold[0], 2);
+            stage(hold[0], 2);
+            fetch(hold[1], 3); fetch(hold[0], 4);
+            qrx_lds_barrier();
+            int t = 0;
+#pragma unroll 1
+            for (; t + 1 < ntile * D; t += 2) {
+                stage(hold[1], t + 3); fetch(hold[1], t + 5);
+                qrx_lds_barrier();
+                stage(hold[0], t + 4); fetch(hold[0], t + 6);
+                qrx_lds_barrier();
+            }
+            if (t < ntile * D) { stage(hold[1], t + 3); qrx_lds_barrier(); }
+            return;
+        }
+        const int c4 = lane >> 2, rq = lane & 3;
+        unsigned soq[4], koq[4];
+        double tqq[NP > 0 ? NP : 1][4];
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+            const int colq = ld - 64 * (win + 1) + 16 * q2 + c4;
+            const int ks = (colq >= coff + lo) ? slotp[colq] : -1;
+            const bool aq = ks > j;
+            const int kq = aq ? ks : n;
+            soq[q2] = aq ? (unsigned)colq * 64u + 16u * rq : 0x80000000u;
+            koq[q2] = aq ? (unsigned)(coff + kq) * 64u + 16u * rq : 0x80000000u;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) tqq[q][q2] = tpc[(size_t)q * ldp + kq];
+        }
+        double2 aq_[AH][4];
+        double2 vq[NP + 1];
+        auto loadq = [&](double2 (&buf)[4], int t) __attribute__((always_inline)) {
+            const unsigned boff = (unsigned)((t * RR + pw * G) >> 3) * ldb;
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const qrx_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, soq[q2], boff, QRX_AUX_LOAD);
+                buf[q2].x = __hiloint2double((int)w.y, (int)w.x);
+                buf[q2].y = __hiloint2double((int)w.w, (int)w.z);
+            }
+        };
+        auto vread = [&](int t) __attribute__((always_inline)) {
+            const double *src = vsb + (size_t)(t % NVB) * (NP + 1) * RR + pw * G + 2 * rq;
+#pragma unroll
+            for (int q = 0; q <= NP; ++q) vq[q] = *reinterpret_cast<const double2 *>(src + (size_t)q * RR);
+        };
+        auto produceq = [&](const double2 (&buf)[4], int t) __attribute__((always_inline)) {
+            const int rbase = t * RR + pw * G;
+            double *dst = ((t & 1) ? pb1 : pb0) + (size_t)(pw * (G / 2) + rq) * PSTR + 2 * c4;
+            double2 est[4];
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                double e0 = buf[q2].x, e1 = buf[q2].y;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const double p0_ = tqq[q][q2] * vq[q].x, p1_ = tqq[q][q2] * vq[q].y;
+                    e0 = e0 - p0_;
+                    e1 = e1 - p1_;
+                }
+                double2 ww;                                             // rows outside the live range: garbage the adder skips
+                ww.x = vq[NP].x * e0;
+                ww.y = vq[NP].y * e1;
+                *reinterpret_cast<double2 *>(dst + 32 * q2) = ww;
+                if (FLUSH) { est[q2].x = e0; est[q2].y = e1; }
+            }
+            if (FLUSH) {
+                // whole sectors, unconditionally (see the lane-per-column producer below); a slot's own position is a dead
+                // column unless it is the column the slot is read from, so no lane of any workgroup reads what another writes
+                const unsigned boff = (unsigned)(rbase >> 3) * ldb;
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) {
+                    qrx_u32x4 w;
+                    w.x = (unsigned)__double2loint(est[q2].x); w.y = (unsigned)__double2hiint(est[q2].x);
+                    w.z = (unsigned)__double2loint(est[q2].y); w.w = (unsigned)__double2hiint(est[q2].y);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, koq[q2], boff, QRX_AUX_STORE);
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < AH - 1; ++i) loadq(aq_[i], i);
+#ifdef QRX_DBG_CLK
+        long long pk0 = wall_clock64(), pwork = 0, pwait = 0, pmem = 0;
+#endif
+        qrx_lds_barrier();
+        vread(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int kt = 0; kt < ntile; ++kt) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const int t = kt * D + i;
+#ifdef QRX_DBG_CLK
+                const long long pa = wall_clock64();
+#endif
+                loadq(aq_[(i + AH - 1) % AH], t + AH - 1);
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef QRX_DBG_CLK
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // (the group of this round and its reflector entries have arrived)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const long long pm = wall_clock64();
+                pmem += pm - pa;
+#endif
+                produceq(aq_[i % AH], t);
+                __builtin_amdgcn_sched_barrier(0);
+                vread(t + 1);                                           // staged by the barrier before this round
+#ifdef QRX_DBG_CLK
+                const long long pbk = wall_clock64();
+#endif
+                qrx_lds_barrier();
+#ifdef QRX_DBG_CLK
+                pwork += pbk - pa; pwait += wall_clock64() - pbk;
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#ifdef QRX_DBG_CLK
+        if (lane == 0 && j >= 99 && j <= 101 && blockIdx.x < 1 && (pw == 0 || pw == NPR - 1))
+            printf("rpw QUAD producer %d wg %d j=100 NP=%d: head %lld work %lld (of it waiting for loads %lld) barrier-wait %lld (x10 ns) rounds %d\n", pw, blockIdx.x, NP,
+                   pk0 - ckk, pwork, pmem, pwait, nround);
+#endif
         return;
     }
     // producer side ---------------------------------------------------------------------------------------------------
@@ -1775,7 +1946,13 @@ k_qrx_finish(int m, int n, int ld, int coff, size_t tst, size_t vst, int cur, in
     }
 }
 
-static constexpr size_t qrx_rpw_lds(int W) { return (size_t)(3 * W / 4) * QRX_RPW_G * 1024; }   // two buffers of 3 W / 4 * 8 rows x 64 lanes x 8 bytes
+// two product buffers of 3 W / 4 * 8 rows x 64 lanes x 8 bytes (QUAD: padded row pairs, + the staged reflector entries)
+static constexpr size_t qrx_rpw_lds(int W, bool quad = false)
+{
+    return quad ? sizeof(double) * ((size_t)(3 * W / 4) * QRX_RPW_G * QRX_RPW_QSTR + (size_t)QRX_RPW_NVB * (QRX_RPW_MAXNP + 1) * (3 * W / 4) * QRX_RPW_G)
+                : (size_t)(3 * W / 4) * QRX_RPW_G * 1024;
+}
+static bool qrx_quad_on() { static const int v = [] { const char *e = getenv("NLH_QRX_QUAD"); return e ? atoi(e) : 1; }(); return v != 0; }
 
 template <int NP, bool FLUSH>
 static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
@@ -1791,8 +1968,11 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     if constexpr (NP > QRX_RPW_MAXNP) { if (rp == 16) rp = 4; }
     if constexpr (NP < 8) {
     if constexpr (NP <= QRX_RPW_MAXNP) {
-    if (rp == 16)
-        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16>), grid, dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+    if (rp == 16 && qrx_quad_on())
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, true>), grid, dim3(64 * 16), qrx_rpw_lds(16, true), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+    else if (rp == 16)
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, false>), grid, dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
     }
     if (rp == 4)
@@ -1831,10 +2011,13 @@ static void dispatch_pass(int np, bool flush, int rp, hipStream_t stream, int p0
 template <int NP>
 static void qrx_rpw_attr()
 {
-    const int lim = (int)qrx_rpw_lds(16);
-    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    if constexpr (qrx_can_flush(NP))
-        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    const int lim = (int)qrx_rpw_lds(16), limq = (int)qrx_rpw_lds(16, true);
+    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
+    if constexpr (qrx_can_flush(NP)) {
+        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
+    }
     if constexpr (NP < QRX_RPW_MAXNP) qrx_rpw_attr<NP + 1>();
 }
 
@@ -1883,7 +2066,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     static const long rp_env = [] { const char *e = getenv("NLH_QRX_RP"); return e ? atol(e) : -1L; }();
     const long rp_max = rp_env >= 0 ? rp_env : QRX_RP_MAX_WG;
     static const long rpw16_env = [] { const char *e = getenv("NLH_QRX_RPW16"); return e ? atol(e) : -1L; }();
-    const long rpw16_max = std::min(rp_max, rpw16_env >= 0 ? rpw16_env : (long)QRX_RPW16_MAX_WG);
+    const long rpw16_max = std::min(rp_max, rpw16_env >= 0 ? rpw16_env : (long)(qrx_quad_on() ? QRX_RPW16_MAX_WG : 128));   // (the lane-per-column producers: 128)
     static const int col_env = [] { const char *e = getenv("NLH_QRX_COL"); return e ? atoi(e) : -1; }();
     if (col_env >= 0 ? nact <= col_env : (long)nact * n <= QRX_COL_MAX_WG) {
         // two product buffers for columns of several chunks, one sized to the column otherwise
