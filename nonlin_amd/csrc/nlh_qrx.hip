@@ -1226,6 +1226,14 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
                                         // its producers read whole sectors per lane quad; ms per solve at 128 / 256 / 384 with them:
                                         // 44 x 4096x256 105.8 / 97.0 / 97.0, 64: 159 / 156 / 156, 128: 225 / 227 / 229, 256 x 2048x128 66.5 / 64.4 / 64.4)
 #endif
+#define QRX_RP_HALF 1632                // pass-form code: the wide form on 32-column half windows
+#ifndef QRX_RPWH_MAX_WG
+#define QRX_RPWH_MAX_WG 256             // ... while a launch has at most this many (problem, half window) pairs (ms per solve, off / 128 /
+                                        // 256 / 512: 13 x 4096x256 68.9 / 62.8 / 62.8 / 62.8, 24: 71.1 / 67.5 / 66.1 / 66.1, 32: 78.4 / 75.6 / 71.9 / 71.9,
+                                        // 44: 91.9 / 91.0 / 88.0 / 91.9, 32 x 2048x128 23.2 / 21.6 / 21.6 / 21.6, 128: 34.6 / 34.2 / 34.1 / 36.6).  The gain is
+                                        // small because the adder, not LDS bandwidth, sets the pace: ~7 ns per row whatever the column count
+                                        // (in-kernel clocks: consume 28.5 -> 26.5 us per 4000 rows with half the columns)
+#endif
 #ifndef QRX_PIV32_MAXM
 #define QRX_PIV32_MAXM 2048
 #endif
@@ -1253,7 +1261,7 @@ __device__ __forceinline__ double qrx_readlane_f64(double x, int l)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 
-template <int NP, bool FLUSH, int W, bool QUAD>
+template <int NP, bool FLUSH, int W, bool QUAD, int CW = 64>
 __global__ void __launch_bounds__(64 * W)
 k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
                double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
@@ -1268,6 +1276,12 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
     // is ever uneven, waves of the adder's SIMD fill in, or surplus ones retire: always exactly NPR producers.)
     constexpr int NPR = 3 * W / 4, G = QRX_RPW_G, AH = QUAD ? QRX_RPW_AHQ : QRX_RPW_AH, D = AH, RR = NPR * G;   // D: rounds per trip of the outer loops
     constexpr int PSTR = QUAD ? QRX_RPW_QSTR : 128;                     // doubles between two row pairs of a product buffer
+    // CW: columns per workgroup.  A window's products go through LDS once in and once out -- 16 bytes of LDS traffic per
+    // matrix element, ~67 bytes per clock all told -- and that, not memory, bounds a workgroup that has its CU to itself
+    // (in-kernel clocks, 32 x 4096x256, a 4000-row pass: the adder busy 29.5 of 34 us, the producers idle 2/3 of the
+    // time).  While the chip has CUs to spare a window is therefore dealt to TWO workgroups of 32 columns (`nwin` then
+    // counts 32-column windows); the adder runs with its upper 32 lanes off.
+    static_assert(CW == 64 || (QUAD && CW == 32), "half windows: the lane-quad producers only");
     static_assert(G == 8, "a row group is one sector per lane");
     __shared__ int simd_of[W];
     constexpr int NPI = NP < QRX_C ? NP : 0;
@@ -1314,8 +1328,9 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
     const int jb = j & ~7, r0 = j & 7, mrel = m - jb;
     const double *vc = Vall + ((size_t)p * 2 + cur) * QRX_C * vst + jb;
     const double *vo = Vall + ((size_t)p * 2 + (cur ^ 1)) * QRX_C * vst + jb;
-    const int col = ld - 64 * (win + 1) + lane;
-    const int kslot = (col >= coff + lo) ? slotp[col] : -1;
+    const bool inw = CW == 64 || lane < CW;
+    const int col = inw ? ld - CW * (win + 1) + lane : ld - 1;
+    const int kslot = (inw && col >= coff + lo) ? slotp[col] : -1;
     const bool act = kslot > j;
     const int k = act ? kslot : n;
     double tq[NP > 0 ? NP : 1];
@@ -1411,8 +1426,10 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
             if (t >= 1 && t <= nround) {
                 const int rbase = (t - 1) * RR;
                 const double *half = ((t - 1) & 1) ? pb1 : pb0;
-                if (rbase >= r0 && rbase + RR <= mrel) consume(half);
-                else consume_edge(half, rbase);
+                if (inw) {                                              // (half windows: the upper 32 lanes stay off, LDS reads included)
+                    if (rbase >= r0 && rbase + RR <= mrel) consume(half);
+                    else consume_edge(half, rbase);
+                }
             }
 #ifdef QRX_DBG_CLK
             const long long cb = wall_clock64();
@@ -1482,12 +1499,13 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
             if (t < ntile * D) { stage(hold[1], t + 3); qrx_lds_barrier(); }
             return;
         }
+        constexpr int NQ = CW / 16;                                      // load instructions per 8-row group
         const int c4 = lane >> 2, rq = lane & 3;
-        unsigned soq[4], koq[4];
-        double tqq[NP > 0 ? NP : 1][4];
+        unsigned soq[NQ], koq[NQ];
+        double tqq[NP > 0 ? NP : 1][NQ];
 #pragma unroll
-        for (int q2 = 0; q2 < 4; ++q2) {
-            const int colq = ld - 64 * (win + 1) + 16 * q2 + c4;
+        for (int q2 = 0; q2 < NQ; ++q2) {
+            const int colq = ld - CW * (win + 1) + 16 * q2 + c4;
             const int ks = (colq >= coff + lo) ? slotp[colq] : -1;
             const bool aq = ks > j;
             const int kq = aq ? ks : n;
@@ -1496,12 +1514,12 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
 #pragma unroll
             for (int q = 0; q < NP; ++q) tqq[q][q2] = tpc[(size_t)q * ldp + kq];
         }
-        double2 aq_[AH][4];
+        double2 aq_[AH][NQ];
         double2 vq[NP + 1];
-        auto loadq = [&](double2 (&buf)[4], int t) __attribute__((always_inline)) {
+        auto loadq = [&](double2 (&buf)[NQ], int t) __attribute__((always_inline)) {
             const unsigned boff = (unsigned)((t * RR + pw * G) >> 3) * ldb;
 #pragma unroll
-            for (int q2 = 0; q2 < 4; ++q2) {
+            for (int q2 = 0; q2 < NQ; ++q2) {
                 const qrx_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, soq[q2], boff, QRX_AUX_LOAD);
                 buf[q2].x = __hiloint2double((int)w.y, (int)w.x);
                 buf[q2].y = __hiloint2double((int)w.w, (int)w.z);
@@ -1512,12 +1530,12 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
 #pragma unroll
             for (int q = 0; q <= NP; ++q) vq[q] = *reinterpret_cast<const double2 *>(src + (size_t)q * RR);
         };
-        auto produceq = [&](const double2 (&buf)[4], int t) __attribute__((always_inline)) {
+        auto produceq = [&](const double2 (&buf)[NQ], int t) __attribute__((always_inline)) {
             const int rbase = t * RR + pw * G;
             double *dst = ((t & 1) ? pb1 : pb0) + (size_t)(pw * (G / 2) + rq) * PSTR + 2 * c4;
-            double2 est[4];
+            double2 est[NQ];
 #pragma unroll
-            for (int q2 = 0; q2 < 4; ++q2) {
+            for (int q2 = 0; q2 < NQ; ++q2) {
                 double e0 = buf[q2].x, e1 = buf[q2].y;
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
@@ -1536,7 +1554,7 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
                 // column unless it is the column the slot is read from, so no lane of any workgroup reads what another writes
                 const unsigned boff = (unsigned)(rbase >> 3) * ldb;
 #pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2) {
+                for (int q2 = 0; q2 < NQ; ++q2) {
                     qrx_u32x4 w;
                     w.x = (unsigned)__double2loint(est[q2].x); w.y = (unsigned)__double2hiint(est[q2].x);
                     w.z = (unsigned)__double2loint(est[q2].y); w.w = (unsigned)__double2hiint(est[q2].y);
@@ -1563,7 +1581,8 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
                 loadq(aq_[(i + AH - 1) % AH], t + AH - 1);
                 __builtin_amdgcn_sched_barrier(0);
 #ifdef QRX_DBG_CLK
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // (the group of this round and its reflector entries have arrived)
+                if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (the group of this round and its reflector entries have arrived)
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const long long pm = wall_clock64();
                 pmem += pm - pa;
@@ -1965,9 +1984,14 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     if constexpr (NP >= 8) rp = 0;
     // the wide row-parallel form keeps its reflector entries in scalar registers (sixteen per slot): at most three pending
     // updates; a launch that inherits more from the form before it takes the four-wave form until the next flush
-    if constexpr (NP > QRX_RPW_MAXNP) { if (rp == 16) rp = 4; }
+    if constexpr (NP > QRX_RPW_MAXNP) { if (rp == 16 || rp == QRX_RP_HALF) rp = 4; }
     if constexpr (NP < 8) {
     if constexpr (NP <= QRX_RPW_MAXNP) {
+    if (rp == QRX_RP_HALF) {                                            // the wide form on half windows (qrx_factor chose it: lane-quad producers on)
+        const int nsw = (n + 1 - lo + 31) / 32;
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, true, 32>), dim3((unsigned)(((nprob + 7) / 8) * 8 * nsw)), dim3(64 * 16), qrx_rpw_lds(16, true), stream, p0, nprob,
+                           nsw, lo, m, n, ld, coff, tst, vst, j, cur, T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+    } else
     if (rp == 16 && qrx_quad_on())
         hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, true>), grid, dim3(64 * 16), qrx_rpw_lds(16, true), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
@@ -2014,9 +2038,11 @@ static void qrx_rpw_attr()
     const int lim = (int)qrx_rpw_lds(16), limq = (int)qrx_rpw_lds(16, true);
     hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
+    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
     if constexpr (qrx_can_flush(NP)) {
         hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
+        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
     }
     if constexpr (NP < QRX_RPW_MAXNP) qrx_rpw_attr<NP + 1>();
 }
@@ -2144,10 +2170,12 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         const int nwin = (n + 1 - lo + 63) / 64;
         const long nwg = (long)nact * nwin;
         // waves per workgroup of the row-parallel pass (16: the wide form, k_qrx_pass_rpw), 0: one wave per window
-        const int rp = nwg <= rpw16_max ? 16 : nwg <= rp_max ? 4 : 0;
+        static const long rpwh_env = [] { const char *e = getenv("NLH_QRX_RPWH"); return e ? atol(e) : -1L; }();
+        const long nwgh = (long)nact * ((n + 1 - lo + 31) / 32);
+        const int rp = nwg <= rpw16_max ? ((qrx_quad_on() && nwgh <= (rpwh_env >= 0 ? rpwh_env : (long)QRX_RPWH_MAX_WG)) ? QRX_RP_HALF : 16) : nwg <= rp_max ? 4 : 0;
         // the wide form keeps at most three pending reflectors (scalar registers): a flush every 4th step; the four-wave
         // form every 8th; full launches every QRX_C-th
-        const int period = forced_period ? forced_period : (rp == 16 ? QRX_RPW_MAXNP + 1 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
+        const int period = forced_period ? forced_period : ((rp == 16 || rp == QRX_RP_HALF) ? QRX_RPW_MAXNP + 1 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
         const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
         const int pf = (flush ? 1 : 0) | (prev_flushed ? 2 : 0);
