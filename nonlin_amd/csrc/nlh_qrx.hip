@@ -1984,9 +1984,13 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     if constexpr (NP >= 8) rp = 0;
     // the wide row-parallel form keeps its reflector entries in scalar registers (sixteen per slot): at most three pending
     // updates; a launch that inherits more from the form before it takes the four-wave form until the next flush
-    if constexpr (NP > QRX_RPW_MAXNP) { if (rp == 16 || rp == QRX_RP_HALF) rp = 4; }
+    if constexpr (NP > QRX_RPW_MAXNP) { if (rp == 16 || rp == QRX_RP_HALF || rp == 8) rp = 4; }
     if constexpr (NP < 8) {
     if constexpr (NP <= QRX_RPW_MAXNP) {
+    if (rp == 8)                                                        // eight waves (adder, stager, six lane-quad producers), two workgroups per CU
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 8, true>), grid, dim3(64 * 8), qrx_rpw_lds(8, true), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+    else
     if (rp == QRX_RP_HALF) {                                            // the wide form on half windows (qrx_factor chose it: lane-quad producers on)
         const int nsw = (n + 1 - lo + 31) / 32;
         hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, true, 32>), dim3((unsigned)(((nprob + 7) / 8) * 8 * nsw)), dim3(64 * 16), qrx_rpw_lds(16, true), stream, p0, nprob,
@@ -2172,10 +2176,16 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         // waves per workgroup of the row-parallel pass (16: the wide form, k_qrx_pass_rpw), 0: one wave per window
         static const long rpwh_env = [] { const char *e = getenv("NLH_QRX_RPWH"); return e ? atol(e) : -1L; }();
         const long nwgh = (long)nact * ((n + 1 - lo + 31) / 32);
-        const int rp = nwg <= rpw16_max ? ((qrx_quad_on() && nwgh <= (rpwh_env >= 0 ? rpwh_env : (long)QRX_RPWH_MAX_WG)) ? QRX_RP_HALF : 16) : nwg <= rp_max ? 4 : 0;
+        // (NLH_QRX_RP8=<pairs>: the lane-quad form with EIGHT waves -- adder, stager, six producers, two workgroups per CU --
+        // instead of the four-wave form up to that many pairs.  Measured, ms per solve off / up to 512: 96 x 4096x256 197.9 /
+        // 192.3, 128: 218.1 / 231.5, 192: 321.8 / 317.8, 192 x 2048x128 55.6 / 53.5, 384: 94.8 / 90.9, 512: 104.8 / 104.3 --
+        // no consistent gain where launches are HBM-bound anyway; left off.)
+        static const long rp8_env = [] { const char *e = getenv("NLH_QRX_RP8"); return e ? atol(e) : 0L; }();
+        const int rp = nwg <= rpw16_max ? ((qrx_quad_on() && nwgh <= (rpwh_env >= 0 ? rpwh_env : (long)QRX_RPWH_MAX_WG)) ? QRX_RP_HALF : 16)
+                       : nwg <= rp_max ? ((qrx_quad_on() && nwg <= rp8_env) ? 8 : 4) : 0;
         // the wide form keeps at most three pending reflectors (scalar registers): a flush every 4th step; the four-wave
         // form every 8th; full launches every QRX_C-th
-        const int period = forced_period ? forced_period : ((rp == 16 || rp == QRX_RP_HALF) ? QRX_RPW_MAXNP + 1 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
+        const int period = forced_period ? forced_period : ((rp == 16 || rp == QRX_RP_HALF || rp == 8) ? QRX_RPW_MAXNP + 1 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
         const bool flush = qrx_can_flush(np) && np >= period - 1;
         tb(0, stream);
         const int pf = (flush ? 1 : 0) | (prev_flushed ? 2 : 0);
