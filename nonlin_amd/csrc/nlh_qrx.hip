@@ -1470,7 +1470,7 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
         if (pw == NPR) {
             // the stager: entries of round t + 3 into LDS during round t (loaded two rounds before that)
             const bool on = lane < RR / 2;                               // 48 lanes x 16 bytes = the 96 rows of a round
-            double2 hold[2][NP + 1];
+            double2 hold[3][NP + 1];
             auto fetch = [&](double2 (&h)[NP + 1], int t) __attribute__((always_inline)) {
 #pragma unroll
                 for (int q = 0; q <= NP; ++q) h[q] = on ? *reinterpret_cast<const double2 *>(vsrc(q, t) + 2 * lane) : make_double2(0.0, 0.0);
@@ -1482,10 +1482,8 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
                         *reinterpret_cast<double2 *>(vsb + ((size_t)(t % NVB) * (NP + 1) + q) * RR + 2 * lane) = h[q];
                 }
             };
-            fetch(hold[0], 0); fetch(hold[1], 1);
-            stage(hold[0], 0); stage(hold[1], 1);
-            fetch(hold[0], 2);
-            stage(hold[0], 2);
+            fetch(hold[0], 0); fetch(hold[1], 1); fetch(hold[2], 2);     // one trip to memory before the first barrier
+            stage(hold[0], 0); stage(hold[1], 1); stage(hold[2], 2);
             fetch(hold[1], 3); fetch(hold[0], 4);
             qrx_lds_barrier();
             int t = 0;
