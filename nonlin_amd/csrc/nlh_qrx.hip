@@ -1748,9 +1748,10 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
 // allocation: padded back to 68 KB it stays at 17.3, and an empty launch costs the same at any LDS size, lds_launch.hip).
 // Same values, same order as the deferred forms: bit-identical.
 #ifndef QRX_COL_MAX_WG
-#define QRX_COL_MAX_WG 3072             // factorisations of at most this many (problem, column) pairs take this form.  ms per
-                                        // solve, this form / the lane-per-column forms: 4096 x 256: 4 problems 59 / 102, 8: 78 / 104,
-                                        // 12: 99 / 109, 16: 118 / 110; 2048 x 128: 8: 19 / 30, 16: 26 / 32, 24: 31 / 33, 32: 37 / 33
+#define QRX_COL_MAX_WG 1536             // factorisations of at most this many (problem, column) pairs take this form.  ms per
+                                        // solve, this form / the wide row-parallel form on half windows (which moved the crossover down
+                                        // from 3072 pairs): 4096 x 256: 4 problems 52.8 / 60.6, 6: 62.3 / 61.2, 8: 71.6 / 61.6, 12: 90.0 / 62.5;
+                                        // 2048 x 128: 8: 17.2 / 20.6, 16: 22.6 / 20.9, 24: 27.9 / 21.3; 1024 x 64: 16: 6.7 / 8.1, 48: 11.4 / 10.3
 #endif
 #define QRX_COL_EL 64                   // terms per lane of the ordered sum (chunks of 4096 rows)
 template <bool PEND>

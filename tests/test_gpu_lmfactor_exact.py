@@ -133,10 +133,10 @@ def test_lmfactor_exact_long_columns_chain_free_norm2(ds, oracle, kind, m, n):
     _check(ds, oracle, a, f)
 
 
-@pytest.mark.parametrize("copies", [1, 40, 60, 100, 120, 200, 300, 1100])
+@pytest.mark.parametrize("copies", [1, 20, 40, 60, 100, 120, 200, 300, 1100])
 def test_lmfactor_exact_every_pass_form(ds, oracle, copies):
-    """The same graded 520 x 70 matrix (two 64-column windows) in batches of 1 / 40 (<= 3072 (problem, column) pairs: the
-    workgroup-per-column sweep), 60, 100 and 120 (120 / 200 / 240 (problem, window) pairs: the wide row-parallel form, sixteen
+    """The same graded 520 x 70 matrix (two 64-column windows) in batches of 1 / 20 (<= 1536 (problem, column) pairs: the
+    workgroup-per-column sweep), 40, 60, 100 and 120 (80 / 120 / 200 / 240 (problem, window) pairs: the wide row-parallel form, sixteen
     waves, producers reading whole sectors per lane quad, on 32-column half windows while those are at most 256 -- 60 copies
     all the way, 100 once one window is left --; at most 256 pairs), 200 (400: four-wave; at most 512), 300 and 1100
     (one wave per window, separate and as the waves of one workgroup); all the same bits."""
