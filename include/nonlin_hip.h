@@ -317,6 +317,19 @@ int nlh_cls_solve_batch_device_h(nlh_handle *h, const nlh_options *opts, double 
                                  const double *xu, int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn,
                                  nlh_device_jacfcn jacfcn, void *ctx, double *x, double *fvec, nlh_iteration_behavior *ib,
                                  int32_t *status);
+/* bfgs%solve (src/nonlin_optimize.f90:557-770) on a batch of problems whose objective is the USER'S device fcnnvar
+ * (reference plugin: fcnnvar_helper, src/nonlin_multi_var.f90:17-44, 93-104 set_fcn, 182-246 gradient): the launcher is an
+ * nlh_device_vecfcn called with m = 1 -- dF[npoints] receives f at each of the npoints points --, gradfcn (NULL: forward
+ * differences, n more points per gradient, built on the device in the reference's order :231-243) an nlh_device_jacfcn
+ * called with m = 1 -- dJ[npoints][n] receives the gradients (set_gradient_fcn, :126-138).  dx [nprob][n] device, in/out;
+ * fout [nprob] host (NULL allowed): f at the solution (:762).  Counts, flags and errors per problem as nlh_bfgs_solve. */
+int nlh_bfgs_solve_batch_device(nlh_handle *h, const nlh_options *opts, int32_t nprob, int32_t n, nlh_device_vecfcn fcn,
+                                nlh_device_jacfcn gradfcn, void *ctx, double *dx, double *fout, nlh_iteration_behavior *ib,
+                                int32_t *status);
+/* ... with x [nprob][n] a HOST array. */
+int nlh_bfgs_solve_batch_device_h(nlh_handle *h, const nlh_options *opts, int32_t nprob, int32_t n, nlh_device_vecfcn fcn,
+                                  nlh_device_jacfcn gradfcn, void *ctx, double *x, double *fout, nlh_iteration_behavior *ib,
+                                  int32_t *status);
 /* The same three behind HOST arrays x [nprob][n] in/out, fvec [nprob][m] out (what the Fortran shim's
  * vecfcn_helper%set_device_fcn + solver%solve / solve_batch call): staged through the handle's buffers. */
 int nlh_lm_solve_batch_device_h(nlh_handle *h, const nlh_options *opts, int32_t nprob, int32_t m, int32_t n,
@@ -343,8 +356,9 @@ int nlh_dq_device_jac(void *ctx, void *hip_stream, int32_t npoints, const int32_
 /* A user's device residual as a MODEL object (what the Fortran shim's vecfcn_helper%set_device_fcn and
  * device_model_batch%create_from_device_fcn hold): nprob problems of m equations in n unknowns each, evaluated by the
  * launchers; nlh_dq_model_eval / _lm_solve / _newton_solve / _quasi_newton_solve accept it (host arrays, the caller's
- * handle; `analytic` selects the jacobianfcn launcher) and so does nlh_dq_model_cls_solve; the bfgs form returns
- * NLH_INVALID_OPERATION_ERROR (bfgs minimises a scalar fcnnvar, not a vecfcn).  Lives on the handle's device (not dealt over a device set: the user's data is wherever the
+ * handle; `analytic` selects the jacobianfcn launcher) and so does nlh_dq_model_cls_solve; the bfgs form takes a model of
+ * ONE function (m = 1: the launcher is the user's fcnnvar, the jacobianfcn launcher its gradient -- nlh_bfgs_solve_batch_device)
+ * and returns NLH_INVALID_OPERATION_ERROR for m > 1 (bfgs minimises a scalar fcnnvar, not a vecfcn).  Lives on the handle's device (not dealt over a device set: the user's data is wherever the
  * user put it).  Freed with nlh_dq_model_destroy; ctx stays the caller's. */
 int nlh_device_fcn_model_create(int32_t nprob, int32_t m, int32_t n, nlh_device_vecfcn fcn, nlh_device_jacfcn jacfcn, void *ctx,
                                 nlh_dq_model **model);

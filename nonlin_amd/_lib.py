@@ -144,6 +144,10 @@ SYMBOLS = {
     "nlh_cls_solve_batch_device_h": (C.c_int, [_H, C.POINTER(Options), C.c_double, C.c_double, c_double_p, c_double_p, C.c_int32, C.c_int32,
                                                C.c_int32, DEVFCN, DEVFCN, C.c_void_p, c_double_p, c_double_p,
                                                C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_bfgs_solve_batch_device": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p, C.c_void_p, c_double_p,
+                                              C.POINTER(IterationBehavior), c_int32_p]),
+    "nlh_bfgs_solve_batch_device_h": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p, c_double_p, c_double_p,
+                                                C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_lm_solve_batch_device_h": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p,
                                               c_double_p, c_double_p, C.POINTER(IterationBehavior), c_int32_p]),
     "nlh_newton_solve_batch_device_h": (C.c_int, [_H, C.POINTER(Options), C.c_int32, C.c_int32, DEVFCN, DEVFCN, C.c_void_p,

@@ -259,17 +259,20 @@ int nlh_bfgs_solve(nlh_handle *h, const nlh_options *o, int32_t n, nlh_fcnnvar f
 // downdate, or a refactorisation) and the two triangular solves for the direction to the first trial point of its line
 // search; every problem with a trial point gets F evaluated there and one turn of the search.  One 8-byte read-back
 // per round.
-static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n, const double *dA,
-                         const double *db, double gamma, double *dx, double *hfout, nlh_iteration_behavior *ib,
-                         int32_t *status)
+// rs: the dense-quadratic family (objective 0.5 ||F(x)||^2), or -- scalar -- a USER'S fcnnvar handed in as a launcher with
+// m = 1 (include/nonlin_hip.h: nlh_bfgs_solve_batch_device): F(x) is the objective itself, the forward-difference gradient
+// is the 1 x n Jacobian of residual_jacobian (the same differences, src/nonlin_multi_var.f90:182-246), rs.jac the user's gradient.
+static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t m, int32_t n, const ResidualSource &rs, bool scalar,
+                         double *dx, double *hfout, nlh_iteration_behavior *ib, int32_t *status)
 {
     int rc;
     if (n > QN_MAX_N) return NLH_ARRAY_SIZE_ERROR;
+    if (scalar != rs.user() || (scalar && m != 1)) return NLH_INVALID_INPUT_ERROR;
     const size_t mn = (size_t)m * n, nn = (size_t)n * n, np = (size_t)nprob;
-    if ((rc = ensure(h, h->P, sizeof(double) * mn * np))) return rc;
+    if (!scalar && (rc = ensure(h, h->P, sizeof(double) * mn * np))) return rc;
     if ((rc = ensure(h, h->bfB, sizeof(double) * nn * np))) return rc;
     if ((rc = ensure(h, h->bfR, sizeof(double) * nn * np))) return rc;
-    if ((rc = ensure(h, h->bfV, sizeof(double) * ((size_t)m + 10 * (size_t)n) * np + sizeof(int32_t) * np + 64))) return rc;
+    if ((rc = ensure(h, h->bfV, sizeof(double) * ((size_t)m + 10 * (size_t)n + 1) * np + sizeof(int32_t) * np + 64))) return rc;
     if ((rc = ensure(h, h->state, sizeof(LmState) * np))) return rc;
     if ((rc = ensure(h, h->misc, sizeof(BfState) * np + 64))) return rc;
     if ((rc = ensure_pinned(h, sizeof(BfState) * np + 64))) return rc;
@@ -285,6 +288,7 @@ static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int
     double *dc = q; q += (size_t)n * np;
     double *dw = q; q += (size_t)n * np;
     double *dxnew = q; q += (size_t)n * np;
+    double *df0 = q; q += np;                                    // (scalar: the objective at x, contiguous)
     int32_t *dinfo = (int32_t *)q;
     LmState *st = (LmState *)h->state.p;
     int32_t *dcounts = (int32_t *)h->misc.p;
@@ -307,17 +311,22 @@ static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int
     const LmState *cst = st;
 
     hipLaunchKernelGGL(k_bfl_reset, dim3(pb), dim3(256), 0, s, nprob, st, bs, dinfo);
-    launch_dq_residual(h, nprob, m, n, dA, db, gamma, dx, dfv, nullptr, st, BF_START);           // :633
-    hipLaunchKernelGGL(k_bfl_start, dim3(nprob), dim3(256), 0, s, m, (const double *)dfv, st, bs);
+    if ((rc = residual_eval(h, rs, nprob, m, n, dx, dfv, nullptr, st, BF_START))) return rc;      // :633
+    hipLaunchKernelGGL(k_bfl_start, dim3(nprob), dim3(256), 0, s, m, (const double *)dfv, st, bs, scalar ? 1 : 0);
     int need_grad = nprob;                                       // upper bound until the first read-back
     // a round costs every live problem an evaluation at least (a trial point, or an iteration's first one)
     const long max_rounds = (long)o->max_evals + (long)o->ls_max_evals + 16;
     for (long round = 0; round < max_rounds; ++round) {
         if (need_grad > 0) {
             // fnh_grad_fcn: n perturbed evaluations, (f_j - f) / h_j (src/nonlin_multi_var.f90:182-246)
-            launch_dq_panel(h, nprob, m, n, dA, db, gamma, dx, dP, st, BF_GRAD);
-            hipLaunchKernelGGL(k_bf_fd_gradient, dim3(n, nprob), dim3(64), 0, s, m, n, (const double *)dP, (const double *)dx, 0.0, dg,
-                               fp_all, bstride, cst, (int)BF_GRAD);
+            if (scalar) {
+                hipLaunchKernelGGL(k_bfl_gather_fp, dim3(pb), dim3(256), 0, s, nprob, (const BfState *)bs, df0);
+                if ((rc = residual_jacobian(h, rs, nprob, 1, n, dx, df0, dg, nullptr, st, BF_GRAD, false, false, true))) return rc;
+            } else {
+                launch_dq_panel(h, nprob, m, n, rs.dA, rs.db, rs.gamma, dx, dP, st, BF_GRAD);
+                hipLaunchKernelGGL(k_bf_fd_gradient, dim3(n, nprob), dim3(64), 0, s, m, n, (const double *)dP, (const double *)dx, 0.0, dg,
+                                   fp_all, bstride, cst, (int)BF_GRAD);
+            }
             hipLaunchKernelGGL(k_bfl_after_grad, dim3(nprob), dim3(256), 0, s, n, bo, (const double *)dx, (const double *)dg, (const double *)dgold,
                                ddx, dy, dxnew, st, bs);
             // :703-712: R = temp I in the first iteration, B = R^T R, B dx
@@ -348,8 +357,9 @@ static int bfgs_lockstep(nlh_handle *h, const nlh_options *o, int32_t nprob, int
             hipLaunchKernelGGL(k_bfl_dir_done, dim3(nprob), dim3(256), 0, s, n, bo, (const double *)dx, (const double *)dg, ddx, (const double *)dw,
                                dxnew, (const int32_t *)dinfo, st, bs);
         }
-        launch_dq_residual(h, nprob, m, n, dA, db, gamma, dxnew, dfv, nullptr, st, BF_TRIAL);
-        hipLaunchKernelGGL(k_bfl_trial, dim3(nprob), dim3(256), 0, s, m, n, bo, dx, dxnew, ddx, (const double *)dg, dgold, (const double *)dfv, st, bs);
+        if ((rc = residual_eval(h, rs, nprob, m, n, dxnew, dfv, nullptr, st, BF_TRIAL))) return rc;
+        hipLaunchKernelGGL(k_bfl_trial, dim3(nprob), dim3(256), 0, s, m, n, bo, dx, dxnew, ddx, (const double *)dg, dgold, (const double *)dfv, st, bs,
+                           scalar ? 1 : 0);
         hipLaunchKernelGGL(k_bfl_count, dim3(1), dim3(256), 0, s, nprob, cst, dcounts);
         HIPCHK(h, hipMemcpyAsync(hcounts, dcounts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (echo) HIPCHK(h, hipMemcpyAsync(hbs, bs, sizeof(BfState), hipMemcpyDeviceToHost, s));
@@ -389,11 +399,14 @@ int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, 
     if (!o || n < 1 || m < 1) return NLH_INVALID_INPUT_ERROR;
     HIPCHK(h, hipSetDevice(h->device));
     static const int bfgs_host = [] { const char *e = getenv("NLH_BFGS_HOSTLOOP"); return e ? atoi(e) : 0; }();
-    if (!bfgs_host)
+    if (!bfgs_host) {
+        ResidualSource rs;
+        rs.dA = dA; rs.db = db; rs.gamma = gamma;
         return lockstep_slices(nprob, [&](int32_t p0, int32_t cnt) {
-            return bfgs_lockstep(h, o, cnt, m, n, dA + (size_t)p0 * m * n, db + (size_t)p0 * m, gamma, dx + (size_t)p0 * n,
+            return bfgs_lockstep(h, o, cnt, m, n, rs.shifted(p0, m, n), false, dx + (size_t)p0 * n,
                                  hfout ? hfout + p0 : nullptr, ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
         });
+    }
     // one problem per call; run_problems deals the problems to worker threads with private handles
     auto solve_one = [&](nlh_handle *h, int p) -> int {
         int rc;
@@ -440,6 +453,54 @@ int nlh_dq_bfgs_solve_batch(nlh_handle *h, const nlh_options *o, int32_t nprob, 
     const int rcb = run_problems(h, nprob, solve_one);
     if (rcb) return rcb;
     HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// bfgs%solve on a batch of problems whose objective is the USER'S device fcnnvar: a launcher of the nlh_device_vecfcn type
+// with m = 1 (dF[npoints] = f at each point); gradfcn (optional, nlh_device_jacfcn with m = 1: dJ[npoints][n] = the
+// gradients) replaces the forward differences as fcnnvar_helper%gradient does (src/nonlin_multi_var.f90:213-217).
+int nlh_bfgs_solve_batch_device(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t n, nlh_device_vecfcn fcn,
+                                nlh_device_jacfcn gradfcn, void *ctx, double *dx, double *hfout, nlh_iteration_behavior *ib,
+                                int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (ib && nprob > 0) memset(ib, 0, sizeof(*ib) * (size_t)nprob);
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;              // src/nonlin_optimize.f90:611-615
+    if (!o || n < 1 || (nprob > 0 && !dx)) return NLH_INVALID_INPUT_ERROR;
+    if (nprob <= 0) return 0;
+    HIPCHK(h, hipSetDevice(h->device));
+    nlh_options oq = *o;
+    if (nprob > 1) oq.print_status = 0;
+    ResidualSource rs;
+    rs.fcn = fcn; rs.jac = gradfcn; rs.ctx = ctx;
+    // (a launcher is asked for nprob * n points at once)
+    const int32_t slice = (int32_t)std::max<int64_t>(1, std::min<int64_t>(NLH_MAX_LOCKSTEP, ((int64_t)1 << 30) / n));
+    for (int32_t p0 = 0; p0 < nprob; p0 += slice) {
+        const int32_t cnt = std::min<int32_t>(slice, nprob - p0);
+        const int rc = bfgs_lockstep(h, &oq, cnt, 1, n, rs.shifted(p0, 1, n), true, dx + (size_t)p0 * n, hfout ? hfout + p0 : nullptr,
+                                     ib ? ib + p0 : nullptr, status ? status + p0 : nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// The same behind a host array.
+int nlh_bfgs_solve_batch_device_h(nlh_handle *h, const nlh_options *o, int32_t nprob, int32_t n, nlh_device_vecfcn fcn,
+                                  nlh_device_jacfcn gradfcn, void *ctx, double *x, double *fout, nlh_iteration_behavior *ib,
+                                  int32_t *status)
+{
+    if (!h) return NLH_ERR_BAD_HANDLE;
+    if (nprob <= 0) return 0;
+    if (!x || !o || n < 1) return NLH_INVALID_INPUT_ERROR;
+    if (!fcn) return NLH_UNDEFINED_FUNCTION_ERROR;
+    int rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = ensure(h, h->xdev, sizeof(double) * (size_t)nprob * n))) return rc;
+    double *dx = (double *)h->xdev.p;
+    HIPCHK(h, hipMemcpyAsync(dx, x, sizeof(double) * (size_t)nprob * n, hipMemcpyHostToDevice, h->stream));
+    if ((rc = nlh_bfgs_solve_batch_device(h, o, nprob, n, fcn, gradfcn, ctx, dx, fout, ib, status))) return rc;
+    HIPCHK(h, hipMemcpyAsync(x, dx, sizeof(double) * (size_t)nprob * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

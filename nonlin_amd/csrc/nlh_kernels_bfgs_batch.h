@@ -59,16 +59,25 @@ k_bfl_reset(int nprob, LmState *__restrict__ st, BfState *__restrict__ bs, int32
     st[p].stage = BF_START;
 }
 
+// the objective at the current point of every problem, contiguous (f0 of the forward differences of a user's fcnnvar)
+static __global__ void __launch_bounds__(256)
+k_bfl_gather_fp(int nprob, const BfState *__restrict__ bs, double *__restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < nprob) out[p] = bs[p].fp;
+}
+
 // :633 after F(x0): f = 0.5 F.F
 static __global__ void __launch_bounds__(256)
-k_bfl_start(int m, const double *__restrict__ fall, LmState *__restrict__ st, BfState *__restrict__ bs)
+k_bfl_start(int m, const double *__restrict__ fall, LmState *__restrict__ st, BfState *__restrict__ bs, int scalar)
 {
     __shared__ __attribute__((aligned(16))) double buf[NT_CHUNK];
     __shared__ double xch[2];
     const int p = blockIdx.x;
     if (st[p].stage != BF_START) return;
     const double *fv = fall + (size_t)p * m;
-    const double f = 0.5 * nt_ordered_sum(m, [&](int i) { return fv[i] * fv[i]; }, buf, xch);
+    // scalar: the user's fcnnvar itself (a launcher with m = 1), not 0.5 F.F of a residual family
+    const double f = scalar ? fv[0] : 0.5 * nt_ordered_sum(m, [&](int i) { return fv[i] * fv[i]; }, buf, xch);
     if (threadIdx.x == 0) { bs[p].fp = f; bs[p].neval = 1; st[p].stage = BF_GRAD; }
 }
 
@@ -223,7 +232,7 @@ k_bfl_dir_done(int n, BfOpts o, const double *__restrict__ xall, const double *_
 static __global__ void __launch_bounds__(256)
 k_bfl_trial(int m, int n, BfOpts o, double *__restrict__ xall, double *__restrict__ xnewall, double *__restrict__ dxall,
             const double *__restrict__ gall, double *__restrict__ goldall, const double *__restrict__ fall,
-            LmState *__restrict__ st, BfState *__restrict__ bs)
+            LmState *__restrict__ st, BfState *__restrict__ bs, int scalar)
 {
     __shared__ __attribute__((aligned(16))) double buf[NT_CHUNK];
     __shared__ double xch[2];
@@ -234,7 +243,7 @@ k_bfl_trial(int m, int n, BfOpts o, double *__restrict__ xall, double *__restric
     const double *g = gall + (size_t)p * n, *fv = fall + (size_t)p * m;
     // (every thread takes its copy of the search state before the first barrier: thread 0 rewrites it at the end)
     const BfState q = *s;
-    const double f = 0.5 * nt_ordered_sum(m, [&](int i) { return fv[i] * fv[i]; }, buf, xch);
+    const double f = scalar ? fv[0] : 0.5 * nt_ordered_sum(m, [&](int i) { return fv[i] * fv[i]; }, buf, xch);
     int add = 1;
     if (o.use_line_search) {
         const int lsn = q.ls_neval + 1, lsi = q.ls_iter + 1;

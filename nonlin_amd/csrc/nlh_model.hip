@@ -370,7 +370,16 @@ int nlh_dq_model_bfgs_solve(nlh_handle *h, const nlh_options *o, const nlh_dq_mo
     nlh_options oq = *o;
     if (md->nprob > 1) oq.print_status = 0;               // (see nlh_dq_model_lm_solve)
     o = &oq;
-    if (md->ufcn) return NLH_INVALID_OPERATION_ERROR;     // (bfgs minimises a scalar fcnnvar: a vector launcher is not its plugin)
+    if (md->ufcn) {
+        // bfgs minimises a scalar fcnnvar: a user's model with ONE function is exactly that (its launcher is called with
+        // m = 1, its jacobianfcn launcher is the gradient); a vector launcher is not bfgs's plugin
+        if (md->m != 1) return NLH_INVALID_OPERATION_ERROR;
+        const int rc = nlh_bfgs_solve_batch_device_h(h, o, md->nprob, md->n, md->ufcn, md->ujac, md->uctx, x, fout, ib, status);
+        if (rc) return rc;
+        if (fvec && fout)                                     // (the model's one "equation": f at the solution)
+            for (int32_t p = 0; p < md->nprob; ++p) fvec[p] = fout[p];
+        return 0;
+    }
     return model_run(h, md, x, true, fvec, ib, status,
                      [&](nlh_handle *ph, const DqPart &pt, nlh_iteration_behavior *pib, int32_t *pst) -> int {
                          std::vector<double> fo(pt.cnt, 0.0);

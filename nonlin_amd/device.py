@@ -224,6 +224,24 @@ class DeviceSolver:
             raise RuntimeError(f"square solve on a device residual returned {rc}")
         return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
 
+    def bfgs_solve_batch_device(self, fcn, ctx, x, grad=None, opts=None):
+        """bfgs%solve for every problem with the USER'S device fcnnvar: fcn a launcher called with m = 1 (dF[npoints] = f),
+        grad (optional) one that fills dJ[npoints][n] with the gradients.  x [nprob][n] device tensor, in place.
+        Returns (fout list, ib list, status list)."""
+        nprob, n = x.shape
+        _chk(x, (nprob, n), "x")
+        ib = (_lib.IterationBehavior * nprob)()
+        status = (C.c_int32 * nprob)()
+        fout = (C.c_double * nprob)()
+        o = opts or self.options(max_evals=500)
+        null = C.cast(None, _lib.DEVFCN)
+        rc = self.lib.nlh_bfgs_solve_batch_device(self.h.ptr, C.byref(o), nprob, n, fcn, grad if grad is not None else null, self._ctxp(ctx),
+                                                  x.data_ptr(), fout, ib, status)
+        self.h.check(rc, "nlh_bfgs_solve_batch_device")
+        if rc:
+            raise RuntimeError(f"nlh_bfgs_solve_batch_device returned {rc}")
+        return [float(v) for v in fout], [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
+
     def fd_jacobian_device(self, fcn, ctx, m, x, fv=None, jac=None):
         """vecfcn_helper%jacobian of every problem of a user's device residual: J [nprob, n, m]."""
         nprob, n = x.shape

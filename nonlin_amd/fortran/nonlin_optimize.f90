@@ -142,8 +142,10 @@ contains
     end subroutine
 
     !> Extension: bfgs%solve (bfgs_solve, :557-770) on the objective 0.5 ||F(x)||^2 of every problem of a device model
-    !> batch (forward-difference gradient).  x(n, count) in / out, fout(count): the objective values, status(count): the
-    !> code each solve would have stopped with (0: converged).
+    !> batch (forward-difference gradient) -- or, for a batch created from the user's own device function with ONE
+    !> function per problem (device_model_batch%create_from_device_fcn, nfcn = 1), on that function itself: the launcher is
+    !> the user's fcnnvar, its optional second launcher the gradient (set_gradient_fcn).  x(n, count) in / out,
+    !> fout(count): the objective values, status(count): the code each solve would have stopped with (0: converged).
     subroutine bfgs_solve_many(this, model, x, fout, ib, status)
         class(bfgs), intent(inout) :: this
         class(device_model_batch), intent(in) :: model

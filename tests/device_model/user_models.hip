@@ -190,4 +190,74 @@ void btri_host_jac(void *ctx, int32_t n, const double *x, int32_t m, double *jac
         for (int32_t i = 0; i < m; ++i) jac[(size_t)j * m + i] = btri_jac(n, x, i, j);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Family 3: a scalar objective (the reference's fcnnvar, src/nonlin_multi_var.f90:17-44), for bfgs -- a chained
+// Rosenbrock function with a per-problem target c:
+//     f(x) = sum_{i = 0}^{n - 2} [ 10 (x_{i+1} - x_i^2)^2 + (c - x_i)^2 ],   terms added in ascending i by ONE thread.
+// Launchers of the nlh_device_vecfcn / nlh_device_jacfcn types called with m = 1 (nlh_bfgs_solve_batch_device); the context
+// is the btri family's (one c per problem).
+__host__ __device__ static inline double crosen_f(int n, const double *x, double c)
+{
+    double s = 0.0;
+    for (int i = 0; i + 1 < n; ++i) {
+        const double d = x[i + 1] - x[i] * x[i], e = c - x[i];
+        const double t = 10.0 * (d * d) + e * e;
+        s = s + t;
+    }
+    return s;
+}
+
+__host__ __device__ static inline double crosen_g(int n, const double *x, int i, double c)
+{
+    double g = 0.0;
+    if (i + 1 < n) {
+        const double d = x[i + 1] - x[i] * x[i], e = c - x[i];
+        g = (-40.0 * d) * x[i] - 2.0 * e;
+    }
+    if (i > 0) {
+        const double dm = x[i] - x[i - 1] * x[i - 1];
+        g = g + 20.0 * dm;
+    }
+    return g;
+}
+
+__global__ void __launch_bounds__(64)
+k_crosen(int npoints, int n, const double *__restrict__ cs, const int32_t *__restrict__ dprob, const double *__restrict__ X, double *__restrict__ F)
+{
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q < npoints) F[q] = crosen_f(n, X + (size_t)q * n, cs[dprob[q]]);
+}
+
+__global__ void __launch_bounds__(256)
+k_crosen_grad(int n, int nblk, const double *__restrict__ cs, const int32_t *__restrict__ dprob, const double *__restrict__ X, double *__restrict__ G)
+{
+    const int q = blockIdx.x / nblk, rb = blockIdx.x - q * nblk;
+    const int i = rb * 256 + threadIdx.x;
+    if (i < n) G[(size_t)q * n + i] = crosen_g(n, X + (size_t)q * n, i, cs[dprob[q]]);
+}
+
+int crosen_launch(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n, const double *dX, int32_t m, double *dF)
+{
+    const btri_dev *b = (const btri_dev *)ctx;
+    if (!b || m != 1) return 1;
+    hipLaunchKernelGGL(k_crosen, dim3((unsigned)((npoints + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, (int)npoints, n, (const double *)b->dc, dprob, dX, dF);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int crosen_launch_grad(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n, const double *dX, int32_t m, double *dG)
+{
+    const btri_dev *b = (const btri_dev *)ctx;
+    if (!b || m != 1) return 1;
+    const int nblk = (n + 255) / 256;
+    hipLaunchKernelGGL(k_crosen_grad, dim3((unsigned)((size_t)npoints * nblk)), dim3(256), 0, (hipStream_t)hip_stream, n, nblk, (const double *)b->dc, dprob, dX, dG);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+double crosen_host_f(double c, int32_t n, const double *x) { return crosen_f(n, x, c); }
+
+void crosen_host_grad(double c, int32_t n, const double *x, double *g)
+{
+    for (int32_t i = 0; i < n; ++i) g[i] = crosen_g(n, x, i, c);
+}
+
 }   // extern "C"

@@ -52,6 +52,18 @@ program device_fcn_suite
             integer(c_int32_t), value :: npoints, n, m
             integer(c_int) :: rc
         end function
+        function crosen_launch(ctx, stream, npoints, dprob, n, dx, m, df) bind(C, name="crosen_launch") result(rc)
+            import :: c_ptr, c_int, c_int32_t
+            type(c_ptr), value :: ctx, stream, dprob, dx, df
+            integer(c_int32_t), value :: npoints, n, m
+            integer(c_int) :: rc
+        end function
+        function crosen_launch_grad(ctx, stream, npoints, dprob, n, dx, m, dg) bind(C, name="crosen_launch_grad") result(rc)
+            import :: c_ptr, c_int, c_int32_t
+            type(c_ptr), value :: ctx, stream, dprob, dx, dg
+            integer(c_int32_t), value :: npoints, n, m
+            integer(c_int) :: rc
+        end function
     end interface
 
     character(len=512) :: path
@@ -63,6 +75,8 @@ program device_fcn_suite
     type(least_squares_solver) :: lm
     type(newton_solver) :: nt
     type(quasi_newton_solver) :: qn
+    type(bfgs) :: bf
+    real(real64), allocatable :: fmin(:)
     type(iteration_behavior) :: ib
     type(iteration_behavior), allocatable :: ibs(:)
     integer(int32), allocatable :: st(:)
@@ -180,7 +194,37 @@ program device_fcn_suite
     call obj%clear_device_model()
     call btri_destroy(bctx)
 
+    ! ---- a scalar objective (the reference's fcnnvar) as a model of ONE function: bfgs%solve_batch; the gradient launcher
+    ! plays set_gradient_fcn, without it the forward differences are built on the device
+    bctx = btri_create(nprob, c)
+    allocate(fmin(nprob))
+    call bf%set_max_fcn_evals(500)
+    call batch%create_from_device_fcn(c_funloc(crosen_launch), bctx, nprob, 1, nq, c_funloc(crosen_launch_grad))
+    x = xs
+    call bf%solve_batch(batch, x, fmin, ibs, st)
+    do k = 1, nprob
+        call report_bfgs("df_bfgs_batch", ibs(k), st(k), fmin(k), x(:,k))
+    end do
+    call batch%destroy()
+    call batch%create_from_device_fcn(c_funloc(crosen_launch), bctx, nprob, 1, nq)
+    x = xs
+    call bf%solve_batch(batch, x, fmin, ibs, st)
+    do k = 1, nprob
+        call report_bfgs("df_bfgs_fd_batch", ibs(k), st(k), fmin(k), x(:,k))
+    end do
+    call batch%destroy()
+    call btri_destroy(bctx)
+
 contains
+    subroutine report_bfgs(name, b, st, fv, x)
+        character(len=*), intent(in) :: name
+        type(iteration_behavior), intent(in) :: b
+        integer(int32), intent(in) :: st
+        real(real64), intent(in) :: fv, x(:)
+        print '(A,1X,I0,3(1X,I0),3(1X,L1),*(1X,Z16.16))', name, st, b%iter_count, b%fcn_count, b%gradient_count, &
+            b%converge_on_fcn, b%converge_on_chng, b%converge_on_zero_diff, fv, x
+    end subroutine
+
     subroutine report(name, b, st, x)
         character(len=*), intent(in) :: name
         type(iteration_behavior), intent(in) :: b

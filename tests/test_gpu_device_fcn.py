@@ -328,7 +328,8 @@ def test_user_device_fcn_through_the_fortran_shim(ds, oracle, tmp_path):
     """vecfcn_helper%set_device_fcn + solver%solve (the reference's own call) and device_model_batch%create_from_device_fcn
     + solve_batch, from a Fortran program linked with the shim, libnonlin_hip.so and the user's own library
     (tests/fortran/device_fcn_suite.f90): least squares on the Lorentzian family, Newton and quasi-Newton on Broyden's
-    tridiagonal family (analytic jacobianfcn launcher, and forward differences) -- every problem bitwise the oracle's."""
+    tridiagonal family (analytic jacobianfcn launcher, and forward differences), bfgs on a chained-Rosenbrock objective (a model
+    of one function; gradient launcher, and forward differences) -- every problem bitwise the oracle's."""
     import os
     import shutil
     import struct
@@ -412,6 +413,19 @@ def test_user_device_fcn_through_the_fortran_shim(ds, oracle, tmp_path):
         cmp(res["df_cls_batch"][p], rc, xo, ibo)
     rc, xo, ibo = cls_oracle(1)
     cmp(res["df_cls_single"][0], rc, xo, ibo)
+    # bfgs%solve_batch on a model of ONE function (the user's fcnnvar launcher; with its gradient launcher, and with forward differences)
+    for key, analytic in (("df_bfgs_batch", True), ("df_bfgs_fd_batch", False)):
+        assert len(res[key]) == nprob
+        for p in range(nprob):
+            cp = float(c[p])
+            f_host = lambda xx: so.crosen_host_f(cp, nq, np.ascontiguousarray(xx).ctypes.data_as(dp))          # noqa: E731
+            g_host = (lambda xx, g: so.crosen_host_grad(cp, nq, np.ascontiguousarray(xx).ctypes.data_as(dp), g.ctypes.data_as(dp))) if analytic else None
+            rc, xo, fo, ibo = oracle.bfgs_solve(f_host, nq, xs[p], grad=g_host, opts=oracle.default_options(max_evals=500))
+            r = res[key][p]
+            assert r["status"] == rc, (key, p, r["status"], rc)
+            assert r["counts"] == (ibo["iter_count"], ibo["fcn_count"], ibo["gradient_count"]), (key, p, r, ibo)
+            assert r["flags"] == ("F", "T" if ibo["converge_on_chng"] else "F", "T" if ibo["converge_on_zero_diff"] else "F")
+            assert r["x"][0] == fo and np.array_equal(r["x"][1:], xo)
 
 
 # ---------------------------------------------------------------------------------------------------- GPU: bounded least squares
@@ -444,3 +458,82 @@ def test_user_family_bounded_least_squares_bitwise(ds, oracle, nprob, m, K):
         bound += int(np.any(xo == lo) or np.any(xo == hi))
     assert nprob == 1 or bound > 0                            # the box did bind somewhere
     batch.close()
+
+
+# ---------------------------------------------------------------------------------------------------- bfgs on a user's fcnnvar
+BKEYS = ("iter_count", "fcn_count", "gradient_count", "converge_on_chng", "converge_on_zero_diff")
+
+
+def test_user_scalar_family_host_twin():
+    """(CPU) the chained-Rosenbrock objective's host twin and its gradient, term by term in the stated order."""
+    so = UM.lib()
+    n, c = 9, 1.2
+    x = np.linspace(-0.7, 0.9, n)
+    f = so.crosen_host_f(c, n, x.ctypes.data_as(dp))
+    s = 0.0
+    for i in range(n - 1):
+        d = x[i + 1] - x[i] * x[i]
+        e = c - x[i]
+        s = s + (10.0 * (d * d) + e * e)
+    assert f == s
+    g = np.zeros(n)
+    so.crosen_host_grad(c, n, x.ctypes.data_as(dp), g.ctypes.data_as(dp))
+    h = 1e-7
+    for i in (0, 4, n - 1):
+        xp = x.copy(); xp[i] += h
+        assert abs((so.crosen_host_f(c, n, xp.ctypes.data_as(dp)) - f) / h - g[i]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("analytic", [False, True])
+@pytest.mark.parametrize("nprob,n,line_search", [(1, 6, True), (50, 12, True), (7, 40, True), (5, 10, False)])
+def test_user_scalar_family_bfgs_bitwise(ds, oracle, nprob, n, analytic, line_search):
+    """bfgs%solve on a user's device fcnnvar (launcher with m = 1; forward-difference gradient built on the device, or the
+    user's gradient launcher): x, f, every count and flag of every problem equal to the CPU oracle driving the same
+    arithmetic as a host callback (nlo_bfgs_solve, src/nonlin_optimize.f90:557-770)."""
+    import torch
+    so = UM.lib()
+    c, x0 = UM.crosen_problems(nprob, n, seed=100 + n)
+    batch = UM.BtriBatch(c)
+    try:
+        okw = dict(max_evals=500, use_line_search=1 if line_search else 0)
+        x = torch.tensor(x0, dtype=torch.float64, device="cuda")
+        fcn = ds._devfcn(batch.crosen_launch)
+        grad = ds._devfcn(batch.crosen_launch_grad) if analytic else None
+        fout, ibs, st = ds.bfgs_solve_batch_device(fcn, batch.ctx, x, grad=grad, opts=ds.options(**okw))
+        xg = x.cpu().numpy()
+        for p in range(nprob):
+            cp = float(c[p])
+            f_host = lambda xx: so.crosen_host_f(cp, n, np.ascontiguousarray(xx).ctypes.data_as(dp))          # noqa: E731
+            g_host = (lambda xx, g: so.crosen_host_grad(cp, n, np.ascontiguousarray(xx).ctypes.data_as(dp), g.ctypes.data_as(dp))) if analytic else None
+            rc, xo, fo, ibo = oracle.bfgs_solve(f_host, n, x0[p], grad=g_host, opts=oracle.default_options(**okw))
+            assert st[p] == rc, (p, st[p], rc)
+            for k in BKEYS:
+                assert ibs[p][k] == ibo[k], (p, k, ibs[p], ibo)
+            assert np.array_equal(xg[p], xo), (p, np.abs(xg[p] - xo).max())
+            assert fout[p] == fo
+    finally:
+        batch.close()
+
+
+@pytest.mark.gpu
+def test_user_scalar_family_bfgs_errors(ds):
+    """No function: NLH_UNDEFINED_FUNCTION_ERROR and zeroed counts (:611-615); a failing launcher is reported."""
+    import torch
+    from nonlin_amd import _lib
+    null = C.cast(None, _lib.DEVFCN)
+    x = torch.zeros((2, 4), dtype=torch.float64, device="cuda")
+    ib = (_lib.IterationBehavior * 2)()
+    ib[0].iter_count = 7
+    o = ds.options()
+    rc = ds.lib.nlh_bfgs_solve_batch_device(ds.h.ptr, C.byref(o), 2, 4, null, null, None, x.data_ptr(), None, ib, None)
+    assert rc == _lib.load().nlh_lm_solve_batch_device(ds.h.ptr, C.byref(o), 1, 4, 2, null, null, None, x.data_ptr(), x.data_ptr(), None, None)
+    assert ib[0].iter_count == 0
+    c, x0 = UM.crosen_problems(2, 4)
+    batch = UM.BtriBatch(c)
+    try:
+        # the btri residual launcher refuses m = 1 (it wants m == n): the library reports the user's failure
+        with pytest.raises(RuntimeError):
+            ds.bfgs_solve_batch_device(ds._devfcn(batch.launch), batch.ctx, torch.tensor(x0, dtype=torch.float64, device="cuda"))
+    finally:
+        batch.close()

@@ -39,6 +39,9 @@ def lib():
         so.btri_create.restype = C.c_void_p
         so.btri_create.argtypes = [C.c_int32, dp]
         so.btri_destroy.argtypes = [C.c_void_p]
+        so.crosen_host_f.restype = C.c_double
+        so.crosen_host_f.argtypes = [C.c_double, C.c_int32, dp]
+        so.crosen_host_grad.argtypes = [C.c_double, C.c_int32, dp, dp]
         _so = so
     return _so
 
@@ -108,6 +111,14 @@ def btri_problems(nprob, n, seed=7, spread=0.3):
     return np.ascontiguousarray(c), np.ascontiguousarray(x0)
 
 
+def crosen_problems(nprob, n, seed=11, spread=0.4):
+    """Chained-Rosenbrock objectives (family 3: a scalar fcnnvar for bfgs): per-problem target c, starts around -0.5."""
+    rng = np.random.default_rng(seed)
+    c = 1.0 + rng.uniform(-0.3, 0.3, nprob)
+    x0 = -0.5 + spread * rng.uniform(-1, 1, (nprob, n))
+    return np.ascontiguousarray(c), np.ascontiguousarray(x0)
+
+
 class BtriBatch:
     def __init__(self, c):
         so = lib()
@@ -118,6 +129,7 @@ class BtriBatch:
             raise RuntimeError("btri_create failed (no GPU?)")
         self.launch, self.launch_jac = so.btri_launch, so.btri_launch_jac
         self.host_fcn, self.host_jac = so.btri_host_fcn, so.btri_host_jac
+        self.crosen_launch, self.crosen_launch_grad = so.crosen_launch, so.crosen_launch_grad   # family 3 shares the context (one c per problem)
 
     def host_ctx(self, p):
         return BtriHost(float(self.c[p]), 0, 0)
