@@ -622,6 +622,41 @@ def device_vecfcn_rows(ds):
               "cpu_oracle_ms": 1e3 * tc * nb / len(sample), "cpu_sample": f"{len(sample)} problems on one core, scaled to {nb}"})
     rows.append(r)
     batch.close()
+
+    # bfgs on a user's device fcnnvar (a launcher called with m = 1; src/nonlin_multi_var.f90:17-44, nonlin_optimize.f90:557-770):
+    # a chained Rosenbrock objective written outside the library, forward-difference gradient built on the device
+    nb, nv = 4096, 40
+    cvals, xs = UM.crosen_problems(nb, nv, seed=2025)
+    sb = UM.BtriBatch(cvals)
+    so = UM.lib()
+    xs0 = torch.tensor(xs, device=ds.device)
+    fcnl = ds._devfcn(sb.crosen_launch)
+    xq = xs0.clone()
+    ds.bfgs_solve_batch_device(fcnl, sb.ctx, xq, opts=ds.options(max_evals=500))
+    torch.cuda.synchronize()
+    xq = xs0.clone()
+    t0 = time.perf_counter()
+    fo_g, ibs, st = ds.bfgs_solve_batch_device(fcnl, sb.ctx, xq, opts=ds.options(max_evals=500))
+    torch.cuda.synchronize()
+    tg = time.perf_counter() - t0
+    xg = xq.cpu().numpy()
+    ok, tc = True, 0.0
+    sample = (0, 1, nb // 2, nb - 1)
+    for p in sample:
+        cp = float(cvals[p])
+        t0 = time.perf_counter()
+        rc, xo, fo, ibo = O.bfgs_solve(lambda xx: so.crosen_host_f(cp, nv, np.ascontiguousarray(xx).ctypes.data_as(dp)), nv, xs[p],
+                                       opts=O.default_options(max_evals=500))
+        tc += time.perf_counter() - t0
+        ok = ok and rc == st[p] and np.array_equal(xo, xg[p]) and fo == fo_g[p] and all(ibs[p][k] == ibo[k] for k in ("iter_count", "fcn_count", "gradient_count"))
+    its = sum(i["iter_count"] for i in ibs)
+    rows.append({"path": f"bfgs on a scalar function written outside the library (chained Rosenbrock, n = {nv}, forward-difference gradient on "
+                         f"the device), {nb} problems, one lock-step batch", "solve_ms": 1e3 * tg, "bfgs_iterations": its,
+                 "bfgs_iterations_per_s": its / tg, "function_evaluations": sum(i["fcn_count"] for i in ibs),
+                 "bitwise_equal_oracle_host_callback": bool(ok), "problems_compared": len(sample),
+                 "cpu_oracle_ms": 1e3 * tc * nb / len(sample),
+                 "cpu_sample": f"{len(sample)} problems on one core through a Python callback (interpreter overhead included), scaled to {nb}"})
+    sb.close()
     return rows
 
 

@@ -56,9 +56,10 @@ def test_bench_single_process():
                                 for r in nt)
     assert not any("cpu_lapack_ms" in r for r in rows if r["path"].startswith("quasi_newton"))
     dv = d["device_vecfcn"]        # the open device-residual path: a user launcher, k_fd_jacobian_qrx timed inside the solve
-    assert len(dv) == 3 and all(r["lm_iterations_per_s"] > 0 and 0.0 < r["fd_jacobian"]["frac"] < 1.0 for r in dv)
+    assert len(dv) == 4 and all(r["lm_iterations_per_s"] > 0 and 0.0 < r["fd_jacobian"]["frac"] < 1.0 for r in dv[:3])
     assert dv[0]["bitwise_equal_builtin_entry_point"] and dv[1]["bitwise_equal_builtin_entry_point"]
     assert dv[2]["bitwise_equal_oracle_host_callback"]
+    assert dv[3]["path"].startswith("bfgs on a scalar function") and dv[3]["bfgs_iterations_per_s"] > 0 and dv[3]["bitwise_equal_oracle_host_callback"]
     assert 0.0 < d["roofline"]["frac_of_achievable"] < 1.2 and d["roofline"]["achievable_peak"] < d["roofline"]["peak"]
     ps = d["predicted_scaling"]    # per-rank batch sizes of config 4 / the 8192-problem run at 1, 2, 4, 8 GPUs, timed on this one
     for key, total in (("config4_1024_problems", 1024), ("strong_8192_problems", 8192)):
