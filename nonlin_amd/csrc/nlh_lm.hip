@@ -471,6 +471,14 @@ static int lm_sub_batches(const nlh_options *o, int nprob, int m, int n)
     if (S <= 0) {                                   // auto: >= 128 problems per sub-batch, at most 3 in flight (measured
         S = nprob / 128;                            // on 512 x 4096x256 exact: 1 / 2 / 3 / 4 -> 1032 / 959 / 928 / 1036 ms)
         if (S > 3) S = 3;
+        // 32 to 255 problems: two halves.  A half of such a batch takes the wide pass form (at most 256 (problem, window)
+        // pairs), whose passes are bound by one adder wave per window rather than by HBM, so two of them side by side
+        // cost little more than one, and the half that holds a straggler runs its rounds at the smaller batch's pace
+        // (ms per solve, one batch / two halves: 4096x256: 16 problems 63.3 / 63.1, 32: 71.4 / 71.1, 44: 87.7 / 76.9,
+        // 48: 132.7 / 120.7, 64: 151.8 / 137.1, 96: 200 / 168, 128: 223 / 207, 192: 316 / 279; 2048x128: 48: 22.7 / 22.3,
+        // 96: 30.5 / 28.5, 128: 34.0 / 32.2, 192: 54.9 / 48.3; 4096x512: 32: 210 / 179; 8192x256: 64: 279 / 236; three
+        // pieces: 16 x 4096x256 98 -- pieces of five problems fall to the column sweep)
+        if (S < 2 && nprob >= 32) S = 2;
         if (o->factor_policy != NLH_FACTOR_EXACT) S = 1;   // the normal-equations pipeline has no long latency-bound
     }                                                      // stage to hide (1 / 2 / 4 -> 40.0 / 40.6 / 41.7 ms)
     if (S > nprob) S = nprob;

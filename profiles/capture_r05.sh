@@ -60,6 +60,8 @@ rm -rf "$OUT/c5auto.MFMA"
 stats devfcn python3 profiles/scripts/devfcn_time.py
 # 4. mid regime: solve times between a handful and a chipful (46 / 47: the first six-iteration problem), kernel shares at 47 and 128
 timeout 900 python3 profiles/sweep_mid.py 4096x256:1,4,8,16,32,46,47,64,128,256 2048x128:1,8,32,64,128,256,512,1024 > "$OUT/r05_sweep_mid.txt" 2>&1
+# ... and with the library's automatic sub-batches (what nlh_default_options gives a caller: two halves from 32 problems on)
+timeout 900 python3 profiles/sweep_mid.py 4096x256:16,32,46,47,64,96,128,192,256 2048x128:32,64,128,192,256,512,1024 --sub=0 >> "$OUT/r05_sweep_mid.txt" 2>&1
 stats mid_4096x256_47 python3 profiles/sweep_mid.py 4096x256:47
 stats mid_2048x128_128 python3 profiles/sweep_mid.py 2048x128:128
 stats lone_4096x256 python3 profiles/sweep_mid.py 4096x256:1
