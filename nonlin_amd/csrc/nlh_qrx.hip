@@ -1201,26 +1201,22 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
 }
 
 // The row-parallel pass, WIDE form: launches of at most QRX_RPW16_MAX_WG (problem, window) pairs -- the straggler rounds of
-// a big batch, small per-rank shares of a sharded batch.  There every workgroup has a CU to itself and k_qrx_pass_rp is
-// bound by that CU: its producers read their reflector entries back as BROADCAST ds_reads ((NP + 1) / 2 sixteen-byte
-// reads per row that each occupy the LDS pipe like a full 1 KB read) and a lone wave per SIMD pays every instruction's
-// latency itself.  Here: sixteen waves per workgroup -- wave 0 the adder, twelve producers, and the three waves that
-// share the adder's SIMD retire at once (the chain of dependent adds wants a SIMD to itself; roles are dealt from the
-// hardware's SIMD id at run time) --, the reflector entries of a producer's eight rows arrive by SCALAR loads (one
-// s_load_dwordx16 per slot and round, requested a barrier ahead) and are scalar operands of the multiplies: no LDS
-// traffic and no VALU work for them; the adder's LDS reads are issued by hand three producers' rows ahead of its adds.
-// Same arithmetic on the same operands in the same order: bit-identical to k_qrx_pass.
-// Measured on the way (in-kernel clocks, 32 x 4096x256, us per pass of ~4000 rows): reflector entries through v_readlane
-// out of a register tile instead of scalar loads -- 2 (NP + 1) more VALU instructions per row -- had the twelve producers
-// at 26 us of produce time against 8 us now; the compiler's own schedule of the adder ("twelve reads, wait for all,
-// twenty-four adds") 30 us of consume against 26; a branch around the flush's stores made the compiler's wait counts
-// assume the path without stores.  What bounds the form from 32 problems of 4096 x 256 on is HBM again: a pass reads
-// 268 MB (45 us = 5.9 TB/s, profiles/ubench/tcp_pattern.hip: a CU alone pulls 20 bytes per clock in the lane-per-column
-// access shape and 39 with whole sectors per lane quad, 256 CUs together 9.7 / 11.3 = the HBM rate) and a flushing pass
-// reads and writes it (118 us) -- which is why the form ends at 128 pairs: beyond, the four-wave form's longer flush
-// period (8 instead of 4 steps; this form keeps at most three pending reflectors in scalar registers) is worth more than
-// its faster passes (ms per solve, this form up to 128 / 256 / 384 pairs: 64 x 4096x256 172 / 184 / 184, 128 x 4096x256
-// 232 / 240 / 253, 192 x 2048x128 60 / 58 / 66; eight-wave workgroups for 257-512 pairs: 128 x 4096x256 257, dropped).
+// a big batch, small per-rank shares of a sharded batch, the halves of a 32-255-problem batch.  There every workgroup has
+// a CU to itself and k_qrx_pass_rp is bound by that CU: its producers read their reflector entries back as BROADCAST
+// ds_reads ((NP + 1) / 2 sixteen-byte reads per row that each occupy the LDS pipe like a full 1 KB read) and a lone wave
+// per SIMD pays every instruction's latency itself.  Here: sixteen waves per workgroup -- wave 0 the ADDER (the ordered sum
+// of :652-653, one column per lane), twelve PRODUCERS (load, apply the pending updates, multiply with the reflector, hand
+// the products over through LDS, store on a flush), one STAGER and two waves that retire at once: the adder's chain of
+// dependent adds wants a SIMD to itself, so roles are dealt from the hardware's SIMD id at run time and only the stager,
+// which sleeps at barriers, shares the adder's SIMD.  The adder's LDS reads are issued by hand three producers' rows
+// ahead of its adds.  Same arithmetic on the same operands in the same order: bit-identical to k_qrx_pass.
+// History of the form (round 4, measured with in-kernel clocks at 32 x 4096x256, us per pass of ~4000 rows): producers that
+// own a COLUMN per lane (16 bytes at a 64-byte stride) with the reflector entries as scalar operands (s_load_dwordx16 per
+// slot and round: no LDS traffic, no VALU work for them) ran a plain pass in 45 us and a flushing one in 100-118; entries
+// through v_readlane out of a register tile had the producers at 26 us of produce time against 8; the compiler's own
+// schedule of the adder ("twelve reads, wait for all, twenty-four adds") 30 us of consume against 26; a branch around the
+// flush's stores made the compiler's wait counts assume the path without stores.  Round 5 replaced those producers by
+// the lane-quad ones below (34 / 78 us) and raised the form's range from 128 to 256 pairs.
 #ifndef QRX_RPW16_MAX_WG
 #define QRX_RPW16_MAX_WG 256            // launches of at most this many (problem, window) pairs take the wide form (128 until
                                         // its producers read whole sectors per lane quad; ms per solve at 128 / 256 / 384 with them:
@@ -1241,27 +1237,22 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
 #define QRX_FEW_MAX 256                 // batches of at most this many active problems take the pivot kernel's FEW instance
 #endif                                  // (32 x 4096x256: 111 instead of 122 ms per solve)
 #ifndef QRX_RPW_MAXNP
-#define QRX_RPW_MAXNP 4                 // pending reflectors the wide form keeps (sixteen SGPRs per slot and round): flush period MAXNP + 1
-                                        // (ms per solve at 3 / 4: 32 x 4096x256 104 / 99, 47: 153 / 152, 64: 164 / 160, 128 x 2048x128 39.4 / 39.1;
-                                        // 5: the slots no longer fit the scalar registers -- 231-394 spilled -- and the kernel faults)
+#define QRX_RPW_MAXNP 4                 // pending reflectors the wide form keeps: flush period MAXNP + 1.  (Round 4, producers with the entries
+                                        // in scalar registers, ms per solve at 3 / 4: 32 x 4096x256 104 / 99, 47: 153 / 152, 64: 164 / 160; 5 did
+                                        // not fit.  The lane-quad producers hold four columns' multipliers per slot: 128 VGPRs at 4.)
 #endif
 #define QRX_RPW_G 8                     // rows per producer and round: one 64-byte sector per lane
-#define QRX_RPW_AH 4                    // row groups in flight per producer
+#ifndef QRX_RPW_AH
+#define QRX_RPW_AH 3                    // row groups in flight per producer (ms per solve at 2 / 3 / 4: 16 x 4096x256 74.6 / 75.6 / 78.9,
+                                        // 44: 97.7 / 95.0 / 99.9; tcp_pattern2: two, three and four groups run alike)
+#endif
 #ifndef QRX_RPW_QSTR
-#define QRX_RPW_QSTR 132                // QUAD: doubles between two row pairs of a product buffer (64 x 2 + 4: lane (c4, r) writes
+#define QRX_RPW_QSTR 132                // doubles between two row pairs of a product buffer (64 x 2 + 4: lane (c4, r) writes
                                         // pair r of column c4 -- eight lanes, eight different 16-byte groups of the 32 banks;
                                         // ms per solve at 132 / 136: 16 x 4096x256 69.8 / 71.7, 44: 92.3 / 93.3, 128 x 2048x128 34.6 / 34.9)
 #endif
-#define QRX_RPW_NVB 4                   // QUAD: rounds of staged reflector entries in LDS
-#ifndef QRX_RPW_AHQ
-#define QRX_RPW_AHQ 3                   // QUAD: row groups in flight per producer (tcp_pattern2: two, three and four groups run alike)
-#endif
-__device__ __forceinline__ double qrx_readlane_f64(double x, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
-}
-
-template <int NP, bool FLUSH, int W, bool QUAD, int CW = 64>
+#define QRX_RPW_NVB 4                   // rounds of staged reflector entries in LDS
+template <int NP, bool FLUSH, int W, int CW = 64>
 __global__ void __launch_bounds__(64 * W)
 k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur,
                double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
@@ -1274,19 +1265,19 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
     // NP).  The W waves of the workgroup land W / 4 on each SIMD; the waves that share wave 0's SIMD retire at once and the
     // other 3 W / 4 are the producers.  (Which waves those are is read from the hardware id at run time; if the placement
     // is ever uneven, waves of the adder's SIMD fill in, or surplus ones retire: always exactly NPR producers.)
-    constexpr int NPR = 3 * W / 4, G = QRX_RPW_G, AH = QUAD ? QRX_RPW_AHQ : QRX_RPW_AH, D = AH, RR = NPR * G;   // D: rounds per trip of the outer loops
-    constexpr int PSTR = QUAD ? QRX_RPW_QSTR : 128;                     // doubles between two row pairs of a product buffer
+    constexpr int NPR = 3 * W / 4, G = QRX_RPW_G, AH = QRX_RPW_AH, D = AH, RR = NPR * G;               // D: rounds per trip of the outer loops
+    constexpr int PSTR = QRX_RPW_QSTR;                                  // doubles between two row pairs of a product buffer
     // CW: columns per workgroup.  A window's products go through LDS once in and once out -- 16 bytes of LDS traffic per
     // matrix element, ~67 bytes per clock all told -- and that, not memory, bounds a workgroup that has its CU to itself
     // (in-kernel clocks, 32 x 4096x256, a 4000-row pass: the adder busy 29.5 of 34 us, the producers idle 2/3 of the
     // time).  While the chip has CUs to spare a window is therefore dealt to TWO workgroups of 32 columns (`nwin` then
     // counts 32-column windows); the adder runs with its upper 32 lanes off.
-    static_assert(CW == 64 || (QUAD && CW == 32), "half windows: the lane-quad producers only");
+    static_assert(CW == 64 || CW == 32, "whole or half windows");
     static_assert(G == 8, "a row group is one sector per lane");
     __shared__ int simd_of[W];
     constexpr int NPI = NP < QRX_C ? NP : 0;
     extern __shared__ __attribute__((aligned(16))) double pbw[];         // [2][RR / 2][PSTR]: the products of a round, row pairs x 64 columns x 2
-                                                                         // (QUAD: then [QRX_RPW_NVB][NP + 1][RR], the staged reflector entries)
+                                                                         // then [QRX_RPW_NVB][NP + 1][RR], the staged reflector entries
     const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
     const int pl = grp * 8 + (r_ & 7), win = r_ >> 3;
     if (pl >= nprob) return;
@@ -1314,8 +1305,8 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
         if (!adder) {
             const bool o = simd_of[wv] != as;
             pw = o ? mine_other : other + mine_same;                     // off-SIMD waves first, then fill-ins
-            if (QUAD) pw = __builtin_amdgcn_readfirstlane(pw);           // (wave-uniform by construction: keeps the loads' block offsets scalar)
-            if (pw >= NPR + (QUAD ? 1 : 0)) return;                      // shares the adder's SIMD (or surplus): retire (QUAD: one of them stays as the stager)
+            pw = __builtin_amdgcn_readfirstlane(pw);                     // (wave-uniform by construction: keeps the loads' block offsets scalar)
+            if (pw >= NPR + 1) return;                                   // shares the adder's SIMD (or surplus): retire -- but for one, the stager
         }
     }
     if (adder) __builtin_amdgcn_s_setprio(3);
@@ -1449,241 +1440,123 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
                                  rdall, waall, Rall, qtfall);
         return;
     }
-    if constexpr (QUAD) {
-        // ------------------------------------------------------------------------------------------------------------
-        // Producers that read WHOLE SECTORS PER LANE QUAD.  In the lane-per-column shape every 16-byte load instruction
-        // touches 64 sectors for a quarter of each, and that is what bounds a CU that has the pass to itself
-        // (profiles/ubench/tcp_pattern2.hip, us per 4096 x 64 window at 32 / 88 / 128 / 188 / 256 workgroups: 49 / 52 / 74 /
-        // 91 / 103, and 123 / 133 / 207 / 262 / 285 with the flush's stores).  Here lanes 4c .. 4c+3 read column c's sector
-        // (1 KB contiguous per instruction, sixteen columns; 26 / 30 / 43 / 62 / 91 us, and 48 / 53 / 131 / 147 / 216 with
-        // stores: whole sectors written by one instruction): lane (c4, r) holds rows 2r, 2r+1 of the four columns 16 q + c4.
-        // The reflector entries are then no longer wave-uniform; as extra vector loads they cost as much as the matrix loads
-        // (+ 60 % with five slots: the CU's limit is load INSTRUCTIONS), so one otherwise idle wave on the adder's SIMD -- the
-        // stager -- copies each round's entries into LDS three rounds ahead and the producers read their row pair back
-        // (one 16-byte LDS read per slot and group).  Same operands, same operations, same order per element: bit-identical.
-        constexpr int NVB = QRX_RPW_NVB;
-        double *vsb = pbw + (size_t)2 * (RR / 2) * PSTR;                 // [NVB][NP + 1][RR]
-        auto vsrc = [&](int q, int t) __attribute__((always_inline)) {  // rounds past the last re-read the last (never used)
-            const int row = min(t, nround - 1) * RR;
-            return ((q < NP) ? vc + (size_t)q * vst : (FLUSH ? vo : vc + (size_t)NPI * vst)) + row;
+    // ------------------------------------------------------------------------------------------------------------
+    // Producers that read WHOLE SECTORS PER LANE QUAD.  In the lane-per-column shape every 16-byte load instruction
+    // touches 64 sectors for a quarter of each, and that is what bounds a CU that has the pass to itself
+    // (profiles/ubench/tcp_pattern2.hip, us per 4096 x 64 window at 32 / 88 / 128 / 188 / 256 workgroups: 49 / 52 / 74 /
+    // 91 / 103, and 123 / 133 / 207 / 262 / 285 with the flush's stores).  Here lanes 4c .. 4c+3 read column c's sector
+    // (1 KB contiguous per instruction, sixteen columns; 26 / 30 / 43 / 62 / 91 us, and 48 / 53 / 131 / 147 / 216 with
+    // stores: whole sectors written by one instruction): lane (c4, r) holds rows 2r, 2r+1 of the four columns 16 q + c4.
+    // The reflector entries are then no longer wave-uniform; as extra vector loads they cost as much as the matrix loads
+    // (+ 60 % with five slots: the CU's limit is load INSTRUCTIONS), so one otherwise idle wave on the adder's SIMD -- the
+    // stager -- copies each round's entries into LDS three rounds ahead and the producers read their row pair back
+    // (one 16-byte LDS read per slot and group).  Same operands, same operations, same order per element: bit-identical.
+    constexpr int NVB = QRX_RPW_NVB;
+    double *vsb = pbw + (size_t)2 * (RR / 2) * PSTR;                 // [NVB][NP + 1][RR]
+    auto vsrc = [&](int q, int t) __attribute__((always_inline)) {  // rounds past the last re-read the last (never used)
+        const int row = min(t, nround - 1) * RR;
+        return ((q < NP) ? vc + (size_t)q * vst : (FLUSH ? vo : vc + (size_t)NPI * vst)) + row;
+    };
+    if (pw == NPR) {
+        // the stager: entries of round t + 3 into LDS during round t (loaded two rounds before that)
+        const bool on = lane < RR / 2;                               // 48 lanes x 16 bytes = the 96 rows of a round
+        double2 hold[3][NP + 1];
+        auto fetch = [&](double2 (&h)[NP + 1], int t) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q <= NP; ++q) h[q] = on ? *reinterpret_cast<const double2 *>(vsrc(q, t) + 2 * lane) : make_double2(0.0, 0.0);
         };
-        if (pw == NPR) {
-            // the stager: entries of round t + 3 into LDS during round t (loaded two rounds before that)
-            const bool on = lane < RR / 2;                               // 48 lanes x 16 bytes = the 96 rows of a round
-            double2 hold[3][NP + 1];
-            auto fetch = [&](double2 (&h)[NP + 1], int t) __attribute__((always_inline)) {
+        auto stage = [&](const double2 (&h)[NP + 1], int t) __attribute__((always_inline)) {
+            if (on) {
 #pragma unroll
-                for (int q = 0; q <= NP; ++q) h[q] = on ? *reinterpret_cast<const double2 *>(vsrc(q, t) + 2 * lane) : make_double2(0.0, 0.0);
-            };
-            auto stage = [&](const double2 (&h)[NP + 1], int t) __attribute__((always_inline)) {
-                if (on) {
-#pragma unroll
-                    for (int q = 0; q <= NP; ++q)
-                        *reinterpret_cast<double2 *>(vsb + ((size_t)(t % NVB) * (NP + 1) + q) * RR + 2 * lane) = h[q];
-                }
-            };
-            fetch(hold[0], 0); fetch(hold[1], 1); fetch(hold[2], 2);     // one trip to memory before the first barrier
-            stage(hold[0], 0); stage(hold[1], 1); stage(hold[2], 2);
-            fetch(hold[1], 3); fetch(hold[0], 4);
-            qrx_lds_barrier();
-            int t = 0;
-#pragma unroll 1
-            for (; t + 1 < ntile * D; t += 2) {
-                stage(hold[1], t + 3); fetch(hold[1], t + 5);
-                qrx_lds_barrier();
-                stage(hold[0], t + 4); fetch(hold[0], t + 6);
-                qrx_lds_barrier();
-            }
-            if (t < ntile * D) { stage(hold[1], t + 3); qrx_lds_barrier(); }
-            return;
-        }
-        constexpr int NQ = CW / 16;                                      // load instructions per 8-row group
-        const int c4 = lane >> 2, rq = lane & 3;
-        unsigned soq[NQ], koq[NQ];
-        double tqq[NP > 0 ? NP : 1][NQ];
-#pragma unroll
-        for (int q2 = 0; q2 < NQ; ++q2) {
-            const int colq = ld - CW * (win + 1) + 16 * q2 + c4;
-            const int ks = (colq >= coff + lo) ? slotp[colq] : -1;
-            const bool aq = ks > j;
-            const int kq = aq ? ks : n;
-            soq[q2] = aq ? (unsigned)colq * 64u + 16u * rq : 0x80000000u;
-            koq[q2] = aq ? (unsigned)(coff + kq) * 64u + 16u * rq : 0x80000000u;
-#pragma unroll
-            for (int q = 0; q < NP; ++q) tqq[q][q2] = tpc[(size_t)q * ldp + kq];
-        }
-        double2 aq_[AH][NQ];
-        double2 vq[NP + 1];
-        auto loadq = [&](double2 (&buf)[NQ], int t) __attribute__((always_inline)) {
-            const unsigned boff = (unsigned)((t * RR + pw * G) >> 3) * ldb;
-#pragma unroll
-            for (int q2 = 0; q2 < NQ; ++q2) {
-                const qrx_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, soq[q2], boff, QRX_AUX_LOAD);
-                buf[q2].x = __hiloint2double((int)w.y, (int)w.x);
-                buf[q2].y = __hiloint2double((int)w.w, (int)w.z);
+                for (int q = 0; q <= NP; ++q)
+                    *reinterpret_cast<double2 *>(vsb + ((size_t)(t % NVB) * (NP + 1) + q) * RR + 2 * lane) = h[q];
             }
         };
-        auto vread = [&](int t) __attribute__((always_inline)) {
-            const double *src = vsb + (size_t)(t % NVB) * (NP + 1) * RR + pw * G + 2 * rq;
-#pragma unroll
-            for (int q = 0; q <= NP; ++q) vq[q] = *reinterpret_cast<const double2 *>(src + (size_t)q * RR);
-        };
-        auto produceq = [&](const double2 (&buf)[NQ], int t) __attribute__((always_inline)) {
-            const int rbase = t * RR + pw * G;
-            double *dst = ((t & 1) ? pb1 : pb0) + (size_t)(pw * (G / 2) + rq) * PSTR + 2 * c4;
-            double2 est[NQ];
-#pragma unroll
-            for (int q2 = 0; q2 < NQ; ++q2) {
-                double e0 = buf[q2].x, e1 = buf[q2].y;
-#pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const double p0_ = tqq[q][q2] * vq[q].x, p1_ = tqq[q][q2] * vq[q].y;
-                    e0 = e0 - p0_;
-                    e1 = e1 - p1_;
-                }
-                double2 ww;                                             // rows outside the live range: garbage the adder skips
-                ww.x = vq[NP].x * e0;
-                ww.y = vq[NP].y * e1;
-                *reinterpret_cast<double2 *>(dst + 32 * q2) = ww;
-                if (FLUSH) { est[q2].x = e0; est[q2].y = e1; }
-            }
-            if (FLUSH) {
-                // whole sectors, unconditionally (see the lane-per-column producer below); a slot's own position is a dead
-                // column unless it is the column the slot is read from, so no lane of any workgroup reads what another writes
-                const unsigned boff = (unsigned)(rbase >> 3) * ldb;
-#pragma unroll
-                for (int q2 = 0; q2 < NQ; ++q2) {
-                    qrx_u32x4 w;
-                    w.x = (unsigned)__double2loint(est[q2].x); w.y = (unsigned)__double2hiint(est[q2].x);
-                    w.z = (unsigned)__double2loint(est[q2].y); w.w = (unsigned)__double2hiint(est[q2].y);
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, koq[q2], boff, QRX_AUX_STORE);
-                }
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < AH - 1; ++i) loadq(aq_[i], i);
-#ifdef QRX_DBG_CLK
-        long long pk0 = wall_clock64(), pwork = 0, pwait = 0, pmem = 0;
-#endif
+        fetch(hold[0], 0); fetch(hold[1], 1); fetch(hold[2], 2);     // one trip to memory before the first barrier
+        stage(hold[0], 0); stage(hold[1], 1); stage(hold[2], 2);
+        fetch(hold[1], 3); fetch(hold[0], 4);
         qrx_lds_barrier();
-        vread(0);
-        __builtin_amdgcn_sched_barrier(0);
+        int t = 0;
 #pragma unroll 1
-        for (int kt = 0; kt < ntile; ++kt) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                const int t = kt * D + i;
-#ifdef QRX_DBG_CLK
-                const long long pa = wall_clock64();
-#endif
-                loadq(aq_[(i + AH - 1) % AH], t + AH - 1);
-                __builtin_amdgcn_sched_barrier(0);
-#ifdef QRX_DBG_CLK
-                if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (the group of this round and its reflector entries have arrived)
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const long long pm = wall_clock64();
-                pmem += pm - pa;
-#endif
-                produceq(aq_[i % AH], t);
-                __builtin_amdgcn_sched_barrier(0);
-                vread(t + 1);                                           // staged by the barrier before this round
-#ifdef QRX_DBG_CLK
-                const long long pbk = wall_clock64();
-#endif
-                qrx_lds_barrier();
-#ifdef QRX_DBG_CLK
-                pwork += pbk - pa; pwait += wall_clock64() - pbk;
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (; t + 1 < ntile * D; t += 2) {
+            stage(hold[1], t + 3); fetch(hold[1], t + 5);
+            qrx_lds_barrier();
+            stage(hold[0], t + 4); fetch(hold[0], t + 6);
+            qrx_lds_barrier();
         }
-#ifdef QRX_DBG_CLK
-        if (lane == 0 && j >= 99 && j <= 101 && blockIdx.x < 1 && (pw == 0 || pw == NPR - 1))
-            printf("rpw QUAD producer %d wg %d j=100 NP=%d: head %lld work %lld (of it waiting for loads %lld) barrier-wait %lld (x10 ns) rounds %d\n", pw, blockIdx.x, NP,
-                   pk0 - ckk, pwork, pmem, pwait, nround);
-#endif
+        if (t < ntile * D) { stage(hold[1], t + 3); qrx_lds_barrier(); }
         return;
     }
-    // producer side ---------------------------------------------------------------------------------------------------
-    // The reflector entries of a producer's eight rows of a round are wave-uniform: one scalar load of 64 bytes per slot
-    // (s_load_dwordx16 into sixteen SGPRs), requested at the end of the round before -- the barrier in between covers its
-    // latency -- and taken by the multiplies as scalar operands: no LDS traffic, no VALU work for them.  (With v_readlane out
-    // of a register tile instead, 2 (NP + 1) extra VALU instructions per row made the producers the bottleneck: twelve
-    // producers x 34 cycles per row on three SIMDs against the ~8 cycles per row the LDS pipe needs for the products.)
-    typedef int qrx_i16 __attribute__((ext_vector_type(16)));
-    qrx_i16 sq[NP + 1];
-    auto sfetch = [&](int t) __attribute__((always_inline)) {            // rounds past the last one re-read the last (never used)
-        const int row = min(t, nround - 1) * RR + pw * G;               // a multiple of 8: 64-byte aligned
+    constexpr int NQ = CW / 16;                                      // load instructions per 8-row group
+    const int c4 = lane >> 2, rq = lane & 3;
+    unsigned soq[NQ], koq[NQ];
+    double tqq[NP > 0 ? NP : 1][NQ];
 #pragma unroll
-        for (int q = 0; q <= NP; ++q) {
-            const double *src = (q < NP) ? vc + (size_t)q * vst + row : (FLUSH ? vo + row : vc + (size_t)NPI * vst + row);
-            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(sq[q]) : "s"(src) : "memory");
-        }
-    };
-    auto swait = [&]() __attribute__((always_inline)) {
-        if constexpr (NP == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]));
-        if constexpr (NP == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]));
-        if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]), "+s"(sq[2]));
-        if constexpr (NP == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]), "+s"(sq[2]), "+s"(sq[3]));
-        if constexpr (NP == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]), "+s"(sq[2]), "+s"(sq[3]), "+s"(sq[4]));
-        if constexpr (NP == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq[0]), "+s"(sq[1]), "+s"(sq[2]), "+s"(sq[3]), "+s"(sq[4]), "+s"(sq[5]));
-        static_assert(NP <= 5, "sixteen SGPRs per slot");
-    };
-    auto sval = [&](int q, int u) __attribute__((always_inline)) { return __hiloint2double(sq[q][2 * u + 1], sq[q][2 * u]); };
-    double a[AH][G];
-    auto load = [&](double (&buf)[G], int t) __attribute__((always_inline)) {                          // the producer's group of round t
+    for (int q2 = 0; q2 < NQ; ++q2) {
+        const int colq = ld - CW * (win + 1) + 16 * q2 + c4;
+        const int ks = (colq >= coff + lo) ? slotp[colq] : -1;
+        const bool aq = ks > j;
+        const int kq = aq ? ks : n;
+        soq[q2] = aq ? (unsigned)colq * 64u + 16u * rq : 0x80000000u;
+        koq[q2] = aq ? (unsigned)(coff + kq) * 64u + 16u * rq : 0x80000000u;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) tqq[q][q2] = tpc[(size_t)q * ldp + kq];
+    }
+    double2 aq_[AH][NQ];
+    double2 vq[NP + 1];
+    auto loadq = [&](double2 (&buf)[NQ], int t) __attribute__((always_inline)) {
         const unsigned boff = (unsigned)((t * RR + pw * G) >> 3) * ldb;
 #pragma unroll
-        for (int q2 = 0; q2 < 4; ++q2) {
-            const qrx_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + 16u * q2, boff, QRX_AUX_LOAD);
-            buf[2 * q2] = __hiloint2double((int)w.y, (int)w.x);
-            buf[2 * q2 + 1] = __hiloint2double((int)w.w, (int)w.z);
+        for (int q2 = 0; q2 < NQ; ++q2) {
+            const qrx_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, soq[q2], boff, QRX_AUX_LOAD);
+            buf[q2].x = __hiloint2double((int)w.y, (int)w.x);
+            buf[q2].y = __hiloint2double((int)w.w, (int)w.z);
         }
     };
-    auto produce = [&](const double (&buf)[G], int t) __attribute__((always_inline)) {
-        const int rbase = t * RR + pw * G;
-        double *dst = ((t & 1) ? pb1 : pb0) + ((size_t)(pw * (G / 2)) * 64 + lane) * 2;
-        double est[8];
+    auto vread = [&](int t) __attribute__((always_inline)) {
+        const double *src = vsb + (size_t)(t % NVB) * (NP + 1) * RR + pw * G + 2 * rq;
 #pragma unroll
-        for (int u = 0; u < G; u += 2) {
-            double e0 = buf[u], e1 = buf[u + 1];
+        for (int q = 0; q <= NP; ++q) vq[q] = *reinterpret_cast<const double2 *>(src + (size_t)q * RR);
+    };
+    auto produceq = [&](const double2 (&buf)[NQ], int t) __attribute__((always_inline)) {
+        const int rbase = t * RR + pw * G;
+        double *dst = ((t & 1) ? pb1 : pb0) + (size_t)(pw * (G / 2) + rq) * PSTR + 2 * c4;
+        double2 est[NQ];
+#pragma unroll
+        for (int q2 = 0; q2 < NQ; ++q2) {
+            double e0 = buf[q2].x, e1 = buf[q2].y;
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const double p0_ = tq[q] * sval(q, u), p1_ = tq[q] * sval(q, u + 1);
+                const double p0_ = tqq[q][q2] * vq[q].x, p1_ = tqq[q][q2] * vq[q].y;
                 e0 = e0 - p0_;
                 e1 = e1 - p1_;
             }
-            double2 ww;                                                 // rows outside the live range: garbage the adder skips
-            ww.x = sval(NP, u) * e0;
-            ww.y = sval(NP, u + 1) * e1;
-            *reinterpret_cast<double2 *>(dst + (size_t)(u >> 1) * 128) = ww;
-            if (FLUSH) { est[u] = e0; est[u + 1] = e1; }
+            double2 ww;                                             // rows outside the live range: garbage the adder skips
+            ww.x = vq[NP].x * e0;
+            ww.y = vq[NP].y * e1;
+            *reinterpret_cast<double2 *>(dst + 32 * q2) = ww;
+            if (FLUSH) { est[q2].x = e0; est[q2].y = e1; }
         }
         if (FLUSH) {
-            // The whole sector, unconditionally.  Rows of the block above row j are dead (final rows of R live in their own
-            // array), rows past m are the padding of the problem's last block, blocks past the matrix are dropped by the
-            // buffer's range check, idle lanes are parked out of range.  A branch around these stores makes the compiler's
-            // wait counts assume the path WITHOUT stores (stores count in vmcnt on this part and retire in issue order), so
-            // that every wait for a load group also waited for the stores of the rounds before: a store acknowledgement
-            // per round, 117 instead of 45 us per 4096-row flushing pass.
+            // whole sectors, unconditionally (see the lane-per-column producer below); a slot's own position is a dead
+            // column unless it is the column the slot is read from, so no lane of any workgroup reads what another writes
             const unsigned boff = (unsigned)(rbase >> 3) * ldb;
 #pragma unroll
-            for (int q2 = 0; q2 < 4; ++q2) {
+            for (int q2 = 0; q2 < NQ; ++q2) {
                 qrx_u32x4 w;
-                w.x = (unsigned)__double2loint(est[2 * q2]); w.y = (unsigned)__double2hiint(est[2 * q2]);
-                w.z = (unsigned)__double2loint(est[2 * q2 + 1]); w.w = (unsigned)__double2hiint(est[2 * q2 + 1]);
-                __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, ko + 16u * q2, boff, QRX_AUX_STORE);
+                w.x = (unsigned)__double2loint(est[q2].x); w.y = (unsigned)__double2hiint(est[q2].x);
+                w.z = (unsigned)__double2loint(est[q2].y); w.w = (unsigned)__double2hiint(est[q2].y);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, koq[q2], boff, QRX_AUX_STORE);
             }
         }
     };
-    sfetch(0);
 #pragma unroll
-    for (int i = 0; i < AH - 1; ++i) load(a[i], i);
+    for (int i = 0; i < AH - 1; ++i) loadq(aq_[i], i);
 #ifdef QRX_DBG_CLK
-    long long pk0 = wall_clock64(), pwork = 0, pwait = 0, psm = 0;
+    long long pk0 = wall_clock64(), pwork = 0, pwait = 0, pmem = 0;
 #endif
     qrx_lds_barrier();
+    vread(0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int kt = 0; kt < ntile; ++kt) {
@@ -1693,22 +1566,20 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
 #ifdef QRX_DBG_CLK
             const long long pa = wall_clock64();
 #endif
-            // (the scheduler fences keep a round's arithmetic behind the round's loads: the products depend on nothing but
-            // registers, and left alone the compiler hoists the arithmetic of every group in flight to the head of the
-            // unrolled rounds -- a full drain of the load pipeline each time)
-            load(a[(i + AH - 1) % AH], t + AH - 1);
-            swait();
-            __builtin_amdgcn_sched_barrier(0);
-            produce(a[i % AH], t);
+            loadq(aq_[(i + AH - 1) % AH], t + AH - 1);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef QRX_DBG_CLK
-            const long long pbs = wall_clock64();
-#endif
-            sfetch(t + 1);                                              // after the last use of this round's entries
-#ifdef QRX_DBG_CLK
+            if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (the group of this round and its reflector entries have arrived)
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long long pm = wall_clock64();
+            pmem += pm - pa;
+#endif
+            produceq(aq_[i % AH], t);
+            __builtin_amdgcn_sched_barrier(0);
+            vread(t + 1);                                           // staged by the barrier before this round
+#ifdef QRX_DBG_CLK
             const long long pbk = wall_clock64();
-            psm += pbk - pbs;
 #endif
             qrx_lds_barrier();
 #ifdef QRX_DBG_CLK
@@ -1719,9 +1590,10 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
     }
 #ifdef QRX_DBG_CLK
     if (lane == 0 && j >= 99 && j <= 101 && blockIdx.x < 1 && (pw == 0 || pw == NPR - 1))
-        printf("rpw producer %d wg %d j=100: head %lld produce+smem %lld (smem+lds drain %lld) barrier-wait %lld (x10 ns) simd %d\n", pw, blockIdx.x, pk0 - ckk, pwork, psm, pwait,
-               simd_of[wv]);
+        printf("rpw producer %d wg %d j=100 NP=%d: head %lld work %lld (of it waiting for loads %lld) barrier-wait %lld (x10 ns) rounds %d\n", pw, blockIdx.x, NP,
+               pk0 - ckk, pwork, pmem, pwait, nround);
 #endif
+    return;
 }
 
 // The pass for a HANDFUL of problems (straggler rounds, one problem alone; factorisations of at most QRX_COL_MAX_WG
@@ -1964,13 +1836,11 @@ k_qrx_finish(int m, int n, int ld, int coff, size_t tst, size_t vst, int cur, in
     }
 }
 
-// two product buffers of 3 W / 4 * 8 rows x 64 lanes x 8 bytes (QUAD: padded row pairs, + the staged reflector entries)
-static constexpr size_t qrx_rpw_lds(int W, bool quad = false)
+// two product buffers of 3 W / 4 * 8 rows x 64 lanes x 8 bytes (row pairs QRX_RPW_QSTR doubles apart), + the staged reflector entries
+static constexpr size_t qrx_rpw_lds(int W)
 {
-    return quad ? sizeof(double) * ((size_t)(3 * W / 4) * QRX_RPW_G * QRX_RPW_QSTR + (size_t)QRX_RPW_NVB * (QRX_RPW_MAXNP + 1) * (3 * W / 4) * QRX_RPW_G)
-                : (size_t)(3 * W / 4) * QRX_RPW_G * 1024;
+    return sizeof(double) * ((size_t)(3 * W / 4) * QRX_RPW_G * QRX_RPW_QSTR + (size_t)QRX_RPW_NVB * (QRX_RPW_MAXNP + 1) * (3 * W / 4) * QRX_RPW_G);
 }
-static bool qrx_quad_on() { static const int v = [] { const char *e = getenv("NLH_QRX_QUAD"); return e ? atoi(e) : 1; }(); return v != 0; }
 
 template <int NP, bool FLUSH>
 static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, int m, int n, int ld, int coff, size_t tst, size_t vst, int j, int cur, double *T, const QrxWs &w,
@@ -1981,25 +1851,20 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     const int nwin = (n + 1 - lo + 63) / 64;                            // live physical columns coff + lo .. coff + n
     const dim3 grid((unsigned)(((nprob + 7) / 8) * 8 * nwin));
     if constexpr (NP >= 8) rp = 0;
-    // the wide row-parallel form keeps its reflector entries in scalar registers (sixteen per slot): at most three pending
-    // updates; a launch that inherits more from the form before it takes the four-wave form until the next flush
+    // the wide row-parallel form holds at most QRX_RPW_MAXNP pending updates (registers); a launch that inherits more from the
+    // form before it takes the four-wave form until the next flush
     if constexpr (NP > QRX_RPW_MAXNP) { if (rp == 16 || rp == QRX_RP_HALF || rp == 8) rp = 4; }
     if constexpr (NP < 8) {
     if constexpr (NP <= QRX_RPW_MAXNP) {
-    if (rp == 8)                                                        // eight waves (adder, stager, six lane-quad producers), two workgroups per CU
-        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 8, true>), grid, dim3(64 * 8), qrx_rpw_lds(8, true), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+    if (rp == 8)                                                        // eight waves (adder, stager, six producers), two workgroups per CU
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 8>), grid, dim3(64 * 8), qrx_rpw_lds(8), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
-    else
-    if (rp == QRX_RP_HALF) {                                            // the wide form on half windows (qrx_factor chose it: lane-quad producers on)
+    else if (rp == QRX_RP_HALF) {                                       // the wide form on half windows
         const int nsw = (n + 1 - lo + 31) / 32;
-        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, true, 32>), dim3((unsigned)(((nprob + 7) / 8) * 8 * nsw)), dim3(64 * 16), qrx_rpw_lds(16, true), stream, p0, nprob,
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, 32>), dim3((unsigned)(((nprob + 7) / 8) * 8 * nsw)), dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob,
                            nsw, lo, m, n, ld, coff, tst, vst, j, cur, T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
-    } else
-    if (rp == 16 && qrx_quad_on())
-        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, true>), grid, dim3(64 * 16), qrx_rpw_lds(16, true), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
-                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
-    else if (rp == 16)
-        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, false>), grid, dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+    } else if (rp == 16)
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16>), grid, dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
                            T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
     }
     if (rp == 4)
@@ -2038,14 +1903,12 @@ static void dispatch_pass(int np, bool flush, int rp, hipStream_t stream, int p0
 template <int NP>
 static void qrx_rpw_attr()
 {
-    const int lim = (int)qrx_rpw_lds(16), limq = (int)qrx_rpw_lds(16, true);
-    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
-    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
+    const int lim = (int)qrx_rpw_lds(16);
+    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, false, 16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     if constexpr (qrx_can_flush(NP)) {
-        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
-        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, limq);
+        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        hipFuncSetAttribute((const void *)k_qrx_pass_rpw<NP, true, 16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     }
     if constexpr (NP < QRX_RPW_MAXNP) qrx_rpw_attr<NP + 1>();
 }
@@ -2095,7 +1958,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     static const long rp_env = [] { const char *e = getenv("NLH_QRX_RP"); return e ? atol(e) : -1L; }();
     const long rp_max = rp_env >= 0 ? rp_env : QRX_RP_MAX_WG;
     static const long rpw16_env = [] { const char *e = getenv("NLH_QRX_RPW16"); return e ? atol(e) : -1L; }();
-    const long rpw16_max = std::min(rp_max, rpw16_env >= 0 ? rpw16_env : (long)(qrx_quad_on() ? QRX_RPW16_MAX_WG : 128));   // (the lane-per-column producers: 128)
+    const long rpw16_max = std::min(rp_max, rpw16_env >= 0 ? rpw16_env : (long)QRX_RPW16_MAX_WG);
     static const int col_env = [] { const char *e = getenv("NLH_QRX_COL"); return e ? atoi(e) : -1; }();
     if (col_env >= 0 ? nact <= col_env : (long)nact * n <= QRX_COL_MAX_WG) {
         // two product buffers for columns of several chunks, one sized to the column otherwise
@@ -2180,8 +2043,8 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
         // 192.3, 128: 218.1 / 231.5, 192: 321.8 / 317.8, 192 x 2048x128 55.6 / 53.5, 384: 94.8 / 90.9, 512: 104.8 / 104.3 --
         // no consistent gain where launches are HBM-bound anyway; left off.)
         static const long rp8_env = [] { const char *e = getenv("NLH_QRX_RP8"); return e ? atol(e) : 0L; }();
-        const int rp = nwg <= rpw16_max ? ((qrx_quad_on() && nwgh <= (rpwh_env >= 0 ? rpwh_env : (long)QRX_RPWH_MAX_WG)) ? QRX_RP_HALF : 16)
-                       : nwg <= rp_max ? ((qrx_quad_on() && nwg <= rp8_env) ? 8 : 4) : 0;
+        const int rp = nwg <= rpw16_max ? (nwgh <= (rpwh_env >= 0 ? rpwh_env : (long)QRX_RPWH_MAX_WG) ? QRX_RP_HALF : 16)
+                       : nwg <= rp_max ? (nwg <= rp8_env ? 8 : 4) : 0;
         // the wide form keeps at most three pending reflectors (scalar registers): a flush every 4th step; the four-wave
         // form every 8th; full launches every QRX_C-th
         const int period = forced_period ? forced_period : ((rp == 16 || rp == QRX_RP_HALF || rp == 8) ? QRX_RPW_MAXNP + 1 : rp == 4 ? (QRX_C < 8 ? QRX_C : 8) : QRX_C);
