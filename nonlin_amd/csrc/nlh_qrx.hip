@@ -110,6 +110,7 @@ struct QrxWs {
     QrxStep *step;     // [nprob]
     int32_t *src;      // [nprob][n + 1]: physical column holding slot k
     int32_t *slotof;   // [nprob][ld]: slot held by a physical column, -1 = consumed / never used
+    int32_t *plist;    // [nprob]: the problems a factorisation works on, compacted (k_qrx_list), -1 = none; nullptr = all
 };
 
 static size_t qrx_carve(void *base, int nprob, int m, int n, QrxWs *w)
@@ -123,11 +124,13 @@ static size_t qrx_carve(void *base, int nprob, int m, int n, QrxWs *w)
     const size_t ost = take(sizeof(QrxStep) * (size_t)nprob);
     const size_t osr = take(sizeof(int32_t) * (size_t)nprob * (n + 1));
     const size_t oso = take(sizeof(int32_t) * (size_t)nprob * qrx_ld(n));
+    const size_t opl = take(sizeof(int32_t) * (size_t)nprob);
     if (w) {
         char *b = (char *)base;
         w->V = (double *)(b + oV); w->tp = (double *)(b + otp); w->rdiag = (double *)(b + ord);
         w->wa = (double *)(b + owa); w->step = (QrxStep *)(b + ost); w->src = (int32_t *)(b + osr);
         w->slotof = (int32_t *)(b + oso);
+        w->plist = (int32_t *)(b + opl);
     }
     return off;
 }
@@ -162,14 +165,48 @@ k_qrx_transpose(int m, int n, int ld, int coff, size_t tst, const double *__rest
 // Initial column norms (:611-616) for a HANDFUL of problems: a workgroup per column (the serial recurrence of flang's
 // NORM2 down the lanes of a wave, as in the pivot kernel) instead of a thread per column -- one 65536 x 512 problem:
 // 25 ms -> well under a millisecond.  Same algorithm on the same elements in the same order: the same bits.
+// The problems due for a factorisation (stage ST_NEED_QR), compacted in ascending order: the launches whose grids are
+// (columns x problems) -- the column sweep, the initial norms -- then cover the ny problems that work instead of every
+// problem of the batch.  In the straggler rounds of a 2048-problem batch a column-sweep launch was 175,000 workgroups of
+// which 256 had work: 124 us per launch against 18 for a problem alone (1.4 % of the headline step).  ny is the host's
+// count (exact: the problems that were at ST_NEED_JAC when the round before ended); entries past the true count are -1,
+// and a problem past ny -- which cannot happen -- would be retired with its flag set rather than silently skipped.
+__global__ void __launch_bounds__(256)
+k_qrx_list(int nprob, int ny, LmState *__restrict__ st, int32_t *__restrict__ plist)
+{
+    __shared__ int wsum[4], base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < nprob; p0 += 256) {
+        const int p = p0 + tid;
+        const bool on = p < nprob && st[p].stage == ST_NEED_QR;
+        const unsigned long long b = __ballot(on);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wid] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int w2 = 0; w2 < wid; ++w2) off += wsum[w2];
+        if (on) {
+            const int pos = off + before;
+            if (pos < ny) plist[pos] = p;
+            else { st[p].flag = 1; st[p].stage = ST_DONE; }
+        }
+        __syncthreads();
+        if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    for (int i = base + tid; i < ny; i += 256) plist[i] = -1;
+}
+
 __global__ void __launch_bounds__(256)
 k_qrx_init_norms(int m, int n, int ld, int coff, size_t tst, const double *__restrict__ T, QrxWs w, LmVecs v,
                  const LmState *__restrict__ st)
 {
     __shared__ __attribute__((aligned(16))) double cd[64 * 64 + 128];
     __shared__ __attribute__((aligned(16))) double aux[40 + 128];
-    const int p = blockIdx.y, k = blockIdx.x;
-    if (st && st[p].stage != ST_NEED_QR) return;
+    const int p = w.plist ? w.plist[blockIdx.y] : (int)blockIdx.y, k = blockIdx.x;
+    if (p < 0 || (st && st[p].stage != ST_NEED_QR)) return;
     const double *a = T + (size_t)p * tst;
     const double nr = norm2_flang_block_lanes<64, 256>([&](int i) { return a[qrx_at(i, coff + k, ld)]; }, m, cd, aux);
     if (threadIdx.x == 0) {
@@ -1631,15 +1668,15 @@ __global__ void __launch_bounds__(256)
 k_qrx_pass_col(int m, int n, int ld, size_t tst, size_t vst, int j, int cur, double *__restrict__ T,
                     const double *__restrict__ Vall, double *__restrict__ tpall, const int32_t *__restrict__ srcall,
                     double *__restrict__ rdall, double *__restrict__ waall, const QrxStep *__restrict__ stepall,
-                    double *__restrict__ Rall, double *__restrict__ qtfall, const LmState *__restrict__ st)
+                    double *__restrict__ Rall, double *__restrict__ qtfall, const LmState *__restrict__ st, const int32_t *__restrict__ plist)
 {
     constexpr int EL = QRX_COL_EL, CAP = 64 * EL, NPREP = 192, NPAIR = CAP / 2, PPT = (NPAIR + NPREP - 1) / NPREP;   // 2048 row pairs, 11 per thread
     // dynamic LDS: two product buffers of CAP + 128 doubles -- one, sized to the column, when the column is a single chunk
     extern __shared__ __attribute__((aligned(16))) double bufs[];
     double *buf[2] = {bufs, bufs + ((m - (j & ~7)) > CAP ? CAP + 128 : 0)};
     __shared__ double xch[2];
-    const int p = blockIdx.y;
-    if (st && st[p].stage != ST_NEED_QR) return;
+    const int p = plist ? plist[blockIdx.y] : (int)blockIdx.y;
+    if (p < 0 || (st && st[p].stage != ST_NEED_QR)) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const bool chain = (wid == NPREP / 64);                             // (wave-uniform)
     const int k = j + 1 + blockIdx.x;
@@ -1942,9 +1979,14 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     // per column walks its 4096 rows alone: 800 us for 47 x 4096x256, whatever the count; k_qrx_init<true> is HBM-bound
     // only from ~1000 problems on)
     static const long initn_env = [] { const char *e = getenv("NLH_QRX_INITN"); return e ? atol(e) : 32768L; }();
+    // launches with (columns x problems) grids cover the problems that work, not the batch (k_qrx_list)
+    const bool use_list = st != nullptr && nact < nprob && (long)nact * n <= std::max<long>(QRX_COL_MAX_WG, initn_env);
+    const int ny = use_list ? nact : nprob;
+    if (use_list) hipLaunchKernelGGL(k_qrx_list, dim3(1), dim3(256), 0, stream, nprob, nact, st, w.plist);
+    else w.plist = nullptr;
     if ((long)nact * n <= std::max<long>(QRX_COL_MAX_WG, initn_env)) {
         hipLaunchKernelGGL(k_qrx_init<false>, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
-        hipLaunchKernelGGL(k_qrx_init_norms, dim3(n, nprob), dim3(256), 0, stream, m, n, ld, coff, tst, (const double *)T, w, v,
+        hipLaunchKernelGGL(k_qrx_init_norms, dim3(n, ny), dim3(256), 0, stream, m, n, ld, coff, tst, (const double *)T, w, v,
                            (const LmState *)st);
     } else {
         hipLaunchKernelGGL(k_qrx_init<true>, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
@@ -2000,13 +2042,13 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
                 te(0, stream);
                 tb(1, stream);
                 if (j == 0)
-                    hipLaunchKernelGGL(k_qrx_pass_col<false>, dim3(n - j, nprob), dim3(256), coll_lds(m, j), stream, m, n, ld, tst, vst, j, cur, T,
+                    hipLaunchKernelGGL(k_qrx_pass_col<false>, dim3(n - j, ny), dim3(256), coll_lds(m, j), stream, m, n, ld, tst, vst, j, cur, T,
                                        (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
-                                       (const LmState *)st);
+                                       (const LmState *)st, (const int32_t *)w.plist);
                 else
-                    hipLaunchKernelGGL(k_qrx_pass_col<true>, dim3(n - j, nprob), dim3(256), coll_lds(m, j), stream, m, n, ld, tst, vst, j, cur, T,
+                    hipLaunchKernelGGL(k_qrx_pass_col<true>, dim3(n - j, ny), dim3(256), coll_lds(m, j), stream, m, n, ld, tst, vst, j, cur, T,
                                        (const double *)w.V, w.tp, (const int32_t *)w.src, w.rdiag, w.wa, (const QrxStep *)w.step, R, v.qtf,
-                                       (const LmState *)st);
+                                       (const LmState *)st, (const int32_t *)w.plist);
                 te(1, stream);
                 if (j > 0) cur ^= 1;
             }
