@@ -111,6 +111,7 @@ struct QrxWs {
     int32_t *src;      // [nprob][n + 1]: physical column holding slot k
     int32_t *slotof;   // [nprob][ld]: slot held by a physical column, -1 = consumed / never used
     int32_t *plist;    // [nprob]: the problems a factorisation works on, compacted (k_qrx_list), -1 = none; nullptr = all
+    int ny;            // ... and how many (host side)
 };
 
 static size_t qrx_carve(void *base, int nprob, int m, int n, QrxWs *w)
@@ -1045,7 +1046,7 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
               double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
               int32_t *__restrict__ srcall, int32_t *__restrict__ slotall, double *__restrict__ rdall,
               double *__restrict__ waall, const QrxStep *__restrict__ stepall, double *__restrict__ Rall,
-              double *__restrict__ qtfall, const LmState *__restrict__ st)
+              double *__restrict__ qtfall, const LmState *__restrict__ st, const int32_t *__restrict__ plist)
 {
     constexpr int NPR = W - 1, G = QRX_RP_G, D = QRX_RP_D, RR = NPR * G, LP = 8;
     static_assert(NP < 8, "the row-parallel pass stages at most eight entries per row");
@@ -1055,8 +1056,8 @@ k_qrx_pass_rp(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int cof
     const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
     const int pl = grp * 8 + (r_ & 7), win = r_ >> 3;
     if (pl >= nprob) return;
-    const int p = p0 + pl;
-    if (st && st[p].stage != ST_NEED_QR) return;
+    const int p = plist ? plist[pl] : p0 + pl;                           // (plist: nprob counts its entries, k_qrx_list)
+    if (p < 0 || (st && st[p].stage != ST_NEED_QR)) return;
     const int lane = threadIdx.x & 63, ldp = n + 1;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block offsets stay scalar
     const bool adder = (wv == 0);
@@ -1295,7 +1296,7 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
                double *__restrict__ T, const double *__restrict__ Vall, double *__restrict__ tpall,
                int32_t *__restrict__ srcall, int32_t *__restrict__ slotall, double *__restrict__ rdall,
                double *__restrict__ waall, const QrxStep *__restrict__ stepall, double *__restrict__ Rall,
-               double *__restrict__ qtfall, const LmState *__restrict__ st)
+               double *__restrict__ qtfall, const LmState *__restrict__ st, const int32_t *__restrict__ plist)
 {
     // The adder's chain of dependent adds wants a SIMD to itself (an add every ~4.6 cycles is 87 % of the SIMD's fp64 issue
     // rate; sharing it round-robin with four producers stretched every add to ~20 cycles: 50 us per 4096-row pass whatever
@@ -1318,8 +1319,8 @@ k_qrx_pass_rpw(int p0, int nprob, int nwin, int lo, int m, int n, int ld, int co
     const int b_ = blockIdx.x, grp = b_ / (8 * nwin), r_ = b_ % (8 * nwin);
     const int pl = grp * 8 + (r_ & 7), win = r_ >> 3;
     if (pl >= nprob) return;
-    const int p = p0 + pl;
-    if (st && st[p].stage != ST_NEED_QR) return;
+    const int p = plist ? plist[pl] : p0 + pl;                           // (plist: nprob counts its entries, k_qrx_list)
+    if (p < 0 || (st && st[p].stage != ST_NEED_QR)) return;
     const int lane = threadIdx.x & 63, ldp = n + 1;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool adder = (wv == 0);
@@ -1887,6 +1888,10 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     // elements) on 512 x 4096x256, 1024 x 2048x128 and a single problem, more waves won every time.
     const int nwin = (n + 1 - lo + 63) / 64;                            // live physical columns coff + lo .. coff + n
     const dim3 grid((unsigned)(((nprob + 7) / 8) * 8 * nwin));
+    // the row-parallel forms over the compacted problems when the factorisation has a list (qrx_factor)
+    const int npl = w.plist ? w.ny : nprob;
+    const int32_t *pls = w.plist;
+    const dim3 gridl((unsigned)(((npl + 7) / 8) * 8 * nwin));
     if constexpr (NP >= 8) rp = 0;
     // the wide row-parallel form holds at most QRX_RPW_MAXNP pending updates (registers); a launch that inherits more from the
     // form before it takes the four-wave form until the next flush
@@ -1894,19 +1899,19 @@ static void launch_pass(int rp, hipStream_t stream, int p0, int nprob, int lo, i
     if constexpr (NP < 8) {
     if constexpr (NP <= QRX_RPW_MAXNP) {
     if (rp == 8)                                                        // eight waves (adder, stager, six producers), two workgroups per CU
-        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 8>), grid, dim3(64 * 8), qrx_rpw_lds(8), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
-                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 8>), gridl, dim3(64 * 8), qrx_rpw_lds(8), stream, p0, npl, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st, pls);
     else if (rp == QRX_RP_HALF) {                                       // the wide form on half windows
         const int nsw = (n + 1 - lo + 31) / 32;
-        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, 32>), dim3((unsigned)(((nprob + 7) / 8) * 8 * nsw)), dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob,
-                           nsw, lo, m, n, ld, coff, tst, vst, j, cur, T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16, 32>), dim3((unsigned)(((npl + 7) / 8) * 8 * nsw)), dim3(64 * 16), qrx_rpw_lds(16), stream, p0, npl,
+                           nsw, lo, m, n, ld, coff, tst, vst, j, cur, T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st, pls);
     } else if (rp == 16)
-        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16>), grid, dim3(64 * 16), qrx_rpw_lds(16), stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
-                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+        hipLaunchKernelGGL((k_qrx_pass_rpw<NP, FLUSH, 16>), gridl, dim3(64 * 16), qrx_rpw_lds(16), stream, p0, npl, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st, pls);
     }
     if (rp == 4)
-        hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 4>), grid, dim3(64 * 4), 0, stream, p0, nprob, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
-                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st);
+        hipLaunchKernelGGL((k_qrx_pass_rp<NP, FLUSH, 4>), gridl, dim3(64 * 4), 0, stream, p0, npl, nwin, lo, m, n, ld, coff, tst, vst, j, cur,
+                           T, (const double *)w.V, w.tp, w.src, w.slotof, w.rdiag, w.wa, (const QrxStep *)w.step, R, qtf, st, pls);
     }
     static const int share_env = [] { const char *e = getenv("NLH_QRX_SHARE"); return e ? atoi(e) : 1; }();
     if (rp == 0 && share_env && nwin >= 2 && nwin <= QRX_SHARE_MAXWIN)
@@ -1984,6 +1989,7 @@ void qrx_factor(hipStream_t stream, int nprob, int m, int n, const double *J, do
     const int ny = use_list ? nact : nprob;
     if (use_list) hipLaunchKernelGGL(k_qrx_list, dim3(1), dim3(256), 0, stream, nprob, nact, st, w.plist);
     else w.plist = nullptr;
+    w.ny = ny;
     if ((long)nact * n <= std::max<long>(QRX_COL_MAX_WG, initn_env)) {
         hipLaunchKernelGGL(k_qrx_init<false>, dim3(nprob), dim3(256), 0, stream, m, n, ld, coff, tst, T, fvec, w, v, (const LmState *)st);
         hipLaunchKernelGGL(k_qrx_init_norms, dim3(n, ny), dim3(256), 0, stream, m, n, ld, coff, tst, (const double *)T, w, v,
