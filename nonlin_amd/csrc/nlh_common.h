@@ -972,6 +972,38 @@ __device__ __forceinline__ double ordered_sum_wave(Get get, int len, double s0)
     return t;
 }
 
+// The same for at most 64 * E terms that the lanes already hold: lane l has terms E l .. E l + E - 1 in d[] (slots past the
+// end must hold -0.0).  All 64 lanes of the wave call; the sum s0 + d(0) + d(1) + ... is returned in every lane.
+template <int E>
+__device__ __forceinline__ double ordered_sum_wave_regs(const double (&d)[E], int len, double s0)
+{
+    double t = s0;
+    const int nl = (len + E - 1) / E;
+    int last = nl - 1;
+    if (nl >= 8) {
+        const int ntrip = (nl + 7) >> 3;
+        last = 8 * ntrip - 1;
+#pragma unroll 1
+        for (int g = 0; g < ntrip; ++g) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                t = nlh_wave_shr1(t);
+#pragma unroll
+                for (int u = 0; u < E; ++u) t = t + d[u];
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int l = 0; l < nl; ++l) {
+            t = nlh_wave_shr1(t);
+#pragma unroll
+            for (int u = 0; u < E; ++u) t = t + d[u];
+        }
+    }
+    if (nl <= 0) return s0;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), last), __builtin_amdgcn_readlane(__double2loint(t), last));
+}
+
 // Sum of term(0..len-1): left-to-right by one thread when EXACT, tree otherwise.  Broadcast.
 template <bool EXACT, typename Term>
 __device__ __forceinline__ double sum_block(Term term, int len, double *red)

@@ -13,6 +13,209 @@
 #include "nlh_common.h"
 #include "nlh_kernels_factor.h"
 
+// -DNLH_DEBUG_LMPAR_CLK: in-kernel clocks (100 MHz) of lmpar's phases, printed by workgroup 0 when its iteration ran
+#ifdef NLH_DEBUG_LMPAR_CLK
+__device__ unsigned long long g_lmclk[16];
+#define LMCLK(i) { __syncthreads(); const unsigned long long t_ = wall_clock64(); if (threadIdx.x == 0) g_lmclk[i] += t_ - lmclk_t; lmclk_t = t_; }
+#define LMCLK_START() unsigned long long lmclk_t = wall_clock64();
+#else
+#define LMCLK(i)
+#define LMCLK_START()
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// The Givens sweeps of lmsolve (:717-765) ON CHIP, n <= LMS_MAX_N (round 6).  Same wavefront as the global-memory form
+// below -- rotation (j,k) at time step t = j + k -- and every datum sees the reference's sequence of operations
+// (bit-identical), but nothing of a time step goes through L2:
+//   * the working row W_j of elimination j lives in the REGISTERS of the wave that owns it (wave j mod NW, slot
+//     (j / NW) mod 8; element i in lane i & 63, register (i >> 6) - v0 with v0 = (k+1) >> 6 the first 64-element chunk
+//     that still holds a live entry -- the registers move down by one whenever k+1 crosses a multiple of 64, so the
+//     entry the next rotation eliminates is always in register 0);
+//   * the columns of S that are live (column k from its first rotation at t = k to its last at t = 2k) sit in an LDS
+//     ring: columns enter and leave in the order of k, so a FIFO; column k occupies the elements i >= 64 v0(k), whole
+//     chunks, so that a chunk of 64 lanes needs NO lane mask: the lanes below the diagonal (i <= k) and beyond n read and
+//     write the column's own padding and carry garbage that nothing reads.  The live band peaks at ~n^2/6 doubles plus
+//     padding (115 KB at n = 256: lmsolve_ring_bytes()); column t + LMS_AHEAD is fetched from global memory during step
+//     t (a load per lane of waves 0..NV-1, stored into the ring a step later), a column's final values go to the lower
+//     triangle of r in global memory straight from the registers of its last rotation (t = 2k);
+//   * sdiag / wa / qtbp / rot as in the global form; one LDS-only barrier per time step.
+// What bounds it: a wave issues at most one instruction per four cycles, so a time step costs (instructions a wave executes)
+// x 4 cycles -- the code of a step is kept to the rotation's arithmetic plus a few scalar instructions per slot
+// (measured: docs/lab_notebook.md).  Before: 6.6 us per time step (two dependent trips to L2 and a full barrier),
+// 3.35 ms per sweep at n = 256.
+// ---------------------------------------------------------------------------------------------------------------
+#define LMS_MAX_N 256
+#define LMS_AHEAD 4
+#define LMS_SLOTS 8
+#define LMS_NV (LMS_MAX_N / 64)
+// doubles column k occupies in the ring: the elements i = 64 v0(k) .. 64 ceil(n / 64) - 1
+__host__ __device__ inline int lms_colsize(int k, int n) { return ((n + 63) & ~63) - (((k + 1) >> 6) << 6); }
+// Column k's place in the ring: behind column k-1, or at the ring's start when it would not fit before the end (a column
+// never straddles the end, so an element's address needs no wrap-around).  The same rule on the host and on the device.
+#define LMS_PLACE(pos, len, cap) (((pos) + (len) > (cap)) ? 0 : (pos))
+// Does a ring of `cap` doubles hold every column from the step it is stored (step max(0, c - AHEAD + 1)) to its last
+// rotation (step 2c) without touching a live one?
+static inline bool lms_ring_fits(int n, int cap)
+{
+    std::vector<int> base(n, 0);
+    int pos = 0;
+    // (column n-1 has no element below the diagonal, but its rotations run over its chunk like any other: it gets its padding)
+    for (int k = 0; k < n; ++k) { const int len = lms_colsize(k, n); pos = LMS_PLACE(pos, len, cap); base[k] = pos; pos += len; }
+    if (pos > cap || lms_colsize(0, n) > cap) return false;
+    for (int c = 0; c < n; ++c) {
+        const int tw = c >= LMS_AHEAD ? c - LMS_AHEAD + 1 : 0, kmin = c >= LMS_AHEAD ? tw / 2 : 0;
+        for (int k = kmin; k < c; ++k)
+            if (base[k] < base[c] + lms_colsize(c, n) && base[c] < base[k] + lms_colsize(k, n)) return false;
+    }
+    return true;
+}
+// LDS the ring needs for an n-by-n sweep by `threads` threads: *cap = doubles of the ring proper (0: the on-chip form does
+// not apply -- n too large, or too few waves for the n/2 rows that are live at a time); returns bytes incl. the offset table.
+static inline size_t lmsolve_ring_bytes(int n, int threads, int *cap)
+{
+    *cap = 0;
+    if (n > LMS_MAX_N || n < 2 || (n + 1) / 2 > (threads / 64) * LMS_SLOTS) return 0;
+    static int cached[LMS_MAX_N + 1];                           // (benign race: every writer stores the same value)
+    int c = cached[n];
+    if (!c) {
+        c = 64;
+        while (!lms_ring_fits(n, c)) c += 64;
+        cached[n] = c;
+    }
+    *cap = c;
+    return sizeof(double) * ((size_t)c + (size_t)(n + 1) / 2 + 8);      // + the table of column offsets (n int32)
+}
+// threads of a k_lmpar workgroup: sixteen waves from n = 65 on (the on-chip sweep needs a wave per eight live rows)
+static inline int lmpar_threads(int n) { return n > 64 ? 1024 : 256; }
+
+template <int NV>
+__device__ __forceinline__ void lmsolve_sweep_lds(int n, double *r, int ldr, double *sdiag, double *wa, double *qtbp,
+                                                  double *rot, double *ring, int cap)
+{
+    const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = BS >> 6, P = nw * LMS_SLOTS;
+    const int nvt = (n + 63) >> 6;                              // chunks of 64 elements in all (<= NV)
+    int32_t *cbt = reinterpret_cast<int32_t *>(ring + cap);    // cbt[k]: where column k (its element 64 v0(k)) starts in the ring
+    if (tid == 0) {
+        int pos = 0;
+        for (int k = 0; k < n; ++k) { const int len = lms_colsize(k, n); pos = LMS_PLACE(pos, len, cap); cbt[k] = pos; pos += len; }
+    }
+    __syncthreads();
+    // columns 0 .. AHEAD-1 straight into the ring
+    {
+        const int kend = LMS_AHEAD < n ? LMS_AHEAD : n;
+        for (int k = 0; k < kend; ++k) {
+            const int base = cbt[k] - (((k + 1) >> 6) << 6);
+            for (int i = k + 1 + tid; i < n; i += BS) ring[base + i] = r[(size_t)k * ldr + i];
+        }
+    }
+    double w[LMS_SLOTS][NV];
+#pragma unroll
+    for (int u = 0; u < LMS_SLOTS; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) w[u][v] = 0.0;
+    int myj = wid + nw * (lane & (LMS_SLOTS - 1));             // lane u < 8: the row in slot u of this wave
+    double ldv = 0.0;                                           // column (t - 1 + AHEAD), chunk wid of its live ones, in flight
+    int ldc = -1;
+    __syncthreads();
+#ifdef NLH_DEBUG_LMPAR_CLK
+    long long ck_ld = 0, ck_form = 0, ck_app = 0, ck_bar = 0, ck0 = clock64(), ck1;
+#define SWCLK(acc) { ck1 = clock64(); acc += ck1 - ck0; ck0 = ck1; }
+#else
+#define SWCLK(acc)
+#endif
+    for (int t = 0; t <= 2 * (n - 1); ++t) {
+        // ring traffic of the look-ahead: store what was fetched during the previous step, fetch the next column
+        if (wid < NV) {
+            if (ldc >= 0) {
+                const int i = (((ldc + 1) >> 6) + wid) * 64 + lane;
+                if (i > ldc && i < n) ring[cbt[ldc] + 64 * wid + lane] = ldv;
+            }
+            const int c = t + LMS_AHEAD;
+            ldc = c < n - 1 ? c : -1;
+            if (ldc >= 0) {
+                const int i = (((c + 1) >> 6) + wid) * 64 + lane;
+                ldv = (i > c && i < n) ? r[(size_t)c * ldr + i] : 0.0;
+            }
+        }
+        SWCLK(ck_ld)
+        // lane u forms the rotation of slot u (:733-748)
+        if (myj + n - 1 < t) myj += P;                          // the slot's row is finished: its next row
+        const bool mine = lane < LMS_SLOTS && myj < n && 2 * myj <= t && t <= myj + n - 1;
+        double mycs = 1.0, mysn = 0.0;
+        int mycb = 0;                                           // ring offset of the column; bit 30: the rotation is applied (:732)
+        if (mine) {
+            const int j = myj, k = t - j;
+            // everything the rotation needs is read before anything is tested (one LDS latency, not three)
+            const double sk = rot[j], rkk = sdiag[k], wk = wa[k], qj = qtbp[j];
+            mycb = cbt[k];
+            if (sk != 0.0) {                                   // :732 (diag(l) == 0, :721, is the sk == 0 case: see the global form)
+                // :733-741, both branches through one divide / square root / divide (the lanes of a wave take different
+                // branches, and a wave pays for every instruction of both): the same operations on the same operands
+                const bool tan_form = !(fabs(rkk) < fabs(sk));  // cs = 0.5 / sqrt(...), sn = cs * (sk / rkk)
+                const double q = (tan_form ? sk : rkk) / (tan_form ? rkk : sk);
+                const double pr = 0.5 / sqrt(0.25 + 0.25 * (q * q));
+                const double ot = pr * q;
+                mycs = tan_form ? pr : ot;
+                mysn = tan_form ? ot : pr;
+                sdiag[k] = mycs * rkk + mysn * sk;             // :745
+                wa[k] = mycs * wk + mysn * qj;                 // :746-748
+                qtbp[j] = -mysn * wk + mycs * qj;
+                mycb |= 1 << 30;
+            }
+        }
+        const int actmask = (int)__builtin_amdgcn_readfirstlane((unsigned)(__ballot(mine) & 0xff));
+        SWCLK(ck_form)
+#pragma unroll
+        for (int u = 0; u < LMS_SLOTS; ++u) {
+            if (!((actmask >> u) & 1)) continue;               // uniform
+            const int j = __builtin_amdgcn_readlane(myj, u), k = t - j;
+            const int cbf = __builtin_amdgcn_readlane(mycb, u), ok = cbf >> 30;
+            const double cs = readlane_f64(mycs, u), sn = readlane_f64(mysn, u);
+            const int hl = (k + 1) & 63, v0 = (k + 1) >> 6, nlive = nvt - v0;   // live chunks: the column's elements 64 (v0 + c) + lane
+            double *col = ring + (cbf & 0x3fffffff) + lane;    // chunk c at col[64 c]
+            if (j == k) {
+                // The row's first rotation (sdiag(j+1:n) = zero, :722) is column k's last: the column's final values go to
+                // the lower triangle of r in memory instead of the ring.  Once per time step, one wave.
+                double *gcol = r + (size_t)k * ldr + 64 * v0 + lane;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    const int i = 64 * (v0 + c) + lane;
+                    w[u][c] = 0.0;
+                    if (c < nlive && i > k && i < n) {
+                        const double rcur = col[64 * c], scur = 0.0;
+                        w[u][c] = ok ? -sn * rcur + cs * scur : 0.0;
+                        gcol[64 * c] = ok ? cs * rcur + sn * scur : rcur;
+                    }
+                }
+            } else {
+                if (hl == 0) {                                 // k+1 crossed a multiple of 64: chunk 0 died, the registers move down
+#pragma unroll
+                    for (int c = 0; c + 1 < NV; ++c) w[u][c] = w[u][c + 1];
+                }
+                if (ok) {                                      // (not ok: rotation skipped, :732 cycle -- row and column untouched)
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) {
+                        if (c < nlive) {                       // uniform; no lane mask (see above)
+                            const double rcur = col[64 * c], scur = w[u][c];
+                            w[u][c] = -sn * rcur + cs * scur;  // :753-757
+                            col[64 * c] = cs * rcur + sn * scur;
+                        }
+                    }
+                }
+            }
+            if (lane == hl && k + 1 < n) rot[j] = w[u][0];     // the entry the row's next rotation eliminates
+        }
+        SWCLK(ck_app)
+        nlh_lds_barrier();
+        SWCLK(ck_bar)
+    }
+#ifdef NLH_DEBUG_LMPAR_CLK
+    if (blockIdx.x == 0 && lane == 0 && (wid == 0 || wid == 5 || wid == 15))
+        printf("[sweep clk64 wave %d, kcycles] loader %lld form %lld apply %lld barrier %lld\n", wid, ck_ld / 1000, ck_form / 1000, ck_app / 1000, ck_bar / 1000);
+#endif
+}
+
 // Faithful lmsolve on the n-by-n R (global, ld = ldr; strict lower triangle is scratch).
 // diagv[l] is the diagonal of sqrt(par) D; x (indexed by original column), sdiag, wa in LDS.
 //
@@ -25,12 +228,14 @@
 // Wrows: n*n doubles of global scratch (working row of elimination j at Wrows + j*n);
 // qtbp: n doubles (LDS), the running qtbpj of each elimination.
 template <bool EXACT>
-__device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, const double *diagv,
+__device__ __forceinline__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, const double *diagv,
                             const double *qtb, double *x, double *sdiag, double *wa, double *red,
                             double *Wrows, double *qtbp, double *rot /* LDS, n + 8 doubles */,
-                            double *sbuf /* LDS, n doubles, EXACT only */)
+                            double *sbuf /* LDS, n doubles, EXACT only */,
+                            double *ring = nullptr /* LDS, lmsolve_ring_doubles(): the on-chip sweep */, int ringcap = 0)
 {
     const int tid = threadIdx.x, BS = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = BS >> 6;
+    LMCLK_START()
     // :710-714, the upper triangle copied into the lower one: eight elements per thread are loaded before any is stored
     // (sources and destinations never overlap, but the compiler cannot know; element by element, every store would
     // wait for its own load: n memory latencies in the column-by-column form)
@@ -48,9 +253,11 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
         }
     }
     for (int j = tid; j < n; j += BS) { x[j] = r[(size_t)j * ldr + j]; wa[j] = qtb[j]; qtbp[j] = 0.0; }
-    for (int e = tid; e < n * n; e += BS) Wrows[e] = 0.0;       // sdiag(j:n) = zero, per elimination (:722)
-    __syncthreads();
-    for (int j = tid; j < n; j += BS) Wrows[(size_t)j * n + j] = diagv[ipvt[j]];   // sdiag(j) = diag(l) (:723)
+    if (!ring) {
+        for (int e = tid; e < n * n; e += BS) Wrows[e] = 0.0;       // sdiag(j:n) = zero, per elimination (:722)
+        __syncthreads();
+        for (int j = tid; j < n; j += BS) Wrows[(size_t)j * n + j] = diagv[ipvt[j]];   // sdiag(j) = diag(l) (:723)
+    }
     __syncthreads();
 
     // State the sweep hands from one time step to the next lives in LDS, so that forming a rotation needs no
@@ -59,6 +266,13 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
     // W_j[k] of working row j that the next rotation of elimination j eliminates.
     for (int j = tid; j < n; j += BS) { sdiag[j] = x[j]; rot[j] = diagv[ipvt[j]]; }
     __syncthreads();
+    LMCLK(0)
+    if (ring) {                                                 // :717-765 on chip (n <= LMS_MAX_N)
+        if (n <= 64) lmsolve_sweep_lds<1>(n, r, ldr, sdiag, wa, qtbp, rot, ring, ringcap);
+        else if (n <= 128) lmsolve_sweep_lds<2>(n, r, ldr, sdiag, wa, qtbp, rot, ring, ringcap);
+        else lmsolve_sweep_lds<LMS_NV>(n, r, ldr, sdiag, wa, qtbp, rot, ring, ringcap);
+    }
+    else
     for (int t = 0; t <= 2 * (n - 1); ++t) {                   // :717-765 as a wavefront
         const int jlo = t - (n - 1) > 0 ? t - (n - 1) : 0, jhi = t >> 1;
         const int nrot = jhi - jlo + 1;
@@ -133,6 +347,8 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
         __syncthreads();
     }
 
+    __syncthreads();      // (the on-chip sweep's columns went to memory by plain stores)
+    LMCLK(1)
     // singular tail (:769-773) and back-substitution on S^T stored in the lower triangle (:774-784)
     int ns = n;
     for (int j = tid; j < n; j += BS)
@@ -141,6 +357,34 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
     __syncthreads();
     for (int j = ns + tid; j < n; j += BS) wa[j] = 0.0;
     __syncthreads();
+    if (EXACT && ring) {
+        // n <= LMS_MAX_N: the whole back-substitution by ONE wave, no barriers -- lane l holds the products E l .. E l + E - 1 of a
+        // column and the ordered sum runs down the lanes (nlh_common.h: 2.2 ns per term against 6 - 10 for a thread that reads
+        // its terms from LDS); the next column's elements are fetched from memory while the chain of this one runs
+        if (wid == 0) {
+            constexpr int E = LMS_MAX_N / 64;
+            double nx[E];
+#pragma unroll
+            for (int u = 0; u < E; ++u) nx[u] = 0.0;             // column ns-1 has no term
+            for (int k = 1; k <= ns; ++k) {
+                const int j = ns - k, len = k - 1;                // terms i = j+1 .. ns-1
+                double d[E];
+#pragma unroll
+                for (int u = 0; u < E; ++u) {
+                    const int q = E * lane + u;
+                    d[u] = q < len ? nx[u] * wa[j + 1 + q] : -0.0;
+                }
+                if (j > 0) {
+                    const double *cn = r + (size_t)(j - 1) * ldr + j;
+#pragma unroll
+                    for (int u = 0; u < E; ++u) { const int q = E * lane + u; nx[u] = q < len + 1 ? cn[q] : 0.0; }
+                }
+                const double sm = ordered_sum_wave_regs<E>(d, len, 0.0);
+                if (lane == 0) wa[j] = (wa[j] - sm) / sdiag[j];
+            }
+        }
+        __syncthreads();
+    } else
     for (int k = 1; k <= ns; ++k) {
         const int j = ns - k;
         const double *colj = r + (size_t)j * ldr;
@@ -160,6 +404,7 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
     }
     for (int j = tid; j < n; j += BS) x[ipvt[j]] = wa[j];       // :787-790
     __syncthreads();
+    LMCLK(2)
 }
 
 // lmpar.  Vectors x, sdiag, wa1, wa2n (the first n entries of the caller's wa4), z are LDS.
@@ -168,14 +413,16 @@ __device__ void lmsolve_dev(int n, double *r, int ldr, const int32_t *ipvt, cons
 // from the Gram matrix (row signs unknown, no Q^T f tail), so only the Gauss-Newton
 // acceptance test is run; returns 1 when the iteration would be needed (=> QR fallback).
 template <bool EXACT>
-__device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, const double *diag,
+__device__ __forceinline__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, const double *diag,
                          const double *qtb, double delta, double *par_io, double tailsq,
                          const double *wa4, double *x, double *sdiag, double *wa1, double *wa2n,
-                         double *z, double *red, double *scratch, double *Wrows, double *rot, int ne_mode)
+                         double *z, double *red, double *scratch, double *Wrows, double *rot, int ne_mode,
+                         double *ring = nullptr, int ringcap = 0)
 {
     const int tid = threadIdx.x, BS = blockDim.x;
     const double p1 = 0.1, p001 = 1.0e-3;
     double par = *par_io;
+    LMCLK_START()
 
     // Gauss-Newton direction (:447-469)
     int nsing = n;
@@ -220,6 +467,7 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
     __syncthreads();
     double dxnorm = nrm2_block<EXACT>([&](int i) { return wa2n[i]; }, n, red, scratch);
     double fp = dxnorm - delta;
+    LMCLK(3)
     if (fp <= p1 * delta) { *par_io = 0.0; return 0; }
     if (ne_mode) return 1;
 
@@ -276,6 +524,7 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
     if (par == 0.0) par = gnorm / dxnorm;
 
     bool at_fixed_point = false;
+    LMCLK(4)
     for (int iter = 1;; ++iter) {                              // :522-563
         // Once an iteration has STARTED with par = +Inf and run to its end, the loop is at a fixed point: the next
         // iteration starts from the same par = parl = +Inf, the same R and qtb (lmsolve restarts from them), computes
@@ -291,7 +540,9 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
         __syncthreads();
         for (int i = tid; i < n; i += BS) wa1[i] = temp * diag[i];
         __syncthreads();
-        lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red, Wrows, z, rot, scratch);
+        LMCLK(5)
+        lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red, Wrows, z, rot, scratch, ring, ringcap);
+        LMCLK(6)
         for (int i = tid; i < n; i += BS) wa2n[i] = diag[i] * x[i];
         __syncthreads();
         if (EXACT) {                                           // :531 deviation A: norm over all m entries
@@ -303,6 +554,7 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
         }
         temp = fp;
         fp = dxnorm - delta;
+        LMCLK(7)
 #ifdef NLH_DEBUG_LMPAR
         if (tid == 0 && blockIdx.x == 0)
             printf("[gpu lmpar] iter=%d par=%.17g parl=%.6g paru=%.6g dxnorm=%.17g fp=%.6g delta=%.6g\n",
@@ -327,7 +579,9 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
             }
             __syncthreads();
         }
+        LMCLK(8)
         temp = nrm2_block<EXACT>([&](int j) { return wa1[j]; }, n, red, scratch);
+        LMCLK(9)
         const double parc = ((fp / delta) / temp) / temp;
         if (fp > 0.0) parl = fmax(parl, par);                  // :558-559
         if (fp < 0.0) paru = fmin(paru, par);
@@ -335,6 +589,14 @@ __device__ int lmpar_dev(int m, int n, double *r, int ldr, const int32_t *ipvt, 
         at_fixed_point = started_inf;
     }
     *par_io = par;
+#ifdef NLH_DEBUG_LMPAR_CLK
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        printf("[lmpar clk, us] lmsolve: copy %.1f sweep %.1f backsub %.1f | GN %.1f bounds %.1f pre %.1f lmsolve(all) %.1f dxnorm %.1f newton-solve %.1f nrm %.1f\n",
+               g_lmclk[0] * 1e-2, g_lmclk[1] * 1e-2, g_lmclk[2] * 1e-2, g_lmclk[3] * 1e-2, g_lmclk[4] * 1e-2, g_lmclk[5] * 1e-2,
+               g_lmclk[6] * 1e-2, g_lmclk[7] * 1e-2, g_lmclk[8] * 1e-2, g_lmclk[9] * 1e-2);
+        for (int i = 0; i < 16; ++i) g_lmclk[i] = 0;
+    }
+#endif
     return 0;
 }
 
@@ -401,40 +663,49 @@ __device__ void ne_recover_signs(int m, int n, const double *J, const int32_t *i
 
 // lmpar for every problem whose factors are ready, then the step and trial point.
 // Dynamic LDS: (6n + 72) doubles, plus 3*NLH_NCH + 8 when EXACT.
-template <bool EXACT>
+template <bool EXACT, bool GV = false>
 __global__ void __launch_bounds__(1024)
 k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ xall,
         const double *__restrict__ wa4all, double *__restrict__ Wall /* [nprob][m*n] scratch */,
         const double *__restrict__ Jall, double *__restrict__ W2all /* [nprob][n*n] scratch */,
-        LmState *__restrict__ st, int want_stage, double *__restrict__ gv = nullptr)
-{   // gv: [nprob][6 n + 8] doubles of global memory for lmpar's n-vectors when they do not fit LDS (n > 3000; the
+        LmState *__restrict__ st, int want_stage, double *__restrict__ gv = nullptr, int ringcap = 0)
+{   // ringcap > 0: lmsolve's sweep on chip, its ring behind the other LDS vectors (lmsolve_ring_doubles(n, threads) doubles).
+    // GV: lmpar's n-vectors in [nprob][6 n + 8] doubles of global memory (gv) when they do not fit LDS (n > 3000; the
     // reference allocates for any n, src/nonlin_least_squares.f90:199-208): the same code through other pointers --
-    // a workgroup's barriers order its own global accesses -- at L2 instead of LDS latency
+    // a workgroup's barriers order its own global accesses -- at L2 instead of LDS latency.  A compile-time switch: with
+    // a run-time choice of the base the compiler loses the vectors' address space and every access to them becomes a
+    // flat_load / flat_store instead of ds_read / ds_write (round 5: the all-accepted path 1.41 -> 2.00 ms).
     extern __shared__ double smem[];
     const int p = blockIdx.x;
     LmState *s = st + p;
     if (s->stage != want_stage) return;
     const int tid = threadIdx.x, BS = blockDim.x;
-    double *nv = gv ? gv + (size_t)p * (6 * (size_t)n + 8) : smem;
+    double *nv = GV ? gv + (size_t)p * (6 * (size_t)n + 8) : smem;
     double *xs = nv, *sdiag = nv + n, *wa1 = nv + 2 * n, *wa2n = nv + 3 * n, *z = nv + 4 * n;
     double *rot = nv + 5 * n;           // n + 8
-    double *red = gv ? smem : nv + 6 * n + 8;
+    double *red = GV ? smem : smem + 6 * n + 8;
     double *scratch = red + 64;
+    double *ring = ringcap > 0 ? scratch + (EXACT ? 3 * NLH_NCH + 8 : 0) : nullptr;
     double *R = Rall + (size_t)p * n * n;
     const int32_t *ipvt = v.ipvt + (size_t)p * n;
     const double *diag = v.diag + (size_t)p * n;
     const double *qtf = v.qtf + (size_t)p * n;
     const double *xc = xall + (size_t)p * n;
-    const int ne_mode = (want_stage == ST_NE_READY);
+    const int ne_mode = !EXACT && (want_stage == ST_NE_READY);
     double *Wp = Wall + (size_t)p * m * n;
 
     double par = s->par;
     const double delta = s->delta;
-    int rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, s->tailsq,
+    // ONE call site of lmpar_dev (it is inlined -- as a called function its LDS pointers would be generic ones): the
+    // normal-equations policy's second pass, after the signs are recovered, is a second trip round this loop
+    int rc, mode = ne_mode;
+    double tailsq_in = s->tailsq;
+    for (;;) {
+        rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, tailsq_in,
                               wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
-                              Wp, rot, ne_mode);
-    __syncthreads();
-    if (rc && !EXACT) {
+                              Wp, rot, mode, ring, ringcap);
+        __syncthreads();
+        if (EXACT || !rc || !mode) break;
         // Deviation A (:531) adds ||wa4(n+1:m)|| to ||D x|| inside the loop.  If that tail alone exceeds
         // 1.1*delta the exit test |fp| <= 0.1*delta can never pass for any par: the reference runs its ten
         // iterations with par growing super-exponentially to +Inf and returns x = 0 (the solve then ends
@@ -455,28 +726,21 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
             par = __builtin_inf();
             rc = 0;
             __syncthreads();
+            break;
         }
-    }
-    if (rc && !s->pivoted) {
-        // the lmpar iteration needs lmfactor's pivot order: ask for the pivoted factorisation
-        if (tid == 0) s->stage = ST_NEED_PCHOL;
-        return;
-    }
-    if (rc) {
+        if (!s->pivoted) {
+            // the lmpar iteration needs lmfactor's pivot order: ask for the pivoted factorisation
+            if (tid == 0) s->stage = ST_NEED_PCHOL;
+            return;
+        }
         // Gauss-Newton step rejected on the normal-equations path: give the factors lmfactor's
         // signs, reconstruct ||(Q^T f)(n+1:m)||^2 = ||f||^2 - ||qtf||^2 for deviation A on the
         // first inner pass (later passes use the rejected trial residual's tail), run full lmpar.
         double tailsq = s->tailsq;
         double *qtfw = v.qtf + (size_t)p * n;
-#ifdef NLH_DEBUG_TIMING
-        const unsigned long long tt0 = wall_clock64();
-#endif
         if (!s->signs_done) {
             ne_recover_signs(m, n, Jall + (size_t)p * m * n, ipvt, R, qtfw, W2all + (size_t)p * n * n, xs, sdiag, wa1);
         }
-#ifdef NLH_DEBUG_TIMING
-        const unsigned long long tt1 = wall_clock64();
-#endif
         if (s->inner_pass == 0) {
             double q2 = 0.0;
             for (int j = tid; j < n; j += BS) q2 = q2 + qtfw[j] * qtfw[j];
@@ -487,14 +751,8 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
         __syncthreads();
         if (tid == 0) { s->signs_done = 1; s->tailsq = tailsq; }
         par = s->par;
-        rc = lmpar_dev<EXACT>(m, n, R, n, ipvt, diag, qtf, delta, &par, tailsq,
-                              wa4all + (size_t)p * m, xs, sdiag, wa1, wa2n, z, red, scratch,
-                              Wp, rot, 0);
-        __syncthreads();
-#ifdef NLH_DEBUG_TIMING
-        if (tid == 0) printf("[lmpar p=%d] signs %.3f ms, full lmpar %.3f ms, par=%g\n", p, (tt1 - tt0) * 1e-5,
-                             (wall_clock64() - tt1) * 1e-5, par);
-#endif
+        tailsq_in = tailsq;
+        mode = 0;
     }
     // :286-291  p = -x_lmpar ; trial = x + p ; pnorm = ||D p||
     double *pw = v.wa1 + (size_t)p * n, *tw = v.wa2 + (size_t)p * n;

@@ -12,7 +12,7 @@
 
 static __global__ void k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const double *diag_all,
                                    const double *qtf_all, const double *delta_all, const double *tailsq_all,
-                                   double *par_all, double *x_all, double *sdiag_all, double *Wall);
+                                   double *par_all, double *x_all, double *sdiag_all, double *Wall, int ringcap);
 
 
 
@@ -27,6 +27,7 @@ void nlh_lm_init_device(int lds_max)
     hipFuncSetAttribute((const void *)k_qr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipFuncSetAttribute((const void *)k_lmpar<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     hipFuncSetAttribute((const void *)k_lmpar_standalone, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
 }
 
@@ -193,6 +194,15 @@ static int launch_gram(nlh_handle *h, int nprob, int m, int n, const double *J, 
 // so that tests reach the global-memory form at small sizes)
 static const int LM_LDS_MAX_N = [] { const char *e = getenv("NLH_LM_LDS_MAX_N"); const int v = e ? atoi(e) : 3000; return v < 3000 ? v : 3000; }();
 
+// LDS of lmsolve's on-chip sweep for a k_lmpar launch (0 / *cap = 0: the global-memory wavefront).  NLH_LMSOLVE_GLOBAL=1
+// (read per call: tests compare the two forms bit for bit) forces the latter at any n.
+static size_t lm_ring_bytes(int n, int threads, int *cap)
+{
+    const char *e = getenv("NLH_LMSOLVE_GLOBAL");
+    if (e && atoi(e)) { *cap = 0; return 0; }
+    return lmsolve_ring_bytes(n, threads, cap);
+}
+
 struct LmWs {
     double *J, *P, *wa4, *scratch, *G, *g, *part, *W2, *R;
     LmVecs v;
@@ -241,7 +251,7 @@ static int lm_workspace(nlh_handle *h, int nprob, int m, int n, LmWs &w, bool ne
 static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, int m, int n, LmWs &w,
                               double *dx, const double *dfvec, int nact = -1, bool jac_in_qrx_layout = false, bool any_fresh = true)
 {   // any_fresh = false: no problem has a fresh Jacobian this round (the exact policy then skips the factorisation's launches)
-    const int ft = factor_threads(n);
+    const int ft = factor_threads(n), lt_ = lmpar_threads(n);
     const size_t shl = sizeof(double) * (size_t)(6 * n + 72);
     if (o->factor_policy == NLH_FACTOR_EXACT) {
         // reference operation order: exact lmfactor + Q^T f (streaming form, the batch advances through the
@@ -262,13 +272,16 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
             // 3,585 LM it/s for one lock-step batch of 2048 x 4096x256, 3,681 -> 3,511 with sub-batches; 47 x 4096x256 153.5 ->
             // 155.7 ms.  docs/lab_notebook.md.)
             Timed t(h, NLH_K_LMPAR);
-            if (n <= LM_LDS_MAX_N)
-                hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(ft), shl + sizeof(double) * (3 * NLH_NCH + 8),
-                                   h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY, (double *)nullptr);
+            if (n <= LM_LDS_MAX_N) {
+                int cap;
+                const size_t rb = lm_ring_bytes(n, lt_, &cap);
+                hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(lt_), shl + sizeof(double) * (3 * NLH_NCH + 8) + rb,
+                                   h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY, (double *)nullptr, cap);
+            }
             else {                                              // lmpar's n-vectors in global memory (the misc buffer)
                 int rc2;
                 if ((rc2 = ensure(h, h->misc, sizeof(double) * (size_t)nprob * (6 * (size_t)n + 8)))) return rc2;
-                hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(ft), sizeof(double) * (size_t)(64 + 3 * NLH_NCH + 8),
+                hipLaunchKernelGGL((k_lmpar<true, true>), dim3(nprob), dim3(ft), sizeof(double) * (size_t)(64 + 3 * NLH_NCH + 8),
                                    h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY, (double *)h->misc.p);
             }
         }
@@ -276,6 +289,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
     }
     int rc = launch_gram(h, nprob, m, n, w.J, dfvec, w.G, w.g, w.st, ST_HAVE_JAC);
     if (rc) return rc;
+    int ringcap;                                                // lmsolve's on-chip sweep (the launches that can reach lmpar's iteration)
+    const size_t ringb = lm_ring_bytes(n, lt_, &ringcap);
     constexpr int NB = 16;
     {   // fast path: blocked Cholesky in natural order, G -> R
         Timed t(h, NLH_K_CHOL);
@@ -326,8 +341,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
     }
     {
         Timed t(h, NLH_K_LMPAR);
-        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.R, w.v, dx, w.wa4, w.P,
-                           w.J, w.W2, w.st, (int)ST_NE_READY);
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(lt_), shl + ringb, h->stream, m, n, w.R, w.v, dx, w.wa4, w.P,
+                           w.J, w.W2, w.st, (int)ST_NE_READY, (double *)nullptr, ringcap);
     }
     {
         Timed t(h, NLH_K_QR);
@@ -337,8 +352,8 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
     }
     {
         Timed t(h, NLH_K_LMPAR);
-        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(ft), shl, h->stream, m, n, w.R, w.v, dx, w.wa4, w.P,
-                           w.J, w.W2, w.st, (int)ST_QR_READY);
+        hipLaunchKernelGGL(k_lmpar<false>, dim3(nprob), dim3(lt_), shl + ringb, h->stream, m, n, w.R, w.v, dx, w.wa4, w.P,
+                           w.J, w.W2, w.st, (int)ST_QR_READY, (double *)nullptr, ringcap);
     }
     return 0;
 }
@@ -791,7 +806,7 @@ int nlh_lmfactor_exact(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, const
 static __global__ void __launch_bounds__(1024)
 k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const double *diag_all,
                    const double *qtf_all, const double *delta_all, const double *tailsq_all, double *par_all,
-                   double *x_all, double *sdiag_all, double *Wall)
+                   double *x_all, double *sdiag_all, double *Wall, int ringcap)
 {
     extern __shared__ double smem[];
     const int p = blockIdx.x, tid = threadIdx.x, BS = blockDim.x;
@@ -801,7 +816,7 @@ k_lmpar_standalone(int n, double *Rall, int ldr, const int32_t *ipvt_all, const 
     double par = par_all[p];
     lmpar_dev<false>(n, n, Rall + (size_t)p * ldr * n, ldr, ipvt_all + (size_t)p * n, diag_all + (size_t)p * n,
                      qtf_all + (size_t)p * n, delta_all[p], &par, tailsq_all[p], nullptr, xs, sdiag, wa1, wa2n, z,
-                     red, nullptr, Wall + (size_t)p * n * n, rot, 0);
+                     red, nullptr, Wall + (size_t)p * n * n, rot, 0, ringcap > 0 ? smem + 6 * n + 72 : nullptr, ringcap);
     __syncthreads();
     for (int j = tid; j < n; j += BS) {
         x_all[(size_t)p * n + j] = xs[j];
@@ -821,9 +836,11 @@ int nlh_lmpar(nlh_handle *h, int32_t nprob, int32_t n, double *dR, int32_t ldr, 
     if (rc) return rc;
     {
         Timed t(h, NLH_K_LMPAR);
-        size_t sh = sizeof(double) * (size_t)(6 * n + 72);
-        hipLaunchKernelGGL(k_lmpar_standalone, dim3(nprob), dim3(factor_threads(n)), sh, h->stream, n, dR, ldr, dipvt,
-                           ddiag, dqtf, ddelta, dtailsq, dpar, dxstep, dsdiag, (double *)h->misc.p);
+        int cap;
+        const size_t rb = lm_ring_bytes(n, lmpar_threads(n), &cap);
+        size_t sh = sizeof(double) * (size_t)(6 * n + 72) + rb;
+        hipLaunchKernelGGL(k_lmpar_standalone, dim3(nprob), dim3(lmpar_threads(n)), sh, h->stream, n, dR, ldr, dipvt,
+                           ddiag, dqtf, ddelta, dtailsq, dpar, dxstep, dsdiag, (double *)h->misc.p, cap);
     }
     HIPCHK(h, hipGetLastError());
     return 0;

@@ -163,6 +163,47 @@ def test_lmpar_binding_trust_region(ds, oracle, m, n, delta_scale):
     np.testing.assert_allclose(sdiag[0].cpu().numpy(), sdiag_o, rtol=1e-10)
 
 
+@pytest.mark.parametrize("n", [2, 3, 17, 63, 64, 65, 95, 96, 127, 128, 129, 191, 200, 255, 256, 257])
+@pytest.mark.parametrize("zero_diag", [False, True])
+def test_lmsolve_on_chip_sweep_is_bitwise_the_global_wavefront(ds, n, zero_diag):
+    """lmsolve's Givens sweeps (src/nonlin_least_squares.f90:717-765) for n <= 256 run out of LDS and registers (columns of S
+    in a ring, working rows in the owning wave's registers: nlh_kernels_lm.h); NLH_LMSOLVE_GLOBAL=1 forces the global-memory
+    wavefront that serves larger n.  Same rotations on the same data in the same order: par, x, sdiag and the S left in
+    R's lower triangle must agree bit for bit -- including eliminations skipped because diag(l) == 0 (:721) and
+    rotations skipped because the entry is already zero (:732).  (n = 257: both runs take the global form.)"""
+    rng = np.random.default_rng(1000 + n)
+    R = np.triu(rng.standard_normal((n, n)))
+    R[np.arange(n), np.arange(n)] += np.sign(R[np.arange(n), np.arange(n)]) * 2.0
+    if zero_diag and n > 4:
+        R[2, 3:] = 0.0                                   # a zero entry for rotations to meet
+    ip = rng.permutation(n).astype(np.int32)
+    diag = np.abs(rng.standard_normal(n)) + 0.5
+    if zero_diag:
+        diag[rng.integers(0, n, size=max(1, n // 8))] = 0.0
+    qtf = rng.standard_normal(n)
+    xgn = np.empty(n)
+    xgn[ip] = np.linalg.solve(R, qtf)                    # the Gauss-Newton step, x(ipvt(j)) = z(j)
+    delta = 0.2 * np.linalg.norm(diag * xgn) + 1e-3
+    f64 = dict(dtype=torch.float64, device="cuda")
+    outs = []
+    for env in ("1", "0"):
+        os.environ["NLH_LMSOLVE_GLOBAL"] = env
+        try:
+            Rd = torch.tensor(np.ascontiguousarray(R.T), device="cuda").unsqueeze(0).repeat(3, 1, 1)
+            par, x, sdiag = ds.lmpar(Rd, torch.tensor(ip, dtype=torch.int32, device="cuda").unsqueeze(0).repeat(3, 1),
+                                     torch.tensor(diag, **f64).unsqueeze(0).repeat(3, 1), torch.tensor(qtf, **f64).unsqueeze(0).repeat(3, 1),
+                                     torch.tensor([float(delta)] * 3, **f64), torch.tensor([0.0] * 3, **f64), torch.tensor([0.0] * 3, **f64))
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("NLH_LMSOLVE_GLOBAL", None)
+        outs.append((par.cpu().numpy(), x.cpu().numpy(), sdiag.cpu().numpy(), Rd.cpu().numpy()))
+    assert outs[0][0][0] > 0.0                            # lmpar's iteration (and with it lmsolve) really ran
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    for q in range(1, 3):                                 # the problems of a launch are independent and identical
+        assert np.array_equal(outs[1][3][q], outs[1][3][0]) and np.array_equal(outs[1][1][q], outs[1][1][0])
+
+
 @pytest.mark.parametrize("n", [2, 37, 130, 300, 600, 1024, 1100])
 def test_lu_bit_exact(ds, oracle, n):
     """lu_factor / solve_lu stand-ins: same pivots, bit-identical factors and solution (n >= 128: the blocked path --
