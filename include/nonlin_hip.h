@@ -45,7 +45,10 @@ extern "C" {
  * NLH_ARRAY_SIZE_ERROR and touches nothing: quasi-Newton and BFGS n <= 8192 (columns per thread of the single-workgroup
  * rotation kernels); least squares under the opt-in NLH_FACTOR_AUTO / NLH_FACTOR_QR policies n <= 3000 (n-vectors in LDS).
  * Least squares under the default NLH_FACTOR_EXACT policy takes any n <= m (beyond 3000 columns lmpar's n-vectors live in
- * global memory).  Row counts are not limited: polynomial fits and bounded least squares beyond 18000 rows keep the
+ * global memory); that is verified at n = 3008 -- the solver's own kernels have no bound in n, but the BUILT-IN
+ * dense-quadratic family (the bench / test residual of nlh_dq_*, not part of the reference) keeps a point's x in LDS and
+ * stops at n = 20000 (NLH_ARRAY_SIZE_ERROR from its launcher); a user's device function has whatever bound its own kernels
+ * have.  Row counts are not limited: polynomial fits and bounded least squares beyond 18000 rows keep the
  * Householder reflector in global memory instead of LDS.
  * The number of problems of a batch is NOT limited: the lock-step drivers carry the problem index in a grid dimension
  * that holds 65535, and a larger batch is solved in slices of 65535 problems, one after the other, inside the entry point

@@ -112,6 +112,9 @@ int nlh_create(nlh_handle **out, int32_t device, void *hip_stream)
     nlh_cls_init_device(lds_max);
     nlh_bfgs_init_device(lds_max);
     nlh_poly_init_device(lds_max);
+    nlh_devfcn_init_device(lds_max);
+    (void)hipFuncSetAttribute((const void *)k_dq_residual<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute((const void *)k_dq_residual2<RB / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     (void)hipGetLastError();
     *out = h;
     return 0;

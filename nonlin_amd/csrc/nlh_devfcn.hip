@@ -449,11 +449,19 @@ k_dqv_jac(int m, int n, int nblk, const double *__restrict__ A, double gamma, co
     for (int k = 0; k < n; ++k) Jq[(size_t)k * m] = s * a[(size_t)k * m];
 }
 
+void nlh_devfcn_init_device(int lds_max)
+{   // x of a point lives in dynamic LDS: beyond 8192 columns that exceeds the 64 KB a kernel gets without asking
+    (void)hipFuncSetAttribute((const void *)k_dqv_fcn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute((const void *)k_dqv_fcn_tile, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute((const void *)k_dqv_jac, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+}
+
 int nlh_dq_device_fcn(void *ctx, void *hip_stream, int32_t npoints, const int32_t *dprob, int32_t n, const double *dX, int32_t m,
                       double *dF)
 {
     const nlh_dq_device_ctx *c = (const nlh_dq_device_ctx *)ctx;
     if (!c || npoints <= 0) return c ? 0 : 1;
+    if (n > NLH_DQ_MAX_N) return NLH_ARRAY_SIZE_ERROR;          // a launcher's failure code is what the solver returns
     const int nblk = (m + 255) / 256;
     hipStream_t s = (hipStream_t)hip_stream;
     // a handful of points (a trial point per problem), or x vectors that do not fit LDS sixteen at a time: point by point
@@ -473,6 +481,7 @@ int nlh_dq_device_jac(void *ctx, void *hip_stream, int32_t npoints, const int32_
 {
     const nlh_dq_device_ctx *c = (const nlh_dq_device_ctx *)ctx;
     if (!c || npoints <= 0) return c ? 0 : 1;
+    if (n > NLH_DQ_MAX_N) return NLH_ARRAY_SIZE_ERROR;
     const int nblk = (m + 255) / 256;
     hipLaunchKernelGGL(k_dqv_jac, dim3((unsigned)((size_t)npoints * nblk)), dim3(256), sizeof(double) * (size_t)n, (hipStream_t)hip_stream, m, n, nblk,
                        c->dA, c->gamma, dprob, dX, dJ);
@@ -493,7 +502,9 @@ int nlh_fd_jacobian_device(nlh_handle *h, int32_t nprob, int32_t m, int32_t n, n
     ResidualSource rs;
     rs.fcn = fcn; rs.jac = jacfcn; rs.ctx = ctx;
     // slices keep the point count of one launcher call (nprob * n) and the panel inside 31 bits / a bounded workspace
-    const int32_t per = (int32_t)std::max<size_t>(1, std::min<size_t>((size_t)nprob, ((size_t)1 << 30) / ((size_t)n * std::max(m, n))));
+    // ... and the problem count inside what the kernels carry in gridDim.y / .z (NLH_MAX_LOCKSTEP, as every other *_device entry point)
+    const int32_t per = (int32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)nprob, (size_t)NLH_MAX_LOCKSTEP),
+                                                                      ((size_t)1 << 30) / ((size_t)n * std::max(m, n))));
     for (int32_t p0 = 0; p0 < nprob; p0 += per) {
         const int32_t cnt = std::min(per, nprob - p0);
         int rc;

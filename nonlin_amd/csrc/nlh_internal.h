@@ -200,6 +200,9 @@ void format_e10_3(double v, char out[16]);
 void nlh_bfgs_init_device(int lds_max);
 void nlh_cls_init_device(int lds_max);
 void nlh_poly_init_device(int lds_max);
+void nlh_devfcn_init_device(int lds_max);        // nlh_devfcn.hip: the built-in family's launcher kernels keep x in LDS
+// columns the built-in dense-quadratic family's kernels accept (x in LDS, lds_max of nlh_create): beyond it NLH_ARRAY_SIZE_ERROR
+static const int32_t NLH_DQ_MAX_N = 20000;
 
 static inline int factor_threads(int n) { return n >= 96 ? 1024 : 256; }
 void print_status(int iter, int nfeval, int njaceval, double xnorm, double fnorm);

@@ -493,7 +493,9 @@ static int lm_sub_batches(const nlh_options *o, int nprob, int m, int n)
         // 48: 132.7 / 120.7, 64: 151.8 / 137.1, 96: 200 / 168, 128: 223 / 207, 192: 316 / 279; 2048x128: 48: 22.7 / 22.3,
         // 96: 30.5 / 28.5, 128: 34.0 / 32.2, 192: 54.9 / 48.3; 4096x512: 32: 210 / 179; 8192x256: 64: 279 / 236; three
         // pieces: 16 x 4096x256 98 -- pieces of five problems fall to the column sweep)
-        if (S < 2 && nprob >= 32) S = 2;
+        // -- measured from 2048x128 up; tiny problems (m n < 65536) have no latency-bound pass to hide and would only pay for
+        // a second host thread, workspace and stream (and have a user's launcher called from two threads): one batch
+        if (S < 2 && nprob >= 32 && (size_t)m * n >= 65536) S = 2;
         if (o->factor_policy != NLH_FACTOR_EXACT) S = 1;   // the normal-equations pipeline has no long latency-bound
     }                                                      // stage to hide (1 / 2 / 4 -> 40.0 / 40.6 / 41.7 ms)
     if (S > nprob) S = nprob;

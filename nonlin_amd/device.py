@@ -213,15 +213,17 @@ class DeviceSolver:
         status = (C.c_int32 * nprob)()
         o = opts or self.options()
         if broyden:
+            name = "nlh_quasi_newton_solve_batch_device"
             rc = self.lib.nlh_quasi_newton_solve_batch_device(self.h.ptr, C.byref(o), int(jdelta), nprob, n, self._devfcn(fcn),
                                                               self._devfcn(jac), self._ctxp(ctx), x.data_ptr(), fvec.data_ptr(),
                                                               ib, status)
         else:
+            name = "nlh_newton_solve_batch_device"
             rc = self.lib.nlh_newton_solve_batch_device(self.h.ptr, C.byref(o), nprob, n, self._devfcn(fcn), self._devfcn(jac),
                                                         self._ctxp(ctx), x.data_ptr(), fvec.data_ptr(), ib, status)
-        self.h.check(rc, "nlh_newton_solve_batch_device")
+        self.h.check(rc, name)
         if rc:
-            raise RuntimeError(f"square solve on a device residual returned {rc}")
+            raise RuntimeError(f"{name} returned {rc}")
         return fvec, [ib[k].as_dict() for k in range(nprob)], [int(status[k]) for k in range(nprob)]
 
     def bfgs_solve_batch_device(self, fcn, ctx, x, grad=None, opts=None):
@@ -234,8 +236,7 @@ class DeviceSolver:
         status = (C.c_int32 * nprob)()
         fout = (C.c_double * nprob)()
         o = opts or self.options(max_evals=500)
-        null = C.cast(None, _lib.DEVFCN)
-        rc = self.lib.nlh_bfgs_solve_batch_device(self.h.ptr, C.byref(o), nprob, n, fcn, grad if grad is not None else null, self._ctxp(ctx),
+        rc = self.lib.nlh_bfgs_solve_batch_device(self.h.ptr, C.byref(o), nprob, n, self._devfcn(fcn), self._devfcn(grad), self._ctxp(ctx),
                                                   x.data_ptr(), fout, ib, status)
         self.h.check(rc, "nlh_bfgs_solve_batch_device")
         if rc:

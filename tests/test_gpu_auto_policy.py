@@ -1,0 +1,91 @@
+"""N1: north_star's own formulation -- J^T J on the fp64 MFMA + Cholesky step solve (NLH_FACTOR_AUTO, the opt-in policy;
+the reference's doc-comment describes it, src/nonlin_least_squares.f90:21-24) -- held to north_star's tolerance where that
+tolerance is well-posed: the ZERO-RESIDUAL variant of SURVEY 8(d)'s family (sigma = 0), at the BASELINE sizes, on the GPU.
+
+Bar: max relative deviation of x <= 1e-10 AND every count and flag equal to the CPU oracle's (strict).  On sigma = 1e-3
+the forward-difference Jacobian makes the last digits of x a function of rounding (the reference itself is
+compiler-dependent at 1e-8 there: tests/test_oracle.py), which is why the bit-exact policy is the default and this one
+carries its measured deviation instead (tests/test_gpu_solvers.py, tests/test_gpu_configs.py).
+
+The oracle's outputs come from tests/golden/zero_residual_oracle.npz (make_zero_residual_oracle.py: the oracle needs a
+minute for the 65536 x 512 solve); a sample is re-derived live here and in tests/test_oracle.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL_X = 1e-10          # north_star: "within 1e-10 relative for fp64 (bit-exact for iteration/eval counts)"
+KEYS = ("iter_count", "fcn_count", "jacobian_count", "converge_on_fcn", "converge_on_chng", "converge_on_zero_diff")
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zero_residual_oracle.npz"))
+GAMMA, SIGMA, SPREAD, SEED0, MAX_EVALS = (float(v) for v in GOLD["params"])
+
+
+def _solve(ds, tag, policy, **okw):
+    m, n, nprob = (int(v) for v in GOLD[f"{tag}_shape"])
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=int(SEED0), gamma=GAMMA, sigma=SIGMA, spread=SPREAD)
+    x = x0.clone()
+    fvec, ibs, status = ds.lm_solve_batch(A, b, GAMMA, x, ds.options(max_evals=int(MAX_EVALS), factor_policy=policy, **okw))
+    torch.cuda.synchronize()
+    return A, b, x0, x.cpu().numpy(), fvec.cpu().numpy(), ibs, status
+
+
+def _check(tag, xg, fg, ibs, status, bitwise=False):
+    xo, co, so, fo = GOLD[f"{tag}_x"], GOLD[f"{tag}_counts"], GOLD[f"{tag}_status"], GOLD[f"{tag}_fnorm"]
+    worst = 0.0
+    for p in range(xo.shape[0]):
+        assert status[p] == so[p], (tag, p, status[p], so[p])
+        assert [ibs[p][k] for k in KEYS] == [int(v) for v in co[p]], (tag, p, ibs[p], co[p])     # strict: every count, every flag
+        rel = float(np.abs(xg[p] - xo[p]).max() / np.abs(xo[p]).max())
+        worst = max(worst, rel)
+        assert rel <= RTOL_X, (tag, p, rel)
+        if bitwise:
+            assert np.array_equal(xg[p], xo[p]), (tag, p)
+        # zero-residual: both ends at rounding level of |b| ~ O(1)
+        assert np.sqrt(np.sum(fg[p] * fg[p])) <= 1e-11 and fo[p] <= 1e-11
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["c2", "c4", "c5"])
+def test_auto_policy_zero_residual_meets_1e10_with_exact_counts(ds, tag):
+    """BASELINE config 2's size (32 problems 4096 x 256, seeds 12345...), config 4's (a 12-problem sample 2048 x 128) and
+    config 5 (one 65536 x 512: k_gram_512 + the multi-CU Cholesky) under NLH_FACTOR_AUTO."""
+    A, b, x0, xg, fg, ibs, status = _solve(ds, tag, 0)
+    worst = _check(tag, xg, fg, ibs, status)
+    assert worst <= RTOL_X
+
+
+@pytest.mark.parametrize("tag", ["c2", "c4"])
+def test_exact_policy_zero_residual_is_bitwise_the_golden_oracle(ds, tag):
+    """The same problems under the default policy: bit for bit the fixture's x (ties the fixture to what the exact path
+    and -- through tests/test_gpu_configs.py -- the live oracle produce)."""
+    A, b, x0, xg, fg, ibs, status = _solve(ds, tag, 2)
+    _check(tag, xg, fg, ibs, status, bitwise=True)
+
+
+def test_golden_fixture_against_the_live_oracle_sample(ds, oracle):
+    """Three problems of the 2048 x 128 case and one 4096 x 256 re-solved by the oracle now: the fixture's bits."""
+    for tag, picks in (("c4", (0, 5, 11)), ("c2", (7,))):
+        m, n, nprob = (int(v) for v in GOLD[f"{tag}_shape"])
+        for p in picks:
+            Ah, bh, xth, x0h = oracle.dq_generate(int(SEED0) + p, m, n, gamma=GAMMA, sigma=SIGMA, spread=SPREAD)
+            rc, xo, fo, ibo, _, _ = oracle.dq_lm_solve(Ah, bh, GAMMA, x0h, opts=oracle.default_options(max_evals=int(MAX_EVALS)))
+            assert rc == GOLD[f"{tag}_status"][p]
+            assert np.array_equal(xo, GOLD[f"{tag}_x"][p])
+            assert [ibo[k] for k in KEYS] == [int(v) for v in GOLD[f"{tag}_counts"][p]]
+
+
+def test_auto_policy_zero_residual_sub_batches_and_shares_are_the_same_bits(ds):
+    """The policy's result for a problem does not depend on its batch: 12 problems 2048 x 128 as one batch, as three
+    sub-batches in flight and as the first 5 alone give the same x bit for bit (what a per-rank share relies on)."""
+    m, n, nprob = (int(v) for v in GOLD["c4_shape"])
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=int(SEED0), gamma=GAMMA, sigma=SIGMA, spread=SPREAD)
+    outs = []
+    for sel, sub in ((slice(None), 1), (slice(None), 3), (slice(0, 5), 1)):
+        x = x0[sel].clone()
+        ds.lm_solve_batch(A[sel], b[sel], GAMMA, x, ds.options(max_evals=int(MAX_EVALS), factor_policy=0, sub_batches=sub))
+        outs.append(x)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0][:5], outs[2])

@@ -54,9 +54,22 @@ def test_bench_single_process():
     nt = [r for r in rows if r["path"].startswith("newton_solver")]           # Newton rows are priced against LAPACK, not the oracle's LU
     assert len(nt) == 3 and all(r["cpu_lapack_ms"] > 0 and r["cpu_lapack_ms"] <= r["cpu_oracle_ms"] * 1.05 and r["gpu_over_cpu_lapack"] > 0
                                 for r in nt)
-    assert not any("cpu_lapack_ms" in r for r in rows if r["path"].startswith("quasi_newton"))
+    # ... and so is every other row whose reference code calls linalg's QR: quasi-Newton (qr_factor + form Q), bounded least
+    # squares (qr_factor / solve_qr), the polynomial fit (solve_least_squares)
+    qr_rows = [r for r in rows if r["path"].startswith(("quasi_newton", "constrained_least_squares", "polynomial%fit"))]
+    assert len(qr_rows) == 4 and all(r["cpu_lapack_ms"] > 0 and r["cpu_lapack_ms"] <= r["cpu_oracle_ms"] * 1.05 and r["gpu_over_cpu_lapack"] > 0
+                                     for r in qr_rows)
     dv = d["device_vecfcn"]        # the open device-residual path: a user launcher, k_fd_jacobian_qrx timed inside the solve
-    assert len(dv) == 4 and all(r["lm_iterations_per_s"] > 0 and 0.0 < r["fd_jacobian"]["frac"] < 1.0 for r in dv[:3])
+    assert len(dv) == 4 and all(r["lm_iterations_per_s"] > 0 for r in dv[:3])
+    assert 0.0 < dv[0]["fd_jacobian"]["frac"] < 1.0            # ONE FD-Jacobian fraction: the one-batch solve; the rows with sub-batches in
+    assert all("fd_jacobian" not in r and r["fd_jacobian_under_concurrent_sub_batches"]["kernel_ms"] > 0 for r in dv[1:3])   # flight say so
+    assert all(r["non_converged"] >= 0 and r["lock_step_rounds"] >= 1 for r in dv[2:4])
+    az = d["auto_policy_zero_residual"]                        # N1: the MFMA / Cholesky policy where 1e-10 is well-posed
+    assert az["value"] > 0 and az["batch"]["non_converged"] == 0 and 0.0 < az["batch"]["gram"]["frac"] < 1.0
+    c5 = az["config5_one_65536x512"]
+    assert c5["within_1e-10_with_exact_counts"] and c5["max_rel_dev_x"] <= 1e-10 and c5["count_or_flag_mismatches"] == 0
+    assert 0.0 < c5["gram"]["frac"] < 1.0 and 0.0 < c5["fd_jacobian"]["frac"] < 1.0
+    assert d["summary"]["value"] == d["value"] and d["summary"]["default_options_identical_x"]
     assert dv[0]["bitwise_equal_builtin_entry_point"] and dv[1]["bitwise_equal_builtin_entry_point"]
     assert dv[2]["bitwise_equal_oracle_host_callback"]
     assert dv[3]["path"].startswith("bfgs on a scalar function") and dv[3]["bfgs_iterations_per_s"] > 0 and dv[3]["bitwise_equal_oracle_host_callback"]

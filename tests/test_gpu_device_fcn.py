@@ -236,6 +236,23 @@ def test_fd_jacobian_device_bitwise(ds, oracle, nprob, m, n):
 
 
 @pytest.mark.gpu
+def test_fd_jacobian_device_more_problems_than_a_grid_dimension(ds, oracle):
+    """70,000 problems of 2 x 2: the problem index rides in gridDim.y / .z of the FD kernels (at most 65535), so the call is
+    served in slices of NLH_MAX_LOCKSTEP like every other *_device entry point (include/nonlin_hip.h: the number of problems
+    of a batch is not limited).  First, last and the problems either side of the slice boundary against the oracle."""
+    import torch
+    nprob, m, n = 70000, 2, 2
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=99, square_shift=True)
+    fcn, jac, ctx = ds.dq_launchers(A, b, 0.5)
+    J = ds.fd_jacobian_device(fcn, ctx, m, x0)
+    torch.cuda.synchronize()
+    for p in (0, 1, 65534, 65535, 65536, nprob - 1):
+        Ah = np.asfortranarray(A[p].cpu().numpy().T)
+        Jo = oracle.dq_fd_jacobian(Ah, b[p].cpu().numpy(), 0.5, x0[p].cpu().numpy())
+        assert np.array_equal(J[p].cpu().numpy().T, Jo), p
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("m,n", [(4096, 256), (2048, 128), (1000, 40), (333, 65), (129, 31), (64, 64)])
 def test_fd_jacobian_into_the_working_matrix_is_the_column_major_one(ds, m, n):
     """k_fd_jacobian_qrx (panel -> the exact factorisation's row-blocked matrix, turned through LDS) against k_fd_jacobian

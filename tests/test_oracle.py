@@ -560,3 +560,20 @@ def test_factor_hook_reproduces_the_oracle_when_given_lmfactor(oracle):
     assert np.abs(x2 - x_ref).max() / np.abs(x_ref).max() < 1e-6
     rc1, x1, f1, ib1 = oracle.dq_lm_solve(A, b, 2.0, x0, opts=oracle.default_options(max_evals=500))[:4]
     assert np.array_equal(x1, x_ref)                                 # the hook was removed
+
+
+def test_zero_residual_golden_fixture_is_the_live_oracle(oracle):
+    """tests/golden/zero_residual_oracle.npz (N1: the MFMA / Cholesky policy at 1e-10 on the zero-residual variant, at sizes
+    where the oracle needs a minute) against the oracle now, on the problems small enough for the CPU suite."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zero_residual_oracle.npz"))
+    gamma, sigma, spread, seed0, max_evals = (float(v) for v in g["params"])
+    assert sigma == 0.0
+    keys = [str(k) for k in g["keys"]]
+    m, n, nprob = (int(v) for v in g["c4_shape"])
+    for p in (0, 11):
+        A, b, xt, x0 = oracle.dq_generate(int(seed0) + p, m, n, gamma=gamma, sigma=sigma, spread=spread)
+        rc, x, f, ib, _, _ = oracle.dq_lm_solve(A, b, gamma, x0, opts=oracle.default_options(max_evals=int(max_evals)))
+        assert rc == g["c4_status"][p] and np.array_equal(x, g["c4_x"][p])
+        assert [ib[k] for k in keys] == [int(v) for v in g["c4_counts"][p]]
+        assert np.abs(x - xt).max() <= 1e-12 * np.abs(xt).max()          # zero residual: the solve lands on x_true
