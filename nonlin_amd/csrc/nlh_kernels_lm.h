@@ -45,7 +45,9 @@ __device__ unsigned long long g_lmclk[16];
 // 3.35 ms per sweep at n = 256.
 // ---------------------------------------------------------------------------------------------------------------
 #define LMS_MAX_N 256
-#define LMS_AHEAD 4
+#define LMS_AHEAD 8         // columns fetched ahead of their first rotation ...
+#define LMS_LDGRP 4         // ... in groups of four (< LMS_AHEAD): a group's loads are issued together and stored four time steps later --
+                            // a load stored one step after its issue made every time step wait a memory latency (1.5 us)
 #define LMS_SLOTS 8
 #define LMS_NV (LMS_MAX_N / 64)
 // doubles column k occupies in the ring: the elements i = 64 v0(k) .. 64 ceil(n / 64) - 1
@@ -53,8 +55,8 @@ __host__ __device__ inline int lms_colsize(int k, int n) { return ((n + 63) & ~6
 // Column k's place in the ring: behind column k-1, or at the ring's start when it would not fit before the end (a column
 // never straddles the end, so an element's address needs no wrap-around).  The same rule on the host and on the device.
 #define LMS_PLACE(pos, len, cap) (((pos) + (len) > (cap)) ? 0 : (pos))
-// Does a ring of `cap` doubles hold every column from the step it is stored (step max(0, c - AHEAD + 1)) to its last
-// rotation (step 2c) without touching a live one?
+// Does a ring of `cap` doubles hold every column from the step it is stored (the step after its load group's, 0 for the
+// first AHEAD columns) to its last rotation (step 2c) without touching a live one?
 static inline bool lms_ring_fits(int n, int cap)
 {
     std::vector<int> base(n, 0);
@@ -63,7 +65,7 @@ static inline bool lms_ring_fits(int n, int cap)
     for (int k = 0; k < n; ++k) { const int len = lms_colsize(k, n); pos = LMS_PLACE(pos, len, cap); base[k] = pos; pos += len; }
     if (pos > cap || lms_colsize(0, n) > cap) return false;
     for (int c = 0; c < n; ++c) {
-        const int tw = c >= LMS_AHEAD ? c - LMS_AHEAD + 1 : 0, kmin = c >= LMS_AHEAD ? tw / 2 : 0;
+        const int tw = c >= LMS_AHEAD ? ((c - LMS_AHEAD) / LMS_LDGRP + 1) * LMS_LDGRP : 0, kmin = c >= LMS_AHEAD ? tw / 2 : 0;
         for (int k = kmin; k < c; ++k)
             if (base[k] < base[c] + lms_colsize(c, n) && base[c] < base[k] + lms_colsize(k, n)) return false;
     }
@@ -85,8 +87,13 @@ static inline size_t lmsolve_ring_bytes(int n, int threads, int *cap)
     *cap = c;
     return sizeof(double) * ((size_t)c + (size_t)(n + 1) / 2 + 8);      // + the table of column offsets (n int32)
 }
-// threads of a k_lmpar workgroup: sixteen waves from n = 65 on (the on-chip sweep needs a wave per eight live rows)
-static inline int lmpar_threads(int n) { return n > 64 ? 1024 : 256; }
+// doubles of LDS behind lmpar's n-vectors for the exact reductions (norm2_flang_block: 3 NLH_NCH + 8; the lanes form of the
+// m-entry norm of deviation A: its chunk + flags, 64 EL + 128 + 40 + threads / 2 with EL = 32 for sixteen waves, else 16)
+__host__ __device__ inline int lmpar_scratch_doubles(int threads) { return threads >= 1024 ? 64 * 32 + 128 + 40 + 512 + 8 : 3 * NLH_NCH + 8; }
+// threads of a k_lmpar workgroup: the on-chip sweep needs a wave per eight live rows (n / 2 rows are live at a time) -- four
+// waves to n = 64, eight to n = 128 (two workgroups then share a CU: families whose trust region binds on most iterations
+// run lmpar's iteration for hundreds of problems at once), sixteen beyond
+static inline int lmpar_threads(int n) { return n > 128 ? 1024 : n > 64 ? 512 : 256; }
 
 template <int NV>
 __device__ __forceinline__ void lmsolve_sweep_lds(int n, double *r, int ldr, double *sdiag, double *wa, double *qtbp,
@@ -115,27 +122,34 @@ __device__ __forceinline__ void lmsolve_sweep_lds(int n, double *r, int ldr, dou
 #pragma unroll
         for (int v = 0; v < NV; ++v) w[u][v] = 0.0;
     int myj = wid + nw * (lane & (LMS_SLOTS - 1));             // lane u < 8: the row in slot u of this wave
-    double ldv = 0.0;                                           // column (t - 1 + AHEAD), chunk wid of its live ones, in flight
+    double ldv[LMS_LDGRP];                                      // chunk wid of the columns ldc .. ldc + LDGRP - 1, in flight
+#pragma unroll
+    for (int d = 0; d < LMS_LDGRP; ++d) ldv[d] = 0.0;
     int ldc = -1;
     __syncthreads();
-#ifdef NLH_DEBUG_LMPAR_CLK
+#ifdef NLH_DEBUG_SWEEP_CLK      // (per time step: four s_memtime reads and their waits -- slows the sweep it measures by a third)
     long long ck_ld = 0, ck_form = 0, ck_app = 0, ck_bar = 0, ck0 = clock64(), ck1;
 #define SWCLK(acc) { ck1 = clock64(); acc += ck1 - ck0; ck0 = ck1; }
 #else
 #define SWCLK(acc)
 #endif
     for (int t = 0; t <= 2 * (n - 1); ++t) {
-        // ring traffic of the look-ahead: store what was fetched during the previous step, fetch the next column
-        if (wid < NV) {
+        // ring traffic of the look-ahead, every LDGRP-th step: store the group fetched LDGRP steps ago, fetch the next one
+        if (wid < NV && (t % LMS_LDGRP) == 0) {
             if (ldc >= 0) {
-                const int i = (((ldc + 1) >> 6) + wid) * 64 + lane;
-                if (i > ldc && i < n) ring[cbt[ldc] + 64 * wid + lane] = ldv;
+#pragma unroll
+                for (int d = 0; d < LMS_LDGRP; ++d) {
+                    const int c = ldc + d, i = (((c + 1) >> 6) + wid) * 64 + lane;
+                    if (c < n - 1 && i > c && i < n) ring[cbt[c] + 64 * wid + lane] = ldv[d];
+                }
             }
-            const int c = t + LMS_AHEAD;
-            ldc = c < n - 1 ? c : -1;
+            ldc = t + LMS_AHEAD < n - 1 ? t + LMS_AHEAD : -1;
             if (ldc >= 0) {
-                const int i = (((c + 1) >> 6) + wid) * 64 + lane;
-                ldv = (i > c && i < n) ? r[(size_t)c * ldr + i] : 0.0;
+#pragma unroll
+                for (int d = 0; d < LMS_LDGRP; ++d) {
+                    const int c = ldc + d, cc = c < n - 1 ? c : n - 2, i = (((cc + 1) >> 6) + wid) * 64 + lane;
+                    ldv[d] = (i > cc && i < n) ? r[(size_t)cc * ldr + i] : 0.0;
+                }
             }
         }
         SWCLK(ck_ld)
@@ -210,7 +224,7 @@ __device__ __forceinline__ void lmsolve_sweep_lds(int n, double *r, int ldr, dou
         nlh_lds_barrier();
         SWCLK(ck_bar)
     }
-#ifdef NLH_DEBUG_LMPAR_CLK
+#ifdef NLH_DEBUG_SWEEP_CLK
     if (blockIdx.x == 0 && lane == 0 && (wid == 0 || wid == 5 || wid == 15))
         printf("[sweep clk64 wave %d, kcycles] loader %lld form %lld apply %lld barrier %lld\n", wid, ck_ld / 1000, ck_form / 1000, ck_app / 1000, ck_bar / 1000);
 #endif
@@ -543,10 +557,18 @@ __device__ __forceinline__ int lmpar_dev(int m, int n, double *r, int ldr, const
         LMCLK(5)
         lmsolve_dev<EXACT>(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2n, red, Wrows, z, rot, scratch, ring, ringcap);
         LMCLK(6)
+#ifdef NLH_DEBUG_LMPAR_CLK
+        if (threadIdx.x == 0) g_lmclk[10] += 1;                 // lmsolve calls
+#endif
         for (int i = tid; i < n; i += BS) wa2n[i] = diag[i] * x[i];
         __syncthreads();
         if (EXACT) {                                           // :531 deviation A: norm over all m entries
-            dxnorm = norm2_flang_block([&](int i) { return i < n ? wa2n[i] : wa4[i]; }, m, scratch);
+            // NORM2 with its recurrence down the lanes of a wave (nlh_common.h; bit-identical to norm2_flang_block, whose
+            // one-thread recurrence cost 130 us per lmpar iteration at m = 4096 -- a third of an iteration at n = 96)
+            auto g = [&](int i) { return i < n ? wa2n[i] : wa4[i]; };
+            if (BS == 1024) dxnorm = norm2_flang_block_lanes<32, 1024>(g, m, scratch, scratch + 64 * 32 + 128);
+            else if (BS == 512) dxnorm = norm2_flang_block_lanes<16, 512>(g, m, scratch, scratch + 64 * 16 + 128);
+            else dxnorm = norm2_flang_block_lanes<16, 256>(g, m, scratch, scratch + 64 * 16 + 128);
         } else {
             double sq = 0.0;
             for (int i = tid; i < n; i += BS) sq = sq + wa2n[i] * wa2n[i];
@@ -591,8 +613,8 @@ __device__ __forceinline__ int lmpar_dev(int m, int n, double *r, int ldr, const
     *par_io = par;
 #ifdef NLH_DEBUG_LMPAR_CLK
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        printf("[lmpar clk, us] lmsolve: copy %.1f sweep %.1f backsub %.1f | GN %.1f bounds %.1f pre %.1f lmsolve(all) %.1f dxnorm %.1f newton-solve %.1f nrm %.1f\n",
-               g_lmclk[0] * 1e-2, g_lmclk[1] * 1e-2, g_lmclk[2] * 1e-2, g_lmclk[3] * 1e-2, g_lmclk[4] * 1e-2, g_lmclk[5] * 1e-2,
+        printf("[lmpar clk, us] n %d, %llu lmsolve calls: copy %.1f sweep %.1f backsub %.1f | GN %.1f bounds %.1f pre %.1f lmsolve(all) %.1f dxnorm %.1f newton-solve %.1f nrm %.1f\n",
+               n, g_lmclk[10], g_lmclk[0] * 1e-2, g_lmclk[1] * 1e-2, g_lmclk[2] * 1e-2, g_lmclk[3] * 1e-2, g_lmclk[4] * 1e-2, g_lmclk[5] * 1e-2,
                g_lmclk[6] * 1e-2, g_lmclk[7] * 1e-2, g_lmclk[8] * 1e-2, g_lmclk[9] * 1e-2);
         for (int i = 0; i < 16; ++i) g_lmclk[i] = 0;
     }
@@ -685,7 +707,7 @@ k_lmpar(int m, int n, double *__restrict__ Rall, LmVecs v, double *__restrict__ 
     double *rot = nv + 5 * n;           // n + 8
     double *red = GV ? smem : smem + 6 * n + 8;
     double *scratch = red + 64;
-    double *ring = ringcap > 0 ? scratch + (EXACT ? 3 * NLH_NCH + 8 : 0) : nullptr;
+    double *ring = ringcap > 0 ? scratch + (EXACT ? lmpar_scratch_doubles(BS) : 0) : nullptr;
     double *R = Rall + (size_t)p * n * n;
     const int32_t *ipvt = v.ipvt + (size_t)p * n;
     const double *diag = v.diag + (size_t)p * n;

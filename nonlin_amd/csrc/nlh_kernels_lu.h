@@ -647,6 +647,7 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
     int pos[RPT];
 #ifdef LU_DBG_CLK       // -DLU_DBG_CLK: in-kernel phase clocks (100 MHz) of the first panel, printed by thread 0
     long long clk[8]; clk[0] = wall_clock64();
+    long long sck[6] = {0, 0, 0, 0, 0, 0};      // core cycles per phase of the step loop, summed over the panel's steps
 #endif
     // loads are unconditional (clamped indices) and all issued before any is used: the compiler puts a load under a
     // condition back under it, and a load in a conditional block is waited for before the next one is issued
@@ -801,8 +802,13 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
 #ifdef LU_DBG_CLK
         if (c == 4) clk[3] = wall_clock64();
         if (c == 12) clk[4] = wall_clock64();
+        long long sc0 = clock64(), sc1;
+#define LUSC(i) { sc1 = clock64(); sck[i] += sc1 - sc0; sc0 = sc1; }
+#else
+#define LUSC(i)
 #endif
         nlh_lds_barrier();                         // LDS only: nothing in the loop goes to global memory
+        LUSC(0)
         // the winning wave: largest key, smallest position among equals
         uint32_t bhi = red_hi[par][0], blo = red_lo[par][0];
         int ppos = red_p[par][0], ws = 0;
@@ -818,6 +824,7 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
 #pragma unroll
         for (int j = 0; j < NB; ++j) u[j] = pr[j];
         const double rcp = pr[NB];
+        LUSC(1)
         const bool nz = u[0] != 0.0;
         int myslot = 0;
 #pragma unroll
@@ -838,7 +845,9 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
             lbuf[(size_t)c * RT + q * T + t] = l[q];
             w[q][0] = FAST ? __builtin_fma(-l[q], u[1], w[q][1]) : w[q][1] - l[q] * u[1];
         }
+        LUSC(2)
         if (c + 1 < nb) search(c + 1);
+        LUSC(3)
 #pragma unroll
         for (int j = 2; j < NB; ++j) {
 #pragma unroll
@@ -846,7 +855,9 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) w[q][NB - 1] = 0.0;
+        LUSC(4)
         if (c + 1 < nb) publish(c + 1);
+        LUSC(5)
     }
 #ifdef LU_DBG_CLK
     clk[5] = wall_clock64();
@@ -887,6 +898,9 @@ k_lu_panel_reg(int n, double *__restrict__ Aall, int32_t *__restrict__ ipvt_all,
     if (t == 0 && p == 0 && (jb == 0 || jb == 512 || jb == 768))
         printf("k_lu_panel_reg<%d,%d> jb %d rows %d: load %lld, first search %lld, steps 0-3 %lld (x10 ns), steps 4-11 %lld, rest %lld, output %lld\n", RPT, NB, jb,
                rows, (clk[1] - clk[0]), (clk[2] - clk[1]), (clk[3] - clk[2]), (clk[4] - clk[3]), (clk[5] - clk[4]), (clk[6] - clk[5]));
+    if (t == 0 && p == 0 && (jb == 0 || jb == 512 || jb == 768))
+        printf("   per step, core cycles (thread 0, %d steps): barrier %lld, winner + u row %lld, multipliers + column c+1 %lld, search %lld, other columns %lld, publish %lld\n",
+               nb, sck[0] / nb, sck[1] / nb, sck[2] / nb, sck[3] / nb, sck[4] / nb, sck[5] / nb);
 #endif
 }
 

@@ -275,13 +275,13 @@ static int lm_factor_and_step(nlh_handle *h, const nlh_options *o, int nprob, in
             if (n <= LM_LDS_MAX_N) {
                 int cap;
                 const size_t rb = lm_ring_bytes(n, lt_, &cap);
-                hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(lt_), shl + sizeof(double) * (3 * NLH_NCH + 8) + rb,
+                hipLaunchKernelGGL(k_lmpar<true>, dim3(nprob), dim3(lt_), shl + sizeof(double) * lmpar_scratch_doubles(lt_) + rb,
                                    h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY, (double *)nullptr, cap);
             }
             else {                                              // lmpar's n-vectors in global memory (the misc buffer)
                 int rc2;
                 if ((rc2 = ensure(h, h->misc, sizeof(double) * (size_t)nprob * (6 * (size_t)n + 8)))) return rc2;
-                hipLaunchKernelGGL((k_lmpar<true, true>), dim3(nprob), dim3(ft), sizeof(double) * (size_t)(64 + 3 * NLH_NCH + 8),
+                hipLaunchKernelGGL((k_lmpar<true, true>), dim3(nprob), dim3(ft), sizeof(double) * (size_t)(64 + lmpar_scratch_doubles(ft)),
                                    h->stream, m, n, w.R, w.v, dx, w.wa4, w.P, w.J, w.W2, w.st, (int)ST_QR_READY, (double *)h->misc.p);
             }
         }
