@@ -939,7 +939,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32,
                     help="problems solved by the CPU oracle: the cpu_baseline timing and the parity sample (0 = skip)")
     ap.add_argument("--extras", type=int, default=1,
-                    help="0 = only the timed steps (profiles/capture_r05.sh: every launch rocprofv3 sees then belongs to a "
+                    help="0 = only the timed steps (profiles/capture_r06.sh: every launch rocprofv3 sees then belongs to a "
                          "warm-up or timed step, so its per-kernel averages are the ones printed here)")
     ap.add_argument("--other-paths", type=int, default=1,
                     help="1 = also time the Newton / quasi-Newton / bounded LSQ / BFGS / polynomial rows (SURVEY 8 a16-a24, "
@@ -1083,7 +1083,7 @@ def main():
         # applied) committed under profiles/: bytes moved per algorithmic byte, scaled to this run's average launch.
         traffic, traffic_src = None, None
         try:
-            pmc_file = next(f for f in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
+            pmc_file = next(f for f in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             prof = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             if (prof["m"], prof["n"], prof.get("policy")) == (m, n, args.policy):
