@@ -639,9 +639,9 @@ def device_vecfcn_rows(ds):
     (k_fd_jacobian_qrx: panel of perturbed residuals -> Jacobian columns in the factorisation's working layout, :274)
     against the HBM roofline, timed with HIP events INSIDE that solve, algorithmic bytes 8 (2 m n + m + 2 n) per Jacobian
     (SURVEY 8(d)).  Rows: the dense-quadratic family re-expressed through the launcher (the headline's 4096 x 256 shape,
-    bitwise the built-in entry point), once as one lock-step batch (the kernel alone on the chip: the roofline row) and
-    once with library defaults (sub-batches on private streams: the kernel shares the chip with other sub-batches'
-    kernels, its event time says less); and a family written outside the library (tests/device_model/user_models.hip,
+    bitwise the built-in entry point), once as one lock-step batch (the kernel alone on the chip: THE FD-Jacobian
+    fraction of this path) and once as three sub-batches on private streams (the kernel shares the chip with other
+    sub-batches' kernels: its event time is labelled as such and is no roofline figure); and a family written outside the library (tests/device_model/user_models.hip,
     Lorentzian peak fits) checked bit for bit against the CPU oracle driving the same arithmetic as a host callback."""
     import ctypes as C
     import numpy as np
@@ -676,7 +676,7 @@ def device_vecfcn_rows(ds):
     fcn, jac, ctx = ds.dq_launchers(A, b, GAMMA)
     xb = x0.clone()
     fb, ibb, stb = ds.lm_solve_batch(A, b, GAMMA, xb, ds.options(max_evals=500))
-    for label, sb in (("one lock-step batch", 1), ("library defaults (sub-batches automatic)", 0)):
+    for label, sb in (("one lock-step batch", 1), ("library defaults (three sub-batches in flight)", 0)):
         def run():
             x = x0.clone()
             fv, ibs, st = ds.lm_solve_batch_device(fcn, ctx, m, x, opts=ds.options(max_evals=500, sub_batches=sb))
@@ -1217,11 +1217,15 @@ def main():
                         "(its per-launch durations are measured live, as `roofline.achieved` requires); the same steps without "
                         "any bracket:", "value_without_brackets": vq, "unit": "LM iterations/s",
                 "overhead_frac": max(0.0, 1.0 - out["value"] / vq)}
-            # the library's default options (several sub-batches in flight): same bits, the product's own throughput
+            # the library's default options (three sub-batches in flight at this size): same bits, the product's own throughput.
+            # Against `roofline.event_bracketing.value_without_brackets` (one batch, no brackets) it is box-dependent, -3 ... +2 %
+            # on the bench family in round 6 (the pivot / lmpar time it hides is paid back by HBM-bound passes sharing the chip:
+            # profiles/r06_overlap_defaults.json); on families with long straggler tails it is worth 25 - 35 % (Lorentzian peaks,
+            # 416 lock-step rounds: 15.0 s with three sub-batches, 20.6 s as one batch), which is why it stays the default
             v, xd, _, _ = run_policy(ds.options(max_evals=max_evals), nrep=min(args.steps, 3))
             out["default_options"] = {"value": v, "unit": "LM iterations/s", "identical_x": bool(torch.equal(xd, x)),
-                                      "note": "nlh_default_options (exact policy, sub_batches = auto: latency-bound stages of one "
-                                              "sub-batch run under the streaming kernels of another)"}
+                                      "note": "nlh_default_options (exact policy, sub_batches = auto: three in flight at this size -- "
+                                              "latency-bound stages of one sub-batch run under the streaming kernels of another)"}
             # latency of BASELINE config 2 taken literally: ONE problem (seed 12345), warm handle
             v1, _, ib1, t1 = run_policy(ds.options(max_evals=max_evals), nrep=3, sel=slice(0, 1))
             out["single_problem"] = {"ms": 1e3 * t1, "lm_iterations": ib1[0]["jacobian_count"], "lm_iterations_per_s": v1,

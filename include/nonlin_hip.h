@@ -96,8 +96,10 @@ typedef struct nlh_options {
                                  residuals also forms jac(:,j) = (f_j - f0)/h_j (:274) in its epilogue and the
                                  residual panel is never written; same operations per element, same bits */
     int32_t sub_batches;      /* 0.  Batched device-model LM solves: number of sub-batches kept in flight on private
-                                 streams (0 = automatic: nprob / 128, at most 3, and two halves for 32 to 255 problems;
-                                 1 = one lock-step batch).  Results do not depend on it */
+                                 streams (0 = automatic: nprob / 128, at most 3, and two halves for 32 to 255 problems of
+                                 m n >= 65536 elements -- smaller problems have no latency-bound pass to hide and stay one
+                                 batch; measurements in nlh_lm.hip, lm_sub_batches; 1 = one lock-step batch).  Results do
+                                 not depend on it */
 } nlh_options;
 
 void nlh_default_options(nlh_options *opts);

@@ -486,6 +486,13 @@ static int lm_sub_batches(const nlh_options *o, int nprob, int m, int n)
     if (S <= 0) {                                   // auto: >= 128 problems per sub-batch, at most 3 in flight (measured
         S = nprob / 128;                            // on 512 x 4096x256 exact: 1 / 2 / 3 / 4 -> 1032 / 959 / 928 / 1036 ms)
         if (S > 3) S = 3;
+        // Round 6 re-measured the cap.  On the bench family (four to six lock-step rounds) three sub-batches against one batch
+        // are a wash since k_lmpar halved: 3,822 / 3,772, 3,694 / 3,772, 3,700 / 3,770, 3,800 / 3,750, 3,640 / 3,755 LM it/s on five
+        // boxes (a kernel trace has a pass resident 94 % of the wall time, profiles/r06_overlap_defaults.json -- but two or three
+        // HBM-bound passes side by side deliver 12 % less than one alone).  On a family with a long straggler tail they are
+        // not: Lorentzian peak fits through a user launcher (tests/device_model, 416 lock-step rounds), 2048 x 4096x96 /
+        // 4096 x 2048x24, seconds per solve: one batch 20.6 / 1.86, THREE 15.0 / 1.51, four 23.8 / 2.22, six 23.0 / 2.59,
+        // eight 27.7 / 3.39, twelve 33.1 / 3.26 (profiles/r06_sub_batch_levers.txt).  Three stays.
         // 32 to 255 problems: two halves.  A half of such a batch takes the wide pass form (at most 256 (problem, window)
         // pairs), whose passes are bound by one adder wave per window rather than by HBM, so two of them side by side
         // cost little more than one, and the half that holds a straggler runs its rounds at the smaller batch's pace
