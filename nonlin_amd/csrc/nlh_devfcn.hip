@@ -178,7 +178,9 @@ static inline int32_t *dv_list(nlh_handle *h) { return (int32_t *)h->dvIdx.p + 1
 // Compacts the problems at `want` into the handle's list and reads their number back (*cnt); returns 0 or a library error.
 // The count lands in the pinned block's header, behind the words the solvers keep their own round read-backs in.
 static const int DV_PINNED_SLOT = 12;                            // int32 index inside the 64-byte header of h->pinned
-static int dv_select(nlh_handle *h, int nprob, const LmState *st, int want, size_t extra_ints, int *cnt)
+// known >= 0: the caller already holds the count (the previous round's read-back says how many problems are due for a
+// Jacobian): the list is built on the device and the host does not wait for it -- one stream synchronisation less per round.
+static int dv_select(nlh_handle *h, int nprob, const LmState *st, int want, size_t extra_ints, int *cnt, int known = -1)
 {
     int rc;
     *cnt = 0;
@@ -186,6 +188,7 @@ static int dv_select(nlh_handle *h, int nprob, const LmState *st, int want, size
     if ((rc = ensure_pinned(h, 64))) return rc;
     int32_t *dcnt = (int32_t *)h->dvIdx.p;
     hipLaunchKernelGGL(k_dv_compact, dim3(1), dim3(1024), 0, h->stream, nprob, st, want, dv_list(h), dcnt);
+    if (known >= 0) { *cnt = known; return 0; }
     int32_t *hcnt = (int32_t *)h->pinned + DV_PINNED_SLOT;
     HIPCHK(h, hipMemcpyAsync(hcnt, dcnt, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -247,7 +250,7 @@ static size_t fd_chunk_bytes()
 }
 
 int residual_jacobian(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int n, const double *x, const double *f0,
-                      double *out, double *panel, const LmState *st, int want, bool to_qrx, bool fuse, bool use_jac)
+                      double *out, double *panel, const LmState *st, int want, bool to_qrx, bool fuse, bool use_jac, int known_cnt)
 {
     if (!rs.user()) {
         if (fuse) launch_dq_panel(h, nprob, m, n, rs.dA, rs.db, rs.gamma, x, out, st, want, f0, to_qrx);
@@ -262,7 +265,7 @@ int residual_jacobian(nlh_handle *h, const ResidualSource &rs, int nprob, int m,
     const bool all = st == nullptr;
     const size_t npts_max = (size_t)nprob * n;
     if (!all) {
-        if ((rc = dv_select(h, nprob, st, want, (size_t)nprob + npts_max, &cnt))) return rc;
+        if ((rc = dv_select(h, nprob, st, want, (size_t)nprob + npts_max, &cnt, known_cnt))) return rc;
         if (cnt == 0) return 0;
     } else if ((rc = ensure(h, h->dvIdx, sizeof(int32_t) * ((size_t)2 * nprob + 16 + npts_max)))) return rc;
     int32_t *list = dv_list(h), *dprob = list + 2 * (size_t)nprob;

@@ -137,7 +137,7 @@ int residual_eval(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int
 // working matrix; panel: scratch of nprob * m * n doubles, distinct from out (the dense-quadratic family's unfused form
 // only: a user's panel lives in a chunk buffer of the handle).  fuse: dense-quadratic family only.
 int residual_jacobian(nlh_handle *h, const ResidualSource &rs, int nprob, int m, int n, const double *x, const double *f0,
-                      double *out, double *panel, const LmState *st, int want, bool to_qrx, bool fuse, bool use_jac);
+                      double *out, double *panel, const LmState *st, int want, bool to_qrx, bool fuse, bool use_jac, int known_cnt = -1);
 
 void launch_sumsq_part(nlh_handle *h, int nprob, int m, int n, const double *f, double *part);   // nlh_lm.hip
 

@@ -433,8 +433,9 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         // A round in which no problem is due for a Jacobian (rejected trial points only) skips the Jacobian and the factorisation's ~3 n launches; lmpar for the repeats still runs.
         const bool any_jac = njac_due > 0;
         if (any_jac) {
+            // (njac_due is exact: the first round has every problem at ST_NEED_JAC, later ones have the previous read-back)
             if ((rc = residual_jacobian(h, rs, nprob, m, n, dx, dfvec, to_qrx ? w.P : w.J, to_qrx ? w.J : w.P, w.st, ST_NEED_JAC, to_qrx,
-                                        fuse, true))) return rc;
+                                        fuse, true, njac_due))) return rc;
             hipLaunchKernelGGL(k_stage_advance, dim3(pb), dim3(256), 0, h->stream, nprob, w.st, (int)ST_NEED_JAC,
                                o->factor_policy != NLH_FACTOR_AUTO ? (int)ST_NEED_QR : (int)ST_HAVE_JAC, 1);
         }
