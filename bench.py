@@ -875,6 +875,19 @@ def auto_policy_zero_residual(ds, m, n, nprob, max_evals):
     row, xg, ibs, st = run(m, n, nprob, 3)
     if (m, n) == (4096, 256):
         row.update(compare("c2", xg, ibs, st))
+    # the WHOLE batch against the exact policy on the same problems (whose x is the oracle's bit for bit wherever the oracle
+    # was run: the golden sample above, `parity`): deviation and count / flag mismatches over all problems
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=SEED0, gamma=GAMMA, sigma=0.0, spread=SPREAD)
+    xe = x0.clone()
+    _, ibe, ste = ds.lm_solve_batch(A, b, GAMMA, xe, ds.options(max_evals=max_evals))
+    xen = xe.cpu().numpy()
+    devs = np.abs(xg - xen).max(axis=1) / np.abs(xen).max(axis=1)
+    row["whole_batch_vs_exact_policy"] = {
+        "problems": nprob, "max_rel_dev_x": float(devs.max()),
+        "count_or_flag_mismatches": int(sum(1 for k in range(nprob) if [ibs[k][q] for q in keys] != [ibe[k][q] for q in keys] or st[k] != ste[k])),
+        "exact_policy_non_converged": int(sum(1 for v in ste if v != 0))}
+    del A, b, xt, x0, xe
+    torch.cuda.empty_cache()
     out["batch"] = row
     out["value"] = row["lm_iterations_per_s"]
     out["unit"] = "LM iterations/s"
@@ -1267,6 +1280,7 @@ def main():
             az = out["auto_policy_zero_residual"]
             summ["auto_policy_zero_residual_value"] = az["value"]
             summ["auto_policy_zero_residual_parity"] = {k: az["batch"].get(k) for k in ("max_rel_dev_x", "count_or_flag_mismatches", "problems_compared")}
+            summ["auto_policy_zero_residual_whole_batch_vs_exact"] = az["batch"].get("whole_batch_vs_exact_policy")
             summ["config5_auto_zero_residual_ms"] = az["config5_one_65536x512"]["solve_ms"]
         if "parity" in out:
             summ["parity_x_bitwise_equal"] = f'{out["parity"]["x_bitwise_equal"]}/{out["parity"]["problems"]}'

@@ -89,3 +89,24 @@ def test_auto_policy_zero_residual_sub_batches_and_shares_are_the_same_bits(ds):
         outs.append(x)
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0][:5], outs[2])
+
+
+def test_auto_policy_zero_residual_all_1024_problems_of_config_4_against_the_exact_policy(ds):
+    """BASELINE config 4 in full (1024 problems 2048 x 128, sigma = 0): the exact policy's result -- bit for bit the oracle's
+    on every sample the suites check (this file, tests/test_gpu_configs.py) -- stands in for the oracle on all 1024, and
+    NLH_FACTOR_AUTO must be within 1e-10 of it with every count and flag equal, problem by problem."""
+    m, n, nprob = 2048, 128, 1024
+    A, b, xt, x0 = ds.generate(nprob, m, n, seed0=int(SEED0), gamma=GAMMA, sigma=SIGMA, spread=SPREAD)
+    res = {}
+    for pol in (2, 0):
+        x = x0.clone()
+        f, ibs, st = ds.lm_solve_batch(A, b, GAMMA, x, ds.options(max_evals=int(MAX_EVALS), factor_policy=pol))
+        res[pol] = (x, ibs, st)
+    xe, xa = res[2][0], res[0][0]
+    rel = ((xa - xe).abs().amax(dim=1) / xe.abs().amax(dim=1)).cpu().numpy()
+    assert float(rel.max()) <= RTOL_X, float(rel.max())
+    assert res[0][2] == res[2][2] and all(s == 0 for s in res[2][2])
+    for p in range(nprob):
+        assert [res[0][1][p][k] for k in KEYS] == [res[2][1][p][k] for k in KEYS], (p, res[0][1][p], res[2][1][p])
+    gold_x = torch.tensor(GOLD["c4_x"], device=xe.device)      # ... and the stand-in is the fixture's bits where the fixture reaches
+    assert torch.equal(xe[:gold_x.shape[0]], gold_x)

@@ -66,6 +66,8 @@ def test_bench_single_process():
     assert all(r["non_converged"] >= 0 and r["lock_step_rounds"] >= 1 for r in dv[2:4])
     az = d["auto_policy_zero_residual"]                        # N1: the MFMA / Cholesky policy where 1e-10 is well-posed
     assert az["value"] > 0 and az["batch"]["non_converged"] == 0 and 0.0 < az["batch"]["gram"]["frac"] < 1.0
+    wb = az["batch"]["whole_batch_vs_exact_policy"]             # every problem of the batch against the exact policy
+    assert wb["problems"] == 16 and wb["max_rel_dev_x"] <= 1e-10 and wb["count_or_flag_mismatches"] == 0
     c5 = az["config5_one_65536x512"]
     assert c5["within_1e-10_with_exact_counts"] and c5["max_rel_dev_x"] <= 1e-10 and c5["count_or_flag_mismatches"] == 0
     assert 0.0 < c5["gram"]["frac"] < 1.0 and 0.0 < c5["fd_jacobian"]["frac"] < 1.0
