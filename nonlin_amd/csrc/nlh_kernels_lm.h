@@ -85,7 +85,8 @@ static inline size_t lmsolve_ring_bytes(int n, int threads, int *cap)
         cached[n] = c;
     }
     *cap = c;
-    return sizeof(double) * ((size_t)c + (size_t)(n + 1) / 2 + 8);      // + the table of column offsets (n int32)
+    // + the table of column offsets (n int32) + the time step's rotations (cs, sn: 2 n doubles; ring offset and flag: n int32)
+    return sizeof(double) * ((size_t)c + (size_t)(n + 1) / 2 + 8 + 2 * (size_t)n + (size_t)(n + 1) / 2 + 8);
 }
 // doubles of LDS behind lmpar's n-vectors for the exact reductions (norm2_flang_block: 3 NLH_NCH + 8; the lanes form of the
 // m-entry norm of deviation A: its chunk + flags, 64 EL + 128 + 40 + threads / 2 with EL = 32 for sixteen waves, else 16)
@@ -103,6 +104,8 @@ __device__ __forceinline__ void lmsolve_sweep_lds(int n, double *r, int ldr, dou
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = BS >> 6, P = nw * LMS_SLOTS;
     const int nvt = (n + 63) >> 6;                              // chunks of 64 elements in all (<= NV)
     int32_t *cbt = reinterpret_cast<int32_t *>(ring + cap);    // cbt[k]: where column k (its element 64 v0(k)) starts in the ring
+    double2 *parcs = reinterpret_cast<double2 *>(ring + cap + (n + 1) / 2 + 8 - ((n + 1) / 2 & 1));   // (cs, sn) of row j's rotation of this time step
+    int32_t *parcb = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(parcs) + 2 * (size_t)n);     // its column's ring offset | applied << 30
     if (tid == 0) {
         int pos = 0;
         for (int k = 0; k < n; ++k) { const int len = lms_colsize(k, n); pos = LMS_PLACE(pos, len, cap); cbt[k] = pos; pos += len; }
@@ -153,39 +156,49 @@ __device__ __forceinline__ void lmsolve_sweep_lds(int n, double *r, int ldr, dou
             }
         }
         SWCLK(ck_ld)
-        // lane u forms the rotation of slot u (:733-748)
+        // The rotations of the time step (:733-748) are formed ONCE, by the first one or two waves -- lane q of them takes row
+        // jlo + q --, and published through LDS; a barrier later every wave applies the rotations of its own slots.  (Until
+        // this form every wave formed its own slots' rotations with 8 of its 64 lanes: 130 instructions per wave and step for
+        // 8 lanes' worth of work, a third of what a step executed.)
         if (myj + n - 1 < t) myj += P;                          // the slot's row is finished: its next row
         const bool mine = lane < LMS_SLOTS && myj < n && 2 * myj <= t && t <= myj + n - 1;
-        double mycs = 1.0, mysn = 0.0;
-        int mycb = 0;                                           // ring offset of the column; bit 30: the rotation is applied (:732)
-        if (mine) {
-            const int j = myj, k = t - j;
-            // everything the rotation needs is read before anything is tested (one LDS latency, not three)
-            const double sk = rot[j], rkk = sdiag[k], wk = wa[k], qj = qtbp[j];
-            mycb = cbt[k];
-            if (sk != 0.0) {                                   // :732 (diag(l) == 0, :721, is the sk == 0 case: see the global form)
-                // :733-741, both branches through one divide / square root / divide (the lanes of a wave take different
-                // branches, and a wave pays for every instruction of both): the same operations on the same operands
-                const bool tan_form = !(fabs(rkk) < fabs(sk));  // cs = 0.5 / sqrt(...), sn = cs * (sk / rkk)
-                const double q = (tan_form ? sk : rkk) / (tan_form ? rkk : sk);
-                const double pr = 0.5 / sqrt(0.25 + 0.25 * (q * q));
-                const double ot = pr * q;
-                mycs = tan_form ? pr : ot;
-                mysn = tan_form ? ot : pr;
-                sdiag[k] = mycs * rkk + mysn * sk;             // :745
-                wa[k] = mycs * wk + mysn * qj;                 // :746-748
-                qtbp[j] = -mysn * wk + mycs * qj;
-                mycb |= 1 << 30;
+        {
+            const int jlo = t - (n - 1) > 0 ? t - (n - 1) : 0, jhi = t >> 1;
+            const int j = jlo + 64 * wid + lane;
+            if (wid < (NV > 2 ? 2 : 1) && j <= jhi) {
+                const int k = t - j;
+                // everything the rotation needs is read before anything is tested (one LDS latency, not three)
+                const double sk = rot[j], rkk = sdiag[k], wk = wa[k], qj = qtbp[j];
+                int cbf = cbt[k];                                // ring offset of the column; bit 30: the rotation is applied (:732)
+                double fcs = 1.0, fsn = 0.0;
+                if (sk != 0.0) {                                   // :732 (diag(l) == 0, :721, is the sk == 0 case: see the global form)
+                    // :733-741, both branches through one divide / square root / divide (the lanes of a wave take different
+                    // branches, and a wave pays for every instruction of both): the same operations on the same operands
+                    const bool tan_form = !(fabs(rkk) < fabs(sk));  // cs = 0.5 / sqrt(...), sn = cs * (sk / rkk)
+                    const double q = (tan_form ? sk : rkk) / (tan_form ? rkk : sk);
+                    const double pr = 0.5 / sqrt(0.25 + 0.25 * (q * q));
+                    const double ot = pr * q;
+                    fcs = tan_form ? pr : ot;
+                    fsn = tan_form ? ot : pr;
+                    sdiag[k] = fcs * rkk + fsn * sk;               // :745
+                    wa[k] = fcs * wk + fsn * qj;                   // :746-748
+                    qtbp[j] = -fsn * wk + fcs * qj;
+                    cbf |= 1 << 30;
+                }
+                parcs[j] = make_double2(fcs, fsn);
+                parcb[j] = cbf;
             }
         }
         const int actmask = (int)__builtin_amdgcn_readfirstlane((unsigned)(__ballot(mine) & 0xff));
+        nlh_lds_barrier();
         SWCLK(ck_form)
 #pragma unroll
         for (int u = 0; u < LMS_SLOTS; ++u) {
             if (!((actmask >> u) & 1)) continue;               // uniform
             const int j = __builtin_amdgcn_readlane(myj, u), k = t - j;
-            const int cbf = __builtin_amdgcn_readlane(mycb, u), ok = cbf >> 30;
-            const double cs = readlane_f64(mycs, u), sn = readlane_f64(mysn, u);
+            const double2 csn = parcs[j];                       // (one address for the whole wave: a broadcast read)
+            const int cbf = __builtin_amdgcn_readfirstlane(parcb[j]), ok = cbf >> 30;
+            const double cs = csn.x, sn = csn.y;
             const int hl = (k + 1) & 63, v0 = (k + 1) >> 6, nlive = nvt - v0;   // live chunks: the column's elements 64 (v0 + c) + lane
             double *col = ring + (cbf & 0x3fffffff) + lane;    // chunk c at col[64 c]
             if (j == k) {
@@ -204,6 +217,7 @@ __device__ __forceinline__ void lmsolve_sweep_lds(int n, double *r, int ldr, dou
                 }
             } else {
                 if (hl == 0) {                                 // k+1 crossed a multiple of 64: chunk 0 died, the registers move down
+                    asm volatile("" ::: "memory");             // (keeps this a branch taken once in 64 steps: as selects it was six instructions per slot and step)
 #pragma unroll
                     for (int c = 0; c + 1 < NV; ++c) w[u][c] = w[u][c + 1];
                 }
