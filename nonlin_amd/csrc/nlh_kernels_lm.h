@@ -38,11 +38,12 @@ __device__ unsigned long long g_lmclk[16];
 //     padding (115 KB at n = 256: lmsolve_ring_bytes()); column t + LMS_AHEAD is fetched from global memory during step
 //     t (a load per lane of waves 0..NV-1, stored into the ring a step later), a column's final values go to the lower
 //     triangle of r in global memory straight from the registers of its last rotation (t = 2k);
-//   * sdiag / wa / qtbp / rot as in the global form; one LDS-only barrier per time step.
+//   * the rotations of a time step (:733-748) are formed once, by the first one or two waves (a lane per rotation), and
+//     published through LDS; sdiag / wa / qtbp / rot as in the global form; two LDS-only barriers per time step.
 // What bounds it: a wave issues at most one instruction per four cycles, so a time step costs (instructions a wave executes)
 // x 4 cycles -- the code of a step is kept to the rotation's arithmetic plus a few scalar instructions per slot
 // (measured: docs/lab_notebook.md).  Before: 6.6 us per time step (two dependent trips to L2 and a full barrier),
-// 3.35 ms per sweep at n = 256.
+// 3.35 - 3.9 ms per sweep at n = 256; now 1.16 ms (2.3 us per step).
 // ---------------------------------------------------------------------------------------------------------------
 #define LMS_MAX_N 256
 #define LMS_AHEAD 8         // columns fetched ahead of their first rotation ...
