@@ -3,6 +3,7 @@
 // src/nonlin_multi_eqn_mult_var.f90:198-277), and its stages as entry points of their own (nlh_gram, nlh_chol_factor,
 // nlh_qr_factor, nlh_lmfactor_exact, nlh_lmpar).
 #include "nlh_internal.h"
+#include <chrono>
 #include "nlh_kernels_gram.h"
 #include "nlh_kernels_factor.h"
 #include "nlh_kernels_lm.h"
@@ -426,6 +427,8 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
     const int max_rounds = o->max_evals + 8;
     int last_printed_iter = -1;
     int nact = nprob, njac_due = nprob;                         // problems still iterating / due for a Jacobian (from the previous round)
+    static const bool dbg_rounds = getenv("NLH_DEBUG_ROUNDS") != nullptr;   // per lock-step round: active problems, Jacobians due, wall ms
+    auto tround = std::chrono::steady_clock::now();
     for (int round = 0; round < max_rounds; ++round) {
         // outer-loop head for problems that need a Jacobian (:221): n perturbed evaluations + FD
         // (the exact factorisation is the Jacobian's only reader: to_qrx writes it in that working layout, no re-layout
@@ -455,6 +458,12 @@ static int lm_solve_range(nlh_handle *h, const nlh_options *o, int32_t nprob, in
         if (echo && h_state[0].stage == ST_NEED_JAC && h_state[0].iter != last_printed_iter) {
             print_status(h_state[0].iter, h_state[0].neval, h_state[0].njac, h_state[0].xnorm, h_state[0].fnorm);
             last_printed_iter = h_state[0].iter;
+        }
+        if (dbg_rounds) {
+            const auto tn = std::chrono::steady_clock::now();
+            fprintf(stderr, "round %d base %d nprob %d active_before %d jac_due_before %d -> active %d ms %.3f\n", round, rs.pbase, nprob, nact, njac_due,
+                    h_active[0], std::chrono::duration<double, std::milli>(tn - tround).count());
+            tround = tn;
         }
         if (*h_active == 0) break;
         nact = h_active[0];
