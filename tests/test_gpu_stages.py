@@ -204,6 +204,39 @@ def test_lmsolve_on_chip_sweep_is_bitwise_the_global_wavefront(ds, n, zero_diag)
         assert np.array_equal(outs[1][3][q], outs[1][3][0]) and np.array_equal(outs[1][1][q], outs[1][1][0])
 
 
+def test_lmsolve_on_chip_sweep_every_size_up_to_256(ds):
+    """Every n from 2 to 256 (ring size, chunk count, register moves at the 64-element boundaries, thread count and the
+    number of forming waves all depend on it), one problem each, every third with zero diagonal entries: on-chip form ==
+    global-memory wavefront, bit for bit (par, x, sdiag, S)."""
+    f64 = dict(dtype=torch.float64, device="cuda")
+    for n in range(2, 257):
+        rng = np.random.default_rng(5000 + n)
+        R = np.triu(rng.standard_normal((n, n)))
+        R[np.arange(n), np.arange(n)] += np.sign(R[np.arange(n), np.arange(n)]) * 2.0
+        ip = rng.permutation(n).astype(np.int32)
+        diag = np.abs(rng.standard_normal(n)) + 0.5
+        if n % 3 == 0:
+            diag[rng.integers(0, n, size=max(1, n // 8))] = 0.0
+        qtf = rng.standard_normal(n)
+        xgn = np.empty(n)
+        xgn[ip] = np.linalg.solve(R, qtf)
+        delta = 0.2 * np.linalg.norm(diag * xgn) + 1e-3
+        outs = []
+        for env in ("1", "0"):
+            os.environ["NLH_LMSOLVE_GLOBAL"] = env
+            try:
+                Rd = torch.tensor(np.ascontiguousarray(R.T), device="cuda").unsqueeze(0)
+                par, x, sdiag = ds.lmpar(Rd, torch.tensor(ip, dtype=torch.int32, device="cuda").unsqueeze(0), torch.tensor(diag, **f64).unsqueeze(0),
+                                         torch.tensor(qtf, **f64).unsqueeze(0), torch.tensor([float(delta)], **f64), torch.tensor([0.0], **f64),
+                                         torch.tensor([0.0], **f64))
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("NLH_LMSOLVE_GLOBAL", None)
+            outs.append((par.cpu().numpy(), x.cpu().numpy(), sdiag.cpu().numpy(), Rd.cpu().numpy()))
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b), n
+
+
 @pytest.mark.parametrize("n", [2, 37, 130, 300, 600, 1024, 1100])
 def test_lu_bit_exact(ds, oracle, n):
     """lu_factor / solve_lu stand-ins: same pivots, bit-identical factors and solution (n >= 128: the blocked path --
