@@ -75,7 +75,9 @@ typedef struct nlh_iteration_behavior {
  * line_search_solver%m_useLineSearch   src/nonlin_solve.f90:30
  * line_search   src/nonlin_linesearch.f90:35-53                              */
 #define NLH_FACTOR_AUTO 0  /* J^T J + pivoted Cholesky; Householder QR when the Gauss-Newton
-                              step is rejected or the Gram matrix is ill-conditioned */
+                              step is rejected or the Gram matrix is ill-conditioned.  Opt-in: within 1e-10 of the
+                              reference with exact counts on zero-residual problems (tests/test_gpu_auto_policy.py),
+                              at the forward-difference noise level (~1e-7) where a residual remains */
 #define NLH_FACTOR_QR   1  /* always the reference's pivoted Householder QR (lmfactor), parallel reductions */
 #define NLH_FACTOR_EXACT 2 /* lmfactor/lmpar with every reduction in the reference's operation order
                               (sequential dot products, flang NORM2): bit-identical to the CPU path */
