@@ -18,6 +18,7 @@ module nonlin_multi_eqn_mult_var
     public :: nlh_callback_ctx
     public :: device_model_batch
     public :: NLH_MODEL_DENSE_QUADRATIC
+    public :: NLH_FACTOR_AUTO, NLH_FACTOR_QR, NLH_FACTOR_EXACT     ! values of equation_solver%factor_policy (from nonlin_hip_c)
     public :: nlh_use_devices
     public :: nlh_vecfcn_trampoline
     public :: nlh_jacfcn_trampoline

@@ -18,6 +18,10 @@ program device_model_suite
     call run_newton(trim(path))
     call get_command_argument(1, path)
     call run_box_and_bfgs(trim(path))
+    if (nargs >= 3) then                                      ! zero-residual problems under the MFMA / Cholesky policy (N1)
+        call get_command_argument(3, path)
+        call run_lm_auto_policy(trim(path))
+    end if
 
 contains
     subroutine load(path, nprob, m, n, gamma, a, b, x0)
@@ -87,6 +91,38 @@ contains
         call lm%solve_batch(batch, x, f, ibs, st)
         do k = 1, nprob
             call report("dm_lm_batch_set", ibs(k), st(k), x(:,k))
+        end do
+        call batch%destroy()
+    end subroutine
+
+    ! least_squares_solver%solve_batch with the extension component factor_policy = NLH_FACTOR_AUTO (J^T J on the fp64 MFMA +
+    ! Cholesky step solve: the formulation the reference's doc-comment names, src/nonlin_least_squares.f90:21-24) and with
+    ! the default NLH_FACTOR_EXACT, on zero-residual problems
+    subroutine run_lm_auto_policy(path)
+        character(len=*), intent(in) :: path
+        integer(int32) :: nprob, m, n, k
+        real(real64) :: gamma
+        real(real64), allocatable :: a(:,:,:), b(:,:), x0(:,:), x(:,:), f(:,:)
+        type(device_model_batch) :: batch
+        type(least_squares_solver) :: lm
+        type(iteration_behavior), allocatable :: ibs(:)
+        integer(int32), allocatable :: st(:)
+
+        call load(path, nprob, m, n, gamma, a, b, x0)
+        call lm%set_max_fcn_evals(500)
+        call batch%create(NLH_MODEL_DENSE_QUADRATIC, a, b, gamma)
+        allocate(x(n, nprob), f(m, nprob), ibs(nprob), st(nprob))
+        lm%factor_policy = NLH_FACTOR_AUTO
+        x = x0
+        call lm%solve_batch(batch, x, f, ibs, st)
+        do k = 1, nprob
+            call report("dm_lm_auto_zero_residual", ibs(k), st(k), x(:,k))
+        end do
+        lm%factor_policy = NLH_FACTOR_EXACT
+        x = x0
+        call lm%solve_batch(batch, x, f, ibs, st)
+        do k = 1, nprob
+            call report("dm_lm_exact_zero_residual", ibs(k), st(k), x(:,k))
         end do
         call batch%destroy()
     end subroutine

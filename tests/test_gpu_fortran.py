@@ -183,13 +183,15 @@ def dm_results(oracle, tmp_path_factory):
     d = tmp_path_factory.mktemp("dm")
     lm_in = _write_problem_file(str(d / "lm.bin"), oracle, [12345 + k for k in range(6)], 512, 64)
     nt_in = _write_problem_file(str(d / "nt.bin"), oracle, [777 + k for k in range(4)], 48, 48, sigma=0.0, square_shift=True)
-    out = subprocess.run([EXE_DM, str(d / "lm.bin"), str(d / "nt.bin")], capture_output=True, text=True, timeout=300)
+    zr_in = _write_problem_file(str(d / "zr.bin"), oracle, [12345 + k for k in range(4)], 2048, 128, sigma=0.0)
+    out = subprocess.run([EXE_DM, str(d / "lm.bin"), str(d / "nt.bin"), str(d / "zr.bin")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr + out.stdout
     res = {}
     for line in out.stdout.splitlines():
         t = line.split()
         res.setdefault(t[0], []).append({"status": int(t[1]), "counts": (int(t[2]), int(t[3]), int(t[4])),
                                          "flags": tuple(t[5:8]), "x": np.array([_unhex(h) for h in t[8:]])})
+    res["_zr_in"] = zr_in
     return res, lm_in, nt_in
 
 
@@ -256,3 +258,20 @@ def test_device_model_other_solver_batches_through_fortran(dm_results, oracle):
         assert r["counts"] == (ibo["iter_count"], ibo["fcn_count"], ibo["gradient_count"]), (r, ibo)
         assert r["flags"] == ("F", "T" if ibo["converge_on_chng"] else "F", "T" if ibo["converge_on_zero_diff"] else "F")
         assert np.array_equal(r["x"][:-1], xo) and r["x"][-1] == fo
+
+
+def test_device_model_auto_policy_on_zero_residual_problems_through_fortran(dm_results, oracle):
+    """N1 from the Fortran side: `lm%factor_policy = NLH_FACTOR_AUTO` (the MFMA J^T J + Cholesky formulation) on four
+    zero-residual 2048 x 128 problems (BASELINE config 4's size): x within 1e-10 of the CPU oracle with every count and
+    flag equal; the default policy on the same problems: the oracle's bits."""
+    res, _, _ = dm_results
+    gamma, data = res["_zr_in"]
+    sols = [oracle.dq_lm_solve(A, b, gamma, x0, opts=oracle.default_options(max_evals=500)) for A, b, xt, x0 in data]
+    assert len(res["dm_lm_auto_zero_residual"]) == len(data) == len(res["dm_lm_exact_zero_residual"])
+    for k, (rc, xo, fo, ibo, _, _) in enumerate(sols):
+        _cmp_dm(res["dm_lm_exact_zero_residual"][k], rc, xo, ibo)
+        r = res["dm_lm_auto_zero_residual"][k]
+        assert r["status"] == rc == 0
+        assert r["counts"] == (ibo["iter_count"], ibo["fcn_count"], ibo["jacobian_count"]), (r, ibo)
+        assert r["flags"] == tuple("T" if ibo[q] else "F" for q in ("converge_on_fcn", "converge_on_chng", "converge_on_zero_diff"))
+        assert np.abs(r["x"] - xo).max() <= 1e-10 * np.abs(xo).max()
