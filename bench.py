@@ -1007,6 +1007,8 @@ def main():
 
     def step():
         x.copy_(x0)
+        fv[0] = None        # the previous step's fvec goes first: its block serves this step (a fresh 67 MB tensor allocated while the
+        #                     old one is alive cost the first timed step a hipMalloc -- tens of ms, once)
         fvec, ibs, status = ds.lm_solve_batch(A, b, gamma, x, opts)
         fv[0] = fvec
         return ibs, status
